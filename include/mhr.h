@@ -1,0 +1,211 @@
+/*
+ * mhr.h - C ABI of the MI355X (gfx950) hot path for multi-head recommendation:
+ * HSTU sequence encoder pieces, item-embedding gather / sparse gradient reduction,
+ * sampled-softmax (NCE) loss, full-catalog multi-head scoring + top-k + merge, Adam.
+ *
+ * The reference (zhykoties/Multi-Head-Recommendation-with-Human-Priors) is pure Python
+ * and has no FFI; the boundary it exposes is the model-registry + trainer contract
+ * (SURVEY.md section 8b).  This ABI sits one level below that contract: each entry point
+ * replaces a group of torch ops inside the reference's HSTU / Collector classes
+ * (citations are file:line under code/REC/).  The Python host side
+ * (multi-head-recommendation-with-human-priors_amd/ops.py) binds it with ctypes.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller unless stated otherwise;
+ *   - no allocation, no synchronisation inside; all work is enqueued on `stream`
+ *     (a hipStream_t passed as void*); calls are re-entrant and graph-capturable;
+ *   - return 0 on success, a negative MHR_E* code otherwise (argument checks happen on the
+ *     host before launch); mhr_last_error() returns a thread-local message;
+ *   - tensors are dense row-major; dtype tags: MHR_F32 = 0, MHR_BF16 = 1;
+ *   - item ids are int64 like the reference's batches.
+ */
+#ifndef MHR_H
+#define MHR_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MHR_F32 0
+#define MHR_BF16 1
+
+#define MHR_OK 0
+#define MHR_EINVAL (-1)   /* bad argument (null pointer, unsupported size/dtype) */
+#define MHR_ELAUNCH (-2)  /* HIP launch failure */
+
+const char* mhr_last_error(void);
+int mhr_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Item embedding.
+ * ---------------------------------------------------------------------------------------- */
+
+/* out[r,:] = table[ids[r],:]  (nn.Embedding forward, model/IDNet/hstu.py:413,637,670,752,883).
+ * Optional fused position add (hstu.py:640-643): when x_out != NULL, ids is viewed as
+ * [n_ids/window_len, window_len] and x_out[b,l,:] = table[ids[b,l],:] + pos_table[l,:] for
+ * l < seq_len (x_out is [n_ids/window_len, seq_len, dim], dtype x_dtype).
+ * `out` may be NULL when only x_out is wanted.  dim % 4 == 0.  ids outside [0,n_rows) are clamped. */
+int mhr_embedding_gather_fwd(const float* table, int64_t n_rows, int dim,
+                             const int64_t* ids, int64_t n_ids,
+                             void* out, int out_dtype,
+                             const float* pos_table, int seq_len, int window_len,
+                             void* x_out, int x_dtype, void* stream);
+
+/* Dense embedding backward (ATen embedding_dense_backward): grad_table[ids[r],:] += grad_rows[r,:]
+ * with float atomics.  grad_table [n_rows, dim] f32 must be zeroed by the caller. */
+int mhr_embedding_scatter_add_bwd(const void* grad_rows, int grad_dtype, const int64_t* ids, int64_t n_ids,
+                                  float* grad_table, int64_t n_rows, int dim, void* stream);
+
+/* Sparse embedding backward, deterministic.  Inputs: ids sorted ascending (`sorted_ids`) with `perm`
+ * giving, for every sorted position, the source row in the caller's gradient rows
+ * (sorted_ids = ids[perm]).  Source rows come from up to two buffers laid end to end:
+ * rows [0, n_a) from grad_a, rows [n_a, n_a+n_b) from grad_b.  Optional `x_grad`
+ * ([n_a/window_len, seq_len, dim] f32): the gradient of the fused position-added copy, added to
+ * source row r < n_a when (r % window_len) < seq_len.
+ * Output: for every segment head position i (first occurrence of an id) out_rows[i,:] = sum of the
+ * segment's source rows (f32), and row_slot[id] = i.  Non-head rows of out_rows are left untouched.
+ * row_slot ([n_rows] int32) must hold -1 everywhere on entry; mhr_adam_rows restores that. */
+int mhr_sparse_rows_segment_sum(const int64_t* sorted_ids, const int64_t* perm, int64_t n_ids,
+                                const void* grad_a, int a_dtype, int64_t n_a,
+                                const void* grad_b, int b_dtype, int64_t n_b,
+                                const float* x_grad, int seq_len, int window_len,
+                                float* out_rows, int32_t* row_slot, int dim, void* stream);
+
+/* Dense AdamW over an embedding table whose gradient is given sparsely (trainer.py:292-299 semantics:
+ * every row is updated every step, untouched rows with g = 0).  For each row: slot = row_slot[row];
+ * g = slot >= 0 ? grad_rows[slot,:] * grad_scale : 0; AdamW update; row_slot[row] = -1.
+ * step is 1-based.  If `row_slot` is NULL, grad_rows is a dense [n_rows, dim] gradient. */
+int mhr_adam_rows(float* w, float* m, float* v, int64_t n_rows, int dim,
+                  const float* grad_rows, int32_t* row_slot, float grad_scale,
+                  float lr, float beta1, float beta2, float eps, float weight_decay, int step, void* stream);
+
+/* Dense AdamW over a flat parameter buffer (all non-table parameters live in one flat buffer). */
+int mhr_adam_flat(float* w, const float* g, float* m, float* v, int64_t n, float grad_scale,
+                  float lr, float beta1, float beta2, float eps, float weight_decay, int step, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Normalisation / gating (HSTU layer, model/IDNet/hstu.py:213-219, 241, 277-285).
+ * ---------------------------------------------------------------------------------------- */
+
+/* Affine-free LayerNorm over the last dim: y = (x - mean) * rstd; saves mean/rstd ([rows] f32, may be NULL). */
+int mhr_layernorm_fwd(const void* x, int x_dtype, void* y, int y_dtype, float* mean, float* rstd,
+                      int64_t rows, int dim, float eps, void* stream);
+/* dx (+)= rstd * (dy - mean(dy) - xhat * mean(dy*xhat));  accumulate != 0 adds into dx (f32 only). */
+int mhr_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* mean, const float* rstd,
+                      void* dx, int dx_dtype, int accumulate, int64_t rows, int dim, void* stream);
+
+/* o = silu(u) * LayerNorm(a) * dropmask   (hstu.py:277-285).  u is a column block of the uvqk GEMM
+ * output: u[r,c] = u_base[r*u_stride + c] (pre-activation; SiLU applied here).  a [rows, dim].
+ * dropout: keep-mask from a counter hash of (seed, r*dim+c), scaled by 1/(1-p); p = 0 disables. */
+int mhr_ln_gate_fwd(const void* u_base, int64_t u_stride, const void* a, int dtype, void* o, int o_dtype,
+                    float* mean, float* rstd, int64_t rows, int dim, float eps,
+                    float dropout_p, uint64_t seed, void* stream);
+/* Backward of the above: given d_o, writes du (pre-activation gradient, into a column block with
+ * row stride du_stride) and da. */
+int mhr_ln_gate_bwd(const void* d_o, int do_dtype, const void* u_base, int64_t u_stride, const void* a, int dtype,
+                    const float* mean, const float* rstd, void* du_base, int64_t du_stride, void* da,
+                    int64_t rows, int dim, float dropout_p, uint64_t seed, void* stream);
+
+/* y[r,:] = x[r,:] / ||x[r,:]||_2  (hstu.py:605-606, 672, 966, 975, 1021); optional norms out ([rows] f32). */
+int mhr_l2norm_rows(const void* x, int x_dtype, void* y, int y_dtype, float* norms, int64_t rows, int dim, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * HSTU pointwise-gated attention (model/IDNet/hstu.py:137-160), fused, never materialises [L,L].
+ *   out[b,n,h,:] = sum_{m<=n, key_valid[b,m]} silu(silu(q)[b,n,h].silu(k)[b,m,h]) / L * silu(v)[b,m,h,:]
+ * q,k,v are column blocks of the pre-activation uvqk GEMM output ([B*L, row_stride] bf16): the inner
+ * SiLU of hstu.py:244-245 is applied on load (apply_silu != 0).  head_dim = dqk = dv, multiple of 8, <= 128.
+ * key_valid [B,L] uint8.  out [B*L, n_heads*head_dim] bf16.  L*head_dim is limited by the 160 KiB LDS
+ * (K and V^T of one (batch, head) are staged whole): L=512 x head_dim=64 and L=200 x 128 fit.
+ * ---------------------------------------------------------------------------------------- */
+int mhr_hstu_attn_fwd(const void* q, const void* k, const void* v, int64_t row_stride,
+                      const uint8_t* key_valid, void* out,
+                      void* act_q, void* act_k, void* act_v, int64_t act_stride,
+                      int B, int L, int n_heads, int head_dim, int apply_silu, void* stream);
+/* act_q/act_k/act_v (optional, all or none): the forward also stores the activated operands
+ * (silu(q), silu(k), silu(v), bf16, row stride act_stride, same head layout) for the backward.
+ *
+ * Backward: given d_out ([B*L, n_heads*head_dim] bf16) writes the gradients w.r.t. the PRE-activation
+ * q,k,v (chain rule through the load-time SiLU included when apply_silu != 0) into column blocks with row
+ * stride d_stride (bf16).  act_* are the activated operands saved by the forward (pass q,k,v themselves
+ * when apply_silu == 0).  Two passes per (batch, head) workgroup, no atomics: bitwise reproducible. */
+int mhr_hstu_attn_bwd(const void* q_pre, const void* k_pre, const void* v_pre, int64_t row_stride,
+                      const void* act_q, const void* act_k, const void* act_v, int64_t act_stride,
+                      const uint8_t* key_valid, const void* d_out,
+                      void* dq, void* dk, void* dv, int64_t d_stride,
+                      int B, int L, int n_heads, int head_dim, int apply_silu, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Sampled softmax with false-negative suppression (model/IDNet/hstu.py:600-619 + F.cross_entropy 697/833).
+ * Tokens are described by row indices instead of compacted copies: token t uses query row
+ * q_rows[q_idx[t]] and positive row p_rows[p_idx[t]] (both raw, L2-normalised inside; io_dtype f32/bf16).
+ * negs [n_neg, dim] bf16 are already L2-normalised.  n_tok is read from device memory (*n_tok_dev)
+ * so data-dependent token counts need no host sync; `tok_cap` bounds the grid.  dim in {16,32,64,128,256}.
+ *   logit_pos = s*cos(q,p); logit_j = s*cos(q,neg_j), dropped when cos(p,neg_j) > thres; s = exp(clamp(logit_scale,0,ln 100))
+ *   loss[t] = logsumexp(logits) - logit_pos;  lse[t] saved for backward.
+ * Optional logs (may be NULL): n_valid[t] = 1 + #kept negatives; rank[t] = #kept negatives with logit > logit_pos
+ * (hstu.py:621-629: nce_samples and top-k accuracy follow from these).
+ * Saved for backward (may be NULL when no backward follows): qn_out/pn_out [tok_cap, dim] bf16 normalised rows,
+ * qnT_out [dim, tok_cap] bf16 (Q^T), q_inv/p_inv [tok_cap] = 1/||row||, s_pos [tok_cap] = cos(q,p).
+ * ---------------------------------------------------------------------------------------- */
+int mhr_nce_fwd(const void* q_rows, const int32_t* q_idx, const void* p_rows, const int32_t* p_idx, int io_dtype,
+                const void* negs, int n_neg, int dim, const int32_t* n_tok_dev, int tok_cap,
+                const float* logit_scale_dev, float thres,
+                float* loss, float* lse, int32_t* n_valid, int32_t* rank,
+                void* qn_out, void* pn_out, void* qnT_out, float* q_inv, float* p_inv, float* s_pos, void* stream);
+/* Backward.  w[t] = d(total loss)/d(loss[t]) (0 for unused slots).  Inputs are the forward's saved tensors plus
+ * negsT [dim, negsT_ld] bf16 (negs transposed, negsT_ld >= n_neg, multiple of 4, zero padded).
+ * Writes per-token gradient rows dq_tok/dp_tok ([tok_cap, dim] f32, w.r.t. the RAW query / positive rows,
+ * normalisation chain rule included; rows t >= n_tok are not written), accumulates d_negs ([n_neg, dim] f32,
+ * float atomics; caller zeroes) w.r.t. the normalised negatives, and atomically adds d(logit_scale parameter)
+ * into *d_logit_scale (may be NULL).  tok_cap % 4 == 0. */
+int mhr_nce_bwd(const void* qn, const void* pn, const void* qnT, const void* negs, const void* negsT, int64_t negsT_ld,
+                int n_neg, int dim, const int32_t* n_tok_dev, int tok_cap,
+                const float* logit_scale_dev, float thres, const float* lse, const float* w,
+                const float* q_inv, const float* p_inv, const float* s_pos,
+                float* dq_tok, float* dp_tok, float* d_negs, float* d_logit_scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Full-catalog multi-head scoring + top-k + cross-head merge
+ * (model/IDNet/hstu.py:965-1015, trainer/trainer.py:724-726, evaluator/collector.py:241-282).
+ * ---------------------------------------------------------------------------------------- */
+
+/* Streaming scorer: for every row r of `users` ([n_rows, dim] bf16, L2-normalised head embeddings,
+ * row r = b*H + h) and every item n in {item_begin + j*item_stride < n_items}: s = users[r].items[n]
+ * (bf16 MFMA, f32 accumulate).  The candidate (s, n) is appended to row r's list when
+ *   s >= tau[r]  &&  (tag_bits[n] & row_bits[r]) != 0  &&  n != 0  &&  n not in history(b = r / H).
+ * tag_bits [n_items] uint32: bit c set when item n belongs to category c, bit 31 always set;
+ * row_bits [n_rows] uint32: the bit the row requires (1<<c, or 1<<31 for unconstrained rows, 0 disables the row).
+ * history: CSR over users: hist_ptr [n_rows/H + 1] int32, hist_items sorted ascending per user (may be NULL).
+ * Lists: cand_val/cand_idx [n_rows, cap]; cand_cnt [n_rows] int32 (caller zeroes) counts all qualifying
+ * candidates, including those beyond cap (overflow is detected by cand_cnt > cap). */
+int mhr_catalog_score_emit(const void* users, int n_rows, int H, const void* items, int64_t n_items, int dim,
+                           int64_t item_begin, int64_t item_stride,
+                           const uint32_t* tag_bits, const uint32_t* row_bits, const float* tau,
+                           const int32_t* hist_ptr, const int64_t* hist_items,
+                           float* cand_val, int32_t* cand_idx, int32_t* cand_cnt, int cap, void* stream);
+
+/* Per-row exact selection of the k best candidates: value descending, index ascending on ties.
+ * Rows with fewer than k candidates are completed with (-inf, lowest item ids not in the list).
+ * out_val/out_idx [n_rows, k]; kth_val [n_rows] (optional) receives the k-th value.
+ * status[r] (optional) = 1 when cand_cnt[r] > cap (list truncated: result not trustworthy). */
+int mhr_topk_select(const float* cand_val, const int32_t* cand_idx, const int32_t* cand_cnt, int cap,
+                    int n_rows, int k, float* out_val, int64_t* out_idx, float* kth_val, int32_t* status,
+                    void* stream);
+
+/* Cross-head merge (collector.py:249-275): per user, the H*k per-head candidates are ordered by value
+ * descending (ties: head, then rank ascending), first occurrences kept, first k returned with their
+ * source head.  vals/idx [B, H, k] -> out_idx [B,k] i64, out_val [B,k] f32, out_src [B,k] i32.
+ * status[b] = number of unique items found (k when the row is complete). */
+int mhr_multihead_merge_dedup(const float* vals, const int64_t* idx, int B, int H, int k,
+                              int64_t* out_idx, float* out_val, int32_t* out_src, int32_t* status, void* stream);
+
+/* Hit matrix (collector.py:300-316): hit[b,j] = 1 when topk_idx[b,j] is among positives[b, 0:n_pos]. */
+int mhr_hit_matrix(const int64_t* topk_idx, int B, int k, const int64_t* positives, int pos_stride, int n_pos,
+                   uint8_t* hit, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MHR_H */

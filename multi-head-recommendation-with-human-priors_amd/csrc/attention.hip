@@ -1,0 +1,453 @@
+// HSTU pointwise-gated attention, forward and backward, for gfx950.
+//
+//   out[b,n,h,:] = sum_{m<=n, valid[b,m]} silu(q[b,n,h].k[b,m,h]) / L * v[b,m,h,:]
+//
+// (reference model/IDNet/hstu.py:137-160; the [B,H,L,L] score tensor the reference materialises three
+// times never leaves registers here).  No softmax, hence no running max / rescale: every 32x32 score
+// tile is independent.
+//
+// Mapping: one 256-thread workgroup (4 waves, one per SIMD) per (batch, head).  Tiles are 32 queries x
+// 32 keys on v_mfma_f32_32x32x16_bf16.  Scores are computed TRANSPOSED (keys on the accumulator rows,
+// queries on the lanes) so that the gated tile, converted to bf16 in registers, is directly the B operand
+// of the second product O^T = V^T . P^T (summing over the accumulator's row index needs no lane
+// movement, cdna guide section 3).  K (row-major) and V^T are staged once per workgroup in LDS with the
+// load-time SiLU of hstu.py:244-245 applied.  The backward runs two passes per workgroup (dK/dV per key
+// block, then dQ per query block) so that no cross-wave reduction or atomic is needed and the result is
+// bitwise reproducible.
+#include "mhr_common.h"
+
+namespace {
+
+__device__ __forceinline__ int crow(int g, int half) { return (g & 3) + 8 * (g >> 2) + 4 * half; }
+
+__device__ __forceinline__ bf16x8 zero8() {
+  bf16x8 z;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) z[i] = (bf16_t)0.0f;
+  return z;
+}
+
+__device__ __forceinline__ bf16x8 silu8(bf16x8 x) {
+  bf16x8 y;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) y[i] = (bf16_t)silu_f((float)x[i]);
+  return y;
+}
+
+// 8 consecutive elements of row `row` at column `koff` of a [rows, stride] bf16 matrix (zeros outside).
+__device__ __forceinline__ bf16x8 load_frag(const bf16_t* base, int64_t stride, int row, int n_rows, int koff, int n_cols) {
+  if (row < n_rows && koff < n_cols) return *reinterpret_cast<const bf16x8*>(base + (int64_t)row * stride + koff);
+  return zero8();
+}
+
+// Fragment for a product that sums over the ROW index of an accumulator tile: element j of lane half h
+// must come from k = base + 16*s + 8*(j>>2) + 4*h + (j&3) (cdna guide section 3, "accumulator tile as
+// the next MFMA's operand").  T is a transposed LDS image [idx][ld] with the summed index contiguous.
+__device__ __forceinline__ bf16x8 read_T_frag(const bf16_t* T, int ld, int idx, int base, int s, int half) {
+  const bf16_t* p = T + idx * ld + base + 16 * s + 4 * half;
+  bf16x4 lo = *reinterpret_cast<const bf16x4*>(p);
+  bf16x4 hi = *reinterpret_cast<const bf16x4*>(p + 8);
+  bf16x8 f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return f;
+}
+
+__device__ __forceinline__ void pack_acc(const f32x16& x, bf16x8& f0, bf16x8& f1) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    f0[j] = (bf16_t)x[j];
+    f1[j] = (bf16_t)x[8 + j];
+  }
+}
+
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) z[i] = 0.f;
+  return z;
+}
+
+// stage a [L, hd] row-major global block transposed into T[HC][ld] (zeros for m >= L or col >= hd)
+template <int HC>
+__device__ __forceinline__ void stage_transposed(bf16_t* T, int ld, const bf16_t* src, int64_t stride, int L, int Lp, int hd,
+                                                 bool do_silu, bf16_t* act, int64_t act_stride) {
+  constexpr int chunks = HC / 8;
+  for (int c = threadIdx.x; c < Lp * chunks; c += blockDim.x) {
+    const int m = c / chunks, d0 = (c % chunks) * 8;
+    bf16x8 val = zero8();
+    if (m < L && d0 < hd) {
+      val = *reinterpret_cast<const bf16x8*>(src + (int64_t)m * stride + d0);
+      if (do_silu) val = silu8(val);
+      if (act) *reinterpret_cast<bf16x8*>(act + (int64_t)m * act_stride + d0) = val;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) T[(d0 + i) * ld + m] = val[i];
+  }
+}
+
+__device__ __forceinline__ void build_valid_mask(uint32_t* vmask, const uint8_t* kv, int L, int nb) {
+  if ((int)threadIdx.x < nb) {
+    uint32_t bits = 0;
+    for (int i = 0; i < 32; ++i) {
+      int m = threadIdx.x * 32 + i;
+      if (m < L && kv[m]) bits |= 1u << i;
+    }
+    vmask[threadIdx.x] = bits;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------
+template <int NKS, int ND>
+__global__ __launch_bounds__(256) void hstu_attn_fwd_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+                                                            const bf16_t* __restrict__ v, int64_t stride,
+                                                            const uint8_t* __restrict__ key_valid, bf16_t* __restrict__ out,
+                                                            int64_t out_stride, bf16_t* act_q, bf16_t* act_k, bf16_t* act_v,
+                                                            int64_t act_stride, int L, int n_heads, int hd, int apply_silu,
+                                                            float inv_n) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int HK = NKS * 16, HC = ND * 32;
+  const int Lp = (L + 31) & ~31, nb = Lp >> 5;
+  const int ldk = HK + 8, ldv = Lp + 8;
+  bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);   // [Lp][ldk]
+  bf16_t* VTs = Ks + Lp * ldk;                    // [HC][ldv]
+  uint32_t* vmask = reinterpret_cast<uint32_t*>(VTs + HC * ldv);
+
+  const int b = blockIdx.x / n_heads, head = blockIdx.x % n_heads;
+  const int64_t row0 = (int64_t)b * L;
+  const bf16_t* qp = q + row0 * stride + head * hd;
+  const bf16_t* kp = k + row0 * stride + head * hd;
+  const bf16_t* vp = v + row0 * stride + head * hd;
+  bf16_t* aq = act_q ? act_q + row0 * act_stride + head * hd : nullptr;
+  bf16_t* ak = act_k ? act_k + row0 * act_stride + head * hd : nullptr;
+  bf16_t* av = act_v ? act_v + row0 * act_stride + head * hd : nullptr;
+  const bool do_silu = apply_silu != 0;
+
+  // K row-major with SiLU applied
+  {
+    constexpr int chunks = HK / 8;
+    for (int c = threadIdx.x; c < Lp * chunks; c += 256) {
+      const int m = c / chunks, k0 = (c % chunks) * 8;
+      bf16x8 val = zero8();
+      if (m < L && k0 < hd) {
+        val = *reinterpret_cast<const bf16x8*>(kp + (int64_t)m * stride + k0);
+        if (do_silu) val = silu8(val);
+        if (ak) *reinterpret_cast<bf16x8*>(ak + (int64_t)m * act_stride + k0) = val;
+      }
+      *reinterpret_cast<bf16x8*>(Ks + m * ldk + k0) = val;
+    }
+  }
+  stage_transposed<HC>(VTs, ldv, vp, stride, L, Lp, hd, do_silu, av, act_stride);
+  build_valid_mask(vmask, key_valid + row0, L, nb);
+  __syncthreads();
+
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, half = lane >> 5;
+  for (int it = 0; it * 4 < nb; ++it) {
+    const int qb = (it & 1) ? it * 4 + (3 - wave) : it * 4 + wave;   // zig-zag: balances the causal triangle
+    if (qb >= nb) continue;
+    const int qrow = qb * 32 + r;
+    bf16x8 qf[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      const int koff = ks * 16 + 8 * half;
+      qf[ks] = load_frag(qp, stride, qrow, L, koff, hd);
+      if (do_silu) qf[ks] = silu8(qf[ks]);
+      if (aq && qrow < L && koff < hd) *reinterpret_cast<bf16x8*>(aq + (int64_t)qrow * act_stride + koff) = qf[ks];
+    }
+    f32x16 o[ND];
+#pragma unroll
+    for (int dc = 0; dc < ND; ++dc) o[dc] = zero16();
+
+    for (int kb = 0; kb <= qb; ++kb) {
+      f32x16 s = zero16();
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (kb * 32 + r) * ldk + ks * 16 + 8 * half);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);   // S^T: rows = keys, cols = queries
+      }
+      const uint32_t vm = vmask[kb];
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        const int kl = crow(g, half);
+        const bool ok = ((vm >> kl) & 1u) && (kb * 32 + kl <= qrow);
+        s[g] = ok ? silu_f(s[g]) * inv_n : 0.f;
+      }
+      bf16x8 p0, p1;
+      pack_acc(s, p0, p1);
+#pragma unroll
+      for (int dc = 0; dc < ND; ++dc) {
+        bf16x8 vt0 = read_T_frag(VTs, ldv, dc * 32 + r, kb * 32, 0, half);
+        o[dc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vt0, p0, o[dc], 0, 0, 0);   // O^T += V^T . P^T
+        bf16x8 vt1 = read_T_frag(VTs, ldv, dc * 32 + r, kb * 32, 1, half);
+        o[dc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vt1, p1, o[dc], 0, 0, 0);
+      }
+    }
+    if (qrow < L) {
+      bf16_t* orow = out + (row0 + qrow) * out_stride + head * hd;
+#pragma unroll
+      for (int dc = 0; dc < ND; ++dc)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int d0 = dc * 32 + 8 * g4 + 4 * half;
+          if (d0 < hd) {
+            bf16x4 w = {(bf16_t)o[dc][4 * g4], (bf16_t)o[dc][4 * g4 + 1], (bf16_t)o[dc][4 * g4 + 2], (bf16_t)o[dc][4 * g4 + 3]};
+            *reinterpret_cast<bf16x4*>(orow + d0) = w;
+          }
+        }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// backward
+// ------------------------------------------------------------------------------------------
+template <int NKS, int ND>
+__global__ __launch_bounds__(256) void hstu_attn_bwd_kernel(
+    const bf16_t* __restrict__ q_pre, const bf16_t* __restrict__ k_pre, const bf16_t* __restrict__ v_pre, int64_t stride,
+    const bf16_t* __restrict__ act_q, const bf16_t* __restrict__ act_k, const bf16_t* __restrict__ act_v, int64_t act_stride,
+    const uint8_t* __restrict__ key_valid, const bf16_t* __restrict__ d_out, int64_t do_stride, bf16_t* __restrict__ dq,
+    bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, int64_t d_stride, int L, int n_heads, int hd, int apply_silu,
+    float inv_n) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int HC = ND * 32;
+  const int Lp = (L + 31) & ~31, nb = Lp >> 5;
+  const int ldt = Lp + 8;
+  bf16_t* T0 = reinterpret_cast<bf16_t*>(smem);   // Q^T in pass A, K^T in pass B   [HC][ldt]
+  bf16_t* T1 = T0 + HC * ldt;                     // dO^T                            [HC][ldt]
+  uint32_t* vmask = reinterpret_cast<uint32_t*>(T1 + HC * ldt);
+
+  const int b = blockIdx.x / n_heads, head = blockIdx.x % n_heads;
+  const int64_t row0 = (int64_t)b * L;
+  const int hoff = head * hd;
+  const bf16_t* aq = act_q + row0 * act_stride + hoff;
+  const bf16_t* ak = act_k + row0 * act_stride + hoff;
+  const bf16_t* av = act_v + row0 * act_stride + hoff;
+  const bf16_t* dop = d_out + row0 * do_stride + hoff;
+  const bool chain = apply_silu != 0;
+
+  stage_transposed<HC>(T0, ldt, aq, act_stride, L, Lp, hd, false, nullptr, 0);
+  stage_transposed<HC>(T1, ldt, dop, do_stride, L, Lp, hd, false, nullptr, 0);
+  build_valid_mask(vmask, key_valid + row0, L, nb);
+  __syncthreads();
+
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, half = lane >> 5;
+
+  // ---- pass A: dK, dV for key block kb (keys on the lanes) -----------------------------------------
+  for (int it = 0; it * 4 < nb; ++it) {
+    const int kb = (it & 1) ? it * 4 + wave : it * 4 + (3 - wave);   // early key blocks are the heavy ones
+    if (kb >= nb) continue;
+    const int key = kb * 32 + r;
+    const bool kvalid = (vmask[kb] >> r) & 1u;
+    bf16x8 kf[NKS], vf[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      kf[ks] = load_frag(ak, act_stride, key, L, ks * 16 + 8 * half, hd);
+      vf[ks] = load_frag(av, act_stride, key, L, ks * 16 + 8 * half, hd);
+    }
+    f32x16 dvacc[ND], dkacc[ND];
+#pragma unroll
+    for (int dc = 0; dc < ND; ++dc) {
+      dvacc[dc] = zero16();
+      dkacc[dc] = zero16();
+    }
+    for (int qb = kb; qb < nb; ++qb) {
+      f32x16 s = zero16(), dp = zero16();
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        bf16x8 qf = load_frag(aq, act_stride, qb * 32 + r, L, ks * 16 + 8 * half, hd);
+        bf16x8 dof = load_frag(dop, do_stride, qb * 32 + r, L, ks * 16 + 8 * half, hd);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, kf[ks], s, 0, 0, 0);      // S: rows = queries, cols = keys
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof, vf[ks], dp, 0, 0, 0);   // dP = dO . V^T
+      }
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        const int qi = qb * 32 + crow(g, half);
+        const bool ok = kvalid && key <= qi;
+        const float x = s[g];
+        const float sig = 1.0f / (1.0f + __expf(-x));
+        s[g] = ok ? x * sig * inv_n : 0.f;                                           // P
+        dp[g] = ok ? dp[g] * inv_n * sig * (1.0f + x * (1.0f - sig)) : 0.f;          // dS
+      }
+      bf16x8 pa0, pa1, da0, da1;
+      pack_acc(s, pa0, pa1);
+      pack_acc(dp, da0, da1);
+#pragma unroll
+      for (int dc = 0; dc < ND; ++dc) {
+        bf16x8 t;
+        t = read_T_frag(T1, ldt, dc * 32 + r, qb * 32, 0, half);
+        dvacc[dc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa0, t, dvacc[dc], 0, 0, 0);   // dV += P^T . dO
+        t = read_T_frag(T1, ldt, dc * 32 + r, qb * 32, 1, half);
+        dvacc[dc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa1, t, dvacc[dc], 0, 0, 0);
+        t = read_T_frag(T0, ldt, dc * 32 + r, qb * 32, 0, half);
+        dkacc[dc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da0, t, dkacc[dc], 0, 0, 0);   // dK += dS^T . Q
+        t = read_T_frag(T0, ldt, dc * 32 + r, qb * 32, 1, half);
+        dkacc[dc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da1, t, dkacc[dc], 0, 0, 0);
+      }
+    }
+    // results: rows (regs) = keys, cols (lanes) = feature
+#pragma unroll
+    for (int dc = 0; dc < ND; ++dc) {
+      const int d = dc * 32 + r;
+      if (d < hd) {
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+          const int m = kb * 32 + crow(g, half);
+          if (m < L) {
+            float gv = dvacc[dc][g], gk = dkacc[dc][g];
+            if (chain) {
+              gv *= dsilu_f((float)v_pre[(row0 + m) * stride + hoff + d]);
+              gk *= dsilu_f((float)k_pre[(row0 + m) * stride + hoff + d]);
+            }
+            dv[(row0 + m) * d_stride + hoff + d] = (bf16_t)gv;
+            dk[(row0 + m) * d_stride + hoff + d] = (bf16_t)gk;
+          }
+        }
+      }
+    }
+  }
+
+  // ---- pass B: dQ for query block qb (queries on the lanes) ----------------------------------------
+  __syncthreads();                      // everyone is done reading Q^T
+  stage_transposed<HC>(T0, ldt, ak, act_stride, L, Lp, hd, false, nullptr, 0);   // K^T
+  __syncthreads();
+  for (int it = 0; it * 4 < nb; ++it) {
+    const int qb = (it & 1) ? it * 4 + (3 - wave) : it * 4 + wave;
+    if (qb >= nb) continue;
+    const int qcol = qb * 32 + r;
+    bf16x8 qf[NKS], dof[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      qf[ks] = load_frag(aq, act_stride, qcol, L, ks * 16 + 8 * half, hd);
+      dof[ks] = load_frag(dop, do_stride, qcol, L, ks * 16 + 8 * half, hd);
+    }
+    f32x16 dqacc[ND];
+#pragma unroll
+    for (int dc = 0; dc < ND; ++dc) dqacc[dc] = zero16();
+    for (int kb = 0; kb <= qb; ++kb) {
+      f32x16 s = zero16(), dp = zero16();
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        bf16x8 kf = load_frag(ak, act_stride, kb * 32 + r, L, ks * 16 + 8 * half, hd);
+        bf16x8 vf = load_frag(av, act_stride, kb * 32 + r, L, ks * 16 + 8 * half, hd);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);      // S^T: rows = keys, cols = queries
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[ks], dp, 0, 0, 0);   // dP^T = V . dO^T
+      }
+      const uint32_t vm = vmask[kb];
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        const int kl = crow(g, half);
+        const bool ok = ((vm >> kl) & 1u) && (kb * 32 + kl <= qcol);
+        const float x = s[g];
+        const float sig = 1.0f / (1.0f + __expf(-x));
+        dp[g] = ok ? dp[g] * inv_n * sig * (1.0f + x * (1.0f - sig)) : 0.f;          // dS^T
+      }
+      bf16x8 a0, a1;
+      pack_acc(dp, a0, a1);
+#pragma unroll
+      for (int dc = 0; dc < ND; ++dc) {
+        bf16x8 t = read_T_frag(T0, ldt, dc * 32 + r, kb * 32, 0, half);
+        dqacc[dc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, t, dqacc[dc], 0, 0, 0);   // dQ += dS . K
+        t = read_T_frag(T0, ldt, dc * 32 + r, kb * 32, 1, half);
+        dqacc[dc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, t, dqacc[dc], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int dc = 0; dc < ND; ++dc) {
+      const int d = dc * 32 + r;
+      if (d < hd) {
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+          const int n = qb * 32 + crow(g, half);
+          if (n < L) {
+            float gq = dqacc[dc][g];
+            if (chain) gq *= dsilu_f((float)q_pre[(row0 + n) * stride + hoff + d]);
+            dq[(row0 + n) * d_stride + hoff + d] = (bf16_t)gq;
+          }
+        }
+      }
+    }
+  }
+}
+
+struct AttnShape {
+  int nks, nd;
+};
+inline bool attn_shape(int hd, AttnShape& s) {
+  if (hd <= 0 || hd % 8 != 0 || hd > 128) return false;
+  if (hd <= 16) s = {1, 1};
+  else if (hd <= 32) s = {2, 1};
+  else if (hd <= 64) s = {4, 2};
+  else s = {8, 4};
+  return true;
+}
+
+}  // namespace
+
+#define ATTN_DISPATCH(shape, MACRO)                  \
+  if (shape.nks == 1) { MACRO(1, 1); }               \
+  else if (shape.nks == 2) { MACRO(2, 1); }          \
+  else if (shape.nks == 4) { MACRO(4, 2); }          \
+  else { MACRO(8, 4); }
+
+extern "C" int mhr_hstu_attn_fwd(const void* q, const void* k, const void* v, int64_t row_stride, const uint8_t* key_valid,
+                                 void* out, void* act_q, void* act_k, void* act_v, int64_t act_stride, int B, int L,
+                                 int n_heads, int head_dim, int apply_silu, void* stream) {
+  MHR_REQUIRE(q && k && v && key_valid && out, "hstu_attn_fwd: null pointer");
+  AttnShape sh;
+  MHR_REQUIRE(attn_shape(head_dim, sh), "hstu_attn_fwd: head_dim=%d unsupported (multiple of 8, <= 128)", head_dim);
+  MHR_REQUIRE(B > 0 && L > 0 && n_heads > 0, "hstu_attn_fwd: bad sizes");
+  MHR_REQUIRE(row_stride % 8 == 0 && (!act_q || act_stride % 8 == 0), "hstu_attn_fwd: strides must be multiples of 8");
+  MHR_REQUIRE((act_q != nullptr) == (act_k != nullptr) && (act_k != nullptr) == (act_v != nullptr),
+              "hstu_attn_fwd: act_q/act_k/act_v must be all set or all null");
+  const int Lp = (L + 31) & ~31, nb = Lp / 32;
+  const int HK = sh.nks * 16, HC = sh.nd * 32;
+  size_t lds = (size_t)Lp * (HK + 8) * 2 + (size_t)HC * (Lp + 8) * 2 + (size_t)nb * 4 + 16;
+  MHR_REQUIRE(lds <= 160 * 1024 && nb <= 256, "hstu_attn_fwd: L=%d head_dim=%d needs %zu B of LDS (> 160 KiB)", L, head_dim, lds);
+  const float inv_n = 1.0f / (float)L;
+  const int64_t out_stride = (int64_t)n_heads * head_dim;
+  hipStream_t s = (hipStream_t)stream;
+#define L_(NKS, ND)                                                                                                    \
+  {                                                                                                                    \
+    auto kern = hstu_attn_fwd_kernel<NKS, ND>;                                                                         \
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL(kern, dim3(B * n_heads), dim3(256), lds, s, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, \
+                       row_stride, key_valid, (bf16_t*)out, out_stride, (bf16_t*)act_q, (bf16_t*)act_k, (bf16_t*)act_v, \
+                       act_stride, L, n_heads, head_dim, apply_silu, inv_n);                                           \
+  }
+  ATTN_DISPATCH(sh, L_);
+#undef L_
+  MHR_CHECK_LAUNCH("hstu_attn_fwd");
+  return MHR_OK;
+}
+
+extern "C" int mhr_hstu_attn_bwd(const void* q_pre, const void* k_pre, const void* v_pre, int64_t row_stride,
+                                 const void* act_q, const void* act_k, const void* act_v, int64_t act_stride,
+                                 const uint8_t* key_valid, const void* d_out, void* dq, void* dk, void* dv, int64_t d_stride,
+                                 int B, int L, int n_heads, int head_dim, int apply_silu, void* stream) {
+  MHR_REQUIRE(act_q && act_k && act_v && key_valid && d_out && dq && dk && dv, "hstu_attn_bwd: null pointer");
+  MHR_REQUIRE(!apply_silu || (q_pre && k_pre && v_pre), "hstu_attn_bwd: pre-activation inputs required with apply_silu");
+  AttnShape sh;
+  MHR_REQUIRE(attn_shape(head_dim, sh), "hstu_attn_bwd: head_dim=%d unsupported (multiple of 8, <= 128)", head_dim);
+  MHR_REQUIRE(B > 0 && L > 0 && n_heads > 0, "hstu_attn_bwd: bad sizes");
+  MHR_REQUIRE(act_stride % 8 == 0 && ((int64_t)n_heads * head_dim) % 8 == 0, "hstu_attn_bwd: strides must be multiples of 8");
+  const int Lp = (L + 31) & ~31, nb = Lp / 32;
+  const int HC = sh.nd * 32;
+  size_t lds = (size_t)2 * HC * (Lp + 8) * 2 + (size_t)nb * 4 + 16;
+  MHR_REQUIRE(lds <= 160 * 1024 && nb <= 256, "hstu_attn_bwd: L=%d head_dim=%d needs %zu B of LDS (> 160 KiB)", L, head_dim, lds);
+  const float inv_n = 1.0f / (float)L;
+  const int64_t do_stride = (int64_t)n_heads * head_dim;
+  hipStream_t s = (hipStream_t)stream;
+#define L_(NKS, ND)                                                                                                    \
+  {                                                                                                                    \
+    auto kern = hstu_attn_bwd_kernel<NKS, ND>;                                                                         \
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL(kern, dim3(B * n_heads), dim3(256), lds, s, (const bf16_t*)q_pre, (const bf16_t*)k_pre,          \
+                       (const bf16_t*)v_pre, row_stride, (const bf16_t*)act_q, (const bf16_t*)act_k, (const bf16_t*)act_v, \
+                       act_stride, key_valid, (const bf16_t*)d_out, do_stride, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv,   \
+                       d_stride, L, n_heads, head_dim, apply_silu, inv_n);                                             \
+  }
+  ATTN_DISPATCH(sh, L_);
+#undef L_
+  MHR_CHECK_LAUNCH("hstu_attn_bwd");
+  return MHR_OK;
+}

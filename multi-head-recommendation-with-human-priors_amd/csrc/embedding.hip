@@ -1,0 +1,291 @@
+// Item-embedding kernels: row gather (+ fused position add), dense atomic scatter-add,
+// deterministic sparse segment-sum, AdamW over the table (sparse gradient, dense update) and over
+// the flat dense-parameter buffer.  All HBM-bound: one wave per 1 KiB-class row, 16 B per lane.
+//
+// Reference ops replaced (file:line under code/REC/): nn.Embedding forward + position add
+// model/IDNet/hstu.py:413,637-643,670,752,883; embedding_dense_backward (autograd);
+// optimizer step trainer/trainer.py:292-299,532.
+#include "mhr_common.h"
+
+// ------------------------------------------------------------------------------------------
+// gather
+// ------------------------------------------------------------------------------------------
+template <typename OT, typename XT>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ table, int64_t n_rows, int dim,
+                                                          const int64_t* __restrict__ ids, int64_t n_ids,
+                                                          OT* __restrict__ out, const float* __restrict__ pos,
+                                                          int seq_len, int window_len, XT* __restrict__ x_out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  constexpr int U = 4;  // rows in flight per wave
+  for (int64_t r0 = wave * U; r0 < n_ids; r0 += n_waves * U) {
+    int64_t id[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int64_t r = r0 + u;
+      int64_t v = r < n_ids ? ids[r] : 0;
+      v = v < 0 ? 0 : (v >= n_rows ? n_rows - 1 : v);
+      id[u] = v;
+    }
+    for (int c = lane * 4; c < dim; c += 256) {
+      f32x4 v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (r0 + u < n_ids) v[u] = *reinterpret_cast<const f32x4*>(table + id[u] * dim + c);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        int64_t r = r0 + u;
+        if (r >= n_ids) continue;
+        if (out) Vec4IO<OT>::store(out + r * dim + c, v[u]);
+        if (x_out) {
+          int64_t b = r / window_len;
+          int l = (int)(r - b * window_len);
+          if (l < seq_len) {
+            f32x4 p = *reinterpret_cast<const f32x4*>(pos + (int64_t)l * dim + c);
+            Vec4IO<XT>::store(x_out + (b * seq_len + l) * dim + c, v[u] + p);
+          }
+        }
+      }
+    }
+  }
+}
+
+extern "C" int mhr_embedding_gather_fwd(const float* table, int64_t n_rows, int dim, const int64_t* ids, int64_t n_ids,
+                                        void* out, int out_dtype, const float* pos_table, int seq_len, int window_len,
+                                        void* x_out, int x_dtype, void* stream) {
+  MHR_REQUIRE(table && ids, "embedding_gather_fwd: null table/ids");
+  MHR_REQUIRE(out || x_out, "embedding_gather_fwd: no output requested");
+  MHR_REQUIRE(dim > 0 && dim % 4 == 0, "embedding_gather_fwd: dim=%d must be a positive multiple of 4", dim);
+  MHR_REQUIRE(n_rows > 0 && n_ids >= 0, "embedding_gather_fwd: bad sizes");
+  if (x_out) {
+    MHR_REQUIRE(pos_table && window_len > 0 && seq_len > 0 && seq_len <= window_len && n_ids % window_len == 0,
+                "embedding_gather_fwd: x_out needs pos_table and n_ids %% window_len == 0 (n_ids=%lld window=%d seq=%d)",
+                (long long)n_ids, window_len, seq_len);
+  }
+  if (n_ids == 0) return MHR_OK;
+  hipStream_t s = (hipStream_t)stream;
+  int grid = mhr_grid_for(n_ids, 16);
+  if (window_len <= 0) window_len = 1;
+#define LAUNCH(OT, XT)                                                                                     \
+  hipLaunchKernelGGL((gather_rows_kernel<OT, XT>), dim3(grid), dim3(256), 0, s, table, n_rows, dim, ids,   \
+                     n_ids, (OT*)out, pos_table, seq_len, window_len, (XT*)x_out)
+  bool ob = out && out_dtype == MHR_BF16, xb = x_out && x_dtype == MHR_BF16;
+  if (ob && xb) LAUNCH(bf16_t, bf16_t);
+  else if (ob) LAUNCH(bf16_t, float);
+  else if (xb) LAUNCH(float, bf16_t);
+  else LAUNCH(float, float);
+#undef LAUNCH
+  MHR_CHECK_LAUNCH("embedding_gather_fwd");
+  return MHR_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// dense scatter-add with float atomics (each wave-instruction adds 256 contiguous bytes of one row)
+// ------------------------------------------------------------------------------------------
+template <typename GT>
+__global__ __launch_bounds__(256) void scatter_add_kernel(const GT* __restrict__ g, const int64_t* __restrict__ ids,
+                                                          int64_t n_ids, float* __restrict__ gt, int64_t n_rows, int dim) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  for (int64_t r = wave; r < n_ids; r += n_waves) {
+    int64_t id = ids[r];
+    if (id < 0 || id >= n_rows) continue;
+    for (int c = lane; c < dim; c += 64) atomicAdd(gt + id * dim + c, (float)g[r * dim + c]);
+  }
+}
+
+extern "C" int mhr_embedding_scatter_add_bwd(const void* grad_rows, int grad_dtype, const int64_t* ids, int64_t n_ids,
+                                             float* grad_table, int64_t n_rows, int dim, void* stream) {
+  MHR_REQUIRE(grad_rows && ids && grad_table, "embedding_scatter_add_bwd: null pointer");
+  MHR_REQUIRE(dim > 0 && n_rows > 0, "embedding_scatter_add_bwd: bad sizes");
+  if (n_ids == 0) return MHR_OK;
+  hipStream_t s = (hipStream_t)stream;
+  int grid = mhr_grid_for(n_ids, 4);
+  if (grad_dtype == MHR_BF16)
+    hipLaunchKernelGGL((scatter_add_kernel<bf16_t>), dim3(grid), dim3(256), 0, s, (const bf16_t*)grad_rows, ids, n_ids,
+                       grad_table, n_rows, dim);
+  else
+    hipLaunchKernelGGL((scatter_add_kernel<float>), dim3(grid), dim3(256), 0, s, (const float*)grad_rows, ids, n_ids,
+                       grad_table, n_rows, dim);
+  MHR_CHECK_LAUNCH("embedding_scatter_add_bwd");
+  return MHR_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// deterministic sparse segment sum over sorted ids
+// ------------------------------------------------------------------------------------------
+template <typename AT, typename BT>
+__global__ __launch_bounds__(256) void segment_sum_kernel(const int64_t* __restrict__ sorted_ids,
+                                                          const int64_t* __restrict__ perm, int64_t n_ids,
+                                                          const AT* __restrict__ ga, int64_t n_a,
+                                                          const BT* __restrict__ gb, int64_t n_b,
+                                                          const float* __restrict__ xg, int seq_len, int window_len,
+                                                          float* __restrict__ out_rows, int32_t* __restrict__ row_slot,
+                                                          int dim) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  for (int64_t i = wave; i < n_ids; i += n_waves) {
+    const int64_t id = sorted_ids[i];
+    if (i > 0 && sorted_ids[i - 1] == id) continue;  // not a segment head
+    for (int c = lane * 4; c < dim; c += 256) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      for (int64_t j = i; j < n_ids && sorted_ids[j] == id; ++j) {
+        const int64_t r = perm[j];
+        if (r < n_a) {
+          acc += Vec4IO<AT>::load(ga + r * dim + c);
+          if (xg) {
+            int64_t b = r / window_len;
+            int l = (int)(r - b * window_len);
+            if (l < seq_len) acc += *reinterpret_cast<const f32x4*>(xg + (b * seq_len + l) * dim + c);
+          }
+        } else if (r - n_a < n_b) {
+          acc += Vec4IO<BT>::load(gb + (r - n_a) * dim + c);
+        }
+      }
+      *reinterpret_cast<f32x4*>(out_rows + i * dim + c) = acc;
+    }
+    if (lane == 0) row_slot[id] = (int32_t)i;
+  }
+}
+
+extern "C" int mhr_sparse_rows_segment_sum(const int64_t* sorted_ids, const int64_t* perm, int64_t n_ids,
+                                           const void* grad_a, int a_dtype, int64_t n_a, const void* grad_b, int b_dtype,
+                                           int64_t n_b, const float* x_grad, int seq_len, int window_len, float* out_rows,
+                                           int32_t* row_slot, int dim, void* stream) {
+  MHR_REQUIRE(sorted_ids && perm && out_rows && row_slot, "sparse_rows_segment_sum: null pointer");
+  MHR_REQUIRE(dim > 0 && dim % 4 == 0, "sparse_rows_segment_sum: dim=%d must be a multiple of 4", dim);
+  MHR_REQUIRE((n_a == 0 || grad_a) && (n_b == 0 || grad_b), "sparse_rows_segment_sum: null gradient buffer");
+  MHR_REQUIRE(n_a + n_b >= n_ids, "sparse_rows_segment_sum: n_a+n_b < n_ids");
+  if (x_grad) MHR_REQUIRE(window_len > 0 && seq_len > 0 && n_a % window_len == 0, "sparse_rows_segment_sum: bad window");
+  if (n_ids == 0) return MHR_OK;
+  if (window_len <= 0) window_len = 1;
+  hipStream_t s = (hipStream_t)stream;
+  int grid = mhr_grid_for(n_ids, 4);
+#define LAUNCH(AT, BT)                                                                                               \
+  hipLaunchKernelGGL((segment_sum_kernel<AT, BT>), dim3(grid), dim3(256), 0, s, sorted_ids, perm, n_ids,             \
+                     (const AT*)grad_a, n_a, (const BT*)grad_b, n_b, x_grad, seq_len, window_len, out_rows, row_slot, dim)
+  bool ab = a_dtype == MHR_BF16, bb = b_dtype == MHR_BF16;
+  if (ab && bb) LAUNCH(bf16_t, bf16_t);
+  else if (ab) LAUNCH(bf16_t, float);
+  else if (bb) LAUNCH(float, bf16_t);
+  else LAUNCH(float, float);
+#undef LAUNCH
+  MHR_CHECK_LAUNCH("sparse_rows_segment_sum");
+  return MHR_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// AdamW
+// ------------------------------------------------------------------------------------------
+struct AdamConst {
+  float beta1, beta2, one_m_beta1, one_m_beta2, eps, decay_mul, step_size, inv_sqrt_bc2, grad_scale;
+};
+
+static AdamConst make_adam(float lr, float beta1, float beta2, float eps, float wd, int step, float grad_scale) {
+  AdamConst a;
+  double bc1 = 1.0 - pow((double)beta1, (double)step);
+  double bc2 = 1.0 - pow((double)beta2, (double)step);
+  a.beta1 = beta1;
+  a.beta2 = beta2;
+  a.one_m_beta1 = 1.0f - beta1;
+  a.one_m_beta2 = 1.0f - beta2;
+  a.eps = eps;
+  a.decay_mul = 1.0f - lr * wd;
+  a.step_size = (float)((double)lr / bc1);
+  a.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+  a.grad_scale = grad_scale;
+  return a;
+}
+
+__device__ __forceinline__ void adam_update4(f32x4& w, f32x4& m, f32x4& v, f32x4 g, const AdamConst& a) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float gk = g[k] * a.grad_scale;
+    float wk = w[k] * a.decay_mul;
+    float mk = a.beta1 * m[k] + a.one_m_beta1 * gk;
+    float vk = a.beta2 * v[k] + a.one_m_beta2 * gk * gk;
+    float denom = sqrtf(vk) * a.inv_sqrt_bc2 + a.eps;
+    w[k] = wk - a.step_size * (mk / denom);
+    m[k] = mk;
+    v[k] = vk;
+  }
+}
+
+__global__ __launch_bounds__(256) void adam_rows_kernel(float* __restrict__ w, float* __restrict__ m, float* __restrict__ v,
+                                                        int64_t n_rows, int dim, const float* __restrict__ grad_rows,
+                                                        int32_t* __restrict__ row_slot, AdamConst a) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  for (int64_t r = wave; r < n_rows; r += n_waves) {
+    int64_t slot = row_slot ? (int64_t)row_slot[r] : r;
+    for (int c = lane * 4; c < dim; c += 256) {
+      const int64_t o = r * dim + c;
+      f32x4 wv = *reinterpret_cast<const f32x4*>(w + o);
+      f32x4 mv = *reinterpret_cast<const f32x4*>(m + o);
+      f32x4 vv = *reinterpret_cast<const f32x4*>(v + o);
+      f32x4 g = {0.f, 0.f, 0.f, 0.f};
+      if (slot >= 0) g = *reinterpret_cast<const f32x4*>(grad_rows + slot * dim + c);
+      adam_update4(wv, mv, vv, g, a);
+      *reinterpret_cast<f32x4*>(w + o) = wv;
+      *reinterpret_cast<f32x4*>(m + o) = mv;
+      *reinterpret_cast<f32x4*>(v + o) = vv;
+    }
+    if (row_slot && slot >= 0 && lane == 0) row_slot[r] = -1;
+  }
+}
+
+extern "C" int mhr_adam_rows(float* w, float* m, float* v, int64_t n_rows, int dim, const float* grad_rows,
+                             int32_t* row_slot, float grad_scale, float lr, float beta1, float beta2, float eps,
+                             float weight_decay, int step, void* stream) {
+  MHR_REQUIRE(w && m && v && grad_rows, "adam_rows: null pointer");
+  MHR_REQUIRE(dim > 0 && dim % 4 == 0 && n_rows > 0 && step >= 1, "adam_rows: bad sizes (dim=%d step=%d)", dim, step);
+  AdamConst a = make_adam(lr, beta1, beta2, eps, weight_decay, step, grad_scale);
+  int grid = mhr_grid_for(n_rows, 4 * 4);
+  hipLaunchKernelGGL(adam_rows_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, m, v, n_rows, dim, grad_rows,
+                     row_slot, a);
+  MHR_CHECK_LAUNCH("adam_rows");
+  return MHR_OK;
+}
+
+__global__ __launch_bounds__(256) void adam_flat_kernel(float* __restrict__ w, const float* __restrict__ g,
+                                                        float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                                        AdamConst a) {
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t nt = (int64_t)gridDim.x * blockDim.x;
+  const int64_t n4 = n / 4;
+  for (int64_t i = tid; i < n4; i += nt) {
+    f32x4 wv = reinterpret_cast<f32x4*>(w)[i], mv = reinterpret_cast<f32x4*>(m)[i], vv = reinterpret_cast<f32x4*>(v)[i];
+    f32x4 gv = reinterpret_cast<const f32x4*>(g)[i];
+    adam_update4(wv, mv, vv, gv, a);
+    reinterpret_cast<f32x4*>(w)[i] = wv;
+    reinterpret_cast<f32x4*>(m)[i] = mv;
+    reinterpret_cast<f32x4*>(v)[i] = vv;
+  }
+  for (int64_t i = n4 * 4 + tid; i < n; i += nt) {  // tail
+    float gk = g[i] * a.grad_scale;
+    float wk = w[i] * a.decay_mul;
+    float mk = a.beta1 * m[i] + a.one_m_beta1 * gk;
+    float vk = a.beta2 * v[i] + a.one_m_beta2 * gk * gk;
+    w[i] = wk - a.step_size * (mk / (sqrtf(vk) * a.inv_sqrt_bc2 + a.eps));
+    m[i] = mk;
+    v[i] = vk;
+  }
+}
+
+extern "C" int mhr_adam_flat(float* w, const float* g, float* m, float* v, int64_t n, float grad_scale, float lr,
+                             float beta1, float beta2, float eps, float weight_decay, int step, void* stream) {
+  MHR_REQUIRE(w && g && m && v, "adam_flat: null pointer");
+  MHR_REQUIRE(n >= 0 && step >= 1, "adam_flat: bad sizes");
+  MHR_REQUIRE(((uintptr_t)w % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)m % 16 == 0) && ((uintptr_t)v % 16 == 0),
+              "adam_flat: buffers must be 16-byte aligned");
+  if (n == 0) return MHR_OK;
+  AdamConst a = make_adam(lr, beta1, beta2, eps, weight_decay, step, grad_scale);
+  int grid = mhr_grid_for(n / 4 + 1, 256, 2048);
+  hipLaunchKernelGGL(adam_flat_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, g, m, v, n, a);
+  MHR_CHECK_LAUNCH("adam_flat");
+  return MHR_OK;
+}

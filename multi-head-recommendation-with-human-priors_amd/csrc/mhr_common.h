@@ -1,0 +1,98 @@
+// Shared device/host helpers for the gfx950 kernels.  Wave = 64 lanes everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/mhr.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define MHR_WAVE 64
+
+// ---- host-side error plumbing ------------------------------------------------------------
+void mhr_set_error(const char* fmt, ...);
+
+#define MHR_REQUIRE(cond, ...)                 \
+  do {                                         \
+    if (!(cond)) {                             \
+      mhr_set_error(__VA_ARGS__);              \
+      return MHR_EINVAL;                       \
+    }                                          \
+  } while (0)
+
+#define MHR_CHECK_LAUNCH(name)                                                     \
+  do {                                                                             \
+    hipError_t e_ = hipGetLastError();                                             \
+    if (e_ != hipSuccess) {                                                        \
+      mhr_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));        \
+      return MHR_ELAUNCH;                                                          \
+    }                                                                              \
+  } while (0)
+
+static inline int mhr_grid_for(int64_t work_items, int per_block, int max_blocks = 2048 * 4) {
+  int64_t b = (work_items + per_block - 1) / per_block;
+  if (b < 1) b = 1;
+  if (b > max_blocks) b = max_blocks;
+  return (int)b;
+}
+
+// ---- device helpers ----------------------------------------------------------------------
+__device__ __forceinline__ float bf2f(bf16_t x) { return (float)x; }
+__device__ __forceinline__ bf16_t f2bf(float x) { return (bf16_t)x; }   // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// d/dx silu(x) = sig * (1 + x * (1 - sig))
+__device__ __forceinline__ float dsilu_f(float x) {
+  float s = 1.0f / (1.0f + __expf(-x));
+  return s * (1.0f + x * (1.0f - s));
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// 4 consecutive elements, f32 or bf16 storage
+template <typename T> struct Vec4IO;
+template <> struct Vec4IO<float> {
+  static __device__ __forceinline__ f32x4 load(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+  static __device__ __forceinline__ void store(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+};
+template <> struct Vec4IO<bf16_t> {
+  static __device__ __forceinline__ f32x4 load(const bf16_t* p) {
+    bf16x4 r = *reinterpret_cast<const bf16x4*>(p);
+    f32x4 v = {(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
+    return v;
+  }
+  static __device__ __forceinline__ void store(bf16_t* p, f32x4 v) {
+    bf16x4 r = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+    *reinterpret_cast<bf16x4*>(p) = r;
+  }
+};
+
+// counter-based uniform in [0,1): splitmix64 finaliser of (seed, index)
+__device__ __forceinline__ float mhr_uniform(uint64_t seed, uint64_t idx) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (float)(z >> 40) * (1.0f / 16777216.0f);
+}

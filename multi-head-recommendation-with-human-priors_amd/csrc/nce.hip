@@ -1,0 +1,618 @@
+// Sampled softmax (InfoNCE) with false-negative suppression, fused forward and backward for gfx950.
+//
+// Reference (file:line under code/REC/): model/IDNet/hstu.py:600-619 (nce_loss) + F.cross_entropy at
+// hstu.py:697/833, called once per prior head.  The reference materialises neg_logits, fix_logits, their
+// concatenation and the log-softmax, each [N_tok, N_neg]; here a logit lives only in an MFMA accumulator.
+//
+//   s_ij = cos(q_i, n_j), f_ij = cos(p_i, n_j), s_i+ = cos(q_i, p_i), scale = exp(clamp(logit_scale, 0, ln 100))
+//   keep_ij = !(f_ij > thres);   lse_i = log( exp(scale*s_i+) + sum_j keep_ij exp(scale*s_ij) );   loss_i = lse_i - scale*s_i+
+//
+// Three kernels on the row-stationary streaming GEMM core (stream_gemm.h), all with S^T orientation
+// (streamed rows on accumulator registers, stationary rows on lanes):
+//   nce_fwd    : tokens stationary (normalised Q and P fragments in registers, 32 tokens per wave), negatives
+//                streamed; two MFMAs per LDS fragment read (s and f share the negative operand); running sums
+//                are one VGPR per lane because |logit| <= scale bounds the exponent (no running max);
+//                also stores the normalised token rows (and Q^T) for the backward.
+//   nce_bwd_q  : tokens stationary; recomputes s,f; G_ij = w_i keep_ij exp(scale*s_ij - lse_i) converted to
+//                bf16 in registers is the A operand of dQn += G . N (N^T tiles streamed from a transposed
+//                copy); finishes with the L2-normalisation chain rule and writes per-token rows (no atomics).
+//   nce_bwd_n  : negatives stationary (32 per wave), token tiles streamed; dN += G^T . Qn accumulated in
+//                registers across all tokens of the workgroup's token split, then one float-atomic pass.
+#include "mhr_common.h"
+#include "stream_gemm.h"
+
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+__device__ __forceinline__ float clamp_scale(const float* logit_scale_dev) {
+  float ls = *logit_scale_dev;
+  ls = fminf(fmaxf(ls, 0.0f), 4.605170185988092f);   // [0, ln 100]  (hstu.py:602)
+  return __expf(ls);
+}
+
+template <typename IT>
+__device__ __forceinline__ void load8(const IT* p, float (&out)[8]);
+template <>
+__device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float (&out)[8]) {
+  bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) out[i] = (float)v[i];
+}
+template <>
+__device__ __forceinline__ void load8<float>(const float* p, float (&out)[8]) {
+  f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    out[i] = a[i];
+    out[4 + i] = b[i];
+  }
+}
+
+// lane (r, half) owns elements k = ks*16 + 8*half + j of row `src`; returns 1/||row||
+template <int NKS, typename IT>
+__device__ __forceinline__ float row_inv_norm(const IT* src, bool live, int half) {
+  float ss = 0.f;
+  if (live) {
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      float v[8];
+      load8<IT>(src + ks * 16 + 8 * half, v);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) ss += v[i] * v[i];
+    }
+  }
+  ss += __shfl_xor(ss, 32, 64);
+  return live ? 1.0f / sqrtf(ss) : 0.f;
+}
+
+template <int NKS, typename IT>
+__device__ __forceinline__ void load_norm_frags(const IT* src, bool live, int half, float inv, bf16x8 (&frag)[NKS]) {
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+    if (live) {
+      float v[8];
+      load8<IT>(src + ks * 16 + 8 * half, v);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) frag[ks][i] = (bf16_t)(v[i] * inv);
+    } else {
+      frag[ks] = sg::zero8();
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------
+template <int NKS, typename IT, bool LOGS>
+__global__ __launch_bounds__(256, 2) void nce_fwd_kernel(const IT* __restrict__ q_rows, const int32_t* __restrict__ q_idx,
+                                                         const IT* __restrict__ p_rows, const int32_t* __restrict__ p_idx,
+                                                         const bf16_t* __restrict__ negs, int n_neg,
+                                                         const int32_t* __restrict__ n_tok_dev, int tok_cap,
+                                                         const float* __restrict__ logit_scale_dev, float thres,
+                                                         float* __restrict__ loss, float* __restrict__ lse_out,
+                                                         int32_t* __restrict__ n_valid, int32_t* __restrict__ rank,
+                                                         bf16_t* __restrict__ qn_out, bf16_t* __restrict__ pn_out,
+                                                         bf16_t* __restrict__ qnT_out, float* __restrict__ q_inv,
+                                                         float* __restrict__ p_inv, float* __restrict__ s_pos_out) {
+  using T = sg::Tile<NKS>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int n_tok = min(*n_tok_dev, tok_cap);
+  const int tok0 = blockIdx.x * 128;
+  if (tok0 >= n_tok) return;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, half = lane >> 5;
+  const int tok = tok0 + wave * 32 + r;
+  const bool live = tok < n_tok;
+
+  bf16x8 frag[2][NKS];   // [0] = normalised query, [1] = normalised positive
+  float qi = 0.f, pi = 0.f;
+  {
+    const IT* qs = q_rows + (live ? (int64_t)q_idx[tok] * T::DIM : 0);
+    const IT* ps = p_rows + (live ? (int64_t)p_idx[tok] * T::DIM : 0);
+    qi = row_inv_norm<NKS, IT>(qs, live, half);
+    pi = row_inv_norm<NKS, IT>(ps, live, half);
+    load_norm_frags<NKS, IT>(qs, live, half, qi, frag[0]);
+    load_norm_frags<NKS, IT>(ps, live, half, pi, frag[1]);
+  }
+  float spos = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) spos += (float)frag[0][ks][i] * (float)frag[1][ks][i];
+  spos += __shfl_xor(spos, 32, 64);
+  if (live) {
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      const int k0 = ks * 16 + 8 * half;
+      if (qn_out) *reinterpret_cast<bf16x8*>(qn_out + (int64_t)tok * T::DIM + k0) = frag[0][ks];
+      if (pn_out) *reinterpret_cast<bf16x8*>(pn_out + (int64_t)tok * T::DIM + k0) = frag[1][ks];
+      if (qnT_out) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) qnT_out[(int64_t)(k0 + i) * tok_cap + tok] = frag[0][ks][i];
+      }
+    }
+    if (half == 0) {
+      if (q_inv) q_inv[tok] = qi;
+      if (p_inv) p_inv[tok] = pi;
+      if (s_pos_out) s_pos_out[tok] = spos;
+    }
+  }
+
+  const float scale = clamp_scale(logit_scale_dev);
+  const float c1 = scale * LOG2E;
+  float sum = 0.f;
+  int nv = 0, rk = 0;
+
+  const int n_tiles = (n_neg + 31) >> 5;
+  auto row_ptr_for = [&](int tile) {
+    return [=](int rr) -> const bf16_t* {
+      const int j = tile * 32 + rr;
+      return j < n_neg ? negs + (int64_t)j * T::DIM : nullptr;
+    };
+  };
+  sg::Stage<NKS> st;
+  st.load(row_ptr_for(0));
+  st.store(smem);
+  __syncthreads();
+  int cur = 0;
+  for (int t = 0; t < n_tiles; ++t) {
+    const bool more = t + 1 < n_tiles;
+    if (more) st.load(row_ptr_for(t + 1));
+    f32x16 acc[2] = {sg::zero16(), sg::zero16()};
+    sg::mma_tile<NKS, 2>(smem + cur * T::BYTES, frag, acc, r, half);
+    const int rem = n_neg - t * 32;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      const bool keep = (sg::crow(g, half) < rem) && !(acc[1][g] > thres);
+      const float e = fast_exp2(acc[0][g] * c1 - c1);
+      sum += keep ? e : 0.f;
+      if (LOGS) {
+        nv += keep ? 1 : 0;
+        rk += (keep && acc[0][g] > spos) ? 1 : 0;
+      }
+    }
+    if (more) st.store(smem + (cur ^ 1) * T::BYTES);
+    __syncthreads();
+    cur ^= 1;
+  }
+  sum += __shfl_xor(sum, 32, 64);
+  if (LOGS) {
+    nv += __shfl_xor(nv, 32, 64);
+    rk += __shfl_xor(rk, 32, 64);
+  }
+  if (live && half == 0) {
+    const float total = sum + fast_exp2(spos * c1 - c1);
+    const float l = scale + __logf(total);
+    lse_out[tok] = l;
+    loss[tok] = l - scale * spos;
+    if (LOGS) {
+      if (n_valid) n_valid[tok] = nv + 1;
+      if (rank) rank[tok] = rk;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// backward, token-stationary: dq_tok, dp_tok, d_logit_scale
+// ------------------------------------------------------------------------------------------
+// transposed negative tile image: [DIM][NT_LD] bf16, 32 negatives per row (+pad: conflict-free 8-byte reads)
+constexpr int NT_LD = 36;
+
+template <int NKS>
+__device__ __forceinline__ bf16x8 read_nt_frag(const bf16_t* NT, int d, int s, int half) {
+  const bf16_t* p = NT + d * NT_LD + 16 * s + 4 * half;
+  bf16x4 lo = *reinterpret_cast<const bf16x4*>(p);
+  bf16x4 hi = *reinterpret_cast<const bf16x4*>(p + 8);
+  bf16x8 f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return f;
+}
+
+// stage columns [col0, col0+32) of a [DIM, ld_src] transposed matrix into the NT image (8-byte pieces)
+template <int NKS>
+struct StageT {
+  static constexpr int DIM = NKS * 16;
+  static constexpr int PIECES = DIM * 8;                      // 8-byte pieces (4 elements)
+  static constexpr int PER_THREAD = (PIECES + 255) / 256;
+  bf16x4 v[PER_THREAD];
+  __device__ __forceinline__ void load(const bf16_t* srcT, int64_t ld_src, int col0, int n_cols) {
+#pragma unroll
+    for (int i = 0; i < PER_THREAD; ++i) {
+      const int id = threadIdx.x + i * 256;
+      if (id < PIECES) {
+        const int d = id >> 3, c = (id & 7) * 4;
+        if (col0 + c + 3 < n_cols) {
+          v[i] = *reinterpret_cast<const bf16x4*>(srcT + (int64_t)d * ld_src + col0 + c);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[i][e] = (col0 + c + e < n_cols) ? srcT[(int64_t)d * ld_src + col0 + c + e] : (bf16_t)0.f;
+        }
+      }
+    }
+  }
+  __device__ __forceinline__ void store(bf16_t* NT) const {
+#pragma unroll
+    for (int i = 0; i < PER_THREAD; ++i) {
+      const int id = threadIdx.x + i * 256;
+      if (id < PIECES) {
+        const int d = id >> 3, c = (id & 7) * 4;
+        *reinterpret_cast<bf16x4*>(NT + d * NT_LD + c) = v[i];
+      }
+    }
+  }
+};
+
+__device__ __forceinline__ void pack_acc(const f32x16& x, bf16x8& f0, bf16x8& f1) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    f0[j] = (bf16_t)x[j];
+    f1[j] = (bf16_t)x[8 + j];
+  }
+}
+
+__device__ __forceinline__ float half_sum(float v) {   // sum over the 32 lanes of one wave half
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <int NKS>
+__global__ __launch_bounds__(256, 1) void nce_bwd_q_kernel(const bf16_t* __restrict__ qn, const bf16_t* __restrict__ pn,
+                                                           const bf16_t* __restrict__ negs, const bf16_t* __restrict__ negsT,
+                                                           int n_neg, int64_t negsT_ld, const int32_t* __restrict__ n_tok_dev,
+                                                           int tok_cap, const float* __restrict__ logit_scale_dev, float thres,
+                                                           const float* __restrict__ lse, const float* __restrict__ w,
+                                                           const float* __restrict__ q_inv, const float* __restrict__ p_inv,
+                                                           const float* __restrict__ s_pos, float* __restrict__ dq_tok,
+                                                           float* __restrict__ dp_tok, float* __restrict__ d_logit_scale) {
+  using T = sg::Tile<NKS>;
+  constexpr int ND = (NKS + 1) / 2;          // 32-column chunks of the feature dim
+  constexpr int NT_BYTES = T::DIM * NT_LD * 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* tiles = smem;                                        // 2 x T::BYTES
+  bf16_t* nts = reinterpret_cast<bf16_t*>(smem + 2 * T::BYTES);      // 2 x [DIM][NT_LD]
+
+  const int n_tok = min(*n_tok_dev, tok_cap);
+  const int tok0 = blockIdx.x * 128;
+  if (tok0 >= n_tok) return;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, half = lane >> 5;
+  const int tok = tok0 + wave * 32 + r;
+  const bool live = tok < n_tok;
+
+  bf16x8 frag[2][NKS];
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+    const int k0 = ks * 16 + 8 * half;
+    frag[0][ks] = live ? *reinterpret_cast<const bf16x8*>(qn + (int64_t)tok * T::DIM + k0) : sg::zero8();
+    frag[1][ks] = live ? *reinterpret_cast<const bf16x8*>(pn + (int64_t)tok * T::DIM + k0) : sg::zero8();
+  }
+  const float scale = clamp_scale(logit_scale_dev);
+  const float c1 = scale * LOG2E;
+  const float my_w = live ? w[tok] : 0.f;
+  const float my_l2 = live ? lse[tok] * LOG2E : 0.f;
+
+  f32x16 dq[ND];
+#pragma unroll
+  for (int dc = 0; dc < ND; ++dc) dq[dc] = sg::zero16();
+  float dsc = 0.f;   // sum_j g_ij * s_ij for my token (my half's rows)
+
+  const int n_tiles = (n_neg + 31) >> 5;
+  auto row_ptr_for = [&](int tile) {
+    return [=](int rr) -> const bf16_t* {
+      const int j = tile * 32 + rr;
+      return j < n_neg ? negs + (int64_t)j * T::DIM : nullptr;
+    };
+  };
+  sg::Stage<NKS> st;
+  StageT<NKS> stt;
+  st.load(row_ptr_for(0));
+  stt.load(negsT, negsT_ld, 0, n_neg);
+  st.store(tiles);
+  stt.store(nts);
+  __syncthreads();
+  int cur = 0;
+  for (int t = 0; t < n_tiles; ++t) {
+    const bool more = t + 1 < n_tiles;
+    if (more) {
+      st.load(row_ptr_for(t + 1));
+      stt.load(negsT, negsT_ld, (t + 1) * 32, n_neg);
+    }
+    f32x16 acc[2] = {sg::zero16(), sg::zero16()};
+    sg::mma_tile<NKS, 2>(tiles + cur * T::BYTES, frag, acc, r, half);
+    const int rem = n_neg - t * 32;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      const bool keep = (sg::crow(g, half) < rem) && !(acc[1][g] > thres);
+      const float gij = keep ? my_w * fast_exp2(acc[0][g] * c1 - my_l2) : 0.f;
+      dsc += gij * acc[0][g];
+      acc[0][g] = gij;
+    }
+    bf16x8 g0, g1;
+    pack_acc(acc[0], g0, g1);   // G^T (negatives on rows) as the A operand: computes G . N
+    const bf16_t* NT = nts + cur * (T::DIM * NT_LD);
+#pragma unroll
+    for (int dc = 0; dc < ND; ++dc) {
+      const int d = dc * 32 + r;
+      if (ND * 32 == T::DIM || d < T::DIM) {
+        dq[dc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g0, read_nt_frag<NKS>(NT, d, 0, half), dq[dc], 0, 0, 0);
+        dq[dc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g1, read_nt_frag<NKS>(NT, d, 1, half), dq[dc], 0, 0, 0);
+      }
+    }
+    if (more) {
+      st.store(tiles + (cur ^ 1) * T::BYTES);
+      stt.store(nts + (cur ^ 1) * (T::DIM * NT_LD));
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- finish: positive term, L2-normalisation chain rule, per-token rows -------------------------
+  // dq[dc][g]: row (reg) = token wave*32 + crow(g,half), column (lane) = feature dc*32 + r
+  float dls = 0.f;
+  dsc += __shfl_xor(dsc, 32, 64);   // both halves hold rows of the same token column -> full sum per token (lane r)
+  if (live && half == 0) {
+    const float ppos = __expf(scale * s_pos[tok] - lse[tok]);
+    dls = dsc + my_w * (ppos - 1.0f) * s_pos[tok];
+  }
+  dls = wave_sum(dls);
+  if (lane == 0 && d_logit_scale) atomicAdd(d_logit_scale, dls * scale);   // d/d(param) with scale = exp(param)
+
+#pragma unroll
+  for (int g = 0; g < 16; ++g) {
+    const int tk = tok0 + wave * 32 + sg::crow(g, half);
+    const bool tl = tk < n_tok;
+    const float wi = tl ? w[tk] : 0.f;
+    const float sp = tl ? s_pos[tk] : 0.f;
+    const float coef = tl ? wi * (__expf(scale * sp - lse[tk]) - 1.0f) : 0.f;   // w (p_pos - 1)
+    float qv[ND], pv[ND], dqn[ND], dpn[ND];
+    float dot_q = 0.f, dot_p = 0.f;
+#pragma unroll
+    for (int dc = 0; dc < ND; ++dc) {
+      const int d = dc * 32 + r;
+      const bool ok = tl && d < T::DIM;
+      qv[dc] = ok ? (float)qn[(int64_t)tk * T::DIM + d] : 0.f;
+      pv[dc] = ok ? (float)pn[(int64_t)tk * T::DIM + d] : 0.f;
+      dqn[dc] = scale * (dq[dc][g] + coef * pv[dc]);
+      dpn[dc] = scale * coef * qv[dc];
+      dot_q += qv[dc] * dqn[dc];
+      dot_p += pv[dc] * dpn[dc];
+    }
+    dot_q = half_sum(dot_q);
+    dot_p = half_sum(dot_p);
+    if (tl) {
+      const float iq = q_inv[tk], ip = p_inv[tk];
+#pragma unroll
+      for (int dc = 0; dc < ND; ++dc) {
+        const int d = dc * 32 + r;
+        if (d < T::DIM) {
+          dq_tok[(int64_t)tk * T::DIM + d] = (dqn[dc] - qv[dc] * dot_q) * iq;
+          dp_tok[(int64_t)tk * T::DIM + d] = (dpn[dc] - pv[dc] * dot_p) * ip;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// backward, negative-stationary: d_negs
+// ------------------------------------------------------------------------------------------
+template <int NKS>
+__global__ __launch_bounds__(256, 1) void nce_bwd_n_kernel(const bf16_t* __restrict__ qn, const bf16_t* __restrict__ pn,
+                                                           const bf16_t* __restrict__ qnT, const bf16_t* __restrict__ negs,
+                                                           int n_neg, const int32_t* __restrict__ n_tok_dev, int tok_cap,
+                                                           int tiles_per_split, const float* __restrict__ logit_scale_dev,
+                                                           float thres, const float* __restrict__ lse,
+                                                           const float* __restrict__ w, float* __restrict__ d_negs) {
+  using T = sg::Tile<NKS>;
+  constexpr int ND = (NKS + 1) / 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // per buffer: Q tile | P tile | Q^T image | 32 x {w, lse*log2e}
+  constexpr int QT_BYTES = T::DIM * NT_LD * 2;
+  constexpr int BUF = 2 * T::BYTES + QT_BYTES + 32 * 8;
+  const int n_tok = min(*n_tok_dev, tok_cap);
+  const int n_tok_tiles = (n_tok + 31) >> 5;
+  const int neg0 = blockIdx.x * 128;
+  const int tt0 = blockIdx.y * tiles_per_split, tt1 = min(n_tok_tiles, tt0 + tiles_per_split);
+  if (tt0 >= tt1) return;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, half = lane >> 5;
+  const int neg = neg0 + wave * 32 + r;                 // my stationary negative (lane column)
+  const bool nlive = neg < n_neg;
+
+  bf16x8 frag[1][NKS];
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks)
+    frag[0][ks] = nlive ? *reinterpret_cast<const bf16x8*>(negs + (int64_t)neg * T::DIM + ks * 16 + 8 * half) : sg::zero8();
+  const float scale = clamp_scale(logit_scale_dev);
+  const float c1 = scale * LOG2E;
+
+  f32x16 dn[ND];
+#pragma unroll
+  for (int dc = 0; dc < ND; ++dc) dn[dc] = sg::zero16();
+
+  auto qrow_for = [&](int tile) {
+    return [=](int rr) -> const bf16_t* {
+      const int tk = tile * 32 + rr;
+      return tk < n_tok ? qn + (int64_t)tk * T::DIM : nullptr;
+    };
+  };
+  auto prow_for = [&](int tile) {
+    return [=](int rr) -> const bf16_t* {
+      const int tk = tile * 32 + rr;
+      return tk < n_tok ? pn + (int64_t)tk * T::DIM : nullptr;
+    };
+  };
+  sg::Stage<NKS> sq, sp;
+  StageT<NKS> sqt;
+  float sc_w = 0.f, sc_l = 0.f;
+  auto load_all = [&](int tile) {
+    sq.load(qrow_for(tile));
+    sp.load(prow_for(tile));
+    sqt.load(qnT, tok_cap, tile * 32, n_tok);
+    if (threadIdx.x < 32) {
+      const int tk = tile * 32 + threadIdx.x;
+      sc_w = tk < n_tok ? w[tk] : 0.f;
+      sc_l = tk < n_tok ? lse[tk] * LOG2E : 0.f;
+    }
+  };
+  auto store_all = [&](int buf) {
+    unsigned char* base = smem + buf * BUF;
+    sq.store(base);
+    sp.store(base + T::BYTES);
+    sqt.store(reinterpret_cast<bf16_t*>(base + 2 * T::BYTES));
+    if (threadIdx.x < 32) {
+      float* sc = reinterpret_cast<float*>(base + 2 * T::BYTES + QT_BYTES);
+      sc[threadIdx.x] = sc_w;
+      sc[32 + threadIdx.x] = sc_l;
+    }
+  };
+  load_all(tt0);
+  store_all(0);
+  __syncthreads();
+  int cur = 0;
+  for (int t = tt0; t < tt1; ++t) {
+    const bool more = t + 1 < tt1;
+    if (more) load_all(t + 1);
+    const unsigned char* base = smem + cur * BUF;
+    f32x16 s[1] = {sg::zero16()}, f[1] = {sg::zero16()};
+    sg::mma_tile<NKS, 1>(base, frag, s, r, half);                 // rows = tokens, cols = negatives
+    sg::mma_tile<NKS, 1>(base + T::BYTES, frag, f, r, half);
+    const float* sc = reinterpret_cast<const float*>(base + 2 * T::BYTES + QT_BYTES);
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      const int tl = sg::crow(g, half);
+      const bool keep = nlive && !(f[0][g] > thres);
+      s[0][g] = keep ? sc[tl] * fast_exp2(s[0][g] * c1 - sc[32 + tl]) : 0.f;   // w == 0 for dead tokens
+    }
+    bf16x8 g0, g1;
+    pack_acc(s[0], g0, g1);   // G (tokens on rows) as the A operand: computes G^T . Qn
+    const bf16_t* QT = reinterpret_cast<const bf16_t*>(base + 2 * T::BYTES);
+#pragma unroll
+    for (int dc = 0; dc < ND; ++dc) {
+      const int d = dc * 32 + r;
+      if (ND * 32 == T::DIM || d < T::DIM) {
+        dn[dc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g0, read_nt_frag<NKS>(QT, d, 0, half), dn[dc], 0, 0, 0);
+        dn[dc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g1, read_nt_frag<NKS>(QT, d, 1, half), dn[dc], 0, 0, 0);
+      }
+    }
+    if (more) store_all(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+  // dn[dc][g]: row (reg) = negative neg0 + wave*32 + crow(g,half), column (lane) = feature dc*32 + r
+#pragma unroll
+  for (int g = 0; g < 16; ++g) {
+    const int nj = neg0 + wave * 32 + sg::crow(g, half);
+    if (nj < n_neg) {
+#pragma unroll
+      for (int dc = 0; dc < ND; ++dc) {
+        const int d = dc * 32 + r;
+        if (d < T::DIM) atomicAdd(d_negs + (int64_t)nj * T::DIM + d, scale * dn[dc][g]);
+      }
+    }
+  }
+}
+
+inline bool nks_for(int dim, int& nks) {
+  switch (dim) {
+    case 16: nks = 1; return true;
+    case 32: nks = 2; return true;
+    case 64: nks = 4; return true;
+    case 128: nks = 8; return true;
+    case 256: nks = 16; return true;
+    default: return false;
+  }
+}
+
+}  // namespace
+
+#define NKS_SWITCH(nks, MACRO) \
+  switch (nks) {               \
+    case 1: MACRO(1); break;   \
+    case 2: MACRO(2); break;   \
+    case 4: MACRO(4); break;   \
+    case 8: MACRO(8); break;   \
+    default: MACRO(16); break; \
+  }
+
+extern "C" int mhr_nce_fwd(const void* q_rows, const int32_t* q_idx, const void* p_rows, const int32_t* p_idx, int io_dtype,
+                           const void* negs, int n_neg, int dim, const int32_t* n_tok_dev, int tok_cap,
+                           const float* logit_scale_dev, float thres, float* loss, float* lse, int32_t* n_valid,
+                           int32_t* rank, void* qn_out, void* pn_out, void* qnT_out, float* q_inv, float* p_inv,
+                           float* s_pos, void* stream) {
+  MHR_REQUIRE(q_rows && q_idx && p_rows && p_idx && negs && n_tok_dev && logit_scale_dev && loss && lse, "nce_fwd: null pointer");
+  int nks;
+  MHR_REQUIRE(nks_for(dim, nks), "nce_fwd: dim=%d unsupported (16/32/64/128/256)", dim);
+  MHR_REQUIRE(n_neg > 0 && tok_cap > 0, "nce_fwd: bad sizes");
+  const int grid = (tok_cap + 127) / 128;
+  hipStream_t s = (hipStream_t)stream;
+  const bool logs = n_valid != nullptr || rank != nullptr;
+#define L_(NKS)                                                                                                             \
+  {                                                                                                                         \
+    size_t lds = 2 * sg::Tile<NKS>::BYTES;                                                                                  \
+    if (io_dtype == MHR_BF16) {                                                                                             \
+      if (logs) hipLaunchKernelGGL((nce_fwd_kernel<NKS, bf16_t, true>), dim3(grid), dim3(256), lds, s, (const bf16_t*)q_rows, \
+                                   q_idx, (const bf16_t*)p_rows, p_idx, (const bf16_t*)negs, n_neg, n_tok_dev, tok_cap,       \
+                                   logit_scale_dev, thres, loss, lse, n_valid, rank, (bf16_t*)qn_out, (bf16_t*)pn_out,        \
+                                   (bf16_t*)qnT_out, q_inv, p_inv, s_pos);                                                    \
+      else hipLaunchKernelGGL((nce_fwd_kernel<NKS, bf16_t, false>), dim3(grid), dim3(256), lds, s, (const bf16_t*)q_rows,     \
+                              q_idx, (const bf16_t*)p_rows, p_idx, (const bf16_t*)negs, n_neg, n_tok_dev, tok_cap,            \
+                              logit_scale_dev, thres, loss, lse, n_valid, rank, (bf16_t*)qn_out, (bf16_t*)pn_out,             \
+                              (bf16_t*)qnT_out, q_inv, p_inv, s_pos);                                                         \
+    } else {                                                                                                                \
+      if (logs) hipLaunchKernelGGL((nce_fwd_kernel<NKS, float, true>), dim3(grid), dim3(256), lds, s, (const float*)q_rows,   \
+                                   q_idx, (const float*)p_rows, p_idx, (const bf16_t*)negs, n_neg, n_tok_dev, tok_cap,        \
+                                   logit_scale_dev, thres, loss, lse, n_valid, rank, (bf16_t*)qn_out, (bf16_t*)pn_out,        \
+                                   (bf16_t*)qnT_out, q_inv, p_inv, s_pos);                                                    \
+      else hipLaunchKernelGGL((nce_fwd_kernel<NKS, float, false>), dim3(grid), dim3(256), lds, s, (const float*)q_rows,       \
+                              q_idx, (const float*)p_rows, p_idx, (const bf16_t*)negs, n_neg, n_tok_dev, tok_cap,             \
+                              logit_scale_dev, thres, loss, lse, n_valid, rank, (bf16_t*)qn_out, (bf16_t*)pn_out,             \
+                              (bf16_t*)qnT_out, q_inv, p_inv, s_pos);                                                         \
+    }                                                                                                                       \
+  }
+  NKS_SWITCH(nks, L_);
+#undef L_
+  MHR_CHECK_LAUNCH("nce_fwd");
+  return MHR_OK;
+}
+
+extern "C" int mhr_nce_bwd(const void* qn, const void* pn, const void* qnT, const void* negs, const void* negsT,
+                           int64_t negsT_ld, int n_neg, int dim, const int32_t* n_tok_dev, int tok_cap, const float* logit_scale_dev, float thres,
+                           const float* lse, const float* w, const float* q_inv, const float* p_inv, const float* s_pos,
+                           float* dq_tok, float* dp_tok, float* d_negs, float* d_logit_scale, void* stream) {
+  MHR_REQUIRE(qn && pn && qnT && negs && negsT && n_tok_dev && logit_scale_dev && lse && w && q_inv && p_inv && s_pos,
+              "nce_bwd: null input pointer");
+  MHR_REQUIRE(dq_tok && dp_tok && d_negs, "nce_bwd: null output pointer");
+  int nks;
+  MHR_REQUIRE(nks_for(dim, nks), "nce_bwd: dim=%d unsupported (16/32/64/128/256)", dim);
+  MHR_REQUIRE(n_neg > 0 && tok_cap > 0 && tok_cap % 4 == 0, "nce_bwd: bad sizes (tok_cap must be a multiple of 4)");
+  MHR_REQUIRE(negsT_ld >= n_neg && negsT_ld % 4 == 0, "nce_bwd: negsT_ld=%lld must be >= n_neg and a multiple of 4", (long long)negsT_ld);
+  hipStream_t s = (hipStream_t)stream;
+  const int grid_q = (tok_cap + 127) / 128;
+  const int n_tok_tiles = (tok_cap + 31) / 32;
+  const int neg_groups = (n_neg + 127) / 128;
+  int splits = (512 + neg_groups - 1) / neg_groups;        // ~512 workgroups
+  if (splits > n_tok_tiles) splits = n_tok_tiles;
+  if (splits < 1) splits = 1;
+  const int tiles_per_split = (n_tok_tiles + splits - 1) / splits;
+#define L_(NKS)                                                                                                            \
+  {                                                                                                                        \
+    using T = sg::Tile<NKS>;                                                                                               \
+    size_t lds_q = 2 * T::BYTES + 2 * (size_t)T::DIM * NT_LD * 2;                                                          \
+    auto kq = nce_bwd_q_kernel<NKS>;                                                                                       \
+    if (lds_q > 64 * 1024) (void)hipFuncSetAttribute((const void*)kq, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q); \
+    hipLaunchKernelGGL(kq, dim3(grid_q), dim3(256), lds_q, s, (const bf16_t*)qn, (const bf16_t*)pn, (const bf16_t*)negs,   \
+                       (const bf16_t*)negsT, n_neg, negsT_ld, n_tok_dev, tok_cap, logit_scale_dev, thres, lse, w,    \
+                       q_inv, p_inv, s_pos, dq_tok, dp_tok, d_logit_scale);                                                \
+    size_t lds_n = 2 * (2 * T::BYTES + (size_t)T::DIM * NT_LD * 2 + 32 * 8);                                              \
+    auto kn = nce_bwd_n_kernel<NKS>;                                                                                       \
+    if (lds_n > 64 * 1024) (void)hipFuncSetAttribute((const void*)kn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_n); \
+    hipLaunchKernelGGL(kn, dim3(neg_groups, splits), dim3(256), lds_n, s, (const bf16_t*)qn, (const bf16_t*)pn,            \
+                       (const bf16_t*)qnT, (const bf16_t*)negs, n_neg, n_tok_dev, tok_cap, tiles_per_split,                \
+                       logit_scale_dev, thres, lse, w, d_negs);                                                            \
+  }
+  NKS_SWITCH(nks, L_);
+#undef L_
+  MHR_CHECK_LAUNCH("nce_bwd");
+  return MHR_OK;
+}

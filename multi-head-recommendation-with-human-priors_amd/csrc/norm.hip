@@ -1,0 +1,373 @@
+// Row-wise normalisation kernels of the HSTU layer: affine-free LayerNorm fwd/bwd, the fused
+// silu(u) * LayerNorm(attn) * dropout gate fwd/bwd, and L2 row normalisation.
+// One wave per row, 16 B (f32) / 8 B (bf16) per lane per 256-column chunk, statistics in f32 by
+// wave shuffles.  HBM-bound.
+//
+// Reference ops replaced: F.layer_norm model/IDNet/hstu.py:213-219 (eps 1e-6, no affine),
+// u * norm(attn) + F.dropout hstu.py:277-285, x / x.norm() hstu.py:605-606,672,966,975,1021.
+#include "mhr_common.h"
+
+template <int NC>
+struct RowRegs {
+  f32x4 v[NC];
+};
+
+template <typename T, int NC>
+__device__ __forceinline__ void load_row(const T* p, int dim, int lane, RowRegs<NC>& r) {
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    int c = lane * 4 + i * 256;
+    if (c < dim) r.v[i] = Vec4IO<T>::load(p + c);
+    else r.v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+}
+template <typename T, int NC>
+__device__ __forceinline__ void store_row(T* p, int dim, int lane, const RowRegs<NC>& r) {
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    int c = lane * 4 + i * 256;
+    if (c < dim) Vec4IO<T>::store(p + c, r.v[i]);
+  }
+}
+template <int NC>
+__device__ __forceinline__ float row_sum(const RowRegs<NC>& r) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NC; ++i) s += (r.v[i][0] + r.v[i][1]) + (r.v[i][2] + r.v[i][3]);
+  return wave_sum(s);
+}
+// mean / rstd with masked tail (columns >= dim hold zeros and must not enter the variance)
+template <int NC>
+__device__ __forceinline__ void row_stats(const RowRegs<NC>& r, int dim, int lane, float eps, float& mean, float& rstd) {
+  mean = row_sum(r) / (float)dim;
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    int c = lane * 4 + i * 256;
+    if (c < dim) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float d = r.v[i][k] - mean;
+        s += d * d;
+      }
+    }
+  }
+  float var = wave_sum(s) / (float)dim;
+  rstd = rsqrtf(var + eps);
+}
+
+#define WAVE_ROW_LOOP(rows)                                                                                         \
+  const int lane = threadIdx.x & 63;                                                                                \
+  const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); \
+  const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);                                                   \
+  for (int64_t row = wave0; row < (rows); row += n_waves)
+
+// ------------------------------------------------------------------------------------------
+// LayerNorm
+// ------------------------------------------------------------------------------------------
+template <typename XT, typename YT, int NC>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const XT* __restrict__ x, YT* __restrict__ y, float* __restrict__ mean_o,
+                                                     float* __restrict__ rstd_o, int64_t rows, int dim, float eps) {
+  WAVE_ROW_LOOP(rows) {
+    RowRegs<NC> r;
+    load_row<XT, NC>(x + row * dim, dim, lane, r);
+    float mean, rstd;
+    row_stats<NC>(r, dim, lane, eps, mean, rstd);
+#pragma unroll
+    for (int i = 0; i < NC; ++i)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) r.v[i][k] = (r.v[i][k] - mean) * rstd;
+    store_row<YT, NC>(y + row * dim, dim, lane, r);
+    if (lane == 0) {
+      if (mean_o) mean_o[row] = mean;
+      if (rstd_o) rstd_o[row] = rstd;
+    }
+  }
+}
+
+template <typename DT, typename XT, typename OT, int NC>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const DT* __restrict__ dy, const XT* __restrict__ x,
+                                                     const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
+                                                     OT* __restrict__ dx, int accumulate, int64_t rows, int dim) {
+  WAVE_ROW_LOOP(rows) {
+    RowRegs<NC> g, xv;
+    load_row<DT, NC>(dy + row * dim, dim, lane, g);
+    load_row<XT, NC>(x + row * dim, dim, lane, xv);
+    const float mean = mean_i[row], rstd = rstd_i[row];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      int c = lane * 4 + i * 256;
+      if (c < dim) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float xh = (xv.v[i][k] - mean) * rstd;
+          xv.v[i][k] = xh;
+          s1 += g.v[i][k];
+          s2 += g.v[i][k] * xh;
+        }
+      }
+    }
+    s1 = wave_sum(s1) / (float)dim;
+    s2 = wave_sum(s2) / (float)dim;
+    RowRegs<NC> o;
+    if (accumulate) load_row<OT, NC>(dx + row * dim, dim, lane, o);
+#pragma unroll
+    for (int i = 0; i < NC; ++i)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float d = rstd * (g.v[i][k] - s1 - xv.v[i][k] * s2);
+        o.v[i][k] = accumulate ? o.v[i][k] + d : d;
+      }
+    store_row<OT, NC>(dx + row * dim, dim, lane, o);
+  }
+}
+
+static inline int nc_for(int dim) { return dim <= 256 ? 1 : dim <= 512 ? 2 : dim <= 1024 ? 4 : 8; }
+
+#define DISPATCH_NC(dim, MACRO) \
+  switch (nc_for(dim)) {        \
+    case 1: MACRO(1); break;    \
+    case 2: MACRO(2); break;    \
+    case 4: MACRO(4); break;    \
+    default: MACRO(8); break;   \
+  }
+
+extern "C" int mhr_layernorm_fwd(const void* x, int x_dtype, void* y, int y_dtype, float* mean, float* rstd, int64_t rows,
+                                 int dim, float eps, void* stream) {
+  MHR_REQUIRE(x && y, "layernorm_fwd: null pointer");
+  MHR_REQUIRE(dim > 0 && dim % 4 == 0 && dim <= 2048, "layernorm_fwd: dim=%d unsupported (multiple of 4, <= 2048)", dim);
+  if (rows <= 0) return MHR_OK;
+  hipStream_t s = (hipStream_t)stream;
+  int grid = mhr_grid_for(rows, 4);
+  bool xb = x_dtype == MHR_BF16, yb = y_dtype == MHR_BF16;
+#define L(NC)                                                                                                           \
+  if (xb && yb) hipLaunchKernelGGL((ln_fwd_kernel<bf16_t, bf16_t, NC>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x,  \
+                                   (bf16_t*)y, mean, rstd, rows, dim, eps);                                             \
+  else if (xb) hipLaunchKernelGGL((ln_fwd_kernel<bf16_t, float, NC>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x,    \
+                                  (float*)y, mean, rstd, rows, dim, eps);                                               \
+  else if (yb) hipLaunchKernelGGL((ln_fwd_kernel<float, bf16_t, NC>), dim3(grid), dim3(256), 0, s, (const float*)x,     \
+                                  (bf16_t*)y, mean, rstd, rows, dim, eps);                                              \
+  else hipLaunchKernelGGL((ln_fwd_kernel<float, float, NC>), dim3(grid), dim3(256), 0, s, (const float*)x, (float*)y,   \
+                          mean, rstd, rows, dim, eps)
+  DISPATCH_NC(dim, L);
+#undef L
+  MHR_CHECK_LAUNCH("layernorm_fwd");
+  return MHR_OK;
+}
+
+extern "C" int mhr_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* mean,
+                                 const float* rstd, void* dx, int dx_dtype, int accumulate, int64_t rows, int dim,
+                                 void* stream) {
+  MHR_REQUIRE(dy && x && mean && rstd && dx, "layernorm_bwd: null pointer");
+  MHR_REQUIRE(dim > 0 && dim % 4 == 0 && dim <= 2048, "layernorm_bwd: dim=%d unsupported", dim);
+  MHR_REQUIRE(!(accumulate && dx_dtype != MHR_F32), "layernorm_bwd: accumulate needs f32 dx");
+  if (rows <= 0) return MHR_OK;
+  hipStream_t s = (hipStream_t)stream;
+  int grid = mhr_grid_for(rows, 4);
+  // supported combinations: dy in {bf16,f32}, x in {f32,bf16}, dx in {f32,bf16}
+#define LK(DT, XT, OT, NC)                                                                                    \
+  hipLaunchKernelGGL((ln_bwd_kernel<DT, XT, OT, NC>), dim3(grid), dim3(256), 0, s, (const DT*)dy, (const XT*)x, mean, \
+                     rstd, (OT*)dx, accumulate, rows, dim)
+#define L(NC)                                                                   \
+  {                                                                             \
+    bool db = dy_dtype == MHR_BF16, xb = x_dtype == MHR_BF16, ob = dx_dtype == MHR_BF16; \
+    if (db && xb && ob) LK(bf16_t, bf16_t, bf16_t, NC);                         \
+    else if (db && xb) LK(bf16_t, bf16_t, float, NC);                           \
+    else if (db && ob) LK(bf16_t, float, bf16_t, NC);                           \
+    else if (db) LK(bf16_t, float, float, NC);                                  \
+    else if (xb && ob) LK(float, bf16_t, bf16_t, NC);                           \
+    else if (xb) LK(float, bf16_t, float, NC);                                  \
+    else if (ob) LK(float, float, bf16_t, NC);                                  \
+    else LK(float, float, float, NC);                                           \
+  }
+  DISPATCH_NC(dim, L);
+#undef L
+#undef LK
+  MHR_CHECK_LAUNCH("layernorm_bwd");
+  return MHR_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// o = silu(u) * LN(a) * dropmask
+// ------------------------------------------------------------------------------------------
+template <typename T, typename OT, int NC>
+__global__ __launch_bounds__(256) void ln_gate_fwd_kernel(const T* __restrict__ u, int64_t u_stride, const T* __restrict__ a,
+                                                          OT* __restrict__ o, float* __restrict__ mean_o,
+                                                          float* __restrict__ rstd_o, int64_t rows, int dim, float eps,
+                                                          float p, float keep_scale, uint64_t seed) {
+  WAVE_ROW_LOOP(rows) {
+    RowRegs<NC> av, uv;
+    load_row<T, NC>(a + row * dim, dim, lane, av);
+    load_row<T, NC>(u + row * u_stride, dim, lane, uv);
+    float mean, rstd;
+    row_stats<NC>(av, dim, lane, eps, mean, rstd);
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      int c = lane * 4 + i * 256;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float val = silu_f(uv.v[i][k]) * ((av.v[i][k] - mean) * rstd);
+        if (p > 0.f) {
+          float r = mhr_uniform(seed, (uint64_t)row * dim + c + k);
+          val = r < p ? 0.f : val * keep_scale;
+        }
+        av.v[i][k] = val;
+      }
+    }
+    store_row<OT, NC>(o + row * dim, dim, lane, av);
+    if (lane == 0) {
+      mean_o[row] = mean;
+      rstd_o[row] = rstd;
+    }
+  }
+}
+
+template <typename GT, typename T, int NC>
+__global__ __launch_bounds__(256) void ln_gate_bwd_kernel(const GT* __restrict__ d_o, const T* __restrict__ u,
+                                                          int64_t u_stride, const T* __restrict__ a,
+                                                          const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
+                                                          T* __restrict__ du, int64_t du_stride, T* __restrict__ da,
+                                                          int64_t rows, int dim, float p, float keep_scale, uint64_t seed) {
+  WAVE_ROW_LOOP(rows) {
+    RowRegs<NC> g, uv, av;
+    load_row<GT, NC>(d_o + row * dim, dim, lane, g);
+    load_row<T, NC>(u + row * u_stride, dim, lane, uv);
+    load_row<T, NC>(a + row * dim, dim, lane, av);
+    const float mean = mean_i[row], rstd = rstd_i[row];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      int c = lane * 4 + i * 256;
+      if (c < dim) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float gk = g.v[i][k];
+          if (p > 0.f) {
+            float r = mhr_uniform(seed, (uint64_t)row * dim + c + k);
+            gk = r < p ? 0.f : gk * keep_scale;
+          }
+          float xh = (av.v[i][k] - mean) * rstd;
+          float up = uv.v[i][k];
+          float su = silu_f(up);
+          float gy = gk * su;                 // grad w.r.t. LN(a)
+          uv.v[i][k] = gk * xh * dsilu_f(up);  // grad w.r.t. pre-activation u
+          av.v[i][k] = xh;
+          g.v[i][k] = gy;
+          s1 += gy;
+          s2 += gy * xh;
+        }
+      }
+    }
+    s1 = wave_sum(s1) / (float)dim;
+    s2 = wave_sum(s2) / (float)dim;
+#pragma unroll
+    for (int i = 0; i < NC; ++i)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) av.v[i][k] = rstd * (g.v[i][k] - s1 - av.v[i][k] * s2);
+    store_row<T, NC>(du + row * du_stride, dim, lane, uv);
+    store_row<T, NC>(da + row * dim, dim, lane, av);
+  }
+}
+
+extern "C" int mhr_ln_gate_fwd(const void* u_base, int64_t u_stride, const void* a, int dtype, void* o, int o_dtype,
+                               float* mean, float* rstd, int64_t rows, int dim, float eps, float dropout_p, uint64_t seed,
+                               void* stream) {
+  MHR_REQUIRE(u_base && a && o && mean && rstd, "ln_gate_fwd: null pointer");
+  MHR_REQUIRE(dim > 0 && dim % 4 == 0 && dim <= 2048 && u_stride >= dim, "ln_gate_fwd: dim=%d / stride unsupported", dim);
+  MHR_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "ln_gate_fwd: dropout_p out of range");
+  if (rows <= 0) return MHR_OK;
+  hipStream_t s = (hipStream_t)stream;
+  int grid = mhr_grid_for(rows, 4);
+  float ks = 1.0f / (1.0f - dropout_p);
+  bool tb = dtype == MHR_BF16, ob = o_dtype == MHR_BF16;
+#define L(NC)                                                                                                             \
+  if (tb && ob) hipLaunchKernelGGL((ln_gate_fwd_kernel<bf16_t, bf16_t, NC>), dim3(grid), dim3(256), 0, s,                 \
+                                   (const bf16_t*)u_base, u_stride, (const bf16_t*)a, (bf16_t*)o, mean, rstd, rows, dim,  \
+                                   eps, dropout_p, ks, seed);                                                            \
+  else if (tb) hipLaunchKernelGGL((ln_gate_fwd_kernel<bf16_t, float, NC>), dim3(grid), dim3(256), 0, s,                   \
+                                  (const bf16_t*)u_base, u_stride, (const bf16_t*)a, (float*)o, mean, rstd, rows, dim,    \
+                                  eps, dropout_p, ks, seed);                                                             \
+  else if (ob) hipLaunchKernelGGL((ln_gate_fwd_kernel<float, bf16_t, NC>), dim3(grid), dim3(256), 0, s,                   \
+                                  (const float*)u_base, u_stride, (const float*)a, (bf16_t*)o, mean, rstd, rows, dim,     \
+                                  eps, dropout_p, ks, seed);                                                             \
+  else hipLaunchKernelGGL((ln_gate_fwd_kernel<float, float, NC>), dim3(grid), dim3(256), 0, s, (const float*)u_base,      \
+                          u_stride, (const float*)a, (float*)o, mean, rstd, rows, dim, eps, dropout_p, ks, seed)
+  DISPATCH_NC(dim, L);
+#undef L
+  MHR_CHECK_LAUNCH("ln_gate_fwd");
+  return MHR_OK;
+}
+
+extern "C" int mhr_ln_gate_bwd(const void* d_o, int do_dtype, const void* u_base, int64_t u_stride, const void* a, int dtype,
+                               const float* mean, const float* rstd, void* du_base, int64_t du_stride, void* da,
+                               int64_t rows, int dim, float dropout_p, uint64_t seed, void* stream) {
+  MHR_REQUIRE(d_o && u_base && a && mean && rstd && du_base && da, "ln_gate_bwd: null pointer");
+  MHR_REQUIRE(dim > 0 && dim % 4 == 0 && dim <= 2048 && u_stride >= dim && du_stride >= dim, "ln_gate_bwd: bad dims");
+  if (rows <= 0) return MHR_OK;
+  hipStream_t s = (hipStream_t)stream;
+  int grid = mhr_grid_for(rows, 4);
+  float ks = 1.0f / (1.0f - dropout_p);
+  bool tb = dtype == MHR_BF16, gb = do_dtype == MHR_BF16;
+#define LK(GT, T, NC)                                                                                                  \
+  hipLaunchKernelGGL((ln_gate_bwd_kernel<GT, T, NC>), dim3(grid), dim3(256), 0, s, (const GT*)d_o, (const T*)u_base,    \
+                     u_stride, (const T*)a, mean, rstd, (T*)du_base, du_stride, (T*)da, rows, dim, dropout_p, ks, seed)
+#define L(NC)                          \
+  if (gb && tb) LK(bf16_t, bf16_t, NC); \
+  else if (gb) LK(bf16_t, float, NC);   \
+  else if (tb) LK(float, bf16_t, NC);   \
+  else LK(float, float, NC)
+  DISPATCH_NC(dim, L);
+#undef L
+#undef LK
+  MHR_CHECK_LAUNCH("ln_gate_bwd");
+  return MHR_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// L2 row normalisation
+// ------------------------------------------------------------------------------------------
+template <typename XT, typename YT, int NC>
+__global__ __launch_bounds__(256) void l2norm_kernel(const XT* __restrict__ x, YT* __restrict__ y, float* __restrict__ norms,
+                                                     int64_t rows, int dim) {
+  WAVE_ROW_LOOP(rows) {
+    RowRegs<NC> r;
+    load_row<XT, NC>(x + row * dim, dim, lane, r);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; ++i)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) s += r.v[i][k] * r.v[i][k];
+    float nrm = sqrtf(wave_sum(s));
+    float inv = 1.0f / nrm;
+#pragma unroll
+    for (int i = 0; i < NC; ++i)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) r.v[i][k] = r.v[i][k] * inv;
+    if (y) store_row<YT, NC>(y + row * dim, dim, lane, r);
+    if (norms && lane == 0) norms[row] = nrm;
+  }
+}
+
+extern "C" int mhr_l2norm_rows(const void* x, int x_dtype, void* y, int y_dtype, float* norms, int64_t rows, int dim,
+                               void* stream) {
+  MHR_REQUIRE(x && (y || norms), "l2norm_rows: null pointer");
+  MHR_REQUIRE(dim > 0 && dim % 4 == 0 && dim <= 2048, "l2norm_rows: dim=%d unsupported", dim);
+  if (rows <= 0) return MHR_OK;
+  hipStream_t s = (hipStream_t)stream;
+  int grid = mhr_grid_for(rows, 4);
+  bool xb = x_dtype == MHR_BF16, yb = y_dtype == MHR_BF16;
+#define L(NC)                                                                                                          \
+  if (xb && yb) hipLaunchKernelGGL((l2norm_kernel<bf16_t, bf16_t, NC>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x, \
+                                   (bf16_t*)y, norms, rows, dim);                                                      \
+  else if (xb) hipLaunchKernelGGL((l2norm_kernel<bf16_t, float, NC>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x,   \
+                                  (float*)y, norms, rows, dim);                                                        \
+  else if (yb) hipLaunchKernelGGL((l2norm_kernel<float, bf16_t, NC>), dim3(grid), dim3(256), 0, s, (const float*)x,    \
+                                  (bf16_t*)y, norms, rows, dim);                                                       \
+  else hipLaunchKernelGGL((l2norm_kernel<float, float, NC>), dim3(grid), dim3(256), 0, s, (const float*)x, (float*)y,  \
+                          norms, rows, dim)
+  DISPATCH_NC(dim, L);
+#undef L
+  MHR_CHECK_LAUNCH("l2norm_rows");
+  return MHR_OK;
+}

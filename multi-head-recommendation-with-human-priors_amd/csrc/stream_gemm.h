@@ -1,0 +1,98 @@
+// Row-stationary streaming GEMM core shared by the catalog scorer and the sampled-softmax kernels.
+//
+//   S^T[streamed row, stationary col] = sum_k  T[streamed row][k] * U[stationary col][k]
+//
+// One 256-thread workgroup = 4 waves.  Each wave keeps RF x 32 "stationary" rows (users / tokens) as
+// MFMA B-operand fragments in registers for the whole kernel (RF*NKS*4 VGPRs, K = 16*NKS <= 256) and the
+// workgroup streams 32-row tiles of the other matrix (items / negatives) through a double-buffered,
+// XOR-swizzled LDS image, so each 16-byte ds_read_b128 of the tile feeds RF MFMAs.  Accumulators hold
+// S^T: streamed rows on the registers, stationary rows on the lanes - so per-stationary-row state
+// (threshold, running sum, mask word) is one VGPR per lane, and no cross-lane work happens in the loop.
+//
+// v_mfma_f32_32x32x16_bf16 lane maps (cdna guide section 3):
+//   A: lane l holds A[row l&31][k = 8*(l>>5) + j];  B: lane l holds B[k = 8*(l>>5) + j][col l&31]
+//   C: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5)
+#pragma once
+#include "mhr_common.h"
+
+namespace sg {
+
+__device__ __forceinline__ int crow(int g, int half) { return (g & 3) + 8 * (g >> 2) + 4 * half; }
+
+__device__ __forceinline__ bf16x8 zero8() {
+  bf16x8 z;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) z[i] = (bf16_t)0.0f;
+  return z;
+}
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) z[i] = 0.f;
+  return z;
+}
+
+template <int NKS>
+struct Tile {
+  static constexpr int DIM = NKS * 16;
+  static constexpr int CH = NKS * 2;                       // 16-byte chunks per row
+  static constexpr int SW = CH >= 16 ? 15 : CH - 1;        // swizzle mask
+  static constexpr int ROW_BYTES = DIM * 2;
+  static constexpr int BYTES = 32 * ROW_BYTES;             // one 32-row tile
+  static constexpr int CHUNKS = 32 * CH;                   // 16-byte chunks per tile
+  static constexpr int PER_THREAD = (CHUNKS + 255) / 256;  // staging chunks per thread
+
+  // byte offset of chunk c of row `row` inside the swizzled tile image
+  static __device__ __forceinline__ int off(int row, int c) { return row * ROW_BYTES + ((c ^ (row & SW)) << 4); }
+
+  // A-operand fragment of k-step ks for lane (r, half)
+  static __device__ __forceinline__ bf16x8 read_a(const unsigned char* tile, int r, int half, int ks) {
+    return *reinterpret_cast<const bf16x8*>(tile + off(r, ks * 2 + half));
+  }
+};
+
+// Staging registers for one tile: each thread moves PER_THREAD 16-byte chunks global -> regs -> LDS.
+template <int NKS>
+struct Stage {
+  bf16x8 v[Tile<NKS>::PER_THREAD];
+
+  // row_ptr(row) returns the global address of the 32-row tile's row `row` (bf16, DIM contiguous) or nullptr.
+  template <typename RowPtr>
+  __device__ __forceinline__ void load(RowPtr row_ptr) {
+    using T = Tile<NKS>;
+#pragma unroll
+    for (int i = 0; i < T::PER_THREAD; ++i) {
+      const int id = threadIdx.x + i * 256;
+      if (id < T::CHUNKS) {
+        const int row = id / T::CH, c = id % T::CH;
+        const bf16_t* p = row_ptr(row);
+        v[i] = p ? *reinterpret_cast<const bf16x8*>(p + c * 8) : zero8();
+      }
+    }
+  }
+  __device__ __forceinline__ void store(unsigned char* tile) const {
+    using T = Tile<NKS>;
+#pragma unroll
+    for (int i = 0; i < T::PER_THREAD; ++i) {
+      const int id = threadIdx.x + i * 256;
+      if (id < T::CHUNKS) {
+        const int row = id / T::CH, c = id % T::CH;
+        *reinterpret_cast<bf16x8*>(tile + T::off(row, c)) = v[i];
+      }
+    }
+  }
+};
+
+// acc[f] (+)= tile . frag[f]^T for the RF stationary fragments
+template <int NKS, int RF>
+__device__ __forceinline__ void mma_tile(const unsigned char* tile, const bf16x8 (&frag)[RF][NKS], f32x16 (&acc)[RF], int r,
+                                         int half) {
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+    const bf16x8 a = Tile<NKS>::read_a(tile, r, half, ks);
+#pragma unroll
+    for (int f = 0; f < RF; ++f) acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, frag[f][ks], acc[f], 0, 0, 0);
+  }
+}
+
+}  // namespace sg

@@ -1,0 +1,357 @@
+"""Thin torch-facing wrappers over the C ABI (include/mhr.h).
+
+PyTorch is plumbing here: device memory (`Tensor.data_ptr()`), the current HIP stream and
+`torch.distributed`.  Every function enqueues hand-written gfx950 kernels from libmhr_hip.so on the
+current stream; none of them synchronises, and none has a CPU or eager fallback.
+"""
+import torch
+
+from . import lib
+
+F32, BF16 = lib.F32, lib.BF16
+
+
+def _dt(t):
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"unsupported dtype {t.dtype} (float32 / bfloat16 only)")
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t, name, dtype=None):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a GPU tensor; the MI355X path has no CPU fallback")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name}: expected a contiguous tensor")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    return t
+
+
+# ------------------------------------------------------------------------------------------------
+# embedding
+# ------------------------------------------------------------------------------------------------
+def embedding_gather(table, ids, out_dtype=torch.bfloat16, pos_table=None, seq_len=0, x_dtype=torch.float32,
+                     want_rows=True):
+    """rows = table[ids] (-> [*ids.shape, D]); with pos_table also x = table[ids[:, :seq_len]] + pos[:seq_len]."""
+    _chk(table, "table", torch.float32)
+    _chk(ids, "ids", torch.int64)
+    D = table.shape[1]
+    n = ids.numel()
+    out = torch.empty(*ids.shape, D, dtype=out_dtype, device=table.device) if want_rows else None
+    x = None
+    window = ids.shape[-1] if pos_table is not None else 0
+    if pos_table is not None:
+        _chk(pos_table, "pos_table", torch.float32)
+        x = torch.empty(*ids.shape[:-1], seq_len, D, dtype=x_dtype, device=table.device)
+    lib.call("mhr_embedding_gather_fwd", table.data_ptr(), table.shape[0], D, ids.data_ptr(), n,
+             _ptr(out), _dt(out) if out is not None else F32, _ptr(pos_table), seq_len, window,
+             _ptr(x), _dt(x) if x is not None else F32, _stream())
+    return out, x
+
+
+def embedding_scatter_add(grad_rows, ids, grad_table):
+    _chk(grad_rows, "grad_rows")
+    _chk(ids, "ids", torch.int64)
+    _chk(grad_table, "grad_table", torch.float32)
+    lib.call("mhr_embedding_scatter_add_bwd", grad_rows.data_ptr(), _dt(grad_rows), ids.data_ptr(), ids.numel(),
+             grad_table.data_ptr(), grad_table.shape[0], grad_table.shape[1], _stream())
+    return grad_table
+
+
+def sparse_rows_segment_sum(sorted_ids, perm, grad_a, grad_b, x_grad, seq_len, window_len, out_rows, row_slot):
+    D = out_rows.shape[-1]
+    n_a = 0 if grad_a is None else grad_a.numel() // D
+    n_b = 0 if grad_b is None else grad_b.numel() // D
+    lib.call("mhr_sparse_rows_segment_sum", sorted_ids.data_ptr(), perm.data_ptr(), sorted_ids.numel(),
+             _ptr(grad_a), _dt(grad_a) if grad_a is not None else F32, n_a,
+             _ptr(grad_b), _dt(grad_b) if grad_b is not None else F32, n_b,
+             _ptr(x_grad), seq_len, window_len, out_rows.data_ptr(), row_slot.data_ptr(), D, _stream())
+
+
+def adam_rows(w, m, v, grad_rows, row_slot, step, lr, grad_scale=1.0, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    lib.call("mhr_adam_rows", w.data_ptr(), m.data_ptr(), v.data_ptr(), w.shape[0], w.shape[1], grad_rows.data_ptr(),
+             _ptr(row_slot), grad_scale, lr, betas[0], betas[1], eps, weight_decay, step, _stream())
+
+
+def adam_flat(w, g, m, v, step, lr, grad_scale=1.0, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    lib.call("mhr_adam_flat", w.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), w.numel(), grad_scale, lr,
+             betas[0], betas[1], eps, weight_decay, step, _stream())
+
+
+# ------------------------------------------------------------------------------------------------
+# normalisation / gate
+# ------------------------------------------------------------------------------------------------
+def layernorm_fwd(x, out_dtype=torch.bfloat16, eps=1e-6):
+    _chk(x, "x")
+    D = x.shape[-1]
+    rows = x.numel() // D
+    y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    lib.call("mhr_layernorm_fwd", x.data_ptr(), _dt(x), y.data_ptr(), _dt(y), mean.data_ptr(), rstd.data_ptr(), rows, D,
+             eps, _stream())
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, mean, rstd, dx=None, accumulate=False, dx_dtype=torch.float32):
+    _chk(dy, "dy")
+    D = x.shape[-1]
+    rows = x.numel() // D
+    if dx is None:
+        dx = torch.empty(x.shape, dtype=dx_dtype, device=x.device)
+    lib.call("mhr_layernorm_bwd", dy.data_ptr(), _dt(dy), x.data_ptr(), _dt(x), mean.data_ptr(), rstd.data_ptr(),
+             dx.data_ptr(), _dt(dx), 1 if accumulate else 0, rows, D, _stream())
+    return dx
+
+
+def ln_gate_fwd(h, a, dim, out_dtype=None, eps=1e-6, dropout_p=0.0, seed=0):
+    """o = silu(h[:, :dim]) * LN(a) * dropmask.  h [rows, stride] pre-activation, a [rows, dim]."""
+    rows = a.numel() // dim
+    o = torch.empty(rows, dim, dtype=out_dtype or a.dtype, device=a.device)
+    mean = torch.empty(rows, dtype=torch.float32, device=a.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=a.device)
+    assert h.dtype == a.dtype
+    lib.call("mhr_ln_gate_fwd", h.data_ptr(), h.stride(0), a.data_ptr(), _dt(a), o.data_ptr(), _dt(o), mean.data_ptr(),
+             rstd.data_ptr(), rows, dim, eps, dropout_p, seed, _stream())
+    return o, mean, rstd
+
+
+def ln_gate_bwd(d_o, h, a, mean, rstd, dh, dim, dropout_p=0.0, seed=0):
+    """writes du into dh[:, :dim]; returns da."""
+    rows = a.numel() // dim
+    da = torch.empty_like(a)
+    lib.call("mhr_ln_gate_bwd", d_o.data_ptr(), _dt(d_o), h.data_ptr(), h.stride(0), a.data_ptr(), _dt(a), mean.data_ptr(),
+             rstd.data_ptr(), dh.data_ptr(), dh.stride(0), da.data_ptr(), rows, dim, dropout_p, seed, _stream())
+    return da
+
+
+def l2norm_rows(x, out_dtype=torch.bfloat16, want_norms=False):
+    _chk(x, "x")
+    D = x.shape[-1]
+    rows = x.numel() // D
+    y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    norms = torch.empty(rows, dtype=torch.float32, device=x.device) if want_norms else None
+    lib.call("mhr_l2norm_rows", x.data_ptr(), _dt(x), y.data_ptr(), _dt(y), _ptr(norms), rows, D, _stream())
+    return (y, norms) if want_norms else y
+
+
+# ------------------------------------------------------------------------------------------------
+# attention
+# ------------------------------------------------------------------------------------------------
+def hstu_attn_fwd(h, key_valid, B, L, n_heads, head_dim, apply_silu=True, save_act=True):
+    """h [B*L, 4*D] bf16 pre-activation uvqk (column blocks u|v|q|k).  Returns (out [B*L, D], act [B*L, 3*D] (q|k|v))."""
+    _chk(h, "h", torch.bfloat16)
+    _chk(key_valid, "key_valid", torch.uint8)
+    D = n_heads * head_dim
+    stride = h.stride(0)
+    esz = 2
+    base = h.data_ptr()
+    v_ptr, q_ptr, k_ptr = base + D * esz, base + 2 * D * esz, base + 3 * D * esz
+    out = torch.empty(B * L, D, dtype=torch.bfloat16, device=h.device)
+    act = torch.empty(B * L, 3 * D, dtype=torch.bfloat16, device=h.device) if save_act else None
+    aq = act.data_ptr() if save_act else 0
+    lib.call("mhr_hstu_attn_fwd", q_ptr, k_ptr, v_ptr, stride, key_valid.data_ptr(), out.data_ptr(),
+             aq, aq + D * esz if save_act else 0, aq + 2 * D * esz if save_act else 0, 3 * D,
+             B, L, n_heads, head_dim, 1 if apply_silu else 0, _stream())
+    return out, act
+
+
+def hstu_attn_bwd(h, act, key_valid, d_out, dh, B, L, n_heads, head_dim, apply_silu=True):
+    """writes dv|dq|dk into dh[:, D:4D] (pre-activation gradients)."""
+    D = n_heads * head_dim
+    esz = 2
+    base, dbase, abase = h.data_ptr(), dh.data_ptr(), act.data_ptr()
+    lib.call("mhr_hstu_attn_bwd", base + 2 * D * esz, base + 3 * D * esz, base + D * esz, h.stride(0),
+             abase, abase + D * esz, abase + 2 * D * esz, act.stride(0), key_valid.data_ptr(), d_out.data_ptr(),
+             dbase + 2 * D * esz, dbase + 3 * D * esz, dbase + D * esz, dh.stride(0),
+             B, L, n_heads, head_dim, 1 if apply_silu else 0, _stream())
+    return dh
+
+
+# ------------------------------------------------------------------------------------------------
+# sampled softmax
+# ------------------------------------------------------------------------------------------------
+class NceSaved:
+    """Tensors the forward keeps for the backward (all preallocated at token capacity)."""
+    __slots__ = ("qn", "pn", "qnT", "q_inv", "p_inv", "s_pos", "lse", "loss", "n_valid", "rank", "negs", "negsT",
+                 "n_tok_dev", "tok_cap", "thres", "dim", "n_neg")
+
+
+def nce_fwd(q_rows, q_idx, p_rows, p_idx, negs, n_tok_dev, tok_cap, logit_scale, thres=0.99, want_logs=False,
+            for_backward=True):
+    """q_rows/p_rows [*, D] (bf16 or f32, same dtype); q_idx/p_idx [tok_cap] int32; negs [n_neg, D] bf16 normalised."""
+    _chk(negs, "negs", torch.bfloat16)
+    _chk(q_idx, "q_idx", torch.int32)
+    _chk(p_idx, "p_idx", torch.int32)
+    _chk(n_tok_dev, "n_tok_dev", torch.int32)
+    _chk(logit_scale, "logit_scale", torch.float32)
+    assert q_rows.dtype == p_rows.dtype
+    dev = negs.device
+    D = negs.shape[1]
+    tok_cap = (tok_cap + 3) // 4 * 4
+    sv = NceSaved()
+    sv.loss = torch.zeros(tok_cap, dtype=torch.float32, device=dev)
+    sv.lse = torch.zeros(tok_cap, dtype=torch.float32, device=dev)
+    sv.n_valid = torch.zeros(tok_cap, dtype=torch.int32, device=dev) if want_logs else None
+    sv.rank = torch.zeros(tok_cap, dtype=torch.int32, device=dev) if want_logs else None
+    if for_backward:
+        sv.qn = torch.empty(tok_cap, D, dtype=torch.bfloat16, device=dev)
+        sv.pn = torch.empty(tok_cap, D, dtype=torch.bfloat16, device=dev)
+        sv.qnT = torch.zeros(D, tok_cap, dtype=torch.bfloat16, device=dev)
+        sv.q_inv = torch.empty(tok_cap, dtype=torch.float32, device=dev)
+        sv.p_inv = torch.empty(tok_cap, dtype=torch.float32, device=dev)
+        sv.s_pos = torch.empty(tok_cap, dtype=torch.float32, device=dev)
+    else:
+        sv.qn = sv.pn = sv.qnT = sv.q_inv = sv.p_inv = sv.s_pos = None
+    sv.negs, sv.negsT = negs, None
+    sv.n_tok_dev, sv.tok_cap, sv.thres, sv.dim, sv.n_neg = n_tok_dev, tok_cap, float(thres), D, negs.shape[0]
+    lib.call("mhr_nce_fwd", q_rows.data_ptr(), q_idx.data_ptr(), p_rows.data_ptr(), p_idx.data_ptr(), _dt(q_rows),
+             negs.data_ptr(), negs.shape[0], D, n_tok_dev.data_ptr(), tok_cap, logit_scale.data_ptr(), float(thres),
+             sv.loss.data_ptr(), sv.lse.data_ptr(), _ptr(sv.n_valid), _ptr(sv.rank), _ptr(sv.qn), _ptr(sv.pn),
+             _ptr(sv.qnT), _ptr(sv.q_inv), _ptr(sv.p_inv), _ptr(sv.s_pos), _stream())
+    return sv
+
+
+def transpose_pad(negs, mult=32):
+    """[n, D] bf16 -> [D, ceil(n/mult)*mult] zero padded (plumbing: a strided copy)."""
+    n, D = negs.shape
+    ld = (n + mult - 1) // mult * mult
+    t = torch.zeros(D, ld, dtype=negs.dtype, device=negs.device)
+    t[:, :n] = negs.t()
+    return t
+
+
+def nce_bwd(sv, w, logit_scale, d_negs=None, d_logit_scale=None):
+    """w [tok_cap] f32 = dLoss/dloss[t].  Returns (dq_tok [tok_cap, D] f32, dp_tok, d_negs [n_neg, D] f32, d_logit_scale [1])."""
+    dev = sv.negs.device
+    D, cap = sv.dim, sv.tok_cap
+    if sv.negsT is None:
+        sv.negsT = transpose_pad(sv.negs)
+    dq = torch.zeros(cap, D, dtype=torch.float32, device=dev)
+    dp = torch.zeros(cap, D, dtype=torch.float32, device=dev)
+    if d_negs is None:
+        d_negs = torch.zeros(sv.n_neg, D, dtype=torch.float32, device=dev)
+    if d_logit_scale is None:
+        d_logit_scale = torch.zeros(1, dtype=torch.float32, device=dev)
+    _chk(w, "w", torch.float32)
+    lib.call("mhr_nce_bwd", sv.qn.data_ptr(), sv.pn.data_ptr(), sv.qnT.data_ptr(), sv.negs.data_ptr(), sv.negsT.data_ptr(),
+             sv.negsT.shape[1], sv.n_neg, D, sv.n_tok_dev.data_ptr(), cap, logit_scale.data_ptr(), sv.thres,
+             sv.lse.data_ptr(), w.data_ptr(), sv.q_inv.data_ptr(), sv.p_inv.data_ptr(), sv.s_pos.data_ptr(),
+             dq.data_ptr(), dp.data_ptr(), d_negs.data_ptr(), d_logit_scale.data_ptr(), _stream())
+    return dq, dp, d_negs, d_logit_scale
+
+
+# ------------------------------------------------------------------------------------------------
+# catalog scoring / top-k / merge
+# ------------------------------------------------------------------------------------------------
+def catalog_emit(users, H, items, tag_bits, row_bits, tau, hist_ptr, hist_items, cap, item_begin=0, item_stride=1,
+                 cand=None):
+    n_rows, D = users.shape
+    dev = users.device
+    if cand is None:
+        cand = (torch.empty(n_rows, cap, dtype=torch.float32, device=dev),
+                torch.empty(n_rows, cap, dtype=torch.int32, device=dev),
+                torch.zeros(n_rows, dtype=torch.int32, device=dev))
+    else:
+        cand[2].zero_()
+    lib.call("mhr_catalog_score_emit", users.data_ptr(), n_rows, H, items.data_ptr(), items.shape[0], D, item_begin,
+             item_stride, _ptr(tag_bits), row_bits.data_ptr(), tau.data_ptr(), _ptr(hist_ptr), _ptr(hist_items),
+             cand[0].data_ptr(), cand[1].data_ptr(), cand[2].data_ptr(), cap, _stream())
+    return cand
+
+
+def topk_select(cand, cap, k):
+    val, idx, cnt = cand
+    n_rows = cnt.shape[0]
+    dev = cnt.device
+    out_val = torch.empty(n_rows, k, dtype=torch.float32, device=dev)
+    out_idx = torch.empty(n_rows, k, dtype=torch.int64, device=dev)
+    kth = torch.empty(n_rows, dtype=torch.float32, device=dev)
+    status = torch.empty(n_rows, dtype=torch.int32, device=dev)
+    lib.call("mhr_topk_select", val.data_ptr(), idx.data_ptr(), cnt.data_ptr(), cap, n_rows, k, out_val.data_ptr(),
+             out_idx.data_ptr(), kth.data_ptr(), status.data_ptr(), _stream())
+    return out_val, out_idx, kth, status
+
+
+def catalog_topk(users, H, items, tag_bits, row_bits, hist_ptr, hist_items, k, cap=4096, target=1024, stats=None):
+    """Exact per-row top-k over the whole catalog (value desc, index asc), rows = (user, head) pairs.
+
+    users [B*H, D] bf16 normalised, items [N, D] bf16 normalised.  Returns (values [B*H,k] f32, indices [B*H,k] i64).
+    Thresholds come from two strided sample passes; exactness is verified (k <= count <= cap per row) and
+    rows that fail are re-run with tau = -inf, so the sampling only affects speed.
+    """
+    n_rows, D = users.shape
+    N = items.shape[0]
+    dev = users.device
+    ninf = torch.full((n_rows,), float("-inf"), dtype=torch.float32, device=dev)
+    if N <= cap:
+        cand = catalog_emit(users, H, items, tag_bits, row_bits, ninf, hist_ptr, hist_items, N)
+        ov, oi, _, _ = topk_select(cand, N, k)
+        return ov, oi
+    s1 = max(1, -(-N // 2048))
+    s2 = max(1, -(-N // 32768))
+    n1, n2 = -(-N // s1), -(-N // s2)
+    t1 = 8
+    t2 = max(k // s2 + 1, target // s2)
+    c1 = catalog_emit(users, H, items, tag_bits, row_bits, ninf, hist_ptr, hist_items, n1, 0, s1)
+    _, _, kth1, _ = topk_select(c1, n1, t1)
+    cap2 = min(n2, 8192)
+    c2 = catalog_emit(users, H, items, tag_bits, row_bits, kth1, hist_ptr, hist_items, cap2, 0, s2)
+    _, _, kth2, st2 = topk_select(c2, cap2, t2)
+    tau = torch.where(torch.isfinite(kth2) & (st2 == 0), kth2, torch.where(st2 == 0, kth1, ninf))
+    tau = torch.where((c2[2] > cap2), ninf, tau)        # truncated sample list: threshold unknown -> exact path decides
+    cand = catalog_emit(users, H, items, tag_bits, row_bits, tau, hist_ptr, hist_items, cap)
+    ov, oi, _, _ = topk_select(cand, cap, k)
+    cnt = cand[2]
+    flagged = (cnt > cap) | ((cnt < k) & (row_bits != 0) & torch.isfinite(tau))
+    if stats is not None:
+        stats["mean_candidates"] = float(cnt.float().mean())
+        stats["flagged_rows"] = int(flagged.sum())
+    if bool(flagged.any()):                               # one host sync per batch; results go to the host anyway
+        users_f = torch.nonzero(flagged.view(-1, H).any(dim=1)).flatten()
+        rows_f = (users_f[:, None] * H + torch.arange(H, device=dev)[None, :]).flatten()
+        sub_ptr, sub_items = None, None
+        if hist_ptr is not None:
+            lens = (hist_ptr[1:] - hist_ptr[:-1])[users_f].long()
+            sub_ptr = torch.zeros(users_f.numel() + 1, dtype=torch.int32, device=dev)
+            sub_ptr[1:] = torch.cumsum(lens, 0).int()
+            starts = hist_ptr[:-1][users_f].long()
+            off = torch.arange(int(lens.sum()), device=dev) - torch.repeat_interleave(sub_ptr[:-1].long(), lens)
+            sub_items = hist_items[torch.repeat_interleave(starts, lens) + off].contiguous()
+        sub_users = users[rows_f].contiguous()
+        sub_bits = row_bits[rows_f].contiguous()
+        sub_tau = torch.full((rows_f.numel(),), float("-inf"), dtype=torch.float32, device=dev)
+        c3 = catalog_emit(sub_users, H, items, tag_bits, sub_bits, sub_tau, sub_ptr, sub_items, N)
+        fv, fi, _, _ = topk_select(c3, N, k)
+        ov[rows_f] = fv
+        oi[rows_f] = fi
+    return ov, oi
+
+
+def multihead_merge_dedup(vals, idx, B, H, k):
+    dev = vals.device
+    out_idx = torch.empty(B, k, dtype=torch.int64, device=dev)
+    out_val = torch.empty(B, k, dtype=torch.float32, device=dev)
+    out_src = torch.empty(B, k, dtype=torch.int32, device=dev)
+    status = torch.empty(B, dtype=torch.int32, device=dev)
+    lib.call("mhr_multihead_merge_dedup", vals.data_ptr(), idx.data_ptr(), B, H, k, out_idx.data_ptr(), out_val.data_ptr(),
+             out_src.data_ptr(), status.data_ptr(), _stream())
+    return out_idx, out_val, out_src, status
+
+
+def hit_matrix(topk_idx, positives, n_pos):
+    B, k = topk_idx.shape
+    hit = torch.empty(B, k, dtype=torch.uint8, device=topk_idx.device)
+    lib.call("mhr_hit_matrix", topk_idx.data_ptr(), B, k, positives.data_ptr(), positives.stride(0), n_pos, hit.data_ptr(),
+             _stream())
+    return hit
