@@ -1,0 +1,241 @@
+#!/usr/bin/env python3
+"""Headline benchmark: user-sequences/sec for HSTU Pixel8M-shaped training (BASELINE.json metric) on N MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is one full optimisation step of the hot path on one synthetic batch per rank: item gather, 8 HSTU layers,
+4 prior heads, per-category sampled softmax over 8192 negatives, backward, RCCL gradient exchange, fused AdamW over all
+parameters including the 454k x 256 item table.  Workload = BASELINE.json configs[1] (cfg1: L=200, P=8, D=256,
+8 layers x 8 heads, C=4 prior heads, N=453 938 items, B=128 per GPU, bf16-mixed).  Inputs are generated on the device
+before the timed region.  Rank 0 prints ONE JSON line.
+
+Extra objects on the line:
+  roofline     - the dominant kernel of the step (by summed HIP-event time inside the timed region), priced by its
+                 ALGORITHMIC flops against the dense bf16 MFMA peak (2.5 PFLOP/s) or, for
+                 HBM-bound kernels, algorithmic bytes against 8 TB/s;
+  cpu_baseline - the CPU oracle's train step on the host cores, on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "multi-head-recommendation-with-human-priors_amd", "code"))
+
+MFMA_PEAK_TFLOPS = 2500.0     # dense bf16, MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="cfg1")
+    ap.add_argument("--mode", default="train", choices=["train", "eval"])
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override (0 = config)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true", help="skip per-kernel HIP events (pure wall-clock run)")
+    return ap.parse_args()
+
+
+def cpu_baseline_train(cfgd, item_num, seconds=20.0):
+    """The oracle's fp32 train step (forward + autograd backward + dense AdamW over every parameter) on the host."""
+    import torch
+    from oracle import hstu_oracle as HO
+    from oracle import optim_oracle as OO
+    import mhr_amd.synth as synth
+    from REC.config.configurator import Config
+    from REC.utils import get_model
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = Config(config_dict=dict(cfgd, device="cpu"))
+    data = synth.SyntheticData(cfg, item_num, "cpu")
+    cfg["int_to_category"] = data.int_to_category
+    torch.manual_seed(2020)
+    model = get_model("HSTU")(cfg, data)
+    w = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    params = {k: w[k].requires_grad_(True) for k, _ in model.named_parameters()}
+    w.update(params)
+    w = HO.tie_repeated_resblocks(w)
+    ocfg = dict(cfgd, category_counts=data.category_counts, category_to_int=data.category_to_int,
+                int_to_category=data.int_to_category)
+    B = 4
+    ocfg["num_negatives"] = cfgd["num_negatives"]
+    data.config = dict(cfgd, num_negatives=cfgd["num_negatives"])
+    state = {k: (torch.zeros_like(p), torch.zeros_like(p)) for k, p in params.items()}
+    n, t_used = 0, 0.0
+    # negatives per sample sized as on the GPU (ceil(num_negatives / B_gpu)); the sample is B=4 windows per step
+    n_neg_gpu = data.n_neg(cfgd["train_batch_size"])
+    while t_used < seconds and n < 50:
+        batch = data.train_batch(B)
+        batch = (batch[0], batch[1][:, :, :n_neg_gpu].contiguous(), batch[2], batch[3])
+        t0 = time.time()
+        out = HO.train_forward(w, ocfg, batch)
+        out["loss"].backward()
+        with torch.no_grad():
+            for k, p in params.items():
+                if p.grad is None:
+                    continue
+                OO.adamw_step(p, p.grad, state[k][0], state[k][1], n + 1, 1e-4)
+                p.grad = None
+        dt = time.time() - t0
+        if n > 0 or dt > seconds:          # first step warms the allocator
+            t_used += dt
+        n += 1
+    steps = max(1, n - 1)
+    return {"value": round(B * steps / max(t_used, 1e-9), 3), "unit": "seq/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} oracle train steps (fwd+bwd+dense AdamW, fp32) of {B} windows at the cfg1 shape with "
+                      f"{n_neg_gpu * B} negatives per pool (GPU batch uses {cfgd['num_negatives']})"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    import mhr_amd.synth as synth
+    from mhr_amd import ops
+    from REC.config.configurator import Config, apply_run_fixups
+    from REC.trainer import Trainer
+    from REC.utils import get_model
+
+    spec = synth.CONFIGS[args.config]
+    cfgd = dict(spec["cfg"], device=dev, total_iters=30000, eval_interval=0, checkpoint_dir=None, save_model_note="bench")
+    if args.batch:
+        cfgd["train_batch_size"] = cfgd["eval_batch_size"] = args.batch
+    cfg = apply_run_fixups(Config(config_dict=cfgd))
+    N = spec["item_num"]
+    data = synth.SyntheticData(cfg, N, dev, seed=2020, rank=rank, world=world)
+    cfg["int_to_category"] = data.int_to_category
+    torch.manual_seed(2020)
+    model = get_model("HSTU")(cfg, data).to(dev)
+    trainer = Trainer(cfg)
+    trainer.setup_model(model)
+    trainer.train_step = 3000            # past the warm-up so lr > 0: every step really moves the parameters
+    B = cfg["train_batch_size"] if args.mode == "train" else cfg["eval_batch_size"]
+    L, P, D, C = cfg["MAX_ITEM_LIST_LENGTH"], cfg["pred_len"], cfg["hstu_embedding_size"], data.C
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    n_steps = args.warmup + args.steps
+    if args.mode == "train":
+        batches = [data.train_batch(B) for _ in range(min(n_steps, 8))]
+        model.train()
+
+        def step(i):
+            return trainer.train_step_fn(batches[i % len(batches)])
+    else:
+        batches = [data.eval_batch(B) for _ in range(min(n_steps, 4))]
+        trainer.compute_item_feature(data.item_tags)
+
+        def step(i):
+            fused, pu, pi, tt, _ = trainer._full_sort_batch_eval(batches[i % len(batches)])
+            trainer.eval_collector.eval_batch_collect(fused, pu, pi)
+            return None
+
+    for i in range(args.warmup):
+        step(i)
+    kernels = ["mhr_nce_fwd", "mhr_nce_bwd_tokens", "mhr_nce_bwd_negs", "mhr_catalog_score_emit", "mhr_hstu_attn_fwd",
+               "mhr_hstu_attn_bwd", "mhr_adam_rows", "mhr_embedding_gather_fwd", "mhr_sparse_rows_segment_sum", "mhr_topk_select"]
+    if not args.no_kernel_events:
+        ops.PROFILE = {k: [] for k in kernels}
+    sync()
+    t0 = time.perf_counter()
+    last = None
+    for i in range(args.steps):
+        last = step(args.warmup + i)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    prof = ops.profile_summary() if ops.PROFILE is not None else {}
+    ops.PROFILE = None
+
+    if rank == 0:
+        value = world * B * args.steps / elapsed
+        out = {
+            "metric": "user-sequences/sec/node (HSTU Pixel8M, seqlen 200)" if args.mode == "train" else "eval users/sec/node (HSTU Pixel8M full-catalog multi-head decode)",
+            "value": round(value, 2), "unit": "seq/s" if args.mode == "train" else "users/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1000 * elapsed / args.steps, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"{args.config}: HSTU Pixel8M-shaped {args.mode} step, L={L} P={P} D={D} {cfg['n_layers']} layers x "
+                                   f"{cfg['n_heads']} heads, {C} prior heads, N={N} items, {cfg['num_negatives']} negatives/pool, "
+                                   f"B={B}/GPU, loss={cfg['loss']}, bf16-mixed, fused AdamW over all parameters",
+                       "global_batch": world * B, "seq_len": L, "parallelism": f"dp{world}"},
+        }
+        if last is not None and args.mode == "train":
+            out["loss"] = round(float(last["loss"]), 4)
+        # ---- roofline of the dominant kernel ----
+        if prof:
+            dom = max(prof.items(), key=lambda kv: kv[1][2])
+            name, (launches, mean_ms, total_ms) = dom
+            per_step = {k: round(v[2] / args.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][2])}
+            n_tok_total = None
+            if name.startswith("mhr_nce"):
+                # algorithmic flops per launch: one category's tokens x negatives x D; N_tok measured on the last batch
+                items, _, mask, tags = batches[(args.warmup + args.steps - 1) % len(batches)]
+                idx = torch.arange(L, device=dev)[None, :] + 1 + torch.arange(P, device=dev)[:, None]
+                mb = mask.bool()
+                valid = mb[:, None, :L] & mb[:, idx]
+                if cfg["loss"] == "prior":
+                    n_tok = float((valid[..., None] & tags[:, idx].bool()).sum()) / C
+                else:
+                    n_tok = float(valid.sum())
+                n_neg = world * B * data.n_neg(B)
+                mult = 4.0                                    # fwd: neg + fix logits; bwd (dQ + dN): 2 x 2 N_tok N_neg D
+                if name != "mhr_nce_fwd":
+                    mult = 2.0                                # each backward kernel: one of dQ / dN
+                flops = mult * n_tok * n_neg * D
+                ach = flops / (mean_ms * 1e-3) / 1e12
+                out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS,
+                                   "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                                   "launch_ms": round(mean_ms, 4), "launches_per_step": launches / args.steps,
+                                   "algorithmic_flops_per_launch": flops, "tokens_per_launch": n_tok, "negatives": n_neg}
+            elif name == "mhr_catalog_score_emit":
+                flops = 2.0 * B * model.medusa_num_heads * D * N      # the full pass dominates; sample passes are 1/14 + 1/222 of it
+                ach = flops / (mean_ms * launches / (args.steps) * 1e-3) / 1e12
+                out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS,
+                                   "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                                   "launch_ms": round(mean_ms, 4), "launches_per_step": launches / args.steps,
+                                   "algorithmic_flops_per_step": flops}
+            else:
+                nbytes = {"mhr_adam_rows": N * D * 24.0, "mhr_embedding_gather_fwd": None}.get(name)
+                if nbytes:
+                    ach = nbytes / (mean_ms * 1e-3) / 1e9
+                    out["roofline"] = {"bound": "hbm", "kernel": name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                                       "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                                       "launch_ms": round(mean_ms, 4)}
+            out["kernel_ms_per_step"] = per_step
+            if "mhr_adam_rows" in prof:
+                ms = prof["mhr_adam_rows"][1]
+                out["adam_rows_GBps"] = round(N * D * 24.0 / (ms * 1e-3) / 1e9, 1)
+        if not args.no_cpu_baseline and world == 1 and args.mode == "train":
+            try:
+                out["cpu_baseline"] = cpu_baseline_train(dict(spec["cfg"]), N)
+            except Exception as e:  # noqa: BLE001 - the baseline must not kill the bench line
+                out["cpu_baseline"] = {"value": None, "error": repr(e)[:200]}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,512 @@
+"""HSTU with multi-head prior-guided decoding, MI355X-native.
+
+Same registry surface, constructor, `forward` / `predict` / `compute_item_all` contract and `state_dict`
+names as the reference `code/REC/model/IDNet/hstu.py` (class HSTU, lines 331-1030), so `get_model("HSTU")`,
+the reference YAML presets and checkpoints keep working.  The arithmetic is not torch eager: embedding
+gather / sparse gradient, LayerNorm, the pointwise-gated attention, the gate, the sampled-softmax loss and
+the catalog scoring + top-k run in hand-written gfx950 kernels (mhr_amd.ops); only the dense projections are
+library GEMMs.  There is no CPU path: on a machine without the HIP library construction still works (for
+state_dict handling) but forward/predict raise.
+
+Differences from the reference that are deliberate:
+  * the relative position/time bias parameters are kept for checkpoint compatibility and never applied
+    (the reference builds them and never calls them, hstu.py:187-189 vs 221-290);
+  * `forward` never synchronises with the host: token sets stay at fixed capacity with device-side counts
+    (the reference's `mask.sum() == 0` / `.any()` branches, hstu.py:722, 815, 861, each cost a sync);
+  * the item table's gradient is left as a deterministic sparse row set on `self.sparse_grad`
+    (set `dense_embedding_grad = True` for the reference's dense `weight.grad`);
+  * `predict_topk` returns per-head top-k without materialising the [B,H,N] score tensor; `predict`
+    still returns dense scores for callers written against the reference.
+"""
+import math
+from collections import defaultdict
+from logging import getLogger
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from REC.model.basemodel import BaseModel, all_gather_ids
+from REC.model.llm_heads import ResBlock
+from REC.utils.enum_type import InputType
+
+
+def truncated_normal(x, mean, std):
+    """Four normal draws per element, the first inside (-2, 2) wins (reference hstu.py:23-31)."""
+    with torch.no_grad():
+        draws = torch.empty(x.shape + (4,), dtype=x.dtype, device=x.device).normal_()
+        inside = (draws < 2) & (draws > -2)
+        first = inside.to(torch.uint8).argmax(dim=-1, keepdim=True)
+        x.copy_(draws.gather(-1, first).squeeze(-1).mul_(std).add_(mean))
+    return x
+
+
+class RelativeBucketedTimeAndPositionBasedBias(nn.Module):
+    """Parameter holder only: `_ts_w` [num_buckets+1], `_pos_w` [2*max_seq_len-1] (reference hstu.py:74-131).
+    The reference never applies this bias in its attention, so neither do we."""
+
+    def __init__(self, max_seq_len, num_buckets):
+        super().__init__()
+        self._ts_w = nn.Parameter(torch.empty(num_buckets + 1).normal_(mean=0, std=0.02))
+        self._pos_w = nn.Parameter(torch.empty(2 * max_seq_len - 1).normal_(mean=0, std=0.02))
+
+
+class SequentialTransductionUnitJagged(nn.Module):
+    """One HSTU block's parameters: `_uvqk` [D, 4D], `_o` Linear(D, D) (reference hstu.py:163-211)."""
+
+    def __init__(self, embedding_dim, n_heads, dropout_ratio, rel_bias=None, eps=1e-6):
+        super().__init__()
+        self._embedding_dim = embedding_dim
+        self._num_heads = n_heads
+        self._dropout_ratio = dropout_ratio
+        self._eps = eps
+        self._rel_attn_bias = rel_bias
+        self._uvqk = nn.Parameter(torch.empty(embedding_dim, 4 * embedding_dim).normal_(mean=0, std=0.02))
+        self._o = nn.Linear(embedding_dim, embedding_dim)
+        nn.init.xavier_uniform_(self._o.weight)
+
+
+class HSTUJagged(nn.Module):
+    def __init__(self, modules):
+        super().__init__()
+        self._attention_layers = nn.ModuleList(modules)
+
+
+class FusedTopK:
+    """Per-head top-k of one eval batch: values [B,H,K] fp32, indices [B,H,K] int64 (value desc, index asc)."""
+    __slots__ = ("values", "indices")
+
+    def __init__(self, values, indices):
+        self.values, self.indices = values, indices
+
+
+class HSTU(BaseModel):
+    input_type = InputType.SEQ
+
+    def __init__(self, config, dataload):
+        super().__init__()
+        self.logger = getLogger()
+        self.item_num = dataload.item_num
+        self._item_embedding_dim = config['item_embedding_size']
+        self._hstu_embedding_dim = D = config['hstu_embedding_size']
+        self.max_seq_length = L = config['MAX_ITEM_LIST_LENGTH']
+        self.pred_len = config['pred_len']
+        self.medusa_lambda = config['medusa_lambda']
+        self.num_segment_head = config['num_segment_head']
+        self.num_prior_head = config['num_prior_head']
+        self.head_interaction = config['head_interaction']
+        if self.head_interaction in ('multiplicative', 'hierarchical'):
+            self.medusa_num_heads = self.num_segment_head * self.num_prior_head
+        elif self.head_interaction == 'additive':
+            self.medusa_num_heads = self.num_segment_head + self.num_prior_head
+        else:
+            raise ValueError(f'Unknown head_interaction: {config["head_interaction"]}')
+        self.medusa_num_layers = nl = config['medusa_num_layers']
+        self.category_by = config['category_by']
+        self._num_blocks = config['n_layers']
+        self._num_heads = config['n_heads']
+        self._dqk = self._dv = D // config['n_heads']
+        self._linear_activation = config['hidden_act'] if config['hidden_act'] else 'silu'
+        if self._linear_activation != 'silu':
+            raise NotImplementedError("only hidden_act='silu' is implemented in the fused kernels")
+        self._linear_dropout_rate = config['hidden_dropout_prob'] or 0.0
+        self._attn_dropout_rate = config['attn_dropout_prob']          # stored, unused (as in the reference)
+        self._enable_relative_attention_bias = bool(config['enable_relative_attention_bias'])
+
+        self.position_embedding = nn.Embedding(L + 1, D)
+        self._hstu = HSTUJagged([
+            SequentialTransductionUnitJagged(
+                D, self._num_heads, self._linear_dropout_rate,
+                RelativeBucketedTimeAndPositionBasedBias(2 * L, 128) if self._enable_relative_attention_bias else None)
+            for _ in range(self._num_blocks)])
+        self.item_embedding = nn.Embedding(self.item_num, self._item_embedding_dim, padding_idx=0)
+        self.item_id_proj_tower = (nn.Identity() if self._item_embedding_dim == D
+                                   else nn.Linear(self._item_embedding_dim, D, bias=False))
+
+        self.loss = config['loss']
+        self.neg_sample_by_cat = bool(config['neg_sample_by_cat']) and self.loss == 'prior'
+        self.pos_sample_mix_ratio = config['pos_sample_mix_ratio'] or 0.0
+        if self.loss not in ('nce', 'prior'):
+            raise NotImplementedError(f"loss={self.loss} is not supported")
+        if config['fix_temp']:
+            self.register_buffer("logit_scale", torch.tensor(np.log(1 / 0.05), dtype=torch.float32))
+        else:
+            self.logit_scale = nn.Parameter(torch.ones([]) * np.log(1 / 0.05))
+        self.nce_thres = config['nce_thres'] if config['nce_thres'] else 0.99
+        self.seg_len = self.pred_len
+        if nl > 0:
+            assert self.pred_len % self.num_segment_head == 0, "pred_len must be divisible by the number of segments"
+            self.seg_len = self.pred_len // self.num_segment_head
+
+        lam = torch.tensor([self.medusa_lambda ** p for p in range(self.pred_len)])
+        self.register_buffer('horizon_discount', lam / lam.sum())
+
+        S, C = self.num_segment_head, self.num_prior_head
+        if nl == 0:
+            self.medusa_head = nn.ModuleList([nn.Identity() for _ in range(self.medusa_num_heads)])
+        elif self.head_interaction == 'hierarchical':
+            self.head_norm = config.get("head_norm", False)
+            self.cat_bottleneck = config.get("cat_bottleneck", False)
+            self.cat_bottleneck_dim = config.get("cat_bottleneck_dim", D // 2)
+            self.share_seg_weights = config.get("share_seg_weights", False)
+            self.use_seg_embed = config.get("segment_embed", False)
+            if self.use_seg_embed:
+                self.segment_emb = nn.Embedding(S, D)
+
+            def cat_block():
+                layers = []
+                if self.cat_bottleneck:
+                    layers += [nn.LayerNorm(D), nn.Linear(D, self.cat_bottleneck_dim), nn.SiLU(),
+                               nn.Linear(self.cat_bottleneck_dim, D)]
+                layers += [ResBlock(D, use_norm=self.head_norm, zero_init=False) for _ in range(nl)]
+                return nn.Sequential(*layers)
+
+            def seg_block():
+                return nn.Sequential(*[ResBlock(D, use_norm=self.head_norm, zero_init=False) for _ in range(nl)])
+
+            self.medusa_cat_head = nn.ModuleList([cat_block() for _ in range(C)])
+            if self.share_seg_weights:
+                shared = seg_block()
+                self.medusa_seg_head = nn.ModuleList([nn.ModuleList([shared for _ in range(S)]) for _ in range(C)])
+            else:
+                self.medusa_seg_head = nn.ModuleList([nn.ModuleList([seg_block() for _ in range(S)]) for _ in range(C)])
+        else:
+            # one ResBlock instance applied `nl` times per head (state_dict keys .0. ... alias it), as in the reference
+            self.medusa_head = nn.ModuleList([nn.Sequential(*([ResBlock(D)] * nl)) for _ in range(self.medusa_num_heads)])
+        if nl > 0 and self.loss != 'prior':
+            assert C == 1, 'Only prior loss is allowed for num_prior_head > 1'
+
+        self.weighted_prior_loss = config['weighted_prior_loss']
+        if self.loss == 'prior' and self.weighted_prior_loss and nl > 0:
+            total = sum(dataload.category_counts.values())
+            self.prior_loss_weight = [0.0] * C
+            for name, cnt in dataload.category_counts.items():
+                self.prior_loss_weight[dataload.category_to_int[name]] = cnt / total
+        else:
+            self.prior_loss_weight = [1.0 / C] * C
+        if self.loss == 'prior' and config['prior_switch'] is not None and nl > 0:
+            raise NotImplementedError("prior_switch heads (reference hstu.py:512-544) are not built yet; set prior_switch: null")
+        self.prior_switch = None
+        self.eval_pred_len = config['eval_pred_len']
+        self.prior_given_at_test = config.get('prior_given_at_test', False)
+        self.given_prior_len = config.get('given_prior_len', self.eval_pred_len) if self.prior_given_at_test else self.eval_pred_len
+        self.int_to_category = config["int_to_category"]
+        self.rank = torch.distributed.get_rank() if torch.distributed.is_initialized() else 0
+
+        self.register_buffer("_attn_mask", torch.triu(torch.ones((L, L), dtype=torch.bool), diagonal=1))
+        self._verbose = False
+        self.reset_params()
+
+        # runtime state of the fused path
+        self.dense_embedding_grad = False
+        self.sparse_grad = None
+        self._row_slot = None
+        self._pending_rows = None
+        self._tok_cache = {}
+        self._item_cache = None
+        self._step_seed = 0
+
+    # ------------------------------------------------------------------------------------------
+    def reset_params(self):
+        """trunc-normal(0.02) for every parameter outside the encoder (reference hstu.py:574-588)."""
+        for name, p in self.named_parameters():
+            if ("_hstu" in name) or ("_embedding_module" in name) or ('logit_scale' in name):
+                continue
+            truncated_normal(p.data, mean=0.0, std=0.02)
+
+    def get_attention_mask(self, item_seq, bidirectional=False):
+        """Kept for callers of the reference API; the fused attention takes the key-valid vector instead."""
+        m = (item_seq != 0).unsqueeze(1).unsqueeze(2)
+        if not bidirectional:
+            m = torch.tril(m.expand((-1, -1, item_seq.size(-1), -1)))
+        return m
+
+    # ------------------------------------------------------------------------------------------
+    # encoder + heads
+    # ------------------------------------------------------------------------------------------
+    def _encode(self, x, key_valid):
+        """x [B,L,D] fp32, key_valid [B,L] uint8 -> [B,L,D] fp32 (reference hstu.py:221-328)."""
+        from REC.model.hstu_functional import HSTUCoreFn, LayerNormFn
+        B, L, D = x.shape
+        x2 = x.reshape(B * L, D)
+        p = self._linear_dropout_rate if self.training else 0.0
+        for i, layer in enumerate(self._hstu._attention_layers):
+            xn = LayerNormFn.apply(x2, layer._eps)
+            h = xn @ layer._uvqk.to(torch.bfloat16)
+            seed = (self._step_seed * 1000003 + i * 7919 + self.rank * 104729) & 0x7FFFFFFFFFFFFFFF
+            o = HSTUCoreFn.apply(h, key_valid, B, L, self._num_heads, self._dqk, layer._eps, p, seed)
+            y = F.linear(o, layer._o.weight.to(torch.bfloat16), layer._o.bias.to(torch.bfloat16))
+            x2 = x2 + y.float()
+        return x2.view(B, L, D)
+
+    def _heads(self, x):
+        """x [..., D] fp32 -> [..., H, D] fp32 (reference hstu.py:652-667, 915-931).  bf16 GEMMs, fp32 residual,
+        like the reference under bf16-mixed autocast."""
+        S, C = self.num_segment_head, self.num_prior_head
+        with torch.autocast(device_type=x.device.type, dtype=torch.bfloat16, enabled=x.is_cuda):
+            if self.medusa_num_layers > 0 and self.head_interaction == 'hierarchical':
+                cat = [self.medusa_cat_head[c](x) for c in range(C)]
+                outs = []
+                for s in range(S):
+                    bias = self.segment_emb.weight[s] if self.use_seg_embed else None
+                    for c in range(C):
+                        h_in = cat[c] if bias is None else cat[c] + bias
+                        outs.append(self.medusa_seg_head[c][s](h_in))
+            else:
+                outs = [head(x) for head in self.medusa_head]
+        return torch.stack([o.float() for o in outs], dim=-2)
+
+    # ------------------------------------------------------------------------------------------
+    # training
+    # ------------------------------------------------------------------------------------------
+    def _token_tables(self, B, device, head_for_p):
+        """Static [B,P,L] index tables: query row in head_embs.view(-1,D), target row in e.view(-1,D), offset p."""
+        key = (B, device, tuple(head_for_p.tolist()))
+        if key not in self._tok_cache:
+            L, P, H = self.max_seq_length, self.pred_len, self.medusa_num_heads
+            b = torch.arange(B, device=device)[:, None, None]
+            p = torch.arange(P, device=device)[None, :, None]
+            l = torch.arange(L, device=device)[None, None, :]
+            hp = head_for_p.to(device)[None, :, None]
+            q_all = ((b * H + hp) * L + l).expand(B, P, L).reshape(-1).int()
+            p_all = (b * (L + P) + l + 1 + p).expand(B, P, L).reshape(-1).int()
+            o_all = p.expand(B, P, L).reshape(-1).long()
+            self._tok_cache[key] = (q_all, p_all, o_all)
+        return self._tok_cache[key]
+
+    def _pool_loss(self, head_rows, e_rows, negs_n, valid, head_for_p, want_logs):
+        """Sum over offsets of lambda_p * mean_{tokens of p} loss, for one negative pool / one token mask.
+        Returns (per_pred_loss [P] fp32, logs or None).  No host sync: compaction by scatter at fixed capacity."""
+        from REC.model.hstu_functional import NceLossFn
+        B, P, L = valid.shape
+        dev = valid.device
+        cap = B * P * L
+        q_all, p_all, o_all = self._token_tables(B, dev, head_for_p)
+        m = valid.reshape(-1)
+        pos = torch.cumsum(m, 0) - 1
+        n_tok = m.sum().to(torch.int32).view(1)
+        tgt = torch.where(m, pos, torch.full_like(pos, cap))
+        q_idx = torch.zeros(cap + 1, dtype=torch.int32, device=dev).scatter_(0, tgt, q_all)[:cap].contiguous()
+        p_idx = torch.zeros(cap + 1, dtype=torch.int32, device=dev).scatter_(0, tgt, p_all)[:cap].contiguous()
+        o_idx = torch.zeros(cap + 1, dtype=torch.long, device=dev).scatter_(0, tgt, o_all)[:cap]
+        logs = {} if want_logs else None
+        loss_tok = NceLossFn.apply(head_rows, e_rows, negs_n, self.logit_scale, q_idx, p_idx, n_tok, cap,
+                                   float(self.nce_thres), want_logs, logs)
+        loss_tok = loss_tok[:cap]
+        live = (torch.arange(cap, device=dev) < n_tok).float()
+        sum_p = torch.zeros(P, dtype=torch.float32, device=dev).index_add_(0, o_idx, loss_tok)
+        cnt_p = torch.zeros(P, dtype=torch.float32, device=dev).index_add_(0, o_idx, live)
+        mean_p = sum_p / cnt_p.clamp_min(1.0)
+        out_logs = None
+        if want_logs:
+            first = live * (o_idx == 0).float()                     # tokens of prediction offset 0
+            n0 = first.sum().clamp_min(1.0)
+            out_logs = {'nce_samples': (logs["n_valid"][:cap].float() * first).sum() / n0}
+            for k in (1, 5, 10, 50, 100):
+                if k > negs_n.shape[0] + 1:
+                    break
+                out_logs[f'nce_top{k}_acc'] = ((logs["rank"][:cap] < k).float() * first).sum() / n0
+        return self.horizon_discount.float() * mean_p, out_logs
+
+    def forward(self, interaction):
+        from REC.model.hstu_functional import EmbeddingGatherFn, L2NormFn
+        items, neg_items, user_mask, pos_tags = interaction
+        if not items.is_cuda:
+            raise RuntimeError("HSTU.forward runs on the MI355X only (no CPU path); move the batch to the GPU")
+        dev = items.device
+        B = items.shape[0]
+        L, P, D = self.max_seq_length, self.pred_len, self._hstu_embedding_dim
+        S, C, H = self.num_segment_head, self.num_prior_head, self.medusa_num_heads
+        mask = user_mask.bool()
+        additive = self.head_interaction == 'additive'
+        self._step_seed += 1
+        if isinstance(self.logit_scale, nn.Parameter):
+            with torch.no_grad():
+                self.logit_scale.clamp_(0, math.log(100))                # reference hstu.py:601-602 (in place)
+
+        # which negative pools the loss reads (reference hstu.py:669-670, 751-752); ids are shared across ranks
+        pools = []
+        if (not self.neg_sample_by_cat) or (self.loss == 'prior' and additive):
+            pools.append(neg_items.shape[1] - 1)
+        if self.loss == 'prior' and self.neg_sample_by_cat:
+            pools += list(range(C))
+        pool_ids = [all_gather_ids(neg_items[:, p].contiguous()).reshape(-1) for p in pools]
+        n_item_ids = B * (L + P)
+        ids_all = torch.cat([items.reshape(-1)] + pool_ids).contiguous()
+        fused_pos = isinstance(self.item_id_proj_tower, nn.Identity)
+        rows_all, x = EmbeddingGatherFn.apply(self.item_embedding.weight, self.position_embedding.weight, ids_all,
+                                              n_item_ids, L, L + P, self)
+        if not fused_pos:
+            rows_all = self.item_id_proj_tower(rows_all)
+            x = rows_all[:n_item_ids].view(B, L + P, D)[:, :L] + self.position_embedding.weight[:L][None]
+        e_rows = rows_all[:n_item_ids]                                   # targets, [B*(L+P), D] fp32
+        negs = {}
+        off = n_item_ids
+        for p, ids in zip(pools, pool_ids):
+            negs[p] = L2NormFn.apply(rows_all[off:off + ids.numel()].contiguous())
+            off += ids.numel()
+
+        key_valid = mask[:, :L].to(torch.uint8).contiguous()
+        out = self._encode(x, key_valid)                                 # [B,L,D] fp32
+        head_embs = self._heads(out).permute(0, 2, 1, 3).contiguous()     # [B,H,L,D]
+        head_rows = head_embs.view(-1, D)
+
+        idx = torch.arange(L, device=dev)[None, :] + 1 + torch.arange(P, device=dev)[:, None]      # [P,L]
+        base_valid = mask[:, None, :L] & mask[:, idx]                                              # [B,P,L]
+        model_out = defaultdict(float)
+        total = torch.zeros((), dtype=torch.float32, device=dev)
+
+        if self.loss == 'nce' or (self.loss == 'prior' and additive):
+            head_for_p = torch.arange(P) // self.seg_len
+            per_p, logs = self._pool_loss(head_rows, e_rows, negs[pools[0]], base_valid, head_for_p, True)
+            total = total + per_p.sum()
+            seg = per_p.detach().view(S, self.seg_len).sum(dim=1)
+            for s in range(S):
+                model_out[f"seg_{s}_loss"] = seg[s]
+            model_out.update(logs)
+
+        if self.loss == 'prior':
+            seg_len = P if additive else self.seg_len
+            seg_for_p = torch.arange(P) // seg_len
+            accum = torch.zeros(P, dtype=torch.float32, device=dev)
+            tag_win = pos_tags[:, idx].bool()                                                      # [B,P,L,C]
+            for c in range(C):
+                name = self.int_to_category[c]
+                valid = base_valid & tag_win[..., c]
+                if self.pos_sample_mix_ratio > 0.0:
+                    valid = base_valid & (tag_win[..., c] | (torch.rand(valid.shape, device=dev) < self.pos_sample_mix_ratio))
+                head_for_p = torch.full((P,), S + c) if additive else seg_for_p * C + c
+                pool = c if self.neg_sample_by_cat else pools[0]
+                per_p, logs = self._pool_loss(head_rows, e_rows, negs[pool], valid, head_for_p, c == 0)
+                per_p = per_p * self.prior_loss_weight[c]
+                total = total + per_p.sum()
+                accum = accum + per_p.detach()
+                model_out[f'head_nce_{name}_loss'] = per_p.sum().detach()
+                if c == 0:
+                    model_out.update(logs)
+            if not additive:
+                seg = accum.view(S, self.seg_len).sum(dim=1)
+                for s in range(S):
+                    model_out[f"seg_{s}_loss"] = model_out[f"seg_{s}_loss"] + seg[s]
+            else:
+                total = total / 2
+        model_out["loss"] = total
+        return model_out
+
+    def finish_sparse_grad(self):
+        """The item table's gradient of the last backward as a SparseRowGrad (after the cross-rank exchange when
+        data parallel).  Called by the fused optimizer."""
+        if self._pending_rows is not None:
+            from REC.model.hstu_functional import reduce_pending_rows
+            reduce_pending_rows(self)
+        return self.sparse_grad
+
+    # ------------------------------------------------------------------------------------------
+    # evaluation
+    # ------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def compute_item_all(self):
+        """L2-normalised (projected) item table, fp32 [N, D] (reference hstu.py:1018-1021)."""
+        from mhr_amd import ops
+        w = self.item_id_proj_tower(self.item_embedding.weight)
+        return ops.l2norm_rows(w.contiguous(), torch.float32)
+
+    @torch.no_grad()
+    def _user_heads(self, item_seq):
+        """[B,L] ids (front zero padded) -> L2-normalised head embeddings [B,H,D] fp32 (reference hstu.py:879-966)."""
+        from mhr_amd import ops
+        B, L = item_seq.shape
+        D = self._hstu_embedding_dim
+        if isinstance(self.item_id_proj_tower, nn.Identity):
+            _, x = ops.embedding_gather(self.item_embedding.weight, item_seq.contiguous(), torch.float32,
+                                        self.position_embedding.weight, L, torch.float32, want_rows=False)
+        else:
+            rows, _ = ops.embedding_gather(self.item_embedding.weight, item_seq.contiguous(), torch.float32)
+            x = self.item_id_proj_tower(rows) + self.position_embedding.weight[:L][None]
+        was_training = self.training
+        self.eval()
+        out = self._encode(x, (item_seq != 0).to(torch.uint8).contiguous())
+        self.train(was_training)
+        heads = self._heads(out[:, -1])                                   # [B,H,D]
+        return ops.l2norm_rows(heads.contiguous(), torch.float32)
+
+    def _row_constraints(self, B, target_tags, device):
+        """Per (user, head) admissible-category bit (int32 bit pattern): bit c for prior heads, bit 31 for
+        unconstrained heads, 0 for heads switched off by `prior_given_at_test` (reference hstu.py:982-999)."""
+        S, C, H = self.num_segment_head, self.num_prior_head, self.medusa_num_heads
+        if self.loss != 'prior':
+            return torch.full((B * H,), -(1 << 31), dtype=torch.int32, device=device)
+        additive = self.head_interaction == 'additive'
+        cat_of_head = torch.tensor([(h - S if h >= S else -1) if additive else h % C for h in range(H)], device=device)
+        bits = torch.where(cat_of_head >= 0, torch.ones_like(cat_of_head) << cat_of_head.clamp_min(0),
+                           torch.full_like(cat_of_head, -(1 << 31)))
+        bits = bits[None, :].expand(B, H).clone()
+        if self.prior_given_at_test:
+            given = target_tags[:, :self.given_prior_len].bool().any(dim=1)                       # [B,C]
+            on = torch.where(cat_of_head[None, :] >= 0, given[:, cat_of_head.clamp_min(0)], torch.ones_like(bits, dtype=torch.bool))
+            bits = torch.where(on, bits, torch.zeros_like(bits))
+        return bits.reshape(-1).to(torch.int32)
+
+    @staticmethod
+    def pack_item_tags(all_item_tags):
+        """[C,N] {0,1} -> [N] int32 bit patterns, bit 31 always set (C <= 31)."""
+        C, N = all_item_tags.shape
+        w = (1 << torch.arange(C, device=all_item_tags.device, dtype=torch.int64))[:, None]
+        bits = (all_item_tags.bool().long() * w).sum(0) | (1 << 31)
+        return torch.where(bits >= (1 << 31), bits - (1 << 32), bits).to(torch.int32)
+
+    @torch.no_grad()
+    def predict_topk(self, item_seq, all_item_feature, all_item_tags, target_tags, history=None, k=200,
+                     suppress_history=True, stats=None):
+        """Fused eval: encoder -> heads -> catalog scoring with tag / pad / history masks -> exact per-head top-k.
+        Replaces reference hstu.py:965-1015 + trainer.py:724-726 + collector.py:245 without the [B,H,N] tensor."""
+        from mhr_amd import ops
+        B = item_seq.shape[0]
+        H = self.medusa_num_heads
+        dev = item_seq.device
+        users = self._user_heads(item_seq).to(torch.bfloat16).view(B * H, -1).contiguous()
+        key = (all_item_feature.data_ptr(), all_item_feature._version, None if all_item_tags is None else all_item_tags.data_ptr())
+        if self._item_cache is None or self._item_cache[0] != key:
+            items_bf = ops.l2norm_rows(all_item_feature.float().contiguous(), torch.bfloat16)      # hstu.py:974-975
+            tag_bits = self.pack_item_tags(all_item_tags) if (all_item_tags is not None and self.loss == 'prior') else None
+            self._item_cache = (key, items_bf, tag_bits)
+        _, items_bf, tag_bits = self._item_cache
+        row_bits = self._row_constraints(B, target_tags, dev)
+        hist_ptr = hist_items = None
+        if suppress_history and history is not None and history[0].numel() > 0:
+            hu, hi = history[0].to(dev), history[1].to(dev)
+            order = torch.argsort(hu * self.item_num + hi)
+            hist_items = hi[order].contiguous()
+            hist_ptr = torch.zeros(B + 1, dtype=torch.int32, device=dev)
+            hist_ptr[1:] = torch.cumsum(torch.bincount(hu, minlength=B), 0).int()
+        vals, idx = ops.catalog_topk(users, H, items_bf, tag_bits, row_bits, hist_ptr, hist_items, k, stats=stats)
+        return FusedTopK(vals.view(B, H, k), idx.view(B, H, k))
+
+    @torch.no_grad()
+    def predict(self, item_seq, time_seq, all_item_feature, all_item_tags, target_tags, save_for_eval=False):
+        """Reference contract: dense scores [B,H,N] fp32 with -inf masks (hstu.py:874-1016).  Kept for callers
+        written against the reference; the fused path is `predict_topk`."""
+        S, C = self.num_segment_head, self.num_prior_head
+        heads = self._user_heads(item_seq)                                                          # [B,H,D] fp32
+        feat = all_item_feature.float()
+        feat = feat / feat.norm(dim=-1, keepdim=True)
+        scores = torch.matmul(heads, feat.t())
+        if self.loss == 'prior':
+            additive = self.head_interaction == 'additive'
+            if self.prior_given_at_test:
+                given = target_tags[:, :self.given_prior_len].bool().any(dim=1)
+                if additive:
+                    scores[:, S:].masked_fill_(~given.unsqueeze(-1), float('-inf'))
+                else:
+                    scores.masked_fill_(~given.repeat(1, S).unsqueeze(-1), float('-inf'))
+            tagm = all_item_tags.bool()
+            if additive:
+                scores[:, S:].masked_fill_(~tagm.unsqueeze(0), float('-inf'))
+            else:
+                scores.masked_fill_(~tagm.repeat(S, 1).unsqueeze(0), float('-inf'))
+        wandb_logs = {'num_samples': self.eval_pred_len * item_seq.shape[0]}
+        saved_user = saved_head = None
+        if save_for_eval:
+            saved_head = heads.float().cpu().numpy()
+        return scores, wandb_logs, saved_user, saved_head

@@ -1,0 +1,197 @@
+"""Autograd glue between the reference-shaped HSTU module and the gfx950 kernels (mhr_amd.ops).
+
+Each Function's forward/backward enqueues hand-written HIP kernels on the current stream; the dense
+projections between them are plain library GEMMs (torch.matmul -> hipBLASLt) as SURVEY.md section 2.3 plans.
+Mixed precision follows the reference's Fabric `bf16-mixed` run: fp32 master weights and residual stream,
+bf16 GEMM operands, fp32 statistics / loss.
+"""
+import torch
+from torch.autograd import Function
+
+from mhr_amd import ops
+
+
+class LayerNormFn(Function):
+    """Affine-free LayerNorm, fp32 in -> bf16 out (reference model/IDNet/hstu.py:213-214, 241)."""
+
+    @staticmethod
+    def forward(ctx, x, eps):
+        y, mean, rstd = ops.layernorm_fwd(x, torch.bfloat16, eps)
+        ctx.save_for_backward(x, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd = ctx.saved_tensors
+        return ops.layernorm_bwd(dy.contiguous(), x, mean, rstd, dx_dtype=torch.float32), None
+
+
+class HSTUCoreFn(Function):
+    """h = LN(x) @ W_uvqk (pre-activation, [B*L, 4D] bf16)  ->  o = silu(u) * LN(attn(silu(q), silu(k), silu(v))) * drop.
+
+    Fuses reference hstu.py:244-285 minus the two GEMMs: the SiLU of the uvqk product is applied on load inside
+    the attention and gate kernels, the [B,H,L,L] score tensor is never formed, and the backward writes all four
+    column blocks of dh in place (du from the gate kernel, dv|dq|dk from the attention kernel).
+    """
+
+    @staticmethod
+    def forward(ctx, h, key_valid, B, L, n_heads, head_dim, eps, dropout_p, seed):
+        D = n_heads * head_dim
+        a, act = ops.hstu_attn_fwd(h, key_valid, B, L, n_heads, head_dim, apply_silu=True, save_act=True)
+        o, mean, rstd = ops.ln_gate_fwd(h, a, D, torch.bfloat16, eps, dropout_p, seed)
+        ctx.save_for_backward(h, key_valid, a, act, mean, rstd)
+        ctx.cfg = (B, L, n_heads, head_dim, dropout_p, seed)
+        return o
+
+    @staticmethod
+    def backward(ctx, d_o):
+        h, key_valid, a, act, mean, rstd = ctx.saved_tensors
+        B, L, n_heads, head_dim, dropout_p, seed = ctx.cfg
+        D = n_heads * head_dim
+        dh = torch.empty_like(h)
+        da = ops.ln_gate_bwd(d_o.contiguous(), h, a, mean, rstd, dh, D, dropout_p, seed)
+        ops.hstu_attn_bwd(h, act, key_valid, da, dh, B, L, n_heads, head_dim, apply_silu=True)
+        return dh, None, None, None, None, None, None, None, None
+
+
+class SparseRowGrad:
+    """Gradient of the item table as (sorted ids, summed rows): what `EmbeddingGatherFn.backward` leaves on the
+    module instead of a dense [item_num, D] tensor.  `rows[i]` is valid where `sorted_ids[i]` starts a segment;
+    `row_slot[id]` points at it (and is reset by the fused Adam)."""
+    __slots__ = ("sorted_ids", "rows", "row_slot", "n_rows")
+
+    def __init__(self, sorted_ids, rows, row_slot, n_rows):
+        self.sorted_ids, self.rows, self.row_slot, self.n_rows = sorted_ids, rows, row_slot, n_rows
+
+    def to_dense(self):
+        """Dense [n_rows, D] view of the gradient (tests / reference-style optimizers)."""
+        head = torch.ones_like(self.sorted_ids, dtype=torch.bool)
+        head[1:] = self.sorted_ids[1:] != self.sorted_ids[:-1]
+        dense = torch.zeros(self.n_rows, self.rows.shape[1], dtype=torch.float32, device=self.rows.device)
+        dense[self.sorted_ids[head]] = self.rows[head]
+        return dense
+
+
+class EmbeddingGatherFn(Function):
+    """rows = table[ids_all] (fp32) and x = table[items[:, :L]] + pos[:L] in one pass over the ids
+    (reference hstu.py:637-643, 670, 752).  ids_all = [items.flatten(), negative ids...].
+
+    Backward: deterministic sparse reduction (sort + segment-sum kernel) into `holder.sparse_grad`; with
+    holder.dense_grad=True the reference's dense `weight.grad` is produced instead (float-atomic scatter-add).
+    """
+
+    @staticmethod
+    def forward(ctx, table, pos_table, ids_all, n_item_ids, L, window, holder):
+        D = table.shape[1]
+        rows = torch.empty(ids_all.numel(), D, dtype=torch.float32, device=table.device)
+        B = n_item_ids // window
+        # items part with the fused position add
+        items = ids_all[:n_item_ids].view(B, window)
+        r_items, x = ops.embedding_gather(table, items, torch.float32, pos_table, L, torch.float32)
+        rows[:n_item_ids] = r_items.view(-1, D)
+        if ids_all.numel() > n_item_ids:
+            r_neg, _ = ops.embedding_gather(table, ids_all[n_item_ids:].contiguous(), torch.float32)
+            rows[n_item_ids:] = r_neg
+        ctx.save_for_backward(ids_all)
+        ctx.meta = (n_item_ids, L, window, holder, table.shape[0], D)
+        return rows, x
+
+    @staticmethod
+    def backward(ctx, d_rows, d_x):
+        (ids_all,) = ctx.saved_tensors
+        n_item_ids, L, window, holder, n_rows, D = ctx.meta
+        dev = ids_all.device
+        d_rows = d_rows.contiguous() if d_rows is not None else torch.zeros(ids_all.numel(), D, device=dev)
+        d_x = d_x.contiguous() if d_x is not None else None
+        d_pos = None
+        if d_x is not None:
+            d_pos = torch.zeros(holder.position_embedding.weight.shape, dtype=torch.float32, device=dev)
+            d_pos[:L] = d_x.sum(dim=0)
+        if getattr(holder, "dense_embedding_grad", False):
+            gt = torch.zeros(n_rows, D, dtype=torch.float32, device=dev)
+            ops.embedding_scatter_add(d_rows, ids_all, gt)
+            if d_x is not None:
+                ops.embedding_scatter_add(d_x.view(-1, D), ids_all[:n_item_ids].view(-1, window)[:, :L].contiguous().view(-1), gt)
+            return gt, d_pos, None, None, None, None, None
+        if holder._row_slot is None or holder._row_slot.numel() != n_rows:
+            holder._row_slot = torch.full((n_rows,), -1, dtype=torch.int32, device=dev)
+        from mhr_amd import distributed as dist_
+        if dist_.world_size() > 1:
+            # data parallel: fold the input-side gradient into the rows and defer the reduction until the
+            # cross-rank exchange (HSTU.finish_sparse_grad, called by the optimizer)
+            if d_x is not None:
+                d_rows[:n_item_ids].view(-1, window, D)[:, :L] += d_x
+            holder._pending_rows = (ids_all, d_rows, n_item_ids)
+            holder.sparse_grad = None
+            return None, d_pos, None, None, None, None, None
+        sorted_ids, perm = torch.sort(ids_all)
+        out_rows = torch.empty(ids_all.numel(), D, dtype=torch.float32, device=dev)
+        ga, gb = d_rows[:n_item_ids], (d_rows[n_item_ids:] if ids_all.numel() > n_item_ids else None)
+        ops.sparse_rows_segment_sum(sorted_ids, perm, ga, gb, d_x, L, window, out_rows, holder._row_slot)
+        holder.sparse_grad = SparseRowGrad(sorted_ids, out_rows, holder._row_slot, n_rows)
+        return None, d_pos, None, None, None, None, None
+
+
+def reduce_pending_rows(holder):
+    """Data-parallel tail of the embedding backward: exchange rows over RCCL, then the deterministic segment-sum."""
+    from mhr_amd import distributed as dist_
+    ids_all, d_rows, n_private = holder._pending_rows
+    holder._pending_rows = None
+    ids, rows = dist_.exchange_sparse_rows(ids_all, d_rows, n_private)
+    sorted_ids, perm = torch.sort(ids)
+    out_rows = torch.empty(ids.numel(), rows.shape[1], dtype=torch.float32, device=rows.device)
+    ops.sparse_rows_segment_sum(sorted_ids, perm, rows.contiguous(), None, None, 0, 0, out_rows, holder._row_slot)
+    holder.sparse_grad = SparseRowGrad(sorted_ids, out_rows, holder._row_slot, holder._row_slot.numel())
+    return holder.sparse_grad
+
+
+class L2NormFn(Function):
+    """y = x / ||x|| in fp32, emitted as bf16 for the MFMA operand (reference hstu.py:672, 754)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        y, norms = ops.l2norm_rows(x, torch.bfloat16, want_norms=True)
+        ctx.save_for_backward(x, norms)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, norms = ctx.saved_tensors
+        n = x / norms[:, None]
+        dy = dy.float()
+        return (dy - n * (n * dy).sum(-1, keepdim=True)) / norms[:, None]
+
+
+class NceLossFn(Function):
+    """Per-token sampled-softmax loss for one negative pool (reference hstu.py:600-619 + cross_entropy).
+
+    q_rows [Rq, D] / p_rows [Rp, D] fp32 (raw head embeddings / target embeddings), token t pairs
+    q_rows[q_idx[t]] with p_rows[p_idx[t]]; negs [n_neg, D] bf16 normalised.  Returns loss [tok_cap] fp32
+    (zeros beyond *n_tok).  No [N_tok, n_neg] tensor is ever materialised.
+    """
+
+    @staticmethod
+    def forward(ctx, q_rows, p_rows, negs, logit_scale, q_idx, p_idx, n_tok_dev, tok_cap, thres, want_logs, logs_out):
+        sv = ops.nce_fwd(q_rows, q_idx, p_rows, p_idx, negs, n_tok_dev, tok_cap, logit_scale.detach().view(1), thres,
+                         want_logs=want_logs, for_backward=True)
+        ctx.sv = sv
+        ctx.save_for_backward(q_idx, p_idx, logit_scale)
+        ctx.shapes = (q_rows.shape, p_rows.shape)
+        if want_logs and logs_out is not None:
+            logs_out["n_valid"], logs_out["rank"] = sv.n_valid, sv.rank
+        return sv.loss
+
+    @staticmethod
+    def backward(ctx, d_loss):
+        q_idx, p_idx, logit_scale = ctx.saved_tensors
+        sv = ctx.sv
+        q_shape, p_shape = ctx.shapes
+        dq_tok, dp_tok, d_negs, d_ls = ops.nce_bwd(sv, d_loss.contiguous().float(), logit_scale.detach().view(1))
+        dq = torch.zeros(q_shape, dtype=torch.float32, device=dq_tok.device)
+        dp = torch.zeros(p_shape, dtype=torch.float32, device=dq_tok.device)
+        # several tokens share a head row / a target row: accumulate (rows beyond n_tok are zero)
+        n = q_idx.numel()
+        dq.index_add_(0, q_idx.long(), dq_tok[:n])
+        dp.index_add_(0, p_idx.long(), dp_tok[:n])
+        ctx.sv = None
+        return dq, dp, d_negs, d_ls.view(logit_scale.shape), None, None, None, None, None, None, None

@@ -1,0 +1,200 @@
+"""Trainer for the fused HSTU path: same `Trainer(config)`, `setup_model`, `fit`, `evaluate` surface and log keys as
+the reference (`code/REC/trainer/trainer.py:55-1153`) without DeepSpeed / Lightning / wandb: plain data-parallel
+replicas over RCCL, the fused AdamW, a cosine warm-up schedule, and the fused multi-head decode in evaluation.
+
+Per train step (reference trainer.py:494-536): model(batch) -> loss.backward() -> [RCCL: dense bucket all-reduce +
+sparse row exchange] -> fused Adam (flat dense params + item table) -> lr schedule.  The reference's two
+`losses.item()` per step are replaced by logging every `update_interval` steps.
+Per eval batch (trainer.py:698-729, 985-990): predict_topk (scores never materialised) -> merge/dedup -> hit matrix.
+"""
+import math
+import os
+import time
+from collections import OrderedDict, defaultdict
+from logging import getLogger
+
+import numpy as np
+import torch
+
+from REC.evaluator import Collector, Evaluator
+from REC.utils import early_stopping
+from REC.utils.lr_scheduler import cosine_warmup_factor
+
+
+class Trainer(object):
+    def __init__(self, config):
+        self.config = config
+        self.logger = getLogger()
+        self.eval_pred_len = config["eval_pred_len"]
+        self.metrics_pred_len_list = config["metrics_pred_len_list"]
+        self.optim_args = config["optim_args"]
+        self.stopping_step = config["stopping_step"]
+        self.valid_metric = (config["valid_metric"] or "NDCG@10").lower()
+        self.valid_metric_bigger = config.get("valid_metric_bigger", True)
+        self.device = config["device"]
+        self.rank = torch.distributed.get_rank() if torch.distributed.is_initialized() else 0
+        self.world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
+        self.total_iters = config["total_iters"]
+        self.accumulate_grad = config.get("accumulate_grad", 1)
+        self.update_interval = config["update_interval"] if config["update_interval"] else 20
+        self.eval_interval = config["eval_interval"]
+        self.scheduler_config = config["scheduler_args"]
+        self.checkpoint_dir = config["checkpoint_dir"]
+        self.saved_model_name = f'{config["model"]}-{config["dataset"]}-{config["save_model_note"]}.pth'
+        self.train_step = 0
+        self.no_improve_times = 0
+        self.best_valid_score = -np.inf if self.valid_metric_bigger else np.inf
+        self.best_valid_result = None
+        self.eval_collector = Collector(config)
+        self.evaluator = Evaluator(config)
+        self.item_feature = None
+        self.all_item_tags = None
+        self.eval_by_cat = config.get("eval_by_cat", True) and config["eval_num_cats"] > 1
+        self.outlier_user_metrics = config["outlier_user_metrics"]
+
+    # ------------------------------------------------------------------------------------------
+    def setup_model(self, model):
+        from mhr_amd.optim import FusedAdamW
+        self.model = model
+        self.optimizer = FusedAdamW(model, lr=self.optim_args['learning_rate'], weight_decay=self.optim_args['weight_decay'])
+
+    def _lr_at(self, step):
+        base = self.optim_args['learning_rate']
+        if not self.scheduler_config:
+            return base
+        warm = self.total_iters * self.scheduler_config.get("warmup", 0.001)
+        return base * cosine_warmup_factor(step, warm, self.total_iters)
+
+    def _check_nan(self, loss):
+        if torch.isnan(loss):
+            raise ValueError('Training loss is nan')
+
+    def train_step_fn(self, data):
+        """One optimisation step (forward, backward, exchange, fused Adam).  Returns the model_out dict (device tensors)."""
+        self.optimizer.param_groups[0]["lr"] = self._lr_at(self.train_step)
+        model_out = self.model(data)
+        loss = model_out["loss"]
+        (loss / self.accumulate_grad).backward()
+        self.train_step += 1
+        self.optimizer.step()
+        self.optimizer.zero_grad()
+        return model_out
+
+    def fit(self, train_data, valid_data=None, verbose=True, saved=True, show_progress=False, callback_fn=None):
+        self.model.train()
+        iterator = iter(train_data)
+        t0 = time.time()
+        running = None
+        for it in range(self.train_step, self.total_iters):
+            try:
+                data = next(iterator)
+            except StopIteration:
+                iterator = iter(train_data)
+                data = next(iterator)
+            data = tuple(d.to(self.device, non_blocking=True) for d in data)
+            out = self.train_step_fn(data)
+            running = out
+            if verbose and self.train_step % self.update_interval == 0:
+                loss = out["loss"].item()                                   # the only host sync of the train loop
+                self._check_nan(out["loss"])
+                if self.rank == 0:
+                    extra = {k: (float(v) if torch.is_tensor(v) else v) for k, v in out.items() if k != "loss"}
+                    self.logger.info(f"step {self.train_step} loss {loss:.4f} lr {self.optimizer.param_groups[0]['lr']:.3e} "
+                                     f"{(time.time() - t0) / self.train_step:.3f}s/step {extra}")
+            if valid_data is not None and self.eval_interval and self.train_step % self.eval_interval == 0:
+                result = self.evaluate(valid_data, load_best_model=False)
+                key = f"pred_{self.metrics_pred_len_list[-1]}"
+                score = result[key].get(self.valid_metric, 0.0)
+                self.best_valid_score, self.no_improve_times, stop, update = early_stopping(
+                    score, self.best_valid_score, self.no_improve_times, self.stopping_step, self.valid_metric_bigger)
+                if update:
+                    self.best_valid_result = result
+                    if saved and self.checkpoint_dir:
+                        self._save_checkpoint()
+                if callback_fn:
+                    callback_fn(self.train_step, score)
+                self.model.train()
+                if stop:
+                    break
+        return self.best_valid_score, self.best_valid_result
+
+    def _save_checkpoint(self):
+        """DP replicas are identical: rank 0 writes model + optimizer state (reference trainer.py:319-340)."""
+        if self.rank == 0:
+            os.makedirs(self.checkpoint_dir, exist_ok=True)
+            torch.save({"model": self.model.state_dict(), "optimizer": self.optimizer.state_dict(), "iter_idx": self.train_step,
+                        "best_valid_score": self.best_valid_score}, os.path.join(self.checkpoint_dir, self.saved_model_name))
+        if self.world > 1:
+            torch.distributed.barrier()
+
+    def resume(self, path):
+        ck = torch.load(path, map_location=self.device, weights_only=True)
+        self.model.load_state_dict(ck["model"])
+        self.optimizer.load_state_dict(ck["optimizer"])
+        self.train_step = int(ck["iter_idx"])
+        self.best_valid_score = ck["best_valid_score"]
+
+    # ------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def compute_item_feature(self, item_tags):
+        """item_tags [N, C] (the data layer's multi-hot) -> cached item table + [C, N] tags (reference trainer.py:731-824)."""
+        self.model.eval()
+        self.item_feature = self.model.module.compute_item_all()
+        self.eval_collector.set_all_tags(item_tags.long())
+        self.all_item_tags = item_tags.long().transpose(0, 1).contiguous()
+
+    @torch.no_grad()
+    def _full_sort_batch_eval(self, batched_data, stats=None):
+        _, item_seq, item_target, history_index, positive_u, time_seq, target_tags, outlier_users = batched_data
+        dev = self.device
+        item_seq, item_target, target_tags = item_seq.to(dev), item_target.to(dev), target_tags.to(dev)
+        hist = history_index if self.config.get("suppress_history", True) else None
+        fused = self.model.module.predict_topk(item_seq, self.item_feature, self.all_item_tags, target_tags, hist,
+                                               k=max(self.config["topk"]), stats=stats)
+        return fused, positive_u, item_target, target_tags, outlier_users
+
+    @torch.no_grad()
+    def evaluate(self, eval_data, load_best_model=False, show_progress=False, init_model=False, item_tags=None):
+        self.model.eval()
+        if item_tags is None:
+            item_tags = eval_data.item_tags
+        self.compute_item_feature(item_tags)
+        n_local = 0
+        for batched in eval_data:
+            fused, positive_u, positive_i, target_tags, outlier = self._full_sort_batch_eval(batched)
+            self.eval_collector.eval_batch_collect(
+                fused, positive_u, positive_i, tag_category=target_tags if self.eval_by_cat else None,
+                outlier_users=outlier if self.outlier_user_metrics is not None else None)
+            n_local += positive_i.shape[0]
+        n_total = getattr(eval_data, "num_total_examples", None)
+        # metric sums -> one packed all-reduce (the reference reduces key by key, trainer.py:1109-1123)
+        results = OrderedDict()
+        struct = self.eval_collector.get_data_struct(-1)
+        results['shared'] = self.evaluator.evaluate(struct, pred_len=-1) if 'rec.rec_tags' in struct else OrderedDict()
+        self.eval_collector.reset_all_tags()
+        for p in self.metrics_pred_len_list:
+            results[f"pred_{p}"] = self.evaluator.evaluate(self.eval_collector.get_data_struct(p), pred_len=p)
+        flat, layout = [float(n_local)], []
+        for name, res in results.items():
+            for k in sorted(res.keys()):
+                v = res[k]
+                if isinstance(v, tuple):
+                    flat += [float(v[0]), float(v[1])]
+                    layout.append((name, k, True))
+                else:
+                    flat.append(float(v))
+                    layout.append((name, k, False))
+        from mhr_amd import distributed as D
+        vec = D.allreduce_metric_sums(torch.tensor(flat, dtype=torch.float64, device=self.device)).tolist()
+        total = n_total if n_total is not None else vec[0]
+        dp = 5 if self.config["metric_decimal_place"] is None else self.config["metric_decimal_place"]
+        summary, i = OrderedDict((name, OrderedDict()) for name in results), 1
+        for name, k, is_tuple in layout:
+            if is_tuple:
+                summary[name][k] = round(vec[i] / max(1, vec[i + 1]), dp)
+                i += 2
+            else:
+                summary[name][k] = round(vec[i] / max(1, total), dp)
+                i += 1
+        self.model.train()
+        return summary

@@ -333,11 +333,13 @@ __global__ __launch_bounds__(256, 1) void nce_bwd_q_kernel(const bf16_t* __restr
     const bf16_t* NT = nts + cur * (T::DIM * NT_LD);
 #pragma unroll
     for (int dc = 0; dc < ND; ++dc) {
+      // MFMA is wave-wide: lanes whose feature column lies beyond DIM (only when DIM < 32) feed zeros
       const int d = dc * 32 + r;
-      if (ND * 32 == T::DIM || d < T::DIM) {
-        dq[dc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g0, read_nt_frag<NKS>(NT, d, 0, half), dq[dc], 0, 0, 0);
-        dq[dc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g1, read_nt_frag<NKS>(NT, d, 1, half), dq[dc], 0, 0, 0);
-      }
+      const bool dok = (ND * 32 == T::DIM) || d < T::DIM;
+      const bf16x8 b0 = dok ? read_nt_frag<NKS>(NT, d, 0, half) : sg::zero8();
+      const bf16x8 b1 = dok ? read_nt_frag<NKS>(NT, d, 1, half) : sg::zero8();
+      dq[dc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g0, b0, dq[dc], 0, 0, 0);
+      dq[dc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g1, b1, dq[dc], 0, 0, 0);
     }
     if (more) {
       st.store(tiles + (cur ^ 1) * T::BYTES);
@@ -490,10 +492,11 @@ __global__ __launch_bounds__(256, 1) void nce_bwd_n_kernel(const bf16_t* __restr
 #pragma unroll
     for (int dc = 0; dc < ND; ++dc) {
       const int d = dc * 32 + r;
-      if (ND * 32 == T::DIM || d < T::DIM) {
-        dn[dc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g0, read_nt_frag<NKS>(QT, d, 0, half), dn[dc], 0, 0, 0);
-        dn[dc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g1, read_nt_frag<NKS>(QT, d, 1, half), dn[dc], 0, 0, 0);
-      }
+      const bool dok = (ND * 32 == T::DIM) || d < T::DIM;
+      const bf16x8 b0 = dok ? read_nt_frag<NKS>(QT, d, 0, half) : sg::zero8();
+      const bf16x8 b1 = dok ? read_nt_frag<NKS>(QT, d, 1, half) : sg::zero8();
+      dn[dc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g0, b0, dn[dc], 0, 0, 0);
+      dn[dc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g1, b1, dn[dc], 0, 0, 0);
     }
     if (more) store_all(cur ^ 1);
     __syncthreads();
@@ -576,19 +579,44 @@ extern "C" int mhr_nce_fwd(const void* q_rows, const int32_t* q_idx, const void*
   return MHR_OK;
 }
 
-extern "C" int mhr_nce_bwd(const void* qn, const void* pn, const void* qnT, const void* negs, const void* negsT,
-                           int64_t negsT_ld, int n_neg, int dim, const int32_t* n_tok_dev, int tok_cap, const float* logit_scale_dev, float thres,
-                           const float* lse, const float* w, const float* q_inv, const float* p_inv, const float* s_pos,
-                           float* dq_tok, float* dp_tok, float* d_negs, float* d_logit_scale, void* stream) {
-  MHR_REQUIRE(qn && pn && qnT && negs && negsT && n_tok_dev && logit_scale_dev && lse && w && q_inv && p_inv && s_pos,
-              "nce_bwd: null input pointer");
-  MHR_REQUIRE(dq_tok && dp_tok && d_negs, "nce_bwd: null output pointer");
+extern "C" int mhr_nce_bwd_tokens(const void* qn, const void* pn, const void* negs, const void* negsT, int64_t negsT_ld,
+                                  int n_neg, int dim, const int32_t* n_tok_dev, int tok_cap, const float* logit_scale_dev,
+                                  float thres, const float* lse, const float* w, const float* q_inv, const float* p_inv,
+                                  const float* s_pos, float* dq_tok, float* dp_tok, float* d_logit_scale, void* stream) {
+  MHR_REQUIRE(qn && pn && negs && negsT && n_tok_dev && logit_scale_dev && lse && w && q_inv && p_inv && s_pos,
+              "nce_bwd_tokens: null input pointer");
+  MHR_REQUIRE(dq_tok && dp_tok, "nce_bwd_tokens: null output pointer");
   int nks;
-  MHR_REQUIRE(nks_for(dim, nks), "nce_bwd: dim=%d unsupported (16/32/64/128/256)", dim);
-  MHR_REQUIRE(n_neg > 0 && tok_cap > 0 && tok_cap % 4 == 0, "nce_bwd: bad sizes (tok_cap must be a multiple of 4)");
-  MHR_REQUIRE(negsT_ld >= n_neg && negsT_ld % 4 == 0, "nce_bwd: negsT_ld=%lld must be >= n_neg and a multiple of 4", (long long)negsT_ld);
+  MHR_REQUIRE(nks_for(dim, nks), "nce_bwd_tokens: dim=%d unsupported (16/32/64/128/256)", dim);
+  MHR_REQUIRE(n_neg > 0 && tok_cap > 0, "nce_bwd_tokens: bad sizes");
+  MHR_REQUIRE(negsT_ld >= n_neg && negsT_ld % 4 == 0, "nce_bwd_tokens: negsT_ld=%lld must be >= n_neg and a multiple of 4",
+              (long long)negsT_ld);
   hipStream_t s = (hipStream_t)stream;
   const int grid_q = (tok_cap + 127) / 128;
+#define L_(NKS)                                                                                                            \
+  {                                                                                                                        \
+    using T = sg::Tile<NKS>;                                                                                               \
+    size_t lds_q = 2 * T::BYTES + 2 * (size_t)T::DIM * NT_LD * 2;                                                          \
+    auto kq = nce_bwd_q_kernel<NKS>;                                                                                       \
+    if (lds_q > 64 * 1024) (void)hipFuncSetAttribute((const void*)kq, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q); \
+    hipLaunchKernelGGL(kq, dim3(grid_q), dim3(256), lds_q, s, (const bf16_t*)qn, (const bf16_t*)pn, (const bf16_t*)negs,   \
+                       (const bf16_t*)negsT, n_neg, negsT_ld, n_tok_dev, tok_cap, logit_scale_dev, thres, lse, w,          \
+                       q_inv, p_inv, s_pos, dq_tok, dp_tok, d_logit_scale);                                                \
+  }
+  NKS_SWITCH(nks, L_);
+#undef L_
+  MHR_CHECK_LAUNCH("nce_bwd_tokens");
+  return MHR_OK;
+}
+
+extern "C" int mhr_nce_bwd_negs(const void* qn, const void* pn, const void* qnT, const void* negs, int n_neg, int dim,
+                                const int32_t* n_tok_dev, int tok_cap, const float* logit_scale_dev, float thres,
+                                const float* lse, const float* w, float* d_negs, void* stream) {
+  MHR_REQUIRE(qn && pn && qnT && negs && n_tok_dev && logit_scale_dev && lse && w && d_negs, "nce_bwd_negs: null pointer");
+  int nks;
+  MHR_REQUIRE(nks_for(dim, nks), "nce_bwd_negs: dim=%d unsupported (16/32/64/128/256)", dim);
+  MHR_REQUIRE(n_neg > 0 && tok_cap > 0 && tok_cap % 4 == 0, "nce_bwd_negs: bad sizes (tok_cap must be a multiple of 4)");
+  hipStream_t s = (hipStream_t)stream;
   const int n_tok_tiles = (tok_cap + 31) / 32;
   const int neg_groups = (n_neg + 127) / 128;
   int splits = (512 + neg_groups - 1) / neg_groups;        // ~512 workgroups
@@ -598,12 +626,6 @@ extern "C" int mhr_nce_bwd(const void* qn, const void* pn, const void* qnT, cons
 #define L_(NKS)                                                                                                            \
   {                                                                                                                        \
     using T = sg::Tile<NKS>;                                                                                               \
-    size_t lds_q = 2 * T::BYTES + 2 * (size_t)T::DIM * NT_LD * 2;                                                          \
-    auto kq = nce_bwd_q_kernel<NKS>;                                                                                       \
-    if (lds_q > 64 * 1024) (void)hipFuncSetAttribute((const void*)kq, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q); \
-    hipLaunchKernelGGL(kq, dim3(grid_q), dim3(256), lds_q, s, (const bf16_t*)qn, (const bf16_t*)pn, (const bf16_t*)negs,   \
-                       (const bf16_t*)negsT, n_neg, negsT_ld, n_tok_dev, tok_cap, logit_scale_dev, thres, lse, w,    \
-                       q_inv, p_inv, s_pos, dq_tok, dp_tok, d_logit_scale);                                                \
     size_t lds_n = 2 * (2 * T::BYTES + (size_t)T::DIM * NT_LD * 2 + 32 * 8);                                              \
     auto kn = nce_bwd_n_kernel<NKS>;                                                                                       \
     if (lds_n > 64 * 1024) (void)hipFuncSetAttribute((const void*)kn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_n); \
@@ -613,6 +635,6 @@ extern "C" int mhr_nce_bwd(const void* qn, const void* pn, const void* qnT, cons
   }
   NKS_SWITCH(nks, L_);
 #undef L_
-  MHR_CHECK_LAUNCH("nce_bwd");
+  MHR_CHECK_LAUNCH("nce_bwd_negs");
   return MHR_OK;
 }

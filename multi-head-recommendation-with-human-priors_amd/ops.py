@@ -10,6 +10,31 @@ from . import lib
 
 F32, BF16 = lib.F32, lib.BF16
 
+# Optional per-launch timing (bench.py): when PROFILE is a dict, calls named in it are bracketed by HIP events
+# recorded on the stream the kernel is launched on; durations are read after a sync by `profile_summary`.
+PROFILE = None
+
+
+def _timed_call(name, *args):
+    if PROFILE is not None and name in PROFILE:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        lib.call(name, *args)
+        e1.record()
+        PROFILE[name].append((e0, e1))
+    else:
+        lib.call(name, *args)
+
+
+def profile_summary():
+    """name -> (launches, mean ms, total ms); call after torch.cuda.synchronize()."""
+    out = {}
+    for name, evs in (PROFILE or {}).items():
+        if evs:
+            ms = [a.elapsed_time(b) for a, b in evs]
+            out[name] = (len(ms), sum(ms) / len(ms), sum(ms))
+    return out
+
 
 def _dt(t):
     if t.dtype == torch.float32:
@@ -53,7 +78,7 @@ def embedding_gather(table, ids, out_dtype=torch.bfloat16, pos_table=None, seq_l
     if pos_table is not None:
         _chk(pos_table, "pos_table", torch.float32)
         x = torch.empty(*ids.shape[:-1], seq_len, D, dtype=x_dtype, device=table.device)
-    lib.call("mhr_embedding_gather_fwd", table.data_ptr(), table.shape[0], D, ids.data_ptr(), n,
+    _timed_call("mhr_embedding_gather_fwd", table.data_ptr(), table.shape[0], D, ids.data_ptr(), n,
              _ptr(out), _dt(out) if out is not None else F32, _ptr(pos_table), seq_len, window,
              _ptr(x), _dt(x) if x is not None else F32, _stream())
     return out, x
@@ -72,14 +97,14 @@ def sparse_rows_segment_sum(sorted_ids, perm, grad_a, grad_b, x_grad, seq_len, w
     D = out_rows.shape[-1]
     n_a = 0 if grad_a is None else grad_a.numel() // D
     n_b = 0 if grad_b is None else grad_b.numel() // D
-    lib.call("mhr_sparse_rows_segment_sum", sorted_ids.data_ptr(), perm.data_ptr(), sorted_ids.numel(),
+    _timed_call("mhr_sparse_rows_segment_sum", sorted_ids.data_ptr(), perm.data_ptr(), sorted_ids.numel(),
              _ptr(grad_a), _dt(grad_a) if grad_a is not None else F32, n_a,
              _ptr(grad_b), _dt(grad_b) if grad_b is not None else F32, n_b,
              _ptr(x_grad), seq_len, window_len, out_rows.data_ptr(), row_slot.data_ptr(), D, _stream())
 
 
 def adam_rows(w, m, v, grad_rows, row_slot, step, lr, grad_scale=1.0, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
-    lib.call("mhr_adam_rows", w.data_ptr(), m.data_ptr(), v.data_ptr(), w.shape[0], w.shape[1], grad_rows.data_ptr(),
+    _timed_call("mhr_adam_rows", w.data_ptr(), m.data_ptr(), v.data_ptr(), w.shape[0], w.shape[1], grad_rows.data_ptr(),
              _ptr(row_slot), grad_scale, lr, betas[0], betas[1], eps, weight_decay, step, _stream())
 
 
@@ -160,7 +185,7 @@ def hstu_attn_fwd(h, key_valid, B, L, n_heads, head_dim, apply_silu=True, save_a
     out = torch.empty(B * L, D, dtype=torch.bfloat16, device=h.device)
     act = torch.empty(B * L, 3 * D, dtype=torch.bfloat16, device=h.device) if save_act else None
     aq = act.data_ptr() if save_act else 0
-    lib.call("mhr_hstu_attn_fwd", q_ptr, k_ptr, v_ptr, stride, key_valid.data_ptr(), out.data_ptr(),
+    _timed_call("mhr_hstu_attn_fwd", q_ptr, k_ptr, v_ptr, stride, key_valid.data_ptr(), out.data_ptr(),
              aq, aq + D * esz if save_act else 0, aq + 2 * D * esz if save_act else 0, 3 * D,
              B, L, n_heads, head_dim, 1 if apply_silu else 0, _stream())
     return out, act
@@ -171,7 +196,7 @@ def hstu_attn_bwd(h, act, key_valid, d_out, dh, B, L, n_heads, head_dim, apply_s
     D = n_heads * head_dim
     esz = 2
     base, dbase, abase = h.data_ptr(), dh.data_ptr(), act.data_ptr()
-    lib.call("mhr_hstu_attn_bwd", base + 2 * D * esz, base + 3 * D * esz, base + D * esz, h.stride(0),
+    _timed_call("mhr_hstu_attn_bwd", base + 2 * D * esz, base + 3 * D * esz, base + D * esz, h.stride(0),
              abase, abase + D * esz, abase + 2 * D * esz, act.stride(0), key_valid.data_ptr(), d_out.data_ptr(),
              dbase + 2 * D * esz, dbase + 3 * D * esz, dbase + D * esz, dh.stride(0),
              B, L, n_heads, head_dim, 1 if apply_silu else 0, _stream())
@@ -215,7 +240,7 @@ def nce_fwd(q_rows, q_idx, p_rows, p_idx, negs, n_tok_dev, tok_cap, logit_scale,
         sv.qn = sv.pn = sv.qnT = sv.q_inv = sv.p_inv = sv.s_pos = None
     sv.negs, sv.negsT = negs, None
     sv.n_tok_dev, sv.tok_cap, sv.thres, sv.dim, sv.n_neg = n_tok_dev, tok_cap, float(thres), D, negs.shape[0]
-    lib.call("mhr_nce_fwd", q_rows.data_ptr(), q_idx.data_ptr(), p_rows.data_ptr(), p_idx.data_ptr(), _dt(q_rows),
+    _timed_call("mhr_nce_fwd", q_rows.data_ptr(), q_idx.data_ptr(), p_rows.data_ptr(), p_idx.data_ptr(), _dt(q_rows),
              negs.data_ptr(), negs.shape[0], D, n_tok_dev.data_ptr(), tok_cap, logit_scale.data_ptr(), float(thres),
              sv.loss.data_ptr(), sv.lse.data_ptr(), _ptr(sv.n_valid), _ptr(sv.rank), _ptr(sv.qn), _ptr(sv.pn),
              _ptr(sv.qnT), _ptr(sv.q_inv), _ptr(sv.p_inv), _ptr(sv.s_pos), _stream())
@@ -244,10 +269,14 @@ def nce_bwd(sv, w, logit_scale, d_negs=None, d_logit_scale=None):
     if d_logit_scale is None:
         d_logit_scale = torch.zeros(1, dtype=torch.float32, device=dev)
     _chk(w, "w", torch.float32)
-    lib.call("mhr_nce_bwd", sv.qn.data_ptr(), sv.pn.data_ptr(), sv.qnT.data_ptr(), sv.negs.data_ptr(), sv.negsT.data_ptr(),
+    st = _stream()
+    _timed_call("mhr_nce_bwd_tokens", sv.qn.data_ptr(), sv.pn.data_ptr(), sv.negs.data_ptr(), sv.negsT.data_ptr(),
              sv.negsT.shape[1], sv.n_neg, D, sv.n_tok_dev.data_ptr(), cap, logit_scale.data_ptr(), sv.thres,
              sv.lse.data_ptr(), w.data_ptr(), sv.q_inv.data_ptr(), sv.p_inv.data_ptr(), sv.s_pos.data_ptr(),
-             dq.data_ptr(), dp.data_ptr(), d_negs.data_ptr(), d_logit_scale.data_ptr(), _stream())
+             dq.data_ptr(), dp.data_ptr(), d_logit_scale.data_ptr(), st)
+    _timed_call("mhr_nce_bwd_negs", sv.qn.data_ptr(), sv.pn.data_ptr(), sv.qnT.data_ptr(), sv.negs.data_ptr(), sv.n_neg, D,
+             sv.n_tok_dev.data_ptr(), cap, logit_scale.data_ptr(), sv.thres, sv.lse.data_ptr(), w.data_ptr(),
+             d_negs.data_ptr(), st)
     return dq, dp, d_negs, d_logit_scale
 
 
@@ -264,7 +293,7 @@ def catalog_emit(users, H, items, tag_bits, row_bits, tau, hist_ptr, hist_items,
                 torch.zeros(n_rows, dtype=torch.int32, device=dev))
     else:
         cand[2].zero_()
-    lib.call("mhr_catalog_score_emit", users.data_ptr(), n_rows, H, items.data_ptr(), items.shape[0], D, item_begin,
+    _timed_call("mhr_catalog_score_emit", users.data_ptr(), n_rows, H, items.data_ptr(), items.shape[0], D, item_begin,
              item_stride, _ptr(tag_bits), row_bits.data_ptr(), tau.data_ptr(), _ptr(hist_ptr), _ptr(hist_items),
              cand[0].data_ptr(), cand[1].data_ptr(), cand[2].data_ptr(), cap, _stream())
     return cand
@@ -278,7 +307,7 @@ def topk_select(cand, cap, k):
     out_idx = torch.empty(n_rows, k, dtype=torch.int64, device=dev)
     kth = torch.empty(n_rows, dtype=torch.float32, device=dev)
     status = torch.empty(n_rows, dtype=torch.int32, device=dev)
-    lib.call("mhr_topk_select", val.data_ptr(), idx.data_ptr(), cnt.data_ptr(), cap, n_rows, k, out_val.data_ptr(),
+    _timed_call("mhr_topk_select", val.data_ptr(), idx.data_ptr(), cnt.data_ptr(), cap, n_rows, k, out_val.data_ptr(),
              out_idx.data_ptr(), kth.data_ptr(), status.data_ptr(), _stream())
     return out_val, out_idx, kth, status
 

@@ -1,0 +1,69 @@
+"""Fused AdamW for the HSTU model: one kernel over the flat dense-parameter buffer, one over the item table whose
+gradient arrives as a sparse row set (reference: DeepSpeed FusedAdam / torch AdamW over every parameter,
+`code/REC/trainer/trainer.py:292-299`; update semantics identical: every table row is updated every step)."""
+import torch
+
+from . import distributed as D
+from . import ops
+
+
+class FusedAdamW:
+    def __init__(self, model, lr=1e-3, weight_decay=0.0, betas=(0.9, 0.999), eps=1e-8):
+        self.model = model
+        self.lr, self.weight_decay, self.betas, self.eps = lr, weight_decay, betas, eps
+        self.step_count = 0
+        self.table = model.item_embedding.weight
+        dev = self.table.device
+        self.t_m = torch.zeros_like(self.table)
+        self.t_v = torch.zeros_like(self.table)
+        self.dense = [p for n, p in model.named_parameters() if p.requires_grad and p is not self.table]
+        seen, uniq = set(), []
+        for p in self.dense:
+            if id(p) not in seen:
+                seen.add(id(p))
+                uniq.append(p)
+        self.dense = uniq
+        sizes = [(p.numel() + 3) // 4 * 4 for p in self.dense]          # keep every view 16-byte aligned
+        total = sum(sizes)
+        self.flat_w = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_m = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_v = torch.zeros(total, dtype=torch.float32, device=dev)
+        off = 0
+        for p, sz in zip(self.dense, sizes):
+            n = p.numel()
+            self.flat_w[off:off + n].copy_(p.data.reshape(-1))
+            p.data = self.flat_w[off:off + n].view(p.shape)
+            p.grad = self.flat_g[off:off + n].view(p.shape)
+            off += sz
+        self.param_groups = [{"lr": lr}]                                 # scheduler-facing view
+
+    def zero_grad(self):
+        self.flat_g.zero_()
+        self.table.grad = None
+        self.model.sparse_grad = None
+
+    def step(self):
+        self.step_count += 1
+        lr = self.param_groups[0]["lr"]
+        W = D.world_size()
+        D.allreduce_mean_(self.flat_g)
+        ops.adam_flat(self.flat_w, self.flat_g, self.flat_m, self.flat_v, self.step_count, lr, 1.0, self.betas, self.eps,
+                      self.weight_decay)
+        sg = self.model.finish_sparse_grad() if hasattr(self.model, "finish_sparse_grad") else self.model.sparse_grad
+        if sg is not None:
+            ops.adam_rows(self.table, self.t_m, self.t_v, sg.rows, sg.row_slot, self.step_count, lr, 1.0 / W, self.betas,
+                          self.eps, self.weight_decay)
+        elif self.table.grad is not None:                                # dense_embedding_grad mode
+            g = self.table.grad
+            D.allreduce_mean_(g)
+            ops.adam_rows(self.table, self.t_m, self.t_v, g, None, self.step_count, lr, 1.0, self.betas, self.eps,
+                          self.weight_decay)
+
+    def state_dict(self):
+        return {"step": self.step_count, "flat_m": self.flat_m, "flat_v": self.flat_v, "t_m": self.t_m, "t_v": self.t_v}
+
+    def load_state_dict(self, sd):
+        self.step_count = int(sd["step"])
+        for k in ("flat_m", "flat_v", "t_m", "t_v"):
+            getattr(self, k).copy_(sd[k])

@@ -276,7 +276,8 @@ def _nce_oracle(q, p, negs_n, ls, thres, w=None):
     neg = qn @ negs_n.T
     fix = pn @ negs_n.T
     keep = ~(fix > thres)
-    logits = torch.cat([pos, neg.masked_fill(~keep, float("-inf"))], -1) * scale
+    # scale first, mask after: -inf * scale would put NaN into d(scale)
+    logits = torch.cat([pos * scale, torch.where(keep, neg * scale, torch.full_like(neg, float("-inf")))], -1)
     loss = torch.logsumexp(logits, -1) - logits[:, 0]
     return loss, logits, keep, neg, pos
 
