@@ -157,16 +157,18 @@ int mhr_nce_fwd(const void* q_rows, const int32_t* q_idx, const void* p_rows, co
 /* Backward, two kernels (one launch each).  w[t] = d(total loss)/d(loss[t]) (0 for unused slots).  Inputs are the
  * forward's saved tensors plus negsT [dim, negsT_ld] bf16 (negs transposed, negsT_ld >= n_neg, multiple of 4,
  * zero padded).
- * mhr_nce_bwd_tokens: token-stationary; writes per-token gradient rows dq_tok/dp_tok ([tok_cap, dim] f32, w.r.t.
- *   the RAW query / positive rows, normalisation chain rule included; rows t >= n_tok are not written; no atomics)
- *   and atomically adds d(logit_scale parameter) into *d_logit_scale (may be NULL).
+ * mhr_nce_bwd_tokens: token-stationary; accumulates the gradient w.r.t. the RAW query / positive rows
+ *   (normalisation chain rule included) into dq_rows[q_idx[t], :] / dp_rows[p_idx[t], :] (f32, same row spaces as the
+ *   forward's q_rows / p_rows; float atomics because several tokens share a row; caller zeroes) and atomically adds
+ *   d(logit_scale parameter) into *d_logit_scale (may be NULL).
  * mhr_nce_bwd_negs: negative-stationary; accumulates d_negs ([n_neg, dim] f32, float atomics across token splits;
  *   caller zeroes) w.r.t. the normalised negatives.  tok_cap % 4 == 0. */
 int mhr_nce_bwd_tokens(const void* qn, const void* pn, const void* negs, const void* negsT, int64_t negsT_ld,
                        int n_neg, int dim, const int32_t* n_tok_dev, int tok_cap,
                        const float* logit_scale_dev, float thres, const float* lse, const float* w,
                        const float* q_inv, const float* p_inv, const float* s_pos,
-                       float* dq_tok, float* dp_tok, float* d_logit_scale, void* stream);
+                       const int32_t* q_idx, const int32_t* p_idx,
+                       float* dq_rows, float* dp_rows, float* d_logit_scale, void* stream);
 int mhr_nce_bwd_negs(const void* qn, const void* pn, const void* qnT, const void* negs, int n_neg, int dim,
                      const int32_t* n_tok_dev, int tok_cap, const float* logit_scale_dev, float thres,
                      const float* lse, const float* w, float* d_negs, void* stream);

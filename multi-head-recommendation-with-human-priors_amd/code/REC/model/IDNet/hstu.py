@@ -335,7 +335,8 @@ class HSTU(BaseModel):
         n_item_ids = B * (L + P)
         ids_all = torch.cat([items.reshape(-1)] + pool_ids).contiguous()
         fused_pos = isinstance(self.item_id_proj_tower, nn.Identity)
-        rows_all, x = EmbeddingGatherFn.apply(self.item_embedding.weight, self.position_embedding.weight, ids_all,
+        rows_all, x = EmbeddingGatherFn.apply(self.item_embedding.weight,
+                                              self.position_embedding.weight if fused_pos else None, ids_all,
                                               n_item_ids, L, L + P, self)
         if not fused_pos:
             rows_all = self.item_id_proj_tower(rows_all)

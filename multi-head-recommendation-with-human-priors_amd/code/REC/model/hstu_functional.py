@@ -87,7 +87,11 @@ class EmbeddingGatherFn(Function):
         B = n_item_ids // window
         # items part with the fused position add
         items = ids_all[:n_item_ids].view(B, window)
-        r_items, x = ops.embedding_gather(table, items, torch.float32, pos_table, L, torch.float32)
+        if pos_table is not None:
+            r_items, x = ops.embedding_gather(table, items, torch.float32, pos_table, L, torch.float32)
+        else:                                  # projection tower in between: the position add happens after it
+            r_items, _ = ops.embedding_gather(table, items, torch.float32)
+            x = torch.zeros(1, device=table.device)
         rows[:n_item_ids] = r_items.view(-1, D)
         if ids_all.numel() > n_item_ids:
             r_neg, _ = ops.embedding_gather(table, ids_all[n_item_ids:].contiguous(), torch.float32)
@@ -102,7 +106,7 @@ class EmbeddingGatherFn(Function):
         n_item_ids, L, window, holder, n_rows, D = ctx.meta
         dev = ids_all.device
         d_rows = d_rows.contiguous() if d_rows is not None else torch.zeros(ids_all.numel(), D, device=dev)
-        d_x = d_x.contiguous() if d_x is not None else None
+        d_x = d_x.contiguous() if (d_x is not None and d_x.dim() == 3) else None
         d_pos = None
         if d_x is not None:
             d_pos = torch.zeros(holder.position_embedding.weight.shape, dtype=torch.float32, device=dev)
@@ -186,12 +190,8 @@ class NceLossFn(Function):
         q_idx, p_idx, logit_scale = ctx.saved_tensors
         sv = ctx.sv
         q_shape, p_shape = ctx.shapes
-        dq_tok, dp_tok, d_negs, d_ls = ops.nce_bwd(sv, d_loss.contiguous().float(), logit_scale.detach().view(1))
-        dq = torch.zeros(q_shape, dtype=torch.float32, device=dq_tok.device)
-        dp = torch.zeros(p_shape, dtype=torch.float32, device=dq_tok.device)
-        # several tokens share a head row / a target row: accumulate (rows beyond n_tok are zero)
-        n = q_idx.numel()
-        dq.index_add_(0, q_idx.long(), dq_tok[:n])
-        dp.index_add_(0, p_idx.long(), dp_tok[:n])
+        dq = torch.zeros(q_shape, dtype=torch.float32, device=d_loss.device)
+        dp = torch.zeros(p_shape, dtype=torch.float32, device=d_loss.device)
+        d_negs, d_ls = ops.nce_bwd(sv, d_loss.contiguous().float(), logit_scale.detach().view(1), q_idx, p_idx, dq, dp)
         ctx.sv = None
         return dq, dp, d_negs, d_ls.view(logit_scale.shape), None, None, None, None, None, None, None

@@ -264,8 +264,9 @@ __global__ __launch_bounds__(256, 1) void nce_bwd_q_kernel(const bf16_t* __restr
                                                            int tok_cap, const float* __restrict__ logit_scale_dev, float thres,
                                                            const float* __restrict__ lse, const float* __restrict__ w,
                                                            const float* __restrict__ q_inv, const float* __restrict__ p_inv,
-                                                           const float* __restrict__ s_pos, float* __restrict__ dq_tok,
-                                                           float* __restrict__ dp_tok, float* __restrict__ d_logit_scale) {
+                                                           const float* __restrict__ s_pos, const int32_t* __restrict__ q_idx,
+                                                           const int32_t* __restrict__ p_idx, float* __restrict__ dq_rows,
+                                                           float* __restrict__ dp_rows, float* __restrict__ d_logit_scale) {
   using T = sg::Tile<NKS>;
   constexpr int ND = (NKS + 1) / 2;          // 32-column chunks of the feature dim
   constexpr int NT_BYTES = T::DIM * NT_LD * 2;
@@ -383,13 +384,17 @@ __global__ __launch_bounds__(256, 1) void nce_bwd_q_kernel(const bf16_t* __restr
     dot_q = half_sum(dot_q);
     dot_p = half_sum(dot_p);
     if (tl) {
+      // several tokens share a head row (offsets p of one segment) or a target row (l + 1 + p = const): accumulate
+      // with float atomics, one 128-byte segment per wave half per instruction (full-rate shape)
       const float iq = q_inv[tk], ip = p_inv[tk];
+      float* qdst = dq_rows + (int64_t)q_idx[tk] * T::DIM;
+      float* pdst = dp_rows + (int64_t)p_idx[tk] * T::DIM;
 #pragma unroll
       for (int dc = 0; dc < ND; ++dc) {
         const int d = dc * 32 + r;
         if (d < T::DIM) {
-          dq_tok[(int64_t)tk * T::DIM + d] = (dqn[dc] - qv[dc] * dot_q) * iq;
-          dp_tok[(int64_t)tk * T::DIM + d] = (dpn[dc] - pv[dc] * dot_p) * ip;
+          atomicAdd(qdst + d, (dqn[dc] - qv[dc] * dot_q) * iq);
+          atomicAdd(pdst + d, (dpn[dc] - pv[dc] * dot_p) * ip);
         }
       }
     }
@@ -582,10 +587,11 @@ extern "C" int mhr_nce_fwd(const void* q_rows, const int32_t* q_idx, const void*
 extern "C" int mhr_nce_bwd_tokens(const void* qn, const void* pn, const void* negs, const void* negsT, int64_t negsT_ld,
                                   int n_neg, int dim, const int32_t* n_tok_dev, int tok_cap, const float* logit_scale_dev,
                                   float thres, const float* lse, const float* w, const float* q_inv, const float* p_inv,
-                                  const float* s_pos, float* dq_tok, float* dp_tok, float* d_logit_scale, void* stream) {
+                                  const float* s_pos, const int32_t* q_idx, const int32_t* p_idx, float* dq_rows,
+                                  float* dp_rows, float* d_logit_scale, void* stream) {
   MHR_REQUIRE(qn && pn && negs && negsT && n_tok_dev && logit_scale_dev && lse && w && q_inv && p_inv && s_pos,
               "nce_bwd_tokens: null input pointer");
-  MHR_REQUIRE(dq_tok && dp_tok, "nce_bwd_tokens: null output pointer");
+  MHR_REQUIRE(q_idx && p_idx && dq_rows && dp_rows, "nce_bwd_tokens: null index/output pointer");
   int nks;
   MHR_REQUIRE(nks_for(dim, nks), "nce_bwd_tokens: dim=%d unsupported (16/32/64/128/256)", dim);
   MHR_REQUIRE(n_neg > 0 && tok_cap > 0, "nce_bwd_tokens: bad sizes");
@@ -601,7 +607,7 @@ extern "C" int mhr_nce_bwd_tokens(const void* qn, const void* pn, const void* ne
     if (lds_q > 64 * 1024) (void)hipFuncSetAttribute((const void*)kq, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q); \
     hipLaunchKernelGGL(kq, dim3(grid_q), dim3(256), lds_q, s, (const bf16_t*)qn, (const bf16_t*)pn, (const bf16_t*)negs,   \
                        (const bf16_t*)negsT, n_neg, negsT_ld, n_tok_dev, tok_cap, logit_scale_dev, thres, lse, w,          \
-                       q_inv, p_inv, s_pos, dq_tok, dp_tok, d_logit_scale);                                                \
+                       q_inv, p_inv, s_pos, q_idx, p_idx, dq_rows, dp_rows, d_logit_scale);                                                \
   }
   NKS_SWITCH(nks, L_);
 #undef L_

@@ -83,6 +83,34 @@ struct Stage {
   }
 };
 
+// Transposed fragment straight from the row-major swizzled tile with ds_read_b64_tr_b16 (cdna guide T10): the
+// B operand of a product that sums over the ROW index of an accumulator tile (rows = this tile's 32 rows):
+// element j of lane half h must be tile[row 16*s + 8*(j>>2) + 4*h + (j&3)][col dc*32 + (lane&31)].
+// Per 16-lane group the instruction reads a 4-row x 16-column block: lane 4q+p supplies the address of row q,
+// columns 4p..4p+3, and lane i receives column i of the 4 rows.  Two reads (rows +0 and +8) make one fragment.
+// EXEC must be all ones.  Columns beyond DIM (only when DIM < 32) read neighbouring rows / zeros: callers mask them.
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+template <int NKS>
+__device__ __forceinline__ bf16x8 read_tr_frag(const unsigned char* tile, int dc, int s, int lane) {
+  using T = Tile<NKS>;
+  const int i = lane & 15, q = i >> 2, p = i & 3, g1 = (lane >> 4) & 1, half = lane >> 5;
+  const int col = dc * 32 + 16 * g1 + 4 * p;
+  const int c = col >> 3, bo = (col & 7) * 2;
+  const int row0 = 16 * s + 4 * half + q, row1 = row0 + 8;
+  const unsigned char* a0 = tile + row0 * T::ROW_BYTES + ((c ^ (row0 & T::SW)) << 4) + bo;
+  const unsigned char* a1 = tile + row1 * T::ROW_BYTES + ((c ^ (row1 & T::SW)) << 4) + bo;
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a1));
+  bf16x8 f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    f[e] = __builtin_bit_cast(bf16_t, lo[e]);
+    f[4 + e] = __builtin_bit_cast(bf16_t, hi[e]);
+  }
+  return f;
+}
+
 // acc[f] (+)= tile . frag[f]^T for the RF stationary fragments
 template <int NKS, int RF>
 __device__ __forceinline__ void mma_tile(const unsigned char* tile, const bf16x8 (&frag)[RF][NKS], f32x16 (&acc)[RF], int r,

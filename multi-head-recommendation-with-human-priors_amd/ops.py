@@ -256,28 +256,29 @@ def transpose_pad(negs, mult=32):
     return t
 
 
-def nce_bwd(sv, w, logit_scale, d_negs=None, d_logit_scale=None):
-    """w [tok_cap] f32 = dLoss/dloss[t].  Returns (dq_tok [tok_cap, D] f32, dp_tok, d_negs [n_neg, D] f32, d_logit_scale [1])."""
+def nce_bwd(sv, w, logit_scale, q_idx, p_idx, dq_rows, dp_rows, d_negs=None, d_logit_scale=None):
+    """w [tok_cap] f32 = dLoss/dloss[t].  Accumulates into dq_rows [Rq, D] / dp_rows [Rp, D] (f32, the forward's row
+    spaces); returns (d_negs [n_neg, D] f32, d_logit_scale [1])."""
     dev = sv.negs.device
     D, cap = sv.dim, sv.tok_cap
     if sv.negsT is None:
         sv.negsT = transpose_pad(sv.negs)
-    dq = torch.zeros(cap, D, dtype=torch.float32, device=dev)
-    dp = torch.zeros(cap, D, dtype=torch.float32, device=dev)
     if d_negs is None:
         d_negs = torch.zeros(sv.n_neg, D, dtype=torch.float32, device=dev)
     if d_logit_scale is None:
         d_logit_scale = torch.zeros(1, dtype=torch.float32, device=dev)
     _chk(w, "w", torch.float32)
+    _chk(dq_rows, "dq_rows", torch.float32)
+    _chk(dp_rows, "dp_rows", torch.float32)
     st = _stream()
     _timed_call("mhr_nce_bwd_tokens", sv.qn.data_ptr(), sv.pn.data_ptr(), sv.negs.data_ptr(), sv.negsT.data_ptr(),
              sv.negsT.shape[1], sv.n_neg, D, sv.n_tok_dev.data_ptr(), cap, logit_scale.data_ptr(), sv.thres,
              sv.lse.data_ptr(), w.data_ptr(), sv.q_inv.data_ptr(), sv.p_inv.data_ptr(), sv.s_pos.data_ptr(),
-             dq.data_ptr(), dp.data_ptr(), d_logit_scale.data_ptr(), st)
+             q_idx.data_ptr(), p_idx.data_ptr(), dq_rows.data_ptr(), dp_rows.data_ptr(), d_logit_scale.data_ptr(), st)
     _timed_call("mhr_nce_bwd_negs", sv.qn.data_ptr(), sv.pn.data_ptr(), sv.qnT.data_ptr(), sv.negs.data_ptr(), sv.n_neg, D,
              sv.n_tok_dev.data_ptr(), cap, logit_scale.data_ptr(), sv.thres, sv.lse.data_ptr(), w.data_ptr(),
              d_negs.data_ptr(), st)
-    return dq, dp, d_negs, d_logit_scale
+    return d_negs, d_logit_scale
 
 
 # ------------------------------------------------------------------------------------------------
