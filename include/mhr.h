@@ -147,30 +147,30 @@ int mhr_hstu_attn_bwd(const void* q_pre, const void* k_pre, const void* v_pre, i
  * Optional logs (may be NULL): n_valid[t] = 1 + #kept negatives; rank[t] = #kept negatives with logit > logit_pos
  * (hstu.py:621-629: nce_samples and top-k accuracy follow from these).
  * Saved for backward (may be NULL when no backward follows): qn_out/pn_out [tok_cap, dim] bf16 normalised rows,
- * qnT_out [dim, tok_cap] bf16 (Q^T), q_inv/p_inv [tok_cap] = 1/||row||, s_pos [tok_cap] = cos(q,p).
+ * supp_out [ceil(n_neg/32), tok_cap] uint32 (bit j of word [t, tok] = negative 32t+j suppressed for that token),
+ * q_inv/p_inv [tok_cap] = 1/||row||, s_pos [tok_cap] = cos(q,p).
  * ---------------------------------------------------------------------------------------- */
 int mhr_nce_fwd(const void* q_rows, const int32_t* q_idx, const void* p_rows, const int32_t* p_idx, int io_dtype,
                 const void* negs, int n_neg, int dim, const int32_t* n_tok_dev, int tok_cap,
                 const float* logit_scale_dev, float thres,
                 float* loss, float* lse, int32_t* n_valid, int32_t* rank,
-                void* qn_out, void* pn_out, void* qnT_out, float* q_inv, float* p_inv, float* s_pos, void* stream);
+                void* qn_out, void* pn_out, uint32_t* supp_out, float* q_inv, float* p_inv, float* s_pos, void* stream);
 /* Backward, two kernels (one launch each).  w[t] = d(total loss)/d(loss[t]) (0 for unused slots).  Inputs are the
- * forward's saved tensors plus negsT [dim, negsT_ld] bf16 (negs transposed, negsT_ld >= n_neg, multiple of 4,
- * zero padded).
+ * forward's saved tensors; the false-negative decisions are replayed from `supp` instead of recomputing cos(p, neg),
+ * and the transposed operands are read from the streamed tiles with ds_read_b64_tr_b16 (no transposed copies).
  * mhr_nce_bwd_tokens: token-stationary; accumulates the gradient w.r.t. the RAW query / positive rows
  *   (normalisation chain rule included) into dq_rows[q_idx[t], :] / dp_rows[p_idx[t], :] (f32, same row spaces as the
  *   forward's q_rows / p_rows; float atomics because several tokens share a row; caller zeroes) and atomically adds
  *   d(logit_scale parameter) into *d_logit_scale (may be NULL).
  * mhr_nce_bwd_negs: negative-stationary; accumulates d_negs ([n_neg, dim] f32, float atomics across token splits;
- *   caller zeroes) w.r.t. the normalised negatives.  tok_cap % 4 == 0. */
-int mhr_nce_bwd_tokens(const void* qn, const void* pn, const void* negs, const void* negsT, int64_t negsT_ld,
-                       int n_neg, int dim, const int32_t* n_tok_dev, int tok_cap,
-                       const float* logit_scale_dev, float thres, const float* lse, const float* w,
-                       const float* q_inv, const float* p_inv, const float* s_pos,
+ *   caller zeroes) w.r.t. the normalised negatives. */
+int mhr_nce_bwd_tokens(const void* qn, const void* pn, const void* negs, const uint32_t* supp, int n_neg, int dim,
+                       const int32_t* n_tok_dev, int tok_cap, const float* logit_scale_dev,
+                       const float* lse, const float* w, const float* q_inv, const float* p_inv, const float* s_pos,
                        const int32_t* q_idx, const int32_t* p_idx,
                        float* dq_rows, float* dp_rows, float* d_logit_scale, void* stream);
-int mhr_nce_bwd_negs(const void* qn, const void* pn, const void* qnT, const void* negs, int n_neg, int dim,
-                     const int32_t* n_tok_dev, int tok_cap, const float* logit_scale_dev, float thres,
+int mhr_nce_bwd_negs(const void* qn, const void* negs, const uint32_t* supp, int n_neg, int dim,
+                     const int32_t* n_tok_dev, int tok_cap, const float* logit_scale_dev,
                      const float* lse, const float* w, float* d_negs, void* stream);
 
 /* ------------------------------------------------------------------------------------------

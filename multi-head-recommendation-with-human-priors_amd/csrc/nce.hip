@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256, 2) void nce_fwd_kernel(const IT* __restrict__ 
                                                          float* __restrict__ loss, float* __restrict__ lse_out,
                                                          int32_t* __restrict__ n_valid, int32_t* __restrict__ rank,
                                                          bf16_t* __restrict__ qn_out, bf16_t* __restrict__ pn_out,
-                                                         bf16_t* __restrict__ qnT_out, float* __restrict__ q_inv,
+                                                         uint32_t* __restrict__ supp_out, float* __restrict__ q_inv,
                                                          float* __restrict__ p_inv, float* __restrict__ s_pos_out) {
   using T = sg::Tile<NKS>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -128,10 +128,6 @@ __global__ __launch_bounds__(256, 2) void nce_fwd_kernel(const IT* __restrict__ 
       const int k0 = ks * 16 + 8 * half;
       if (qn_out) *reinterpret_cast<bf16x8*>(qn_out + (int64_t)tok * T::DIM + k0) = frag[0][ks];
       if (pn_out) *reinterpret_cast<bf16x8*>(pn_out + (int64_t)tok * T::DIM + k0) = frag[1][ks];
-      if (qnT_out) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) qnT_out[(int64_t)(k0 + i) * tok_cap + tok] = frag[0][ks][i];
-      }
     }
     if (half == 0) {
       if (q_inv) q_inv[tok] = qi;
@@ -163,15 +159,22 @@ __global__ __launch_bounds__(256, 2) void nce_fwd_kernel(const IT* __restrict__ 
     f32x16 acc[2] = {sg::zero16(), sg::zero16()};
     sg::mma_tile<NKS, 2>(smem + cur * T::BYTES, frag, acc, r, half);
     const int rem = n_neg - t * 32;
+    uint32_t sbits = 0;
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
-      const bool keep = (sg::crow(g, half) < rem) && !(acc[1][g] > thres);
+      const bool supp = acc[1][g] > thres;               // false negative: cos(positive, negative) > thres
+      const bool keep = (sg::crow(g, half) < rem) && !supp;
       const float e = fast_exp2(acc[0][g] * c1 - c1);
       sum += keep ? e : 0.f;
+      sbits |= supp ? (1u << sg::crow(g, half)) : 0u;
       if (LOGS) {
         nv += keep ? 1 : 0;
         rk += (keep && acc[0][g] > spos) ? 1 : 0;
       }
+    }
+    if (supp_out) {                                       // one word per (negative tile, token): bit j = negative t*32+j suppressed
+      sbits |= __shfl_xor(sbits, 32, 64);
+      if (live && half == 0) supp_out[(int64_t)t * tok_cap + tok] = sbits;
     }
     if (more) st.store(smem + (cur ^ 1) * T::BYTES);
     __syncthreads();
@@ -195,54 +198,8 @@ __global__ __launch_bounds__(256, 2) void nce_fwd_kernel(const IT* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------
-// backward, token-stationary: dq_tok, dp_tok, d_logit_scale
+// backward, token-stationary: dq_rows, dp_rows, d_logit_scale
 // ------------------------------------------------------------------------------------------
-// transposed negative tile image: [DIM][NT_LD] bf16, 32 negatives per row (+pad: conflict-free 8-byte reads)
-constexpr int NT_LD = 36;
-
-template <int NKS>
-__device__ __forceinline__ bf16x8 read_nt_frag(const bf16_t* NT, int d, int s, int half) {
-  const bf16_t* p = NT + d * NT_LD + 16 * s + 4 * half;
-  bf16x4 lo = *reinterpret_cast<const bf16x4*>(p);
-  bf16x4 hi = *reinterpret_cast<const bf16x4*>(p + 8);
-  bf16x8 f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-  return f;
-}
-
-// stage columns [col0, col0+32) of a [DIM, ld_src] transposed matrix into the NT image (8-byte pieces)
-template <int NKS>
-struct StageT {
-  static constexpr int DIM = NKS * 16;
-  static constexpr int PIECES = DIM * 8;                      // 8-byte pieces (4 elements)
-  static constexpr int PER_THREAD = (PIECES + 255) / 256;
-  bf16x4 v[PER_THREAD];
-  __device__ __forceinline__ void load(const bf16_t* srcT, int64_t ld_src, int col0, int n_cols) {
-#pragma unroll
-    for (int i = 0; i < PER_THREAD; ++i) {
-      const int id = threadIdx.x + i * 256;
-      if (id < PIECES) {
-        const int d = id >> 3, c = (id & 7) * 4;
-        if (col0 + c + 3 < n_cols) {
-          v[i] = *reinterpret_cast<const bf16x4*>(srcT + (int64_t)d * ld_src + col0 + c);
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[i][e] = (col0 + c + e < n_cols) ? srcT[(int64_t)d * ld_src + col0 + c + e] : (bf16_t)0.f;
-        }
-      }
-    }
-  }
-  __device__ __forceinline__ void store(bf16_t* NT) const {
-#pragma unroll
-    for (int i = 0; i < PER_THREAD; ++i) {
-      const int id = threadIdx.x + i * 256;
-      if (id < PIECES) {
-        const int d = id >> 3, c = (id & 7) * 4;
-        *reinterpret_cast<bf16x4*>(NT + d * NT_LD + c) = v[i];
-      }
-    }
-  }
-};
-
 __device__ __forceinline__ void pack_acc(const f32x16& x, bf16x8& f0, bf16x8& f1) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -259,9 +216,9 @@ __device__ __forceinline__ float half_sum(float v) {   // sum over the 32 lanes 
 
 template <int NKS>
 __global__ __launch_bounds__(256, 1) void nce_bwd_q_kernel(const bf16_t* __restrict__ qn, const bf16_t* __restrict__ pn,
-                                                           const bf16_t* __restrict__ negs, const bf16_t* __restrict__ negsT,
-                                                           int n_neg, int64_t negsT_ld, const int32_t* __restrict__ n_tok_dev,
-                                                           int tok_cap, const float* __restrict__ logit_scale_dev, float thres,
+                                                           const bf16_t* __restrict__ negs, const uint32_t* __restrict__ supp,
+                                                           int n_neg, const int32_t* __restrict__ n_tok_dev, int tok_cap,
+                                                           const float* __restrict__ logit_scale_dev,
                                                            const float* __restrict__ lse, const float* __restrict__ w,
                                                            const float* __restrict__ q_inv, const float* __restrict__ p_inv,
                                                            const float* __restrict__ s_pos, const int32_t* __restrict__ q_idx,
@@ -269,10 +226,8 @@ __global__ __launch_bounds__(256, 1) void nce_bwd_q_kernel(const bf16_t* __restr
                                                            float* __restrict__ dp_rows, float* __restrict__ d_logit_scale) {
   using T = sg::Tile<NKS>;
   constexpr int ND = (NKS + 1) / 2;          // 32-column chunks of the feature dim
-  constexpr int NT_BYTES = T::DIM * NT_LD * 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* tiles = smem;                                        // 2 x T::BYTES
-  bf16_t* nts = reinterpret_cast<bf16_t*>(smem + 2 * T::BYTES);      // 2 x [DIM][NT_LD]
+  unsigned char* tiles = smem;               // 2 x T::BYTES
 
   const int n_tok = min(*n_tok_dev, tok_cap);
   const int tok0 = blockIdx.x * 128;
@@ -281,13 +236,10 @@ __global__ __launch_bounds__(256, 1) void nce_bwd_q_kernel(const bf16_t* __restr
   const int tok = tok0 + wave * 32 + r;
   const bool live = tok < n_tok;
 
-  bf16x8 frag[2][NKS];
+  bf16x8 frag[1][NKS];
 #pragma unroll
-  for (int ks = 0; ks < NKS; ++ks) {
-    const int k0 = ks * 16 + 8 * half;
-    frag[0][ks] = live ? *reinterpret_cast<const bf16x8*>(qn + (int64_t)tok * T::DIM + k0) : sg::zero8();
-    frag[1][ks] = live ? *reinterpret_cast<const bf16x8*>(pn + (int64_t)tok * T::DIM + k0) : sg::zero8();
-  }
+  for (int ks = 0; ks < NKS; ++ks)
+    frag[0][ks] = live ? *reinterpret_cast<const bf16x8*>(qn + (int64_t)tok * T::DIM + ks * 16 + 8 * half) : sg::zero8();
   const float scale = clamp_scale(logit_scale_dev);
   const float c1 = scale * LOG2E;
   const float my_w = live ? w[tok] : 0.f;
@@ -306,51 +258,44 @@ __global__ __launch_bounds__(256, 1) void nce_bwd_q_kernel(const bf16_t* __restr
     };
   };
   sg::Stage<NKS> st;
-  StageT<NKS> stt;
   st.load(row_ptr_for(0));
-  stt.load(negsT, negsT_ld, 0, n_neg);
+  uint32_t sw = live ? supp[tok] : 0u;
   st.store(tiles);
-  stt.store(nts);
   __syncthreads();
   int cur = 0;
   for (int t = 0; t < n_tiles; ++t) {
     const bool more = t + 1 < n_tiles;
+    uint32_t sw_next = 0u;
     if (more) {
       st.load(row_ptr_for(t + 1));
-      stt.load(negsT, negsT_ld, (t + 1) * 32, n_neg);
+      sw_next = live ? supp[(int64_t)(t + 1) * tok_cap + tok] : 0u;
     }
-    f32x16 acc[2] = {sg::zero16(), sg::zero16()};
-    sg::mma_tile<NKS, 2>(tiles + cur * T::BYTES, frag, acc, r, half);
+    const unsigned char* tile = tiles + cur * T::BYTES;
+    f32x16 acc[1] = {sg::zero16()};
+    sg::mma_tile<NKS, 1>(tile, frag, acc, r, half);        // S^T: rows = negatives, cols = tokens
     const int rem = n_neg - t * 32;
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
-      const bool keep = (sg::crow(g, half) < rem) && !(acc[1][g] > thres);
+      const int nl = sg::crow(g, half);
+      const bool keep = (nl < rem) && !((sw >> nl) & 1u);
       const float gij = keep ? my_w * fast_exp2(acc[0][g] * c1 - my_l2) : 0.f;
       dsc += gij * acc[0][g];
       acc[0][g] = gij;
     }
     bf16x8 g0, g1;
     pack_acc(acc[0], g0, g1);   // G^T (negatives on rows) as the A operand: computes G . N
-    const bf16_t* NT = nts + cur * (T::DIM * NT_LD);
 #pragma unroll
     for (int dc = 0; dc < ND; ++dc) {
-      // MFMA is wave-wide: lanes whose feature column lies beyond DIM (only when DIM < 32) feed zeros
-      const int d = dc * 32 + r;
-      const bool dok = (ND * 32 == T::DIM) || d < T::DIM;
-      const bf16x8 b0 = dok ? read_nt_frag<NKS>(NT, d, 0, half) : sg::zero8();
-      const bf16x8 b1 = dok ? read_nt_frag<NKS>(NT, d, 1, half) : sg::zero8();
-      dq[dc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g0, b0, dq[dc], 0, 0, 0);
-      dq[dc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g1, b1, dq[dc], 0, 0, 0);
+      dq[dc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g0, sg::read_tr_frag<NKS>(tile, dc, 0, lane), dq[dc], 0, 0, 0);
+      dq[dc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g1, sg::read_tr_frag<NKS>(tile, dc, 1, lane), dq[dc], 0, 0, 0);
     }
-    if (more) {
-      st.store(tiles + (cur ^ 1) * T::BYTES);
-      stt.store(nts + (cur ^ 1) * (T::DIM * NT_LD));
-    }
+    if (more) st.store(tiles + (cur ^ 1) * T::BYTES);
+    sw = sw_next;
     __syncthreads();
     cur ^= 1;
   }
 
-  // ---- finish: positive term, L2-normalisation chain rule, per-token rows -------------------------
+  // ---- finish: positive term, L2-normalisation chain rule, accumulation into the source rows -------
   // dq[dc][g]: row (reg) = token wave*32 + crow(g,half), column (lane) = feature dc*32 + r
   float dls = 0.f;
   dsc += __shfl_xor(dsc, 32, 64);   // both halves hold rows of the same token column -> full sum per token (lane r)
@@ -376,7 +321,7 @@ __global__ __launch_bounds__(256, 1) void nce_bwd_q_kernel(const bf16_t* __restr
       const bool ok = tl && d < T::DIM;
       qv[dc] = ok ? (float)qn[(int64_t)tk * T::DIM + d] : 0.f;
       pv[dc] = ok ? (float)pn[(int64_t)tk * T::DIM + d] : 0.f;
-      dqn[dc] = scale * (dq[dc][g] + coef * pv[dc]);
+      dqn[dc] = ok ? scale * (dq[dc][g] + coef * pv[dc]) : 0.f;
       dpn[dc] = scale * coef * qv[dc];
       dot_q += qv[dc] * dqn[dc];
       dot_p += pv[dc] * dpn[dc];
@@ -405,18 +350,17 @@ __global__ __launch_bounds__(256, 1) void nce_bwd_q_kernel(const bf16_t* __restr
 // backward, negative-stationary: d_negs
 // ------------------------------------------------------------------------------------------
 template <int NKS>
-__global__ __launch_bounds__(256, 1) void nce_bwd_n_kernel(const bf16_t* __restrict__ qn, const bf16_t* __restrict__ pn,
-                                                           const bf16_t* __restrict__ qnT, const bf16_t* __restrict__ negs,
-                                                           int n_neg, const int32_t* __restrict__ n_tok_dev, int tok_cap,
+__global__ __launch_bounds__(256, 1) void nce_bwd_n_kernel(const bf16_t* __restrict__ qn, const bf16_t* __restrict__ negs,
+                                                           const uint32_t* __restrict__ supp, int n_neg,
+                                                           const int32_t* __restrict__ n_tok_dev, int tok_cap,
                                                            int tiles_per_split, const float* __restrict__ logit_scale_dev,
-                                                           float thres, const float* __restrict__ lse,
-                                                           const float* __restrict__ w, float* __restrict__ d_negs) {
+                                                           const float* __restrict__ lse, const float* __restrict__ w,
+                                                           float* __restrict__ d_negs) {
   using T = sg::Tile<NKS>;
   constexpr int ND = (NKS + 1) / 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  // per buffer: Q tile | P tile | Q^T image | 32 x {w, lse*log2e}
-  constexpr int QT_BYTES = T::DIM * NT_LD * 2;
-  constexpr int BUF = 2 * T::BYTES + QT_BYTES + 32 * 8;
+  // per buffer: Q tile | 32 x {w, lse*log2e} | 4 x 32 suppression words (one row per wave's negative tile)
+  constexpr int BUF = T::BYTES + 32 * 8 + 128 * 4;
   const int n_tok = min(*n_tok_dev, tok_cap);
   const int n_tok_tiles = (n_tok + 31) >> 5;
   const int neg0 = blockIdx.x * 128;
@@ -425,6 +369,7 @@ __global__ __launch_bounds__(256, 1) void nce_bwd_n_kernel(const bf16_t* __restr
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, half = lane >> 5;
   const int neg = neg0 + wave * 32 + r;                 // my stationary negative (lane column)
   const bool nlive = neg < n_neg;
+  const int n_neg_tiles = (n_neg + 31) >> 5;
 
   bf16x8 frag[1][NKS];
 #pragma unroll
@@ -443,35 +388,25 @@ __global__ __launch_bounds__(256, 1) void nce_bwd_n_kernel(const bf16_t* __restr
       return tk < n_tok ? qn + (int64_t)tk * T::DIM : nullptr;
     };
   };
-  auto prow_for = [&](int tile) {
-    return [=](int rr) -> const bf16_t* {
-      const int tk = tile * 32 + rr;
-      return tk < n_tok ? pn + (int64_t)tk * T::DIM : nullptr;
-    };
-  };
-  sg::Stage<NKS> sq, sp;
-  StageT<NKS> sqt;
-  float sc_w = 0.f, sc_l = 0.f;
+  sg::Stage<NKS> sq;
+  float sc_v = 0.f;
+  uint32_t sw_v = 0u;
   auto load_all = [&](int tile) {
     sq.load(qrow_for(tile));
-    sp.load(prow_for(tile));
-    sqt.load(qnT, tok_cap, tile * 32, n_tok);
-    if (threadIdx.x < 32) {
-      const int tk = tile * 32 + threadIdx.x;
-      sc_w = tk < n_tok ? w[tk] : 0.f;
-      sc_l = tk < n_tok ? lse[tk] * LOG2E : 0.f;
+    if (threadIdx.x < 64) {                           // 32 x w, 32 x lse*log2e
+      const int tk = tile * 32 + (threadIdx.x & 31);
+      const bool ok = tk < n_tok;
+      sc_v = threadIdx.x < 32 ? (ok ? w[tk] : 0.f) : (ok ? lse[tk] * LOG2E : 0.f);
+    } else if (threadIdx.x < 192) {                   // 4 negative tiles x 32 tokens suppression words
+      const int i = threadIdx.x - 64, nt = (neg0 >> 5) + (i >> 5), tk = tile * 32 + (i & 31);
+      sw_v = (nt < n_neg_tiles && tk < n_tok) ? supp[(int64_t)nt * tok_cap + tk] : 0u;
     }
   };
   auto store_all = [&](int buf) {
     unsigned char* base = smem + buf * BUF;
     sq.store(base);
-    sp.store(base + T::BYTES);
-    sqt.store(reinterpret_cast<bf16_t*>(base + 2 * T::BYTES));
-    if (threadIdx.x < 32) {
-      float* sc = reinterpret_cast<float*>(base + 2 * T::BYTES + QT_BYTES);
-      sc[threadIdx.x] = sc_w;
-      sc[32 + threadIdx.x] = sc_l;
-    }
+    if (threadIdx.x < 64) reinterpret_cast<float*>(base + T::BYTES)[threadIdx.x] = sc_v;
+    else if (threadIdx.x < 192) reinterpret_cast<uint32_t*>(base + T::BYTES + 256)[threadIdx.x - 64] = sw_v;
   };
   load_all(tt0);
   store_all(0);
@@ -481,27 +416,22 @@ __global__ __launch_bounds__(256, 1) void nce_bwd_n_kernel(const bf16_t* __restr
     const bool more = t + 1 < tt1;
     if (more) load_all(t + 1);
     const unsigned char* base = smem + cur * BUF;
-    f32x16 s[1] = {sg::zero16()}, f[1] = {sg::zero16()};
+    f32x16 s[1] = {sg::zero16()};
     sg::mma_tile<NKS, 1>(base, frag, s, r, half);                 // rows = tokens, cols = negatives
-    sg::mma_tile<NKS, 1>(base + T::BYTES, frag, f, r, half);
-    const float* sc = reinterpret_cast<const float*>(base + 2 * T::BYTES + QT_BYTES);
+    const float* sc = reinterpret_cast<const float*>(base + T::BYTES);
+    const uint32_t* swd = reinterpret_cast<const uint32_t*>(base + T::BYTES + 256) + wave * 32;
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
       const int tl = sg::crow(g, half);
-      const bool keep = nlive && !(f[0][g] > thres);
+      const bool keep = nlive && !((swd[tl] >> r) & 1u);
       s[0][g] = keep ? sc[tl] * fast_exp2(s[0][g] * c1 - sc[32 + tl]) : 0.f;   // w == 0 for dead tokens
     }
     bf16x8 g0, g1;
     pack_acc(s[0], g0, g1);   // G (tokens on rows) as the A operand: computes G^T . Qn
-    const bf16_t* QT = reinterpret_cast<const bf16_t*>(base + 2 * T::BYTES);
 #pragma unroll
     for (int dc = 0; dc < ND; ++dc) {
-      const int d = dc * 32 + r;
-      const bool dok = (ND * 32 == T::DIM) || d < T::DIM;
-      const bf16x8 b0 = dok ? read_nt_frag<NKS>(QT, d, 0, half) : sg::zero8();
-      const bf16x8 b1 = dok ? read_nt_frag<NKS>(QT, d, 1, half) : sg::zero8();
-      dn[dc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g0, b0, dn[dc], 0, 0, 0);
-      dn[dc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g1, b1, dn[dc], 0, 0, 0);
+      dn[dc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g0, sg::read_tr_frag<NKS>(base, dc, 0, lane), dn[dc], 0, 0, 0);
+      dn[dc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g1, sg::read_tr_frag<NKS>(base, dc, 1, lane), dn[dc], 0, 0, 0);
     }
     if (more) store_all(cur ^ 1);
     __syncthreads();
@@ -546,7 +476,7 @@ inline bool nks_for(int dim, int& nks) {
 extern "C" int mhr_nce_fwd(const void* q_rows, const int32_t* q_idx, const void* p_rows, const int32_t* p_idx, int io_dtype,
                            const void* negs, int n_neg, int dim, const int32_t* n_tok_dev, int tok_cap,
                            const float* logit_scale_dev, float thres, float* loss, float* lse, int32_t* n_valid,
-                           int32_t* rank, void* qn_out, void* pn_out, void* qnT_out, float* q_inv, float* p_inv,
+                           int32_t* rank, void* qn_out, void* pn_out, uint32_t* supp_out, float* q_inv, float* p_inv,
                            float* s_pos, void* stream) {
   MHR_REQUIRE(q_rows && q_idx && p_rows && p_idx && negs && n_tok_dev && logit_scale_dev && loss && lse, "nce_fwd: null pointer");
   int nks;
@@ -562,20 +492,20 @@ extern "C" int mhr_nce_fwd(const void* q_rows, const int32_t* q_idx, const void*
       if (logs) hipLaunchKernelGGL((nce_fwd_kernel<NKS, bf16_t, true>), dim3(grid), dim3(256), lds, s, (const bf16_t*)q_rows, \
                                    q_idx, (const bf16_t*)p_rows, p_idx, (const bf16_t*)negs, n_neg, n_tok_dev, tok_cap,       \
                                    logit_scale_dev, thres, loss, lse, n_valid, rank, (bf16_t*)qn_out, (bf16_t*)pn_out,        \
-                                   (bf16_t*)qnT_out, q_inv, p_inv, s_pos);                                                    \
+                                   supp_out, q_inv, p_inv, s_pos);                                                    \
       else hipLaunchKernelGGL((nce_fwd_kernel<NKS, bf16_t, false>), dim3(grid), dim3(256), lds, s, (const bf16_t*)q_rows,     \
                               q_idx, (const bf16_t*)p_rows, p_idx, (const bf16_t*)negs, n_neg, n_tok_dev, tok_cap,            \
                               logit_scale_dev, thres, loss, lse, n_valid, rank, (bf16_t*)qn_out, (bf16_t*)pn_out,             \
-                              (bf16_t*)qnT_out, q_inv, p_inv, s_pos);                                                         \
+                              supp_out, q_inv, p_inv, s_pos);                                                         \
     } else {                                                                                                                \
       if (logs) hipLaunchKernelGGL((nce_fwd_kernel<NKS, float, true>), dim3(grid), dim3(256), lds, s, (const float*)q_rows,   \
                                    q_idx, (const float*)p_rows, p_idx, (const bf16_t*)negs, n_neg, n_tok_dev, tok_cap,        \
                                    logit_scale_dev, thres, loss, lse, n_valid, rank, (bf16_t*)qn_out, (bf16_t*)pn_out,        \
-                                   (bf16_t*)qnT_out, q_inv, p_inv, s_pos);                                                    \
+                                   supp_out, q_inv, p_inv, s_pos);                                                    \
       else hipLaunchKernelGGL((nce_fwd_kernel<NKS, float, false>), dim3(grid), dim3(256), lds, s, (const float*)q_rows,       \
                               q_idx, (const float*)p_rows, p_idx, (const bf16_t*)negs, n_neg, n_tok_dev, tok_cap,             \
                               logit_scale_dev, thres, loss, lse, n_valid, rank, (bf16_t*)qn_out, (bf16_t*)pn_out,             \
-                              (bf16_t*)qnT_out, q_inv, p_inv, s_pos);                                                         \
+                              supp_out, q_inv, p_inv, s_pos);                                                         \
     }                                                                                                                       \
   }
   NKS_SWITCH(nks, L_);
@@ -584,30 +514,25 @@ extern "C" int mhr_nce_fwd(const void* q_rows, const int32_t* q_idx, const void*
   return MHR_OK;
 }
 
-extern "C" int mhr_nce_bwd_tokens(const void* qn, const void* pn, const void* negs, const void* negsT, int64_t negsT_ld,
-                                  int n_neg, int dim, const int32_t* n_tok_dev, int tok_cap, const float* logit_scale_dev,
-                                  float thres, const float* lse, const float* w, const float* q_inv, const float* p_inv,
-                                  const float* s_pos, const int32_t* q_idx, const int32_t* p_idx, float* dq_rows,
-                                  float* dp_rows, float* d_logit_scale, void* stream) {
-  MHR_REQUIRE(qn && pn && negs && negsT && n_tok_dev && logit_scale_dev && lse && w && q_inv && p_inv && s_pos,
+extern "C" int mhr_nce_bwd_tokens(const void* qn, const void* pn, const void* negs, const uint32_t* supp, int n_neg, int dim,
+                                  const int32_t* n_tok_dev, int tok_cap, const float* logit_scale_dev, const float* lse,
+                                  const float* w, const float* q_inv, const float* p_inv, const float* s_pos,
+                                  const int32_t* q_idx, const int32_t* p_idx, float* dq_rows, float* dp_rows,
+                                  float* d_logit_scale, void* stream) {
+  MHR_REQUIRE(qn && pn && negs && supp && n_tok_dev && logit_scale_dev && lse && w && q_inv && p_inv && s_pos,
               "nce_bwd_tokens: null input pointer");
   MHR_REQUIRE(q_idx && p_idx && dq_rows && dp_rows, "nce_bwd_tokens: null index/output pointer");
   int nks;
   MHR_REQUIRE(nks_for(dim, nks), "nce_bwd_tokens: dim=%d unsupported (16/32/64/128/256)", dim);
   MHR_REQUIRE(n_neg > 0 && tok_cap > 0, "nce_bwd_tokens: bad sizes");
-  MHR_REQUIRE(negsT_ld >= n_neg && negsT_ld % 4 == 0, "nce_bwd_tokens: negsT_ld=%lld must be >= n_neg and a multiple of 4",
-              (long long)negsT_ld);
   hipStream_t s = (hipStream_t)stream;
   const int grid_q = (tok_cap + 127) / 128;
-#define L_(NKS)                                                                                                            \
-  {                                                                                                                        \
-    using T = sg::Tile<NKS>;                                                                                               \
-    size_t lds_q = 2 * T::BYTES + 2 * (size_t)T::DIM * NT_LD * 2;                                                          \
-    auto kq = nce_bwd_q_kernel<NKS>;                                                                                       \
-    if (lds_q > 64 * 1024) (void)hipFuncSetAttribute((const void*)kq, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q); \
-    hipLaunchKernelGGL(kq, dim3(grid_q), dim3(256), lds_q, s, (const bf16_t*)qn, (const bf16_t*)pn, (const bf16_t*)negs,   \
-                       (const bf16_t*)negsT, n_neg, negsT_ld, n_tok_dev, tok_cap, logit_scale_dev, thres, lse, w,          \
-                       q_inv, p_inv, s_pos, q_idx, p_idx, dq_rows, dp_rows, d_logit_scale);                                                \
+#define L_(NKS)                                                                                                          \
+  {                                                                                                                      \
+    size_t lds_q = 2 * sg::Tile<NKS>::BYTES;                                                                             \
+    hipLaunchKernelGGL((nce_bwd_q_kernel<NKS>), dim3(grid_q), dim3(256), lds_q, s, (const bf16_t*)qn, (const bf16_t*)pn, \
+                       (const bf16_t*)negs, supp, n_neg, n_tok_dev, tok_cap, logit_scale_dev, lse, w, q_inv, p_inv,      \
+                       s_pos, q_idx, p_idx, dq_rows, dp_rows, d_logit_scale);                                            \
   }
   NKS_SWITCH(nks, L_);
 #undef L_
@@ -615,13 +540,13 @@ extern "C" int mhr_nce_bwd_tokens(const void* qn, const void* pn, const void* ne
   return MHR_OK;
 }
 
-extern "C" int mhr_nce_bwd_negs(const void* qn, const void* pn, const void* qnT, const void* negs, int n_neg, int dim,
-                                const int32_t* n_tok_dev, int tok_cap, const float* logit_scale_dev, float thres,
-                                const float* lse, const float* w, float* d_negs, void* stream) {
-  MHR_REQUIRE(qn && pn && qnT && negs && n_tok_dev && logit_scale_dev && lse && w && d_negs, "nce_bwd_negs: null pointer");
+extern "C" int mhr_nce_bwd_negs(const void* qn, const void* negs, const uint32_t* supp, int n_neg, int dim,
+                                const int32_t* n_tok_dev, int tok_cap, const float* logit_scale_dev, const float* lse,
+                                const float* w, float* d_negs, void* stream) {
+  MHR_REQUIRE(qn && negs && supp && n_tok_dev && logit_scale_dev && lse && w && d_negs, "nce_bwd_negs: null pointer");
   int nks;
   MHR_REQUIRE(nks_for(dim, nks), "nce_bwd_negs: dim=%d unsupported (16/32/64/128/256)", dim);
-  MHR_REQUIRE(n_neg > 0 && tok_cap > 0 && tok_cap % 4 == 0, "nce_bwd_negs: bad sizes (tok_cap must be a multiple of 4)");
+  MHR_REQUIRE(n_neg > 0 && tok_cap > 0, "nce_bwd_negs: bad sizes");
   hipStream_t s = (hipStream_t)stream;
   const int n_tok_tiles = (tok_cap + 31) / 32;
   const int neg_groups = (n_neg + 127) / 128;
@@ -629,15 +554,12 @@ extern "C" int mhr_nce_bwd_negs(const void* qn, const void* pn, const void* qnT,
   if (splits > n_tok_tiles) splits = n_tok_tiles;
   if (splits < 1) splits = 1;
   const int tiles_per_split = (n_tok_tiles + splits - 1) / splits;
-#define L_(NKS)                                                                                                            \
-  {                                                                                                                        \
-    using T = sg::Tile<NKS>;                                                                                               \
-    size_t lds_n = 2 * (2 * T::BYTES + (size_t)T::DIM * NT_LD * 2 + 32 * 8);                                              \
-    auto kn = nce_bwd_n_kernel<NKS>;                                                                                       \
-    if (lds_n > 64 * 1024) (void)hipFuncSetAttribute((const void*)kn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_n); \
-    hipLaunchKernelGGL(kn, dim3(neg_groups, splits), dim3(256), lds_n, s, (const bf16_t*)qn, (const bf16_t*)pn,            \
-                       (const bf16_t*)qnT, (const bf16_t*)negs, n_neg, n_tok_dev, tok_cap, tiles_per_split,                \
-                       logit_scale_dev, thres, lse, w, d_negs);                                                            \
+#define L_(NKS)                                                                                                        \
+  {                                                                                                                    \
+    size_t lds_n = 2 * (sg::Tile<NKS>::BYTES + 32 * 8 + 128 * 4);                                                      \
+    hipLaunchKernelGGL((nce_bwd_n_kernel<NKS>), dim3(neg_groups, splits), dim3(256), lds_n, s, (const bf16_t*)qn,      \
+                       (const bf16_t*)negs, supp, n_neg, n_tok_dev, tok_cap, tiles_per_split, logit_scale_dev, lse, w, \
+                       d_negs);                                                                                        \
   }
   NKS_SWITCH(nks, L_);
 #undef L_

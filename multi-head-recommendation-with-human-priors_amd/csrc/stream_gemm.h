@@ -89,26 +89,21 @@ struct Stage {
 // Per 16-lane group the instruction reads a 4-row x 16-column block: lane 4q+p supplies the address of row q,
 // columns 4p..4p+3, and lane i receives column i of the 4 rows.  Two reads (rows +0 and +8) make one fragment.
 // EXEC must be all ones.  Columns beyond DIM (only when DIM < 32) read neighbouring rows / zeros: callers mask them.
-typedef __attribute__((ext_vector_type(4))) short s16x4;
-
+// (The _v4i16 form of the builtin followed by per-element bit casts is mis-optimised by hipcc 7.2 - all four
+// elements collapse to element 0 - so the _v4bf16 form and a whole-vector shuffle are used.)
 template <int NKS>
 __device__ __forceinline__ bf16x8 read_tr_frag(const unsigned char* tile, int dc, int s, int lane) {
   using T = Tile<NKS>;
+  typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
   const int i = lane & 15, q = i >> 2, p = i & 3, g1 = (lane >> 4) & 1, half = lane >> 5;
   const int col = dc * 32 + 16 * g1 + 4 * p;
   const int c = col >> 3, bo = (col & 7) * 2;
   const int row0 = 16 * s + 4 * half + q, row1 = row0 + 8;
   const unsigned char* a0 = tile + row0 * T::ROW_BYTES + ((c ^ (row0 & T::SW)) << 4) + bo;
   const unsigned char* a1 = tile + row1 * T::ROW_BYTES + ((c ^ (row1 & T::SW)) << 4) + bo;
-  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
-  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a1));
-  bf16x8 f;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    f[e] = __builtin_bit_cast(bf16_t, lo[e]);
-    f[4 + e] = __builtin_bit_cast(bf16_t, hi[e]);
-  }
-  return f;
+  bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(a0));
+  bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(a1));
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
 // acc[f] (+)= tile . frag[f]^T for the RF stationary fragments

@@ -208,7 +208,7 @@ def hstu_attn_bwd(h, act, key_valid, d_out, dh, B, L, n_heads, head_dim, apply_s
 # ------------------------------------------------------------------------------------------------
 class NceSaved:
     """Tensors the forward keeps for the backward (all preallocated at token capacity)."""
-    __slots__ = ("qn", "pn", "qnT", "q_inv", "p_inv", "s_pos", "lse", "loss", "n_valid", "rank", "negs", "negsT",
+    __slots__ = ("qn", "pn", "supp", "q_inv", "p_inv", "s_pos", "lse", "loss", "n_valid", "rank", "negs",
                  "n_tok_dev", "tok_cap", "thres", "dim", "n_neg")
 
 
@@ -232,28 +232,19 @@ def nce_fwd(q_rows, q_idx, p_rows, p_idx, negs, n_tok_dev, tok_cap, logit_scale,
     if for_backward:
         sv.qn = torch.empty(tok_cap, D, dtype=torch.bfloat16, device=dev)
         sv.pn = torch.empty(tok_cap, D, dtype=torch.bfloat16, device=dev)
-        sv.qnT = torch.zeros(D, tok_cap, dtype=torch.bfloat16, device=dev)
+        sv.supp = torch.empty((negs.shape[0] + 31) // 32, tok_cap, dtype=torch.int32, device=dev)
         sv.q_inv = torch.empty(tok_cap, dtype=torch.float32, device=dev)
         sv.p_inv = torch.empty(tok_cap, dtype=torch.float32, device=dev)
         sv.s_pos = torch.empty(tok_cap, dtype=torch.float32, device=dev)
     else:
-        sv.qn = sv.pn = sv.qnT = sv.q_inv = sv.p_inv = sv.s_pos = None
-    sv.negs, sv.negsT = negs, None
+        sv.qn = sv.pn = sv.supp = sv.q_inv = sv.p_inv = sv.s_pos = None
+    sv.negs = negs
     sv.n_tok_dev, sv.tok_cap, sv.thres, sv.dim, sv.n_neg = n_tok_dev, tok_cap, float(thres), D, negs.shape[0]
     _timed_call("mhr_nce_fwd", q_rows.data_ptr(), q_idx.data_ptr(), p_rows.data_ptr(), p_idx.data_ptr(), _dt(q_rows),
              negs.data_ptr(), negs.shape[0], D, n_tok_dev.data_ptr(), tok_cap, logit_scale.data_ptr(), float(thres),
              sv.loss.data_ptr(), sv.lse.data_ptr(), _ptr(sv.n_valid), _ptr(sv.rank), _ptr(sv.qn), _ptr(sv.pn),
-             _ptr(sv.qnT), _ptr(sv.q_inv), _ptr(sv.p_inv), _ptr(sv.s_pos), _stream())
+             _ptr(sv.supp), _ptr(sv.q_inv), _ptr(sv.p_inv), _ptr(sv.s_pos), _stream())
     return sv
-
-
-def transpose_pad(negs, mult=32):
-    """[n, D] bf16 -> [D, ceil(n/mult)*mult] zero padded (plumbing: a strided copy)."""
-    n, D = negs.shape
-    ld = (n + mult - 1) // mult * mult
-    t = torch.zeros(D, ld, dtype=negs.dtype, device=negs.device)
-    t[:, :n] = negs.t()
-    return t
 
 
 def nce_bwd(sv, w, logit_scale, q_idx, p_idx, dq_rows, dp_rows, d_negs=None, d_logit_scale=None):
@@ -261,8 +252,6 @@ def nce_bwd(sv, w, logit_scale, q_idx, p_idx, dq_rows, dp_rows, d_negs=None, d_l
     spaces); returns (d_negs [n_neg, D] f32, d_logit_scale [1])."""
     dev = sv.negs.device
     D, cap = sv.dim, sv.tok_cap
-    if sv.negsT is None:
-        sv.negsT = transpose_pad(sv.negs)
     if d_negs is None:
         d_negs = torch.zeros(sv.n_neg, D, dtype=torch.float32, device=dev)
     if d_logit_scale is None:
@@ -271,13 +260,12 @@ def nce_bwd(sv, w, logit_scale, q_idx, p_idx, dq_rows, dp_rows, d_negs=None, d_l
     _chk(dq_rows, "dq_rows", torch.float32)
     _chk(dp_rows, "dp_rows", torch.float32)
     st = _stream()
-    _timed_call("mhr_nce_bwd_tokens", sv.qn.data_ptr(), sv.pn.data_ptr(), sv.negs.data_ptr(), sv.negsT.data_ptr(),
-             sv.negsT.shape[1], sv.n_neg, D, sv.n_tok_dev.data_ptr(), cap, logit_scale.data_ptr(), sv.thres,
-             sv.lse.data_ptr(), w.data_ptr(), sv.q_inv.data_ptr(), sv.p_inv.data_ptr(), sv.s_pos.data_ptr(),
-             q_idx.data_ptr(), p_idx.data_ptr(), dq_rows.data_ptr(), dp_rows.data_ptr(), d_logit_scale.data_ptr(), st)
-    _timed_call("mhr_nce_bwd_negs", sv.qn.data_ptr(), sv.pn.data_ptr(), sv.qnT.data_ptr(), sv.negs.data_ptr(), sv.n_neg, D,
-             sv.n_tok_dev.data_ptr(), cap, logit_scale.data_ptr(), sv.thres, sv.lse.data_ptr(), w.data_ptr(),
-             d_negs.data_ptr(), st)
+    _timed_call("mhr_nce_bwd_tokens", sv.qn.data_ptr(), sv.pn.data_ptr(), sv.negs.data_ptr(), sv.supp.data_ptr(), sv.n_neg, D,
+                sv.n_tok_dev.data_ptr(), cap, logit_scale.data_ptr(), sv.lse.data_ptr(), w.data_ptr(), sv.q_inv.data_ptr(),
+                sv.p_inv.data_ptr(), sv.s_pos.data_ptr(), q_idx.data_ptr(), p_idx.data_ptr(), dq_rows.data_ptr(),
+                dp_rows.data_ptr(), d_logit_scale.data_ptr(), st)
+    _timed_call("mhr_nce_bwd_negs", sv.qn.data_ptr(), sv.negs.data_ptr(), sv.supp.data_ptr(), sv.n_neg, D,
+                sv.n_tok_dev.data_ptr(), cap, logit_scale.data_ptr(), sv.lse.data_ptr(), w.data_ptr(), d_negs.data_ptr(), st)
     return d_negs, d_logit_scale
 
 

@@ -1,0 +1,44 @@
+// In-situ check of sg::read_tr_frag against its contract on the swizzled tile image.
+#include "../multi-head-recommendation-with-human-priors_amd/csrc/stream_gemm.h"
+#include <vector>
+void mhr_set_error(const char*, ...) {}
+template <int NKS>
+__global__ void k(const bf16_t* src, float* out, int dc, int s) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  sg::Stage<NKS> st;
+  st.load([=](int rr) -> const bf16_t* { return src + rr * sg::Tile<NKS>::DIM; });
+  st.store(smem);
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    bf16x8 f = sg::read_tr_frag<NKS>(smem, dc, s, threadIdx.x);
+    for (int j = 0; j < 8; ++j) out[threadIdx.x * 8 + j] = (float)f[j];
+  }
+}
+template <int NKS>
+int run() {
+  const int DIM = NKS * 16;
+  int bad = 0;
+  for (int mode = 0; mode < 2; ++mode) {
+    std::vector<bf16_t> h(32 * DIM);
+    for (int r = 0; r < 32; ++r) for (int c = 0; c < DIM; ++c) h[r * DIM + c] = (bf16_t)(float)(mode ? c : r);
+    bf16_t* d; float* o;
+    (void)hipMalloc(&d, h.size() * 2); (void)hipMalloc(&o, 512 * 4);
+    (void)hipMemcpy(d, h.data(), h.size() * 2, hipMemcpyHostToDevice);
+    for (int dc = 0; dc < (NKS + 1) / 2; ++dc) for (int s = 0; s < 2; ++s) {
+      hipLaunchKernelGGL((k<NKS>), dim3(1), dim3(256), sg::Tile<NKS>::BYTES, 0, d, o, dc, s);
+      float ho[512]; (void)hipMemcpy(ho, o, sizeof(ho), hipMemcpyDeviceToHost);
+      for (int lane = 0; lane < 64; ++lane) {
+        int half = lane >> 5, col = dc * 32 + (lane & 31);
+        if (col >= DIM) continue;
+        for (int j = 0; j < 8; ++j) {
+          int row = 16 * s + 8 * (j >> 2) + 4 * half + (j & 3);
+          float want = mode ? col : row;
+          if (ho[lane * 8 + j] != want) { if (bad < 10) printf("NKS=%d mode=%d dc=%d s=%d lane=%d j=%d got %g want %g\n", NKS, mode, dc, s, lane, j, ho[lane*8+j], want); ++bad; }
+        }
+      }
+    }
+  }
+  printf("NKS=%d bad=%d\n", NKS, bad);
+  return bad;
+}
+int main() { int b = run<1>() + run<4>() + run<16>(); return b != 0; }
