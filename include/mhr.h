@@ -142,8 +142,12 @@ int mhr_hstu_attn_bwd(const void* q_pre, const void* k_pre, const void* v_pre, i
  * q_rows[q_idx[t]] and positive row p_rows[p_idx[t]] (both raw, L2-normalised inside; io_dtype f32/bf16).
  * negs [n_neg, dim] bf16 are already L2-normalised.  n_tok is read from device memory (*n_tok_dev)
  * so data-dependent token counts need no host sync; `tok_cap` bounds the grid.  dim in {16,32,64,128,256}.
+ * GROUPS: one launch serves n_groups independent (token list, negative pool) problems - the prior categories of a
+ * step - laid out along a leading axis: q_idx/p_idx/w/lse/loss/... [n_groups, tok_cap], n_tok_dev [n_groups],
+ * negs [n_groups, n_neg, dim], qn/pn [n_groups, tok_cap, dim], supp [n_groups, ceil(n_neg/32), tok_cap],
+ * d_negs [n_groups, n_neg, dim]; q_rows / p_rows / dq_rows / dp_rows are shared row spaces.
  *   logit_pos = s*cos(q,p); logit_j = s*cos(q,neg_j), dropped when cos(p,neg_j) > thres; s = exp(clamp(logit_scale,0,ln 100))
- *   loss[t] = logsumexp(logits) - logit_pos;  lse[t] saved for backward.
+ *   loss[t] = logsumexp(logits) - logit_pos;  lse[t] saved for backward (both written by mhr_nce_finalize).
  * Optional logs (may be NULL): n_valid[t] = 1 + #kept negatives; rank[t] = #kept negatives with logit > logit_pos
  * (hstu.py:621-629: nce_samples and top-k accuracy follow from these).
  * Saved for backward (may be NULL when no backward follows): qn_out/pn_out [tok_cap, dim] bf16 normalised rows,
@@ -151,10 +155,16 @@ int mhr_hstu_attn_bwd(const void* q_pre, const void* k_pre, const void* v_pre, i
  * q_inv/p_inv [tok_cap] = 1/||row||, s_pos [tok_cap] = cos(q,p).
  * ---------------------------------------------------------------------------------------- */
 int mhr_nce_fwd(const void* q_rows, const int32_t* q_idx, const void* p_rows, const int32_t* p_idx, int io_dtype,
-                const void* negs, int n_neg, int dim, const int32_t* n_tok_dev, int tok_cap,
+                const void* negs, int n_neg, int dim, int n_groups, const int32_t* n_tok_dev, int tok_cap,
                 const float* logit_scale_dev, float thres,
-                float* loss, float* lse, int32_t* n_valid, int32_t* rank,
+                float* sum_out, int32_t* n_valid, int32_t* rank,
                 void* qn_out, void* pn_out, uint32_t* supp_out, float* q_inv, float* p_inv, float* s_pos, void* stream);
+/* The forward is split over negative ranges (grid.y) so that (token block, negative range) units fill the chip
+ * without a tail: each unit adds its partial sum_j keep*exp(scale*(s_j - 1)) into sum_out[t] (and its counts into
+ * n_valid / rank) with atomics - the caller zeroes sum_out, n_valid, rank - and mhr_nce_finalize produces
+ * lse[t] = scale + log(sum[t] + exp(scale*(s_pos[t]-1))), loss[t] = lse[t] - scale*s_pos[t], n_valid[t] += 1. */
+int mhr_nce_finalize(const float* sum, const float* s_pos, int n_groups, const int32_t* n_tok_dev, int tok_cap,
+                     const float* logit_scale_dev, float* loss, float* lse, int32_t* n_valid, void* stream);
 /* Backward, two kernels (one launch each).  w[t] = d(total loss)/d(loss[t]) (0 for unused slots).  Inputs are the
  * forward's saved tensors; the false-negative decisions are replayed from `supp` instead of recomputing cos(p, neg),
  * and the transposed operands are read from the streamed tiles with ds_read_b64_tr_b16 (no transposed copies).
@@ -165,11 +175,11 @@ int mhr_nce_fwd(const void* q_rows, const int32_t* q_idx, const void* p_rows, co
  * mhr_nce_bwd_negs: negative-stationary; accumulates d_negs ([n_neg, dim] f32, float atomics across token splits;
  *   caller zeroes) w.r.t. the normalised negatives. */
 int mhr_nce_bwd_tokens(const void* qn, const void* pn, const void* negs, const uint32_t* supp, int n_neg, int dim,
-                       const int32_t* n_tok_dev, int tok_cap, const float* logit_scale_dev,
+                       int n_groups, const int32_t* n_tok_dev, int tok_cap, const float* logit_scale_dev,
                        const float* lse, const float* w, const float* q_inv, const float* p_inv, const float* s_pos,
                        const int32_t* q_idx, const int32_t* p_idx,
                        float* dq_rows, float* dp_rows, float* d_logit_scale, void* stream);
-int mhr_nce_bwd_negs(const void* qn, const void* negs, const uint32_t* supp, int n_neg, int dim,
+int mhr_nce_bwd_negs(const void* qn, const void* negs, const uint32_t* supp, int n_neg, int dim, int n_groups,
                      const int32_t* n_tok_dev, int tok_cap, const float* logit_scale_dev,
                      const float* lse, const float* w, float* d_negs, void* stream);
 

@@ -261,53 +261,60 @@ class HSTU(BaseModel):
     # training
     # ------------------------------------------------------------------------------------------
     def _token_tables(self, B, device, head_for_p):
-        """Static [B,P,L] index tables: query row in head_embs.view(-1,D), target row in e.view(-1,D), offset p."""
-        key = (B, device, tuple(head_for_p.tolist()))
+        """Static index tables for G groups: query row in head_embs.view(-1,D) [G, B*P*L], target row in
+        e.view(-1,D) [B*P*L], prediction offset [B*P*L].  head_for_p: [G, P] long (head used by group g at offset p)."""
+        key = (B, str(device), tuple(head_for_p.reshape(-1).tolist()))
         if key not in self._tok_cache:
             L, P, H = self.max_seq_length, self.pred_len, self.medusa_num_heads
-            b = torch.arange(B, device=device)[:, None, None]
-            p = torch.arange(P, device=device)[None, :, None]
-            l = torch.arange(L, device=device)[None, None, :]
-            hp = head_for_p.to(device)[None, :, None]
-            q_all = ((b * H + hp) * L + l).expand(B, P, L).reshape(-1).int()
-            p_all = (b * (L + P) + l + 1 + p).expand(B, P, L).reshape(-1).int()
-            o_all = p.expand(B, P, L).reshape(-1).long()
+            b = torch.arange(B, device=device)[None, :, None, None]
+            p = torch.arange(P, device=device)[None, None, :, None]
+            l = torch.arange(L, device=device)[None, None, None, :]
+            hp = head_for_p.to(device)[:, None, :, None]                                        # [G,1,P,1]
+            G = hp.shape[0]
+            q_all = ((b * H + hp) * L + l).expand(G, B, P, L).reshape(G, -1).int().contiguous()
+            p_all = (b * (L + P) + l + 1 + p).expand(1, B, P, L).reshape(-1).int()
+            o_all = p.expand(1, B, P, L).reshape(-1).long()
             self._tok_cache[key] = (q_all, p_all, o_all)
         return self._tok_cache[key]
 
-    def _pool_loss(self, head_rows, e_rows, negs_n, valid, head_for_p, want_logs):
-        """Sum over offsets of lambda_p * mean_{tokens of p} loss, for one negative pool / one token mask.
-        Returns (per_pred_loss [P] fp32, logs or None).  No host sync: compaction by scatter at fixed capacity."""
+    def _grouped_loss(self, head_rows, e_rows, negs_g, valid_g, head_for_p, log_group):
+        """Sampled-softmax loss of G (token mask, negative pool) groups in ONE fused launch per kernel.
+        valid_g [G,B,P,L] bool, negs_g [G,n_neg,D] bf16, head_for_p [G,P].  Returns (mean loss per (group, offset)
+        [G,P] fp32, logs of `log_group` or None).  No host sync: tokens are compacted by scatter at fixed capacity
+        and the live counts stay on the device (reference: boolean-mask compaction + `mask.sum() == 0` host branch,
+        hstu.py:688-690, 814-829)."""
         from REC.model.hstu_functional import NceLossFn
-        B, P, L = valid.shape
-        dev = valid.device
+        G, B, P, L = valid_g.shape
+        dev = valid_g.device
         cap = B * P * L
         q_all, p_all, o_all = self._token_tables(B, dev, head_for_p)
-        m = valid.reshape(-1)
-        pos = torch.cumsum(m, 0) - 1
-        n_tok = m.sum().to(torch.int32).view(1)
+        m = valid_g.reshape(G, cap)
+        pos = torch.cumsum(m, 1) - 1
+        n_tok = m.sum(1).to(torch.int32)
         tgt = torch.where(m, pos, torch.full_like(pos, cap))
-        q_idx = torch.zeros(cap + 1, dtype=torch.int32, device=dev).scatter_(0, tgt, q_all)[:cap].contiguous()
-        p_idx = torch.zeros(cap + 1, dtype=torch.int32, device=dev).scatter_(0, tgt, p_all)[:cap].contiguous()
-        o_idx = torch.zeros(cap + 1, dtype=torch.long, device=dev).scatter_(0, tgt, o_all)[:cap]
+        q_idx = torch.zeros(G, cap + 1, dtype=torch.int32, device=dev).scatter_(1, tgt, q_all)[:, :cap].contiguous()
+        p_idx = torch.zeros(G, cap + 1, dtype=torch.int32, device=dev).scatter_(1, tgt, p_all.expand(G, cap))[:, :cap].contiguous()
+        o_idx = torch.zeros(G, cap + 1, dtype=torch.long, device=dev).scatter_(1, tgt, o_all.expand(G, cap))[:, :cap]
+        want_logs = log_group is not None
         logs = {} if want_logs else None
-        loss_tok = NceLossFn.apply(head_rows, e_rows, negs_n, self.logit_scale, q_idx, p_idx, n_tok, cap,
-                                   float(self.nce_thres), want_logs, logs)
-        loss_tok = loss_tok[:cap]
-        live = (torch.arange(cap, device=dev) < n_tok).float()
-        sum_p = torch.zeros(P, dtype=torch.float32, device=dev).index_add_(0, o_idx, loss_tok)
-        cnt_p = torch.zeros(P, dtype=torch.float32, device=dev).index_add_(0, o_idx, live)
-        mean_p = sum_p / cnt_p.clamp_min(1.0)
+        loss_tok = NceLossFn.apply(head_rows, e_rows, negs_g, self.logit_scale, q_idx, p_idx, n_tok, cap,
+                                   float(self.nce_thres), want_logs, logs)                          # [G, cap]
+        live = (torch.arange(cap, device=dev)[None, :] < n_tok[:, None]).float()
+        flat = (torch.arange(G, device=dev)[:, None] * P + o_idx).reshape(-1)
+        sum_p = torch.zeros(G * P, dtype=torch.float32, device=dev).index_add_(0, flat, loss_tok.reshape(-1))
+        cnt_p = torch.zeros(G * P, dtype=torch.float32, device=dev).index_add_(0, flat, live.reshape(-1))
+        mean_p = (sum_p / cnt_p.clamp_min(1.0)).view(G, P)
         out_logs = None
         if want_logs:
-            first = live * (o_idx == 0).float()                     # tokens of prediction offset 0
+            g = log_group
+            first = live[g] * (o_idx[g] == 0).float()                     # tokens of prediction offset 0
             n0 = first.sum().clamp_min(1.0)
-            out_logs = {'nce_samples': (logs["n_valid"][:cap].float() * first).sum() / n0}
+            out_logs = {'nce_samples': (logs["n_valid"][g].float() * first).sum() / n0}
             for k in (1, 5, 10, 50, 100):
-                if k > negs_n.shape[0] + 1:
+                if k > negs_g.shape[1] + 1:
                     break
-                out_logs[f'nce_top{k}_acc'] = ((logs["rank"][:cap] < k).float() * first).sum() / n0
-        return self.horizon_discount.float() * mean_p, out_logs
+                out_logs[f'nce_top{k}_acc'] = ((logs["rank"][g] < k).float() * first).sum() / n0
+        return mean_p, out_logs
 
     def forward(self, interaction):
         from REC.model.hstu_functional import EmbeddingGatherFn, L2NormFn
@@ -332,6 +339,7 @@ class HSTU(BaseModel):
         if self.loss == 'prior' and self.neg_sample_by_cat:
             pools += list(range(C))
         pool_ids = [all_gather_ids(neg_items[:, p].contiguous()).reshape(-1) for p in pools]
+        n_pool = pool_ids[0].numel()
         n_item_ids = B * (L + P)
         ids_all = torch.cat([items.reshape(-1)] + pool_ids).contiguous()
         fused_pos = isinstance(self.item_id_proj_tower, nn.Identity)
@@ -342,11 +350,8 @@ class HSTU(BaseModel):
             rows_all = self.item_id_proj_tower(rows_all)
             x = rows_all[:n_item_ids].view(B, L + P, D)[:, :L] + self.position_embedding.weight[:L][None]
         e_rows = rows_all[:n_item_ids]                                   # targets, [B*(L+P), D] fp32
-        negs = {}
-        off = n_item_ids
-        for p, ids in zip(pools, pool_ids):
-            negs[p] = L2NormFn.apply(rows_all[off:off + ids.numel()].contiguous())
-            off += ids.numel()
+        negs_pools = L2NormFn.apply(rows_all[n_item_ids:].contiguous()).view(len(pools), n_pool, D)
+        pool_slot = {p: i for i, p in enumerate(pools)}
 
         key_valid = mask[:, :L].to(torch.uint8).contiguous()
         out = self._encode(x, key_valid)                                 # [B,L,D] fp32
@@ -355,43 +360,50 @@ class HSTU(BaseModel):
 
         idx = torch.arange(L, device=dev)[None, :] + 1 + torch.arange(P, device=dev)[:, None]      # [P,L]
         base_valid = mask[:, None, :L] & mask[:, idx]                                              # [B,P,L]
-        model_out = defaultdict(float)
-        total = torch.zeros((), dtype=torch.float32, device=dev)
 
+        # one group per (token mask, head assignment, negative pool): the nce branch and every prior category
+        groups = []                       # (valid [B,P,L], head_for_p [P], pool slot, weight, kind, index)
         if self.loss == 'nce' or (self.loss == 'prior' and additive):
-            head_for_p = torch.arange(P) // self.seg_len
-            per_p, logs = self._pool_loss(head_rows, e_rows, negs[pools[0]], base_valid, head_for_p, True)
-            total = total + per_p.sum()
-            seg = per_p.detach().view(S, self.seg_len).sum(dim=1)
-            for s in range(S):
-                model_out[f"seg_{s}_loss"] = seg[s]
-            model_out.update(logs)
-
+            groups.append((base_valid, torch.arange(P) // self.seg_len, pool_slot[pools[0]], 1.0, 'nce', 0))
         if self.loss == 'prior':
             seg_len = P if additive else self.seg_len
             seg_for_p = torch.arange(P) // seg_len
-            accum = torch.zeros(P, dtype=torch.float32, device=dev)
             tag_win = pos_tags[:, idx].bool()                                                      # [B,P,L,C]
             for c in range(C):
-                name = self.int_to_category[c]
                 valid = base_valid & tag_win[..., c]
                 if self.pos_sample_mix_ratio > 0.0:
                     valid = base_valid & (tag_win[..., c] | (torch.rand(valid.shape, device=dev) < self.pos_sample_mix_ratio))
                 head_for_p = torch.full((P,), S + c) if additive else seg_for_p * C + c
-                pool = c if self.neg_sample_by_cat else pools[0]
-                per_p, logs = self._pool_loss(head_rows, e_rows, negs[pool], valid, head_for_p, c == 0)
-                per_p = per_p * self.prior_loss_weight[c]
-                total = total + per_p.sum()
-                accum = accum + per_p.detach()
-                model_out[f'head_nce_{name}_loss'] = per_p.sum().detach()
-                if c == 0:
-                    model_out.update(logs)
+                pool = pool_slot[c] if self.neg_sample_by_cat else pool_slot[pools[0]]
+                groups.append((valid, head_for_p, pool, float(self.prior_loss_weight[c]), 'prior', c))
+        valid_g = torch.stack([g[0] for g in groups])
+        head_for_p_g = torch.stack([g[1] for g in groups])
+        slots = [g[2] for g in groups]
+        negs_g = negs_pools if slots == list(range(len(pools))) else negs_pools[torch.tensor(slots, device=dev)]
+        # reference: top-k logs come from the nce branch, then are overwritten by prior category 0 (hstu.py:723, 863)
+        log_group = max(i for i, g in enumerate(groups) if g[4] == 'nce' or g[5] == 0)
+        mean_gp, logs = self._grouped_loss(head_rows, e_rows, negs_g.contiguous(), valid_g, head_for_p_g, log_group)
+        per_gp = mean_gp * self.horizon_discount.float()[None, :] * torch.tensor([g[3] for g in groups], device=dev)[:, None]
+
+        model_out = defaultdict(float)
+        total = per_gp.sum()
+        accum = torch.zeros(P, dtype=torch.float32, device=dev)
+        for i, g in enumerate(groups):
+            if g[4] == 'nce':
+                seg = per_gp[i].detach().view(S, self.seg_len).sum(dim=1)
+                for s_ in range(S):
+                    model_out[f"seg_{s_}_loss"] = seg[s_]
+            else:
+                model_out[f'head_nce_{self.int_to_category[g[5]]}_loss'] = per_gp[i].sum().detach()
+                accum = accum + per_gp[i].detach()
+        if self.loss == 'prior':
             if not additive:
                 seg = accum.view(S, self.seg_len).sum(dim=1)
-                for s in range(S):
-                    model_out[f"seg_{s}_loss"] = model_out[f"seg_{s}_loss"] + seg[s]
+                for s_ in range(S):
+                    model_out[f"seg_{s_}_loss"] = model_out[f"seg_{s_}_loss"] + seg[s_]
             else:
                 total = total / 2
+        model_out.update(logs)
         model_out["loss"] = total
         return model_out
 

@@ -167,11 +167,12 @@ class L2NormFn(Function):
 
 
 class NceLossFn(Function):
-    """Per-token sampled-softmax loss for one negative pool (reference hstu.py:600-619 + cross_entropy).
+    """Per-token sampled-softmax loss of G groups (negative pools / prior categories) in one launch per kernel
+    (reference hstu.py:600-619 + cross_entropy, called once per prior head there).
 
-    q_rows [Rq, D] / p_rows [Rp, D] fp32 (raw head embeddings / target embeddings), token t pairs
-    q_rows[q_idx[t]] with p_rows[p_idx[t]]; negs [n_neg, D] bf16 normalised.  Returns loss [tok_cap] fp32
-    (zeros beyond *n_tok).  No [N_tok, n_neg] tensor is ever materialised.
+    q_rows [Rq, D] / p_rows [Rp, D] fp32 (raw head embeddings / target embeddings, shared by the groups); token t of
+    group g pairs q_rows[q_idx[g,t]] with p_rows[p_idx[g,t]]; negs [G, n_neg, D] bf16 normalised.  Returns loss
+    [G, tok_cap] fp32 (zeros beyond n_tok[g]).  No [N_tok, n_neg] tensor is ever materialised.
     """
 
     @staticmethod

@@ -87,21 +87,42 @@ __device__ __forceinline__ void load_norm_frags(const IT* src, bool live, int ha
 // forward
 // ------------------------------------------------------------------------------------------
 template <int NKS, typename IT, bool LOGS>
-__global__ __launch_bounds__(256, 2) void nce_fwd_kernel(const IT* __restrict__ q_rows, const int32_t* __restrict__ q_idx,
-                                                         const IT* __restrict__ p_rows, const int32_t* __restrict__ p_idx,
-                                                         const bf16_t* __restrict__ negs, int n_neg,
-                                                         const int32_t* __restrict__ n_tok_dev, int tok_cap,
+__global__ __launch_bounds__(256, 2) void nce_fwd_kernel(const IT* __restrict__ q_rows, const int32_t* q_idx,
+                                                         const IT* __restrict__ p_rows, const int32_t* p_idx,
+                                                         const bf16_t* negs, int n_neg,
+                                                         const int32_t* n_tok_dev, int tok_cap,
                                                          const float* __restrict__ logit_scale_dev, float thres,
-                                                         float* __restrict__ loss, float* __restrict__ lse_out,
-                                                         int32_t* __restrict__ n_valid, int32_t* __restrict__ rank,
-                                                         bf16_t* __restrict__ qn_out, bf16_t* __restrict__ pn_out,
-                                                         uint32_t* __restrict__ supp_out, float* __restrict__ q_inv,
-                                                         float* __restrict__ p_inv, float* __restrict__ s_pos_out) {
+                                                         int tiles_per_split, float* sum_out,
+                                                         int32_t* n_valid, int32_t* rank,
+                                                         bf16_t* qn_out, bf16_t* pn_out,
+                                                         uint32_t* supp_out, float* q_inv,
+                                                         float* p_inv, float* s_pos_out) {
   using T = sg::Tile<NKS>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // blockIdx.z selects the group (negative pool / prior category): every per-token array is [groups, tok_cap(, D)],
+  // negatives are [groups, n_neg, D]; query / positive source rows are shared.
+  {
+    const int64_t grp = blockIdx.z, to = grp * tok_cap;
+    q_idx += to; p_idx += to; n_tok_dev += grp; negs += grp * (int64_t)n_neg * T::DIM; sum_out += to;
+    if (n_valid) n_valid += to;
+    if (rank) rank += to;
+    if (qn_out) qn_out += to * T::DIM;
+    if (pn_out) pn_out += to * T::DIM;
+    if (supp_out) supp_out += grp * (int64_t)((n_neg + 31) >> 5) * tok_cap;
+    if (q_inv) q_inv += to;
+    if (p_inv) p_inv += to;
+    s_pos_out += to;
+  }
   const int n_tok = min(*n_tok_dev, tok_cap);
   const int tok0 = blockIdx.x * 128;
   if (tok0 >= n_tok) return;
+  // blockIdx.y selects a contiguous range of negative tiles: (token block, negative range) units keep the
+  // 512 workgroup slots busy without a long tail; partial sums meet in sum_out (float atomics) and
+  // mhr_nce_finalize turns them into lse / loss.
+  const int n_tiles = (n_neg + 31) >> 5;
+  const int t_begin = blockIdx.y * tiles_per_split, t_end = min(n_tiles, t_begin + tiles_per_split);
+  if (t_begin >= t_end) return;
+  const bool first_split = blockIdx.y == 0;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, half = lane >> 5;
   const int tok = tok0 + wave * 32 + r;
   const bool live = tok < n_tok;
@@ -122,7 +143,7 @@ __global__ __launch_bounds__(256, 2) void nce_fwd_kernel(const IT* __restrict__ 
 #pragma unroll
     for (int i = 0; i < 8; ++i) spos += (float)frag[0][ks][i] * (float)frag[1][ks][i];
   spos += __shfl_xor(spos, 32, 64);
-  if (live) {
+  if (live && first_split) {
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
       const int k0 = ks * 16 + 8 * half;
@@ -141,7 +162,6 @@ __global__ __launch_bounds__(256, 2) void nce_fwd_kernel(const IT* __restrict__ 
   float sum = 0.f;
   int nv = 0, rk = 0;
 
-  const int n_tiles = (n_neg + 31) >> 5;
   auto row_ptr_for = [&](int tile) {
     return [=](int rr) -> const bf16_t* {
       const int j = tile * 32 + rr;
@@ -149,12 +169,12 @@ __global__ __launch_bounds__(256, 2) void nce_fwd_kernel(const IT* __restrict__ 
     };
   };
   sg::Stage<NKS> st;
-  st.load(row_ptr_for(0));
+  st.load(row_ptr_for(t_begin));
   st.store(smem);
   __syncthreads();
   int cur = 0;
-  for (int t = 0; t < n_tiles; ++t) {
-    const bool more = t + 1 < n_tiles;
+  for (int t = t_begin; t < t_end; ++t) {
+    const bool more = t + 1 < t_end;
     if (more) st.load(row_ptr_for(t + 1));
     f32x16 acc[2] = {sg::zero16(), sg::zero16()};
     sg::mma_tile<NKS, 2>(smem + cur * T::BYTES, frag, acc, r, half);
@@ -186,15 +206,33 @@ __global__ __launch_bounds__(256, 2) void nce_fwd_kernel(const IT* __restrict__ 
     rk += __shfl_xor(rk, 32, 64);
   }
   if (live && half == 0) {
-    const float total = sum + fast_exp2(spos * c1 - c1);
-    const float l = scale + __logf(total);
-    lse_out[tok] = l;
-    loss[tok] = l - scale * spos;
+    atomicAdd(sum_out + tok, sum);
     if (LOGS) {
-      if (n_valid) n_valid[tok] = nv + 1;
-      if (rank) rank[tok] = rk;
+      if (n_valid) atomicAdd(n_valid + tok, nv);
+      if (rank) atomicAdd(rank + tok, rk);
     }
   }
+}
+
+// lse / loss from the partial sums of all negative ranges
+__global__ __launch_bounds__(256) void nce_finalize_kernel(const float* sum, const float* s_pos,
+                                                           const int32_t* __restrict__ n_tok_dev, int tok_cap,
+                                                           const float* __restrict__ logit_scale_dev,
+                                                           float* loss, float* lse, int32_t* n_valid) {
+  const int64_t to = (int64_t)blockIdx.y * tok_cap;
+  sum += to; s_pos += to; loss += to; lse += to;
+  if (n_valid) n_valid += to;
+  const int n_tok = min(n_tok_dev[blockIdx.y], tok_cap);
+  const int tok = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tok >= n_tok) return;
+  const float scale = clamp_scale(logit_scale_dev);
+  const float c1 = scale * LOG2E;
+  const float sp = s_pos[tok];
+  const float total = sum[tok] + fast_exp2(sp * c1 - c1);
+  const float l = scale + __logf(total);
+  lse[tok] = l;
+  loss[tok] = l - scale * sp;
+  if (n_valid) n_valid[tok] += 1;        // the positive itself (hstu.py:622: logits > finfo.min / 100)
 }
 
 // ------------------------------------------------------------------------------------------
@@ -215,23 +253,32 @@ __device__ __forceinline__ float half_sum(float v) {   // sum over the 32 lanes 
 }
 
 template <int NKS>
-__global__ __launch_bounds__(256, 1) void nce_bwd_q_kernel(const bf16_t* __restrict__ qn, const bf16_t* __restrict__ pn,
-                                                           const bf16_t* __restrict__ negs, const uint32_t* __restrict__ supp,
-                                                           int n_neg, const int32_t* __restrict__ n_tok_dev, int tok_cap,
-                                                           const float* __restrict__ logit_scale_dev,
-                                                           const float* __restrict__ lse, const float* __restrict__ w,
-                                                           const float* __restrict__ q_inv, const float* __restrict__ p_inv,
-                                                           const float* __restrict__ s_pos, const int32_t* __restrict__ q_idx,
-                                                           const int32_t* __restrict__ p_idx, float* __restrict__ dq_rows,
+__global__ __launch_bounds__(256, 1) void nce_bwd_q_kernel(const bf16_t* qn, const bf16_t* pn,
+                                                           const bf16_t* negs, const uint32_t* supp,
+                                                           int n_neg, const int32_t* n_tok_dev, int tok_cap,
+                                                           int tiles_per_split, const float* __restrict__ logit_scale_dev,
+                                                           const float* lse, const float* w,
+                                                           const float* q_inv, const float* p_inv,
+                                                           const float* s_pos, const int32_t* q_idx,
+                                                           const int32_t* p_idx, float* __restrict__ dq_rows,
                                                            float* __restrict__ dp_rows, float* __restrict__ d_logit_scale) {
   using T = sg::Tile<NKS>;
   constexpr int ND = (NKS + 1) / 2;          // 32-column chunks of the feature dim
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* tiles = smem;               // 2 x T::BYTES
-
+  {
+    const int64_t grp = blockIdx.z, to = grp * tok_cap;
+    qn += to * T::DIM; pn += to * T::DIM; negs += grp * (int64_t)n_neg * T::DIM;
+    supp += grp * (int64_t)((n_neg + 31) >> 5) * tok_cap;
+    n_tok_dev += grp; lse += to; w += to; q_inv += to; p_inv += to; s_pos += to; q_idx += to; p_idx += to;
+  }
   const int n_tok = min(*n_tok_dev, tok_cap);
   const int tok0 = blockIdx.x * 128;
   if (tok0 >= n_tok) return;
+  const int n_tiles = (n_neg + 31) >> 5;
+  const int t_begin = blockIdx.y * tiles_per_split, t_end = min(n_tiles, t_begin + tiles_per_split);
+  if (t_begin >= t_end) return;
+  const bool first_split = blockIdx.y == 0;       // owns the positive-pair terms
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, half = lane >> 5;
   const int tok = tok0 + wave * 32 + r;
   const bool live = tok < n_tok;
@@ -250,7 +297,6 @@ __global__ __launch_bounds__(256, 1) void nce_bwd_q_kernel(const bf16_t* __restr
   for (int dc = 0; dc < ND; ++dc) dq[dc] = sg::zero16();
   float dsc = 0.f;   // sum_j g_ij * s_ij for my token (my half's rows)
 
-  const int n_tiles = (n_neg + 31) >> 5;
   auto row_ptr_for = [&](int tile) {
     return [=](int rr) -> const bf16_t* {
       const int j = tile * 32 + rr;
@@ -258,13 +304,13 @@ __global__ __launch_bounds__(256, 1) void nce_bwd_q_kernel(const bf16_t* __restr
     };
   };
   sg::Stage<NKS> st;
-  st.load(row_ptr_for(0));
-  uint32_t sw = live ? supp[tok] : 0u;
+  st.load(row_ptr_for(t_begin));
+  uint32_t sw = live ? supp[(int64_t)t_begin * tok_cap + tok] : 0u;
   st.store(tiles);
   __syncthreads();
   int cur = 0;
-  for (int t = 0; t < n_tiles; ++t) {
-    const bool more = t + 1 < n_tiles;
+  for (int t = t_begin; t < t_end; ++t) {
+    const bool more = t + 1 < t_end;
     uint32_t sw_next = 0u;
     if (more) {
       st.load(row_ptr_for(t + 1));
@@ -301,7 +347,7 @@ __global__ __launch_bounds__(256, 1) void nce_bwd_q_kernel(const bf16_t* __restr
   dsc += __shfl_xor(dsc, 32, 64);   // both halves hold rows of the same token column -> full sum per token (lane r)
   if (live && half == 0) {
     const float ppos = __expf(scale * s_pos[tok] - lse[tok]);
-    dls = dsc + my_w * (ppos - 1.0f) * s_pos[tok];
+    dls = dsc + (first_split ? my_w * (ppos - 1.0f) * s_pos[tok] : 0.f);
   }
   dls = wave_sum(dls);
   if (lane == 0 && d_logit_scale) atomicAdd(d_logit_scale, dls * scale);   // d/d(param) with scale = exp(param)
@@ -312,7 +358,7 @@ __global__ __launch_bounds__(256, 1) void nce_bwd_q_kernel(const bf16_t* __restr
     const bool tl = tk < n_tok;
     const float wi = tl ? w[tk] : 0.f;
     const float sp = tl ? s_pos[tk] : 0.f;
-    const float coef = tl ? wi * (__expf(scale * sp - lse[tk]) - 1.0f) : 0.f;   // w (p_pos - 1)
+    const float coef = (tl && first_split) ? wi * (__expf(scale * sp - lse[tk]) - 1.0f) : 0.f;   // w (p_pos - 1)
     float qv[ND], pv[ND], dqn[ND], dpn[ND];
     float dot_q = 0.f, dot_p = 0.f;
 #pragma unroll
@@ -339,7 +385,7 @@ __global__ __launch_bounds__(256, 1) void nce_bwd_q_kernel(const bf16_t* __restr
         const int d = dc * 32 + r;
         if (d < T::DIM) {
           atomicAdd(qdst + d, (dqn[dc] - qv[dc] * dot_q) * iq);
-          atomicAdd(pdst + d, (dpn[dc] - pv[dc] * dot_p) * ip);
+          if (first_split) atomicAdd(pdst + d, (dpn[dc] - pv[dc] * dot_p) * ip);
         }
       }
     }
@@ -350,21 +396,28 @@ __global__ __launch_bounds__(256, 1) void nce_bwd_q_kernel(const bf16_t* __restr
 // backward, negative-stationary: d_negs
 // ------------------------------------------------------------------------------------------
 template <int NKS>
-__global__ __launch_bounds__(256, 1) void nce_bwd_n_kernel(const bf16_t* __restrict__ qn, const bf16_t* __restrict__ negs,
-                                                           const uint32_t* __restrict__ supp, int n_neg,
-                                                           const int32_t* __restrict__ n_tok_dev, int tok_cap,
-                                                           int tiles_per_split, const float* __restrict__ logit_scale_dev,
-                                                           const float* __restrict__ lse, const float* __restrict__ w,
-                                                           float* __restrict__ d_negs) {
+__global__ __launch_bounds__(256, 1) void nce_bwd_n_kernel(const bf16_t* qn, const bf16_t* negs,
+                                                           const uint32_t* supp, int n_neg,
+                                                           const int32_t* n_tok_dev, int tok_cap,
+                                                           const float* __restrict__ logit_scale_dev,
+                                                           const float* lse, const float* w,
+                                                           float* d_negs) {
   using T = sg::Tile<NKS>;
   constexpr int ND = (NKS + 1) / 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // per buffer: Q tile | 32 x {w, lse*log2e} | 4 x 32 suppression words (one row per wave's negative tile)
   constexpr int BUF = T::BYTES + 32 * 8 + 128 * 4;
+  {
+    const int64_t grp = blockIdx.z, to = grp * tok_cap;
+    qn += to * T::DIM; negs += grp * (int64_t)n_neg * T::DIM; supp += grp * (int64_t)((n_neg + 31) >> 5) * tok_cap;
+    n_tok_dev += grp; lse += to; w += to; d_negs += grp * (int64_t)n_neg * T::DIM;
+  }
   const int n_tok = min(*n_tok_dev, tok_cap);
   const int n_tok_tiles = (n_tok + 31) >> 5;
   const int neg0 = blockIdx.x * 128;
-  const int tt0 = blockIdx.y * tiles_per_split, tt1 = min(n_tok_tiles, tt0 + tiles_per_split);
+  // token tiles are dealt round-robin over gridDim.y so that every split gets an equal share of the LIVE tiles
+  // whatever *n_tok_dev is (the host only knows the capacity)
+  const int tt0 = blockIdx.y, tstep = gridDim.y, tt1 = n_tok_tiles;
   if (tt0 >= tt1) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, half = lane >> 5;
   const int neg = neg0 + wave * 32 + r;                 // my stationary negative (lane column)
@@ -412,9 +465,9 @@ __global__ __launch_bounds__(256, 1) void nce_bwd_n_kernel(const bf16_t* __restr
   store_all(0);
   __syncthreads();
   int cur = 0;
-  for (int t = tt0; t < tt1; ++t) {
-    const bool more = t + 1 < tt1;
-    if (more) load_all(t + 1);
+  for (int t = tt0; t < tt1; t += tstep) {
+    const bool more = t + tstep < tt1;
+    if (more) load_all(t + tstep);
     const unsigned char* base = smem + cur * BUF;
     f32x16 s[1] = {sg::zero16()};
     sg::mma_tile<NKS, 1>(base, frag, s, r, half);                 // rows = tokens, cols = negatives
@@ -473,49 +526,64 @@ inline bool nks_for(int dim, int& nks) {
     default: MACRO(16); break; \
   }
 
+static inline int nce_splits(int n_tiles, int n_groups, int want, int& tiles_per_split) {
+  // (token block, negative range, group) units should outnumber the ~512 workgroup slots several times; groups
+  // already multiply the unit count, so fewer negative ranges are needed (each range repeats the prologue/epilogue)
+  int splits = want / (n_groups > 0 ? n_groups : 1);
+  if (splits < 1) splits = 1;
+  while (splits > 1 && n_tiles / splits < 32) splits >>= 1;
+  tiles_per_split = (n_tiles + splits - 1) / splits;
+  return (n_tiles + tiles_per_split - 1) / tiles_per_split;
+}
+
 extern "C" int mhr_nce_fwd(const void* q_rows, const int32_t* q_idx, const void* p_rows, const int32_t* p_idx, int io_dtype,
-                           const void* negs, int n_neg, int dim, const int32_t* n_tok_dev, int tok_cap,
-                           const float* logit_scale_dev, float thres, float* loss, float* lse, int32_t* n_valid,
-                           int32_t* rank, void* qn_out, void* pn_out, uint32_t* supp_out, float* q_inv, float* p_inv,
-                           float* s_pos, void* stream) {
-  MHR_REQUIRE(q_rows && q_idx && p_rows && p_idx && negs && n_tok_dev && logit_scale_dev && loss && lse, "nce_fwd: null pointer");
+                           const void* negs, int n_neg, int dim, int n_groups, const int32_t* n_tok_dev, int tok_cap,
+                           const float* logit_scale_dev, float thres, float* sum_out, int32_t* n_valid, int32_t* rank,
+                           void* qn_out, void* pn_out, uint32_t* supp_out, float* q_inv, float* p_inv, float* s_pos,
+                           void* stream) {
+  MHR_REQUIRE(q_rows && q_idx && p_rows && p_idx && negs && n_tok_dev && logit_scale_dev && sum_out && s_pos,
+              "nce_fwd: null pointer");
   int nks;
   MHR_REQUIRE(nks_for(dim, nks), "nce_fwd: dim=%d unsupported (16/32/64/128/256)", dim);
-  MHR_REQUIRE(n_neg > 0 && tok_cap > 0, "nce_fwd: bad sizes");
-  const int grid = (tok_cap + 127) / 128;
+  MHR_REQUIRE(n_neg > 0 && tok_cap > 0 && n_groups >= 1 && n_groups <= 65535, "nce_fwd: bad sizes");
+  int tps;
+  const int splits = nce_splits((n_neg + 31) / 32, n_groups, 4, tps);
+  const dim3 grid((tok_cap + 127) / 128, splits, n_groups);
   hipStream_t s = (hipStream_t)stream;
   const bool logs = n_valid != nullptr || rank != nullptr;
-#define L_(NKS)                                                                                                             \
-  {                                                                                                                         \
-    size_t lds = 2 * sg::Tile<NKS>::BYTES;                                                                                  \
-    if (io_dtype == MHR_BF16) {                                                                                             \
-      if (logs) hipLaunchKernelGGL((nce_fwd_kernel<NKS, bf16_t, true>), dim3(grid), dim3(256), lds, s, (const bf16_t*)q_rows, \
-                                   q_idx, (const bf16_t*)p_rows, p_idx, (const bf16_t*)negs, n_neg, n_tok_dev, tok_cap,       \
-                                   logit_scale_dev, thres, loss, lse, n_valid, rank, (bf16_t*)qn_out, (bf16_t*)pn_out,        \
-                                   supp_out, q_inv, p_inv, s_pos);                                                    \
-      else hipLaunchKernelGGL((nce_fwd_kernel<NKS, bf16_t, false>), dim3(grid), dim3(256), lds, s, (const bf16_t*)q_rows,     \
-                              q_idx, (const bf16_t*)p_rows, p_idx, (const bf16_t*)negs, n_neg, n_tok_dev, tok_cap,            \
-                              logit_scale_dev, thres, loss, lse, n_valid, rank, (bf16_t*)qn_out, (bf16_t*)pn_out,             \
-                              supp_out, q_inv, p_inv, s_pos);                                                         \
-    } else {                                                                                                                \
-      if (logs) hipLaunchKernelGGL((nce_fwd_kernel<NKS, float, true>), dim3(grid), dim3(256), lds, s, (const float*)q_rows,   \
-                                   q_idx, (const float*)p_rows, p_idx, (const bf16_t*)negs, n_neg, n_tok_dev, tok_cap,        \
-                                   logit_scale_dev, thres, loss, lse, n_valid, rank, (bf16_t*)qn_out, (bf16_t*)pn_out,        \
-                                   supp_out, q_inv, p_inv, s_pos);                                                    \
-      else hipLaunchKernelGGL((nce_fwd_kernel<NKS, float, false>), dim3(grid), dim3(256), lds, s, (const float*)q_rows,       \
-                              q_idx, (const float*)p_rows, p_idx, (const bf16_t*)negs, n_neg, n_tok_dev, tok_cap,             \
-                              logit_scale_dev, thres, loss, lse, n_valid, rank, (bf16_t*)qn_out, (bf16_t*)pn_out,             \
-                              supp_out, q_inv, p_inv, s_pos);                                                         \
-    }                                                                                                                       \
+#define ARGS(IT)                                                                                                         \
+  (const IT*)q_rows, q_idx, (const IT*)p_rows, p_idx, (const bf16_t*)negs, n_neg, n_tok_dev, tok_cap, logit_scale_dev,   \
+      thres, tps, sum_out, n_valid, rank, (bf16_t*)qn_out, (bf16_t*)pn_out, supp_out, q_inv, p_inv, s_pos
+#define L_(NKS)                                                                                                          \
+  {                                                                                                                      \
+    size_t lds = 2 * sg::Tile<NKS>::BYTES;                                                                               \
+    if (io_dtype == MHR_BF16) {                                                                                          \
+      if (logs) hipLaunchKernelGGL((nce_fwd_kernel<NKS, bf16_t, true>), grid, dim3(256), lds, s, ARGS(bf16_t));          \
+      else hipLaunchKernelGGL((nce_fwd_kernel<NKS, bf16_t, false>), grid, dim3(256), lds, s, ARGS(bf16_t));              \
+    } else {                                                                                                             \
+      if (logs) hipLaunchKernelGGL((nce_fwd_kernel<NKS, float, true>), grid, dim3(256), lds, s, ARGS(float));            \
+      else hipLaunchKernelGGL((nce_fwd_kernel<NKS, float, false>), grid, dim3(256), lds, s, ARGS(float));                \
+    }                                                                                                                    \
   }
   NKS_SWITCH(nks, L_);
 #undef L_
+#undef ARGS
   MHR_CHECK_LAUNCH("nce_fwd");
   return MHR_OK;
 }
 
+extern "C" int mhr_nce_finalize(const float* sum, const float* s_pos, int n_groups, const int32_t* n_tok_dev, int tok_cap,
+                                const float* logit_scale_dev, float* loss, float* lse, int32_t* n_valid, void* stream) {
+  MHR_REQUIRE(sum && s_pos && n_tok_dev && logit_scale_dev && loss && lse, "nce_finalize: null pointer");
+  MHR_REQUIRE(tok_cap > 0 && n_groups >= 1 && n_groups <= 65535, "nce_finalize: bad sizes");
+  hipLaunchKernelGGL(nce_finalize_kernel, dim3((tok_cap + 255) / 256, n_groups), dim3(256), 0, (hipStream_t)stream, sum, s_pos,
+                     n_tok_dev, tok_cap, logit_scale_dev, loss, lse, n_valid);
+  MHR_CHECK_LAUNCH("nce_finalize");
+  return MHR_OK;
+}
+
 extern "C" int mhr_nce_bwd_tokens(const void* qn, const void* pn, const void* negs, const uint32_t* supp, int n_neg, int dim,
-                                  const int32_t* n_tok_dev, int tok_cap, const float* logit_scale_dev, const float* lse,
+                                  int n_groups, const int32_t* n_tok_dev, int tok_cap, const float* logit_scale_dev, const float* lse,
                                   const float* w, const float* q_inv, const float* p_inv, const float* s_pos,
                                   const int32_t* q_idx, const int32_t* p_idx, float* dq_rows, float* dp_rows,
                                   float* d_logit_scale, void* stream) {
@@ -524,14 +592,16 @@ extern "C" int mhr_nce_bwd_tokens(const void* qn, const void* pn, const void* ne
   MHR_REQUIRE(q_idx && p_idx && dq_rows && dp_rows, "nce_bwd_tokens: null index/output pointer");
   int nks;
   MHR_REQUIRE(nks_for(dim, nks), "nce_bwd_tokens: dim=%d unsupported (16/32/64/128/256)", dim);
-  MHR_REQUIRE(n_neg > 0 && tok_cap > 0, "nce_bwd_tokens: bad sizes");
+  MHR_REQUIRE(n_neg > 0 && tok_cap > 0 && n_groups >= 1 && n_groups <= 65535, "nce_bwd_tokens: bad sizes");
   hipStream_t s = (hipStream_t)stream;
-  const int grid_q = (tok_cap + 127) / 128;
+  int tps;
+  const int splits = nce_splits((n_neg + 31) / 32, n_groups, 2, tps);   // every range repeats the atomic epilogue
+  const dim3 grid_q((tok_cap + 127) / 128, splits, n_groups);
 #define L_(NKS)                                                                                                          \
   {                                                                                                                      \
     size_t lds_q = 2 * sg::Tile<NKS>::BYTES;                                                                             \
-    hipLaunchKernelGGL((nce_bwd_q_kernel<NKS>), dim3(grid_q), dim3(256), lds_q, s, (const bf16_t*)qn, (const bf16_t*)pn, \
-                       (const bf16_t*)negs, supp, n_neg, n_tok_dev, tok_cap, logit_scale_dev, lse, w, q_inv, p_inv,      \
+    hipLaunchKernelGGL((nce_bwd_q_kernel<NKS>), grid_q, dim3(256), lds_q, s, (const bf16_t*)qn, (const bf16_t*)pn,       \
+                       (const bf16_t*)negs, supp, n_neg, n_tok_dev, tok_cap, tps, logit_scale_dev, lse, w, q_inv, p_inv, \
                        s_pos, q_idx, p_idx, dq_rows, dp_rows, d_logit_scale);                                            \
   }
   NKS_SWITCH(nks, L_);
@@ -540,26 +610,24 @@ extern "C" int mhr_nce_bwd_tokens(const void* qn, const void* pn, const void* ne
   return MHR_OK;
 }
 
-extern "C" int mhr_nce_bwd_negs(const void* qn, const void* negs, const uint32_t* supp, int n_neg, int dim,
+extern "C" int mhr_nce_bwd_negs(const void* qn, const void* negs, const uint32_t* supp, int n_neg, int dim, int n_groups,
                                 const int32_t* n_tok_dev, int tok_cap, const float* logit_scale_dev, const float* lse,
                                 const float* w, float* d_negs, void* stream) {
   MHR_REQUIRE(qn && negs && supp && n_tok_dev && logit_scale_dev && lse && w && d_negs, "nce_bwd_negs: null pointer");
   int nks;
   MHR_REQUIRE(nks_for(dim, nks), "nce_bwd_negs: dim=%d unsupported (16/32/64/128/256)", dim);
-  MHR_REQUIRE(n_neg > 0 && tok_cap > 0, "nce_bwd_negs: bad sizes");
+  MHR_REQUIRE(n_neg > 0 && tok_cap > 0 && n_groups >= 1 && n_groups <= 65535, "nce_bwd_negs: bad sizes");
   hipStream_t s = (hipStream_t)stream;
   const int n_tok_tiles = (tok_cap + 31) / 32;
   const int neg_groups = (n_neg + 127) / 128;
-  int splits = (512 + neg_groups - 1) / neg_groups;        // ~512 workgroups
+  int splits = (2048 / n_groups + neg_groups - 1) / neg_groups;   // ~2048 workgroups in all, token tiles dealt round-robin
   if (splits > n_tok_tiles) splits = n_tok_tiles;
   if (splits < 1) splits = 1;
-  const int tiles_per_split = (n_tok_tiles + splits - 1) / splits;
 #define L_(NKS)                                                                                                        \
   {                                                                                                                    \
     size_t lds_n = 2 * (sg::Tile<NKS>::BYTES + 32 * 8 + 128 * 4);                                                      \
-    hipLaunchKernelGGL((nce_bwd_n_kernel<NKS>), dim3(neg_groups, splits), dim3(256), lds_n, s, (const bf16_t*)qn,      \
-                       (const bf16_t*)negs, supp, n_neg, n_tok_dev, tok_cap, tiles_per_split, logit_scale_dev, lse, w, \
-                       d_negs);                                                                                        \
+    hipLaunchKernelGGL((nce_bwd_n_kernel<NKS>), dim3(neg_groups, splits, n_groups), dim3(256), lds_n, s, (const bf16_t*)qn,      \
+                       (const bf16_t*)negs, supp, n_neg, n_tok_dev, tok_cap, logit_scale_dev, lse, w, d_negs);          \
   }
   NKS_SWITCH(nks, L_);
 #undef L_

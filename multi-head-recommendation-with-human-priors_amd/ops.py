@@ -209,12 +209,16 @@ def hstu_attn_bwd(h, act, key_valid, d_out, dh, B, L, n_heads, head_dim, apply_s
 class NceSaved:
     """Tensors the forward keeps for the backward (all preallocated at token capacity)."""
     __slots__ = ("qn", "pn", "supp", "q_inv", "p_inv", "s_pos", "lse", "loss", "n_valid", "rank", "negs",
-                 "n_tok_dev", "tok_cap", "thres", "dim", "n_neg")
+                 "n_tok_dev", "tok_cap", "thres", "dim", "n_neg", "groups")
 
 
 def nce_fwd(q_rows, q_idx, p_rows, p_idx, negs, n_tok_dev, tok_cap, logit_scale, thres=0.99, want_logs=False,
             for_backward=True):
-    """q_rows/p_rows [*, D] (bf16 or f32, same dtype); q_idx/p_idx [tok_cap] int32; negs [n_neg, D] bf16 normalised."""
+    """Grouped sampled softmax.  q_rows/p_rows [*, D] (bf16 or f32, same dtype, shared by all groups);
+    q_idx/p_idx [G, tok_cap] int32; negs [G, n_neg, D] bf16 normalised; n_tok_dev [G] int32.
+    (1-D q_idx / 2-D negs are accepted as a single group.)  Saved tensors carry the leading group axis."""
+    if q_idx.dim() == 1:
+        q_idx, p_idx, negs, n_tok_dev = q_idx[None], p_idx[None], negs[None], n_tok_dev.view(1)
     _chk(negs, "negs", torch.bfloat16)
     _chk(q_idx, "q_idx", torch.int32)
     _chk(p_idx, "p_idx", torch.int32)
@@ -222,38 +226,44 @@ def nce_fwd(q_rows, q_idx, p_rows, p_idx, negs, n_tok_dev, tok_cap, logit_scale,
     _chk(logit_scale, "logit_scale", torch.float32)
     assert q_rows.dtype == p_rows.dtype
     dev = negs.device
-    D = negs.shape[1]
-    tok_cap = (tok_cap + 3) // 4 * 4
+    G, n_neg, D = negs.shape
+    assert q_idx.shape == (G, tok_cap) and p_idx.shape == (G, tok_cap) and n_tok_dev.numel() == G
     sv = NceSaved()
-    sv.loss = torch.zeros(tok_cap, dtype=torch.float32, device=dev)
-    sv.lse = torch.zeros(tok_cap, dtype=torch.float32, device=dev)
-    sv.n_valid = torch.zeros(tok_cap, dtype=torch.int32, device=dev) if want_logs else None
-    sv.rank = torch.zeros(tok_cap, dtype=torch.int32, device=dev) if want_logs else None
+    sv.loss = torch.zeros(G, tok_cap, dtype=torch.float32, device=dev)
+    sv.lse = torch.zeros(G, tok_cap, dtype=torch.float32, device=dev)
+    sv.n_valid = torch.zeros(G, tok_cap, dtype=torch.int32, device=dev) if want_logs else None
+    sv.rank = torch.zeros(G, tok_cap, dtype=torch.int32, device=dev) if want_logs else None
+    sv.s_pos = torch.empty(G, tok_cap, dtype=torch.float32, device=dev)
     if for_backward:
-        sv.qn = torch.empty(tok_cap, D, dtype=torch.bfloat16, device=dev)
-        sv.pn = torch.empty(tok_cap, D, dtype=torch.bfloat16, device=dev)
-        sv.supp = torch.empty((negs.shape[0] + 31) // 32, tok_cap, dtype=torch.int32, device=dev)
-        sv.q_inv = torch.empty(tok_cap, dtype=torch.float32, device=dev)
-        sv.p_inv = torch.empty(tok_cap, dtype=torch.float32, device=dev)
-        sv.s_pos = torch.empty(tok_cap, dtype=torch.float32, device=dev)
+        sv.qn = torch.empty(G, tok_cap, D, dtype=torch.bfloat16, device=dev)
+        sv.pn = torch.empty(G, tok_cap, D, dtype=torch.bfloat16, device=dev)
+        sv.supp = torch.empty(G, (n_neg + 31) // 32, tok_cap, dtype=torch.int32, device=dev)
+        sv.q_inv = torch.empty(G, tok_cap, dtype=torch.float32, device=dev)
+        sv.p_inv = torch.empty(G, tok_cap, dtype=torch.float32, device=dev)
     else:
-        sv.qn = sv.pn = sv.supp = sv.q_inv = sv.p_inv = sv.s_pos = None
+        sv.qn = sv.pn = sv.supp = sv.q_inv = sv.p_inv = None
     sv.negs = negs
-    sv.n_tok_dev, sv.tok_cap, sv.thres, sv.dim, sv.n_neg = n_tok_dev, tok_cap, float(thres), D, negs.shape[0]
+    sv.n_tok_dev, sv.tok_cap, sv.thres, sv.dim, sv.n_neg, sv.groups = n_tok_dev, tok_cap, float(thres), D, n_neg, G
+    ssum = torch.zeros(G, tok_cap, dtype=torch.float32, device=dev)
+    st = _stream()
     _timed_call("mhr_nce_fwd", q_rows.data_ptr(), q_idx.data_ptr(), p_rows.data_ptr(), p_idx.data_ptr(), _dt(q_rows),
-             negs.data_ptr(), negs.shape[0], D, n_tok_dev.data_ptr(), tok_cap, logit_scale.data_ptr(), float(thres),
-             sv.loss.data_ptr(), sv.lse.data_ptr(), _ptr(sv.n_valid), _ptr(sv.rank), _ptr(sv.qn), _ptr(sv.pn),
-             _ptr(sv.supp), _ptr(sv.q_inv), _ptr(sv.p_inv), _ptr(sv.s_pos), _stream())
+                negs.data_ptr(), n_neg, D, G, n_tok_dev.data_ptr(), tok_cap, logit_scale.data_ptr(), float(thres),
+                ssum.data_ptr(), _ptr(sv.n_valid), _ptr(sv.rank), _ptr(sv.qn), _ptr(sv.pn),
+                _ptr(sv.supp), _ptr(sv.q_inv), _ptr(sv.p_inv), _ptr(sv.s_pos), st)
+    lib.call("mhr_nce_finalize", ssum.data_ptr(), sv.s_pos.data_ptr(), G, n_tok_dev.data_ptr(), tok_cap,
+             logit_scale.data_ptr(), sv.loss.data_ptr(), sv.lse.data_ptr(), _ptr(sv.n_valid), st)
     return sv
 
 
 def nce_bwd(sv, w, logit_scale, q_idx, p_idx, dq_rows, dp_rows, d_negs=None, d_logit_scale=None):
-    """w [tok_cap] f32 = dLoss/dloss[t].  Accumulates into dq_rows [Rq, D] / dp_rows [Rp, D] (f32, the forward's row
-    spaces); returns (d_negs [n_neg, D] f32, d_logit_scale [1])."""
+    """w [G, tok_cap] f32 = dLoss/dloss[g, t].  Accumulates into dq_rows [Rq, D] / dp_rows [Rp, D] (f32, the
+    forward's shared row spaces); returns (d_negs [G, n_neg, D] f32, d_logit_scale [1])."""
     dev = sv.negs.device
-    D, cap = sv.dim, sv.tok_cap
+    D, cap, G = sv.dim, sv.tok_cap, sv.groups
+    if q_idx.dim() == 1:
+        q_idx, p_idx, w = q_idx[None], p_idx[None], w[None]
     if d_negs is None:
-        d_negs = torch.zeros(sv.n_neg, D, dtype=torch.float32, device=dev)
+        d_negs = torch.zeros(G, sv.n_neg, D, dtype=torch.float32, device=dev)
     if d_logit_scale is None:
         d_logit_scale = torch.zeros(1, dtype=torch.float32, device=dev)
     _chk(w, "w", torch.float32)
@@ -261,10 +271,10 @@ def nce_bwd(sv, w, logit_scale, q_idx, p_idx, dq_rows, dp_rows, d_negs=None, d_l
     _chk(dp_rows, "dp_rows", torch.float32)
     st = _stream()
     _timed_call("mhr_nce_bwd_tokens", sv.qn.data_ptr(), sv.pn.data_ptr(), sv.negs.data_ptr(), sv.supp.data_ptr(), sv.n_neg, D,
-                sv.n_tok_dev.data_ptr(), cap, logit_scale.data_ptr(), sv.lse.data_ptr(), w.data_ptr(), sv.q_inv.data_ptr(),
+                G, sv.n_tok_dev.data_ptr(), cap, logit_scale.data_ptr(), sv.lse.data_ptr(), w.data_ptr(), sv.q_inv.data_ptr(),
                 sv.p_inv.data_ptr(), sv.s_pos.data_ptr(), q_idx.data_ptr(), p_idx.data_ptr(), dq_rows.data_ptr(),
                 dp_rows.data_ptr(), d_logit_scale.data_ptr(), st)
-    _timed_call("mhr_nce_bwd_negs", sv.qn.data_ptr(), sv.negs.data_ptr(), sv.supp.data_ptr(), sv.n_neg, D,
+    _timed_call("mhr_nce_bwd_negs", sv.qn.data_ptr(), sv.negs.data_ptr(), sv.supp.data_ptr(), sv.n_neg, D, G,
                 sv.n_tok_dev.data_ptr(), cap, logit_scale.data_ptr(), sv.lse.data_ptr(), w.data_ptr(), d_negs.data_ptr(), st)
     return d_negs, d_logit_scale
 

@@ -310,12 +310,12 @@ def test_nce_fwd_bwd(ops, D, n_tok, n_neg, dtype):
     lsr = ls.clone().requires_grad_(True)
     loss, logits, keep, neg, pos = _nce_oracle(q, p, nn_, lsr, 0.99)
     # 1e-4 relative on logits-derived quantities (north star tolerance)
-    np.testing.assert_allclose(sv.loss.cpu().numpy()[:n_tok], loss.detach().numpy(), rtol=1e-4, atol=1e-4)
-    assert float(sv.loss[n_tok:].abs().max()) == 0.0
+    np.testing.assert_allclose(sv.loss.cpu().numpy()[0, :n_tok], loss.detach().numpy(), rtol=1e-4, atol=1e-4)
+    assert float(sv.loss[0, n_tok:].abs().max()) == 0.0
     assert keep.sum() < keep.numel()                                               # suppression exercised
-    np.testing.assert_array_equal(sv.n_valid.cpu().numpy()[:n_tok], (keep.sum(-1) + 1).numpy())
+    np.testing.assert_array_equal(sv.n_valid.cpu().numpy()[0, :n_tok], (keep.sum(-1) + 1).numpy())
     rank_ref = (keep & (neg > pos)).sum(-1)
-    assert int((sv.rank.cpu()[:n_tok] - rank_ref).abs().max()) <= 1               # ties at fp32 rounding level
+    assert int((sv.rank.cpu()[0, :n_tok] - rank_ref).abs().max()) <= 1            # ties at fp32 rounding level
     w = torch.rand(cap, generator=g)
     w[n_tok:] = 0
     (loss * w[:n_tok]).sum().backward()
@@ -326,11 +326,52 @@ def test_nce_fwd_bwd(ops, D, n_tok, n_neg, dtype):
     # several tokens may share a source row: compare in the row space
     dq_ref = torch.zeros(n_src, D).index_add_(0, q_idx.long(), q.grad)
     dp_ref = torch.zeros(n_src, D).index_add_(0, p_idx.long(), p.grad)
-    for name, got, ref in (("dq", dq_rows.cpu(), dq_ref), ("dp", dp_rows.cpu(), dp_ref), ("dneg", dn.cpu(), nn_.grad)):
+    for name, got, ref in (("dq", dq_rows.cpu(), dq_ref), ("dp", dp_rows.cpu(), dp_ref), ("dneg", dn.cpu()[0], nn_.grad)):
         gs = float(ref.abs().max())
         err = float((got - ref).abs().max())
         assert err < 2e-2 * gs, (name, err, gs)
     assert abs(float(dls.cpu()) - float(lsr.grad)) < 2e-2 * abs(float(lsr.grad)) + 1e-4
+
+
+def test_nce_grouped_launch_equals_per_group(ops):
+    """Three groups (different token lists, negative pools and live counts, one of them EMPTY) in one launch."""
+    g = torch.Generator().manual_seed(99)
+    D, n_src, n_neg, cap, G = 64, 300, 160, 256, 3
+    q_rows = torch.randn(n_src, D, generator=g)
+    p_rows = torch.randn(n_src, D, generator=g)
+    n_toks = [200, 0, 77]
+    qi = torch.randint(0, n_src, (G, cap), generator=g).int()
+    pi = torch.randint(0, n_src, (G, cap), generator=g).int()
+    negs = bf(HO.l2n(torch.randn(G, n_neg, D, generator=g)))
+    ls = torch.tensor([math.log(20.0)]).cuda()
+    ntd = torch.tensor(n_toks, dtype=torch.int32).cuda()
+    sv = ops.nce_fwd(dev(q_rows), dev(qi), dev(p_rows), dev(pi), dev(negs), ntd, cap, ls, 0.99, want_logs=True)
+    w = torch.rand(G, cap, generator=g)
+    dq, dp = torch.zeros(n_src, D).cuda(), torch.zeros(n_src, D).cuda()
+    dn, dls = ops.nce_bwd(sv, dev(w), ls, dev(qi), dev(pi), dq, dp)
+    torch.cuda.synchronize()
+    dq_ref, dp_ref = torch.zeros(n_src, D), torch.zeros(n_src, D)
+    dls_ref = 0.0
+    for gi in range(G):
+        n = n_toks[gi]
+        assert float(sv.loss[gi, n:].abs().max()) == 0.0
+        if n == 0:
+            assert float(dn[gi].abs().max()) == 0.0
+            continue
+        q = q_rows[qi[gi, :n].long()].clone().requires_grad_(True)
+        p = p_rows[pi[gi, :n].long()].clone().requires_grad_(True)
+        nn_ = negs[gi].float().clone().requires_grad_(True)
+        lsr = torch.tensor(math.log(20.0), requires_grad=True)
+        loss, *_ = _nce_oracle(q, p, nn_, lsr, 0.99)
+        np.testing.assert_allclose(sv.loss.cpu().numpy()[gi, :n], loss.detach().numpy(), rtol=1e-4, atol=1e-4)
+        (loss * w[gi, :n]).sum().backward()
+        dq_ref.index_add_(0, qi[gi, :n].long(), q.grad)
+        dp_ref.index_add_(0, pi[gi, :n].long(), p.grad)
+        dls_ref += float(lsr.grad)
+        assert float((dn[gi].cpu() - nn_.grad).abs().max()) < 2e-2 * float(nn_.grad.abs().max())
+    assert float((dq.cpu() - dq_ref).abs().max()) < 2e-2 * float(dq_ref.abs().max())
+    assert float((dp.cpu() - dp_ref).abs().max()) < 2e-2 * float(dp_ref.abs().max())
+    assert abs(float(dls.cpu()) - dls_ref) < 2e-2 * abs(dls_ref) + 1e-4
 
 
 # ------------------------------------------------------------------------------------------------
