@@ -189,25 +189,32 @@ def main():
             per_step = {k: round(v[2] / args.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][2])}
             n_tok_total = None
             if name.startswith("mhr_nce"):
-                # algorithmic flops per launch: one category's tokens x negatives x D; N_tok measured on the last batch
+                # algorithmic flops per launch: ONE launch serves all groups (prior categories): sum over groups of
+                # live tokens x negatives x D; N_tok measured on the last batch of the timed region
                 items, _, mask, tags = batches[(args.warmup + args.steps - 1) % len(batches)]
                 idx = torch.arange(L, device=dev)[None, :] + 1 + torch.arange(P, device=dev)[:, None]
                 mb = mask.bool()
                 valid = mb[:, None, :L] & mb[:, idx]
                 if cfg["loss"] == "prior":
-                    n_tok = float((valid[..., None] & tags[:, idx].bool()).sum()) / C
+                    n_tok = float((valid[..., None] & tags[:, idx].bool()).sum())          # summed over the C groups
+                    n_groups = C
                 else:
                     n_tok = float(valid.sum())
+                    n_groups = 1
                 n_neg = world * B * data.n_neg(B)
-                mult = 4.0                                    # fwd: neg + fix logits; bwd (dQ + dN): 2 x 2 N_tok N_neg D
+                mult = 4.0                                    # fwd: neg + fix logits = 2 x 2 N_tok N_neg D
                 if name != "mhr_nce_fwd":
-                    mult = 2.0                                # each backward kernel: one of dQ / dN
+                    mult = 2.0                                # each backward kernel: one of dQ / dN (recompute not counted)
                 flops = mult * n_tok * n_neg * D
                 ach = flops / (mean_ms * 1e-3) / 1e12
                 out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS,
                                    "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None,
                                    "launch_ms": round(mean_ms, 4), "launches_per_step": launches / args.steps,
-                                   "algorithmic_flops_per_launch": flops, "tokens_per_launch": n_tok, "negatives": n_neg}
+                                   "algorithmic_flops_per_launch": flops, "tokens_per_launch": n_tok, "groups": n_groups,
+                                   "negatives_per_group": n_neg}
+                # all three sampled-softmax kernels, same accounting (fwd 4x, bwd 2x each)
+                out["nce_kernels_TFLOPs"] = {k: round((4.0 if k == "mhr_nce_fwd" else 2.0) * n_tok * n_neg * D / (v[1] * 1e-3) / 1e12, 1)
+                                             for k, v in prof.items() if k.startswith("mhr_nce")}
             elif name == "mhr_catalog_score_emit":
                 flops = 2.0 * B * model.medusa_num_heads * D * N      # the full pass dominates; sample passes are 1/14 + 1/222 of it
                 ach = flops / (mean_ms * launches / (args.steps) * 1e-3) / 1e12

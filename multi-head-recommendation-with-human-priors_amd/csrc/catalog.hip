@@ -44,8 +44,7 @@ __global__ __launch_bounds__(256, 2) void catalog_emit_kernel(
   using T = sg::Tile<NKS>;
   constexpr int RF = 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* tiles = smem;                                            // 2 x T::BYTES
-  uint32_t* tagt = reinterpret_cast<uint32_t*>(smem + 2 * T::BYTES);      // 2 x 32
+  unsigned char* tiles = smem;                                            // 3 x T::BYTES (LDS-DMA ring)
 
   // XCD-aware decode: workgroups with equal blockIdx % 8 share an XCD (L2); the R row tiles that stream the
   // same item slice are placed on one XCD so the slice is fetched from HBM once and re-read from that L2.
@@ -69,8 +68,8 @@ __global__ __launch_bounds__(256, 2) void catalog_emit_kernel(
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks)
       frag[f][ks] = live ? *reinterpret_cast<const bf16x8*>(users + (int64_t)row[f] * T::DIM + ks * 16 + 8 * half) : sg::zero8();
-    my_tau[f] = live ? tau[row[f]] : INFINITY;
     my_bits[f] = live ? row_bits[row[f]] : 0u;
+    my_tau[f] = (live && my_bits[f] != 0u) ? tau[row[f]] : INFINITY;     // rows switched off never pass the threshold test
     hp0[f] = hp1[f] = 0;
     if (live && hist_ptr) {
       const int b = row[f] / H;
@@ -80,73 +79,62 @@ __global__ __launch_bounds__(256, 2) void catalog_emit_kernel(
   }
 
   auto item_of = [&](int tile, int rr) -> int64_t { return item_begin + ((int64_t)tile * 32 + rr) * item_stride; };
+  // item tiles stream through a 3-deep LDS-DMA ring; rows past the catalog are clamped and never emitted
+  using D = sg::Dma<NKS>;
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
   auto row_ptr_for = [&](int tile) {
     return [=](int rr) -> const bf16_t* {
       const int64_t n = item_begin + ((int64_t)tile * 32 + rr) * item_stride;
-      return n < n_items ? items + n * T::DIM : nullptr;
+      return items + (n < n_items ? n : n_items - 1) * T::DIM;
     };
   };
-  auto tag_for = [&](int tile, int rr) -> uint32_t {
-    const int64_t n = item_of(tile, rr);
-    if (n >= n_items || n == 0) return 0u;                 // out of range, or the pad id (trainer.py:724)
-    return tag_bits ? tag_bits[n] : 0x80000000u;
-  };
-
-  sg::Stage<NKS> st;
-  st.load(row_ptr_for(t0));
-  uint32_t tg = threadIdx.x < 32 ? tag_for(t0, threadIdx.x) : 0u;
-  st.store(tiles);
-  if (threadIdx.x < 32) tagt[threadIdx.x] = tg;
-  __syncthreads();
-
-  int cur = 0;
-  for (int t = t0; t < t1; ++t) {
-    const bool more = t + 1 < t1;
-    if (more) {
-      st.load(row_ptr_for(t + 1));
-      if (threadIdx.x < 32) tg = tag_for(t + 1, threadIdx.x);
-    }
+  const int n_loc = t1 - t0;
+  D::issue(tiles, row_ptr_for(t0), wv, lane);
+  if (n_loc > 1) D::issue(tiles + T::BYTES, row_ptr_for(t0 + 1), wv, lane);
+  int cur = 0, nxt = 2;
+  for (int i = 0; i < n_loc; ++i) {
+    const int t = t0 + i;
+    if (i + 1 < n_loc) sg::wait_vmcnt<D::PW>(); else sg::wait_vmcnt<0>();
+    sg::ring_barrier();
+    if (i + 2 < n_loc) D::issue(tiles + nxt * T::BYTES, row_ptr_for(t + 2), wv, lane);
     f32x16 acc[RF];
 #pragma unroll
     for (int f = 0; f < RF; ++f) acc[f] = sg::zero16();
     sg::mma_tile<NKS, RF>(tiles + cur * T::BYTES, frag, acc, r, half);
 
-    const uint32_t* tt = tagt + cur * 32;
 #pragma unroll
     for (int f = 0; f < RF; ++f) {
 #pragma unroll
       for (int g = 0; g < 16; ++g) {
-        const int il = sg::crow(g, half);
         const float s = acc[f][g];
-        if (s >= my_tau[f] && (tt[il] & my_bits[f])) {
-          const int64_t n = item_of(t, il);
-          bool seen = false;
-          if (hist_items) {                                 // trainer.py:725-726: the user's own history
-            int lo = hp0[f], hi = hp1[f];
-            while (lo < hi) {
-              const int mid = (lo + hi) >> 1;
-              const int64_t hv = hist_items[mid];
-              if (hv < n) lo = mid + 1;
-              else hi = mid;
+        if (s >= my_tau[f]) {                                // rare once tau is set: everything below is off the hot path
+          const int64_t n = item_of(t, sg::crow(g, half));
+          if (n < n_items && n != 0) {                       // n == 0: the pad id (trainer.py:724)
+            const uint32_t tb = tag_bits ? tag_bits[n] : 0x80000000u;
+            bool ok = (tb & my_bits[f]) != 0u;
+            if (ok && hist_items) {                          // trainer.py:725-726: the user's own history
+              int lo = hp0[f], hi = hp1[f];
+              while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                const int64_t hv = hist_items[mid];
+                if (hv < n) lo = mid + 1;
+                else hi = mid;
+              }
+              ok = !(lo < hp1[f] && hist_items[lo] == n);
             }
-            seen = lo < hp1[f] && hist_items[lo] == n;
-          }
-          if (!seen) {
-            const int pos = atomicAdd(cand_cnt + row[f], 1);
-            if (pos < cap) {
-              cand_val[(int64_t)row[f] * cap + pos] = s;
-              cand_idx[(int64_t)row[f] * cap + pos] = (int32_t)n;
+            if (ok) {
+              const int pos = atomicAdd(cand_cnt + row[f], 1);
+              if (pos < cap) {
+                cand_val[(int64_t)row[f] * cap + pos] = s;
+                cand_idx[(int64_t)row[f] * cap + pos] = (int32_t)n;
+              }
             }
           }
         }
       }
     }
-    if (more) {
-      st.store(tiles + (cur ^ 1) * T::BYTES);
-      if (threadIdx.x < 32) tagt[(cur ^ 1) * 32 + threadIdx.x] = tg;
-    }
-    __syncthreads();
-    cur ^= 1;
+    cur = cur == 2 ? 0 : cur + 1;
+    nxt = nxt == 2 ? 0 : nxt + 1;
   }
 }
 
@@ -397,7 +385,7 @@ extern "C" int mhr_catalog_score_emit(const void* users, int n_rows, int H, cons
   hipStream_t s = (hipStream_t)stream;
 #define L_(NKS)                                                                                                          \
   {                                                                                                                      \
-    size_t lds = 2 * sg::Tile<NKS>::BYTES + 2 * 32 * 4;                                                                  \
+    size_t lds = 3 * sg::Tile<NKS>::BYTES;                                                                               \
     hipLaunchKernelGGL((catalog_emit_kernel<NKS>), dim3(grid), dim3(256), lds, s, (const bf16_t*)users, n_rows, H,       \
                        (const bf16_t*)items, n_items, item_begin, item_stride, n_tiles, R, n_slices, tag_bits, row_bits, \
                        tau, hist_ptr, hist_items, cand_val, cand_idx, cand_cnt, cap);                                    \

@@ -162,20 +162,21 @@ __global__ __launch_bounds__(256, 2) void nce_fwd_kernel(const IT* __restrict__ 
   float sum = 0.f;
   int nv = 0, rk = 0;
 
+  // negative tiles stream through a 3-deep LDS-DMA ring (stream_gemm.h); rows past n_neg are clamped (masked by `rem`)
+  using D = sg::Dma<NKS>;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   auto row_ptr_for = [&](int tile) {
-    return [=](int rr) -> const bf16_t* {
-      const int j = tile * 32 + rr;
-      return j < n_neg ? negs + (int64_t)j * T::DIM : nullptr;
-    };
+    return [=](int rr) -> const bf16_t* { return negs + (int64_t)min(tile * 32 + rr, n_neg - 1) * T::DIM; };
   };
-  sg::Stage<NKS> st;
-  st.load(row_ptr_for(t_begin));
-  st.store(smem);
-  __syncthreads();
-  int cur = 0;
-  for (int t = t_begin; t < t_end; ++t) {
-    const bool more = t + 1 < t_end;
-    if (more) st.load(row_ptr_for(t + 1));
+  const int n_loc = t_end - t_begin;
+  D::issue(smem, row_ptr_for(t_begin), wv, lane);
+  if (n_loc > 1) D::issue(smem + T::BYTES, row_ptr_for(t_begin + 1), wv, lane);
+  int cur = 0, nxt = 2;
+  for (int i = 0; i < n_loc; ++i) {
+    const int t = t_begin + i;
+    if (i + 1 < n_loc) sg::wait_vmcnt<D::PW>(); else sg::wait_vmcnt<0>();
+    sg::ring_barrier();
+    if (i + 2 < n_loc) D::issue(smem + nxt * T::BYTES, row_ptr_for(t + 2), wv, lane);
     f32x16 acc[2] = {sg::zero16(), sg::zero16()};
     sg::mma_tile<NKS, 2>(smem + cur * T::BYTES, frag, acc, r, half);
     const int rem = n_neg - t * 32;
@@ -196,9 +197,8 @@ __global__ __launch_bounds__(256, 2) void nce_fwd_kernel(const IT* __restrict__ 
       sbits |= __shfl_xor(sbits, 32, 64);
       if (live && half == 0) supp_out[(int64_t)t * tok_cap + tok] = sbits;
     }
-    if (more) st.store(smem + (cur ^ 1) * T::BYTES);
-    __syncthreads();
-    cur ^= 1;
+    cur = cur == 2 ? 0 : cur + 1;
+    nxt = nxt == 2 ? 0 : nxt + 1;
   }
   sum += __shfl_xor(sum, 32, 64);
   if (LOGS) {
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256, 1) void nce_bwd_q_kernel(const bf16_t* qn, con
   using T = sg::Tile<NKS>;
   constexpr int ND = (NKS + 1) / 2;          // 32-column chunks of the feature dim
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* tiles = smem;               // 2 x T::BYTES
+  unsigned char* tiles = smem;               // 3 x T::BYTES, then 3 x 1 KiB of suppression words
   {
     const int64_t grp = blockIdx.z, to = grp * tok_cap;
     qn += to * T::DIM; pn += to * T::DIM; negs += grp * (int64_t)n_neg * T::DIM;
@@ -297,26 +297,29 @@ __global__ __launch_bounds__(256, 1) void nce_bwd_q_kernel(const bf16_t* qn, con
   for (int dc = 0; dc < ND; ++dc) dq[dc] = sg::zero16();
   float dsc = 0.f;   // sum_j g_ij * s_ij for my token (my half's rows)
 
+  // negative tiles + this wave's 32 suppression words per tile stream through a 3-deep LDS-DMA ring
+  using D = sg::Dma<NKS>;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  unsigned char* words = smem + 3 * T::BYTES;                       // 3 x [4 waves][64] uint32
   auto row_ptr_for = [&](int tile) {
-    return [=](int rr) -> const bf16_t* {
-      const int j = tile * 32 + rr;
-      return j < n_neg ? negs + (int64_t)j * T::DIM : nullptr;
-    };
+    return [=](int rr) -> const bf16_t* { return negs + (int64_t)min(tile * 32 + rr, n_neg - 1) * T::DIM; };
   };
-  sg::Stage<NKS> st;
-  st.load(row_ptr_for(t_begin));
-  uint32_t sw = live ? supp[(int64_t)t_begin * tok_cap + tok] : 0u;
-  st.store(tiles);
-  __syncthreads();
-  int cur = 0;
-  for (int t = t_begin; t < t_end; ++t) {
-    const bool more = t + 1 < t_end;
-    uint32_t sw_next = 0u;
-    if (more) {
-      st.load(row_ptr_for(t + 1));
-      sw_next = live ? supp[(int64_t)(t + 1) * tok_cap + tok] : 0u;
-    }
+  const int tokc = min(tok, tok_cap - 1);
+  auto issue_all = [&](int buf, int tile) {
+    D::issue(tiles + buf * T::BYTES, row_ptr_for(tile), wv, lane);
+    sg::dma_words(supp + (int64_t)tile * tok_cap + tokc, words + buf * 1024 + wv * 256);
+  };
+  const int n_loc = t_end - t_begin;
+  issue_all(0, t_begin);
+  if (n_loc > 1) issue_all(1, t_begin + 1);
+  int cur = 0, nxt = 2;
+  for (int i = 0; i < n_loc; ++i) {
+    const int t = t_begin + i;
+    if (i + 1 < n_loc) sg::wait_vmcnt<D::PW + 1>(); else sg::wait_vmcnt<0>();
+    sg::ring_barrier();
+    if (i + 2 < n_loc) issue_all(nxt, t + 2);
     const unsigned char* tile = tiles + cur * T::BYTES;
+    const uint32_t sw = live ? reinterpret_cast<const uint32_t*>(words + cur * 1024 + wv * 256)[lane] : 0u;
     f32x16 acc[1] = {sg::zero16()};
     sg::mma_tile<NKS, 1>(tile, frag, acc, r, half);        // S^T: rows = negatives, cols = tokens
     const int rem = n_neg - t * 32;
@@ -335,10 +338,8 @@ __global__ __launch_bounds__(256, 1) void nce_bwd_q_kernel(const bf16_t* qn, con
       dq[dc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g0, sg::read_tr_frag<NKS>(tile, dc, 0, lane), dq[dc], 0, 0, 0);
       dq[dc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g1, sg::read_tr_frag<NKS>(tile, dc, 1, lane), dq[dc], 0, 0, 0);
     }
-    if (more) st.store(tiles + (cur ^ 1) * T::BYTES);
-    sw = sw_next;
-    __syncthreads();
-    cur ^= 1;
+    cur = cur == 2 ? 0 : cur + 1;
+    nxt = nxt == 2 ? 0 : nxt + 1;
   }
 
   // ---- finish: positive term, L2-normalisation chain rule, accumulation into the source rows -------
@@ -405,8 +406,10 @@ __global__ __launch_bounds__(256, 1) void nce_bwd_n_kernel(const bf16_t* qn, con
   using T = sg::Tile<NKS>;
   constexpr int ND = (NKS + 1) / 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  // per buffer: Q tile | 32 x {w, lse*log2e} | 4 x 32 suppression words (one row per wave's negative tile)
-  constexpr int BUF = T::BYTES + 32 * 8 + 128 * 4;
+  // per ring slot: Q tile | [4 waves][64] words: lanes 0-31 = suppression words of that wave's negative tile for the
+  // 32 tokens, lanes 32-63 = w (wave 0) / lse (wave 1) of the 32 tokens
+  constexpr int BUF = T::BYTES + 1024;
+  using D = sg::Dma<NKS>;
   {
     const int64_t grp = blockIdx.z, to = grp * tok_cap;
     qn += to * T::DIM; negs += grp * (int64_t)n_neg * T::DIM; supp += grp * (int64_t)((n_neg + 31) >> 5) * tok_cap;
@@ -420,6 +423,7 @@ __global__ __launch_bounds__(256, 1) void nce_bwd_n_kernel(const bf16_t* qn, con
   const int tt0 = blockIdx.y, tstep = gridDim.y, tt1 = n_tok_tiles;
   if (tt0 >= tt1) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, half = lane >> 5;
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
   const int neg = neg0 + wave * 32 + r;                 // my stationary negative (lane column)
   const bool nlive = neg < n_neg;
   const int n_neg_tiles = (n_neg + 31) >> 5;
@@ -436,48 +440,40 @@ __global__ __launch_bounds__(256, 1) void nce_bwd_n_kernel(const bf16_t* qn, con
   for (int dc = 0; dc < ND; ++dc) dn[dc] = sg::zero16();
 
   auto qrow_for = [&](int tile) {
-    return [=](int rr) -> const bf16_t* {
-      const int tk = tile * 32 + rr;
-      return tk < n_tok ? qn + (int64_t)tk * T::DIM : nullptr;
-    };
+    return [=](int rr) -> const bf16_t* { return qn + (int64_t)min(tile * 32 + rr, n_tok - 1) * T::DIM; };
   };
-  sg::Stage<NKS> sq;
-  float sc_v = 0.f;
-  uint32_t sw_v = 0u;
-  auto load_all = [&](int tile) {
-    sq.load(qrow_for(tile));
-    if (threadIdx.x < 64) {                           // 32 x w, 32 x lse*log2e
-      const int tk = tile * 32 + (threadIdx.x & 31);
-      const bool ok = tk < n_tok;
-      sc_v = threadIdx.x < 32 ? (ok ? w[tk] : 0.f) : (ok ? lse[tk] * LOG2E : 0.f);
-    } else if (threadIdx.x < 192) {                   // 4 negative tiles x 32 tokens suppression words
-      const int i = threadIdx.x - 64, nt = (neg0 >> 5) + (i >> 5), tk = tile * 32 + (i & 31);
-      sw_v = (nt < n_neg_tiles && tk < n_tok) ? supp[(int64_t)nt * tok_cap + tk] : 0u;
-    }
-  };
-  auto store_all = [&](int buf) {
+  const int my_nt = min((neg0 >> 5) + wv, n_neg_tiles - 1);
+  auto issue_all = [&](int buf, int tile) {
     unsigned char* base = smem + buf * BUF;
-    sq.store(base);
-    if (threadIdx.x < 64) reinterpret_cast<float*>(base + T::BYTES)[threadIdx.x] = sc_v;
-    else if (threadIdx.x < 192) reinterpret_cast<uint32_t*>(base + T::BYTES + 256)[threadIdx.x - 64] = sw_v;
+    D::issue(base, qrow_for(tile), wv, lane);
+    const int tk = min(tile * 32 + r, tok_cap - 1);
+    const void* src = supp + (int64_t)my_nt * tok_cap + tk;
+    if (half == 1 && wv == 0) src = w + tk;
+    if (half == 1 && wv == 1) src = lse + tk;
+    sg::dma_words(src, base + T::BYTES + wv * 256);
   };
-  load_all(tt0);
-  store_all(0);
-  __syncthreads();
-  int cur = 0;
-  for (int t = tt0; t < tt1; t += tstep) {
-    const bool more = t + tstep < tt1;
-    if (more) load_all(t + tstep);
+  const int n_loc = (tt1 - tt0 + tstep - 1) / tstep;
+  issue_all(0, tt0);
+  if (n_loc > 1) issue_all(1, tt0 + tstep);
+  int cur = 0, nxt = 2;
+  for (int i = 0; i < n_loc; ++i) {
+    const int t = tt0 + i * tstep;
+    if (i + 1 < n_loc) sg::wait_vmcnt<D::PW + 1>(); else sg::wait_vmcnt<0>();
+    sg::ring_barrier();
+    if (i + 2 < n_loc) issue_all(nxt, t + 2 * tstep);
     const unsigned char* base = smem + cur * BUF;
     f32x16 s[1] = {sg::zero16()};
     sg::mma_tile<NKS, 1>(base, frag, s, r, half);                 // rows = tokens, cols = negatives
-    const float* sc = reinterpret_cast<const float*>(base + T::BYTES);
-    const uint32_t* swd = reinterpret_cast<const uint32_t*>(base + T::BYTES + 256) + wave * 32;
+    const uint32_t* wd = reinterpret_cast<const uint32_t*>(base + T::BYTES);
+    const uint32_t* swd = wd + wv * 64;                              // suppression words of my wave's negative tile
+    const float* wsc = reinterpret_cast<const float*>(wd + 32);      // w      of the tile's 32 tokens (wave 0, upper half)
+    const float* lsc = reinterpret_cast<const float*>(wd + 64 + 32); // lse    of the tile's 32 tokens (wave 1, upper half)
+    const int trem = n_tok - t * 32;                                 // tokens past n_tok contribute nothing
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
       const int tl = sg::crow(g, half);
-      const bool keep = nlive && !((swd[tl] >> r) & 1u);
-      s[0][g] = keep ? sc[tl] * fast_exp2(s[0][g] * c1 - sc[32 + tl]) : 0.f;   // w == 0 for dead tokens
+      const bool keep = nlive && (tl < trem) && !((swd[tl] >> r) & 1u);
+      s[0][g] = keep ? wsc[tl] * fast_exp2(s[0][g] * c1 - lsc[tl] * LOG2E) : 0.f;
     }
     bf16x8 g0, g1;
     pack_acc(s[0], g0, g1);   // G (tokens on rows) as the A operand: computes G^T . Qn
@@ -486,9 +482,8 @@ __global__ __launch_bounds__(256, 1) void nce_bwd_n_kernel(const bf16_t* qn, con
       dn[dc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g0, sg::read_tr_frag<NKS>(base, dc, 0, lane), dn[dc], 0, 0, 0);
       dn[dc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g1, sg::read_tr_frag<NKS>(base, dc, 1, lane), dn[dc], 0, 0, 0);
     }
-    if (more) store_all(cur ^ 1);
-    __syncthreads();
-    cur ^= 1;
+    cur = cur == 2 ? 0 : cur + 1;
+    nxt = nxt == 2 ? 0 : nxt + 1;
   }
   // dn[dc][g]: row (reg) = negative neg0 + wave*32 + crow(g,half), column (lane) = feature dc*32 + r
 #pragma unroll
@@ -556,7 +551,7 @@ extern "C" int mhr_nce_fwd(const void* q_rows, const int32_t* q_idx, const void*
       thres, tps, sum_out, n_valid, rank, (bf16_t*)qn_out, (bf16_t*)pn_out, supp_out, q_inv, p_inv, s_pos
 #define L_(NKS)                                                                                                          \
   {                                                                                                                      \
-    size_t lds = 2 * sg::Tile<NKS>::BYTES;                                                                               \
+    size_t lds = 3 * sg::Tile<NKS>::BYTES;                                                                               \
     if (io_dtype == MHR_BF16) {                                                                                          \
       if (logs) hipLaunchKernelGGL((nce_fwd_kernel<NKS, bf16_t, true>), grid, dim3(256), lds, s, ARGS(bf16_t));          \
       else hipLaunchKernelGGL((nce_fwd_kernel<NKS, bf16_t, false>), grid, dim3(256), lds, s, ARGS(bf16_t));              \
@@ -599,7 +594,7 @@ extern "C" int mhr_nce_bwd_tokens(const void* qn, const void* pn, const void* ne
   const dim3 grid_q((tok_cap + 127) / 128, splits, n_groups);
 #define L_(NKS)                                                                                                          \
   {                                                                                                                      \
-    size_t lds_q = 2 * sg::Tile<NKS>::BYTES;                                                                             \
+    size_t lds_q = 3 * sg::Tile<NKS>::BYTES + 3 * 1024;                                                                  \
     hipLaunchKernelGGL((nce_bwd_q_kernel<NKS>), grid_q, dim3(256), lds_q, s, (const bf16_t*)qn, (const bf16_t*)pn,       \
                        (const bf16_t*)negs, supp, n_neg, n_tok_dev, tok_cap, tps, logit_scale_dev, lse, w, q_inv, p_inv, \
                        s_pos, q_idx, p_idx, dq_rows, dp_rows, d_logit_scale);                                            \
@@ -625,7 +620,7 @@ extern "C" int mhr_nce_bwd_negs(const void* qn, const void* negs, const uint32_t
   if (splits < 1) splits = 1;
 #define L_(NKS)                                                                                                        \
   {                                                                                                                    \
-    size_t lds_n = 2 * (sg::Tile<NKS>::BYTES + 32 * 8 + 128 * 4);                                                      \
+    size_t lds_n = 3 * (sg::Tile<NKS>::BYTES + 1024);                                                                  \
     hipLaunchKernelGGL((nce_bwd_n_kernel<NKS>), dim3(neg_groups, splits, n_groups), dim3(256), lds_n, s, (const bf16_t*)qn,      \
                        (const bf16_t*)negs, supp, n_neg, n_tok_dev, tok_cap, logit_scale_dev, lse, w, d_negs);          \
   }

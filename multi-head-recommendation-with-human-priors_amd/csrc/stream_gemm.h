@@ -112,6 +112,69 @@ __device__ __forceinline__ bf16x8 read_tr_frag(const unsigned char* tile, int dc
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// LDS-DMA staging (global_load_lds_dwordx4): tiles go HBM/L2 -> LDS without passing through registers.
+// One wave-instruction writes 1 KiB of LDS linearly (wave-uniform base + lane*16), so the XOR swizzle is applied
+// on the per-lane SOURCE address (cdna guide section 5.4 rule 21): the lane that fills slot `s` of row `row`
+// fetches chunk s ^ key(row).  Tiles rotate through a 3-deep ring: while tile t is consumed, t+1 and t+2 are in
+// flight; a wave waits for its own pieces with a counted `s_waitcnt vmcnt(N)` and a raw s_barrier publishes them
+// (no __syncthreads(): its implicit vmcnt(0) would drain the ring).  Inside such a loop there must be no ordinary
+// global load (hipcc would wait vmcnt(0) for it); stores and atomics only make the counted wait conservative.
+// ---------------------------------------------------------------------------------------------------------
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  static_assert(N >= 0 && N <= 10, "extend wait_vmcnt");
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+}
+
+__device__ __forceinline__ void ring_barrier() {
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int NKS>
+struct Dma {
+  using T = Tile<NKS>;
+  static constexpr int PIECES = T::BYTES / 1024;          // 1-KiB pieces per tile
+  static constexpr int PW = (PIECES + 3) / 4;             // pieces issued per wave per tile (waves beyond PIECES issue none)
+  static_assert(T::BYTES % 1024 == 0, "tile must be a whole number of 1-KiB pieces");
+
+  // row_ptr(row) must return a VALID global address for every row 0..31 (clamp out-of-range rows; their scores are
+  // masked by the caller) - a DMA cannot zero-fill.
+  template <typename RowPtr>
+  static __device__ __forceinline__ void issue(unsigned char* tile, RowPtr row_ptr, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < PW; ++i) {
+      const int pc = wave * PW + i;                        // wave-uniform
+      if (pc < PIECES) {
+        const int pos = pc * 1024 + lane * 16;
+        const int row = pos / T::ROW_BYTES, slot = (pos % T::ROW_BYTES) >> 4;
+        const bf16_t* src = row_ptr(row) + ((slot ^ T::key(row)) << 3);
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(tile + pc * 1024), 16, 0, 0);
+      }
+    }
+  }
+};
+
+// one 4-byte word per lane -> 256 bytes of LDS at a wave-uniform base (per-token scalars / mask words)
+__device__ __forceinline__ void dma_words(const void* lane_src, unsigned char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((gptr_t)lane_src, (lptr_t)lds_wave_base, 4, 0, 0);
+}
+
 // acc[f] (+)= tile . frag[f]^T for the RF stationary fragments
 template <int NKS, int RF>
 __device__ __forceinline__ void mma_tile(const unsigned char* tile, const bf16x8 (&frag)[RF][NKS], f32x16 (&acc)[RF], int r,
