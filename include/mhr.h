@@ -65,7 +65,8 @@ int mhr_embedding_scatter_add_bwd(const void* grad_rows, int grad_dtype, const i
  * ([n_a/window_len, seq_len, dim] f32): the gradient of the fused position-added copy, added to
  * source row r < n_a when (r % window_len) < seq_len.
  * Output: for every segment head position i (first occurrence of an id) out_rows[i,:] = sum of the
- * segment's source rows (f32), and row_slot[id] = i.  Non-head rows of out_rows are left untouched.
+ * segment's source rows (f32), and row_slot[id] = i.  out_rows ([n_ids, dim] f32) must be ZEROED by the caller
+ * (segments longer than a 32-row chunk are combined with float atomics); non-head rows stay zero.
  * row_slot ([n_rows] int32) must hold -1 everywhere on entry; mhr_adam_rows restores that. */
 int mhr_sparse_rows_segment_sum(const int64_t* sorted_ids, const int64_t* perm, int64_t n_ids,
                                 const void* grad_a, int a_dtype, int64_t n_a,

@@ -129,7 +129,7 @@ class EmbeddingGatherFn(Function):
             holder.sparse_grad = None
             return None, d_pos, None, None, None, None, None
         sorted_ids, perm = torch.sort(ids_all)
-        out_rows = torch.empty(ids_all.numel(), D, dtype=torch.float32, device=dev)
+        out_rows = torch.zeros(ids_all.numel(), D, dtype=torch.float32, device=dev)
         ga, gb = d_rows[:n_item_ids], (d_rows[n_item_ids:] if ids_all.numel() > n_item_ids else None)
         ops.sparse_rows_segment_sum(sorted_ids, perm, ga, gb, d_x, L, window, out_rows, holder._row_slot)
         holder.sparse_grad = SparseRowGrad(sorted_ids, out_rows, holder._row_slot, n_rows)
@@ -143,7 +143,7 @@ def reduce_pending_rows(holder):
     holder._pending_rows = None
     ids, rows = dist_.exchange_sparse_rows(ids_all, d_rows, n_private)
     sorted_ids, perm = torch.sort(ids)
-    out_rows = torch.empty(ids.numel(), rows.shape[1], dtype=torch.float32, device=rows.device)
+    out_rows = torch.zeros(ids.numel(), rows.shape[1], dtype=torch.float32, device=rows.device)
     ops.sparse_rows_segment_sum(sorted_ids, perm, rows.contiguous(), None, None, 0, 0, out_rows, holder._row_slot)
     holder.sparse_grad = SparseRowGrad(sorted_ids, out_rows, holder._row_slot, holder._row_slot.numel())
     return holder.sparse_grad

@@ -309,6 +309,9 @@ __global__ __launch_bounds__(256, 1) void nce_bwd_q_kernel(const bf16_t* qn, con
     D::issue(tiles + buf * T::BYTES, row_ptr_for(tile), wv, lane);
     sg::dma_words(supp + (int64_t)tile * tok_cap + tokc, words + buf * 1024 + wv * 256);
   };
+  // (A one-tile software skew - dQ += G(t-1).N(t-1) issued beside the VALU epilogue of tile t with
+  // sched_group_barrier hints - was measured 5-15 % SLOWER here: hipcc shuffles the 128 accumulators between the VGPR
+  // and AGPR halves of the register file around the interleaved region.  The straight order below is what ships.)
   const int n_loc = t_end - t_begin;
   issue_all(0, t_begin);
   if (n_loc > 1) issue_all(1, t_begin + 1);
@@ -321,23 +324,20 @@ __global__ __launch_bounds__(256, 1) void nce_bwd_q_kernel(const bf16_t* qn, con
     const unsigned char* tile = tiles + cur * T::BYTES;
     const uint32_t sw = live ? reinterpret_cast<const uint32_t*>(words + cur * 1024 + wv * 256)[lane] : 0u;
     f32x16 acc[1] = {sg::zero16()};
-    sg::mma_tile<NKS, 1>(tile, frag, acc, r, half);        // S^T: rows = negatives, cols = tokens
+    sg::mma_tile<NKS, 1, 4>(tile, frag, acc, r, half);     // S^T: rows = negatives, cols = tokens
     const int rem = n_neg - t * 32;
+    // rows past n_neg and suppressed pairs: one 32-bit "dead" mask per lane, tested branch-free
+    const uint32_t dead = sw | (rem >= 32 ? 0u : (0xFFFFFFFFu << (rem > 0 ? rem : 0)));
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
-      const int nl = sg::crow(g, half);
-      const bool keep = (nl < rem) && !((sw >> nl) & 1u);
-      const float gij = keep ? my_w * fast_exp2(acc[0][g] * c1 - my_l2) : 0.f;
+      const float e = my_w * fast_exp2(acc[0][g] * c1 - my_l2);
+      const float gij = ((dead >> sg::crow(g, half)) & 1u) ? 0.f : e;
       dsc += gij * acc[0][g];
       acc[0][g] = gij;
     }
     bf16x8 g0, g1;
     pack_acc(acc[0], g0, g1);   // G^T (negatives on rows) as the A operand: computes G . N
-#pragma unroll
-    for (int dc = 0; dc < ND; ++dc) {
-      dq[dc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g0, sg::read_tr_frag<NKS>(tile, dc, 0, lane), dq[dc], 0, 0, 0);
-      dq[dc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g1, sg::read_tr_frag<NKS>(tile, dc, 1, lane), dq[dc], 0, 0, 0);
-    }
+    sg::mma_tile_tr<NKS, ND>(tile, g0, g1, dq, lane);
     cur = cur == 2 ? 0 : cur + 1;
     nxt = nxt == 2 ? 0 : nxt + 1;
   }
@@ -463,25 +463,39 @@ __global__ __launch_bounds__(256, 1) void nce_bwd_n_kernel(const bf16_t* qn, con
     if (i + 2 < n_loc) issue_all(nxt, t + 2 * tstep);
     const unsigned char* base = smem + cur * BUF;
     f32x16 s[1] = {sg::zero16()};
-    sg::mma_tile<NKS, 1>(base, frag, s, r, half);                 // rows = tokens, cols = negatives
+    sg::mma_tile<NKS, 1, 4>(base, frag, s, r, half);              // rows = tokens, cols = negatives
     const uint32_t* wd = reinterpret_cast<const uint32_t*>(base + T::BYTES);
     const uint32_t* swd = wd + wv * 64;                              // suppression words of my wave's negative tile
     const float* wsc = reinterpret_cast<const float*>(wd + 32);      // w      of the tile's 32 tokens (wave 0, upper half)
     const float* lsc = reinterpret_cast<const float*>(wd + 64 + 32); // lse    of the tile's 32 tokens (wave 1, upper half)
     const int trem = n_tok - t * 32;                                 // tokens past n_tok contribute nothing
+    // per-token scalars of my 16 accumulator rows: 4 runs of 4 consecutive tokens -> 16-byte LDS reads, no branches
+    const int tb = 4 * half;
+    float wr[16], lr[16];
+    uint32_t sr[16];
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const f32x4 w4 = *reinterpret_cast<const f32x4*>(wsc + 8 * q4 + tb);
+      const f32x4 l4 = *reinterpret_cast<const f32x4*>(lsc + 8 * q4 + tb);
+      const __attribute__((ext_vector_type(4))) uint32_t s4 =
+          *reinterpret_cast<const __attribute__((ext_vector_type(4))) uint32_t*>(swd + 8 * q4 + tb);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        wr[4 * q4 + e] = w4[e];
+        lr[4 * q4 + e] = l4[e];
+        sr[4 * q4 + e] = s4[e];
+      }
+    }
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
       const int tl = sg::crow(g, half);
-      const bool keep = nlive && (tl < trem) && !((swd[tl] >> r) & 1u);
-      s[0][g] = keep ? wsc[tl] * fast_exp2(s[0][g] * c1 - lsc[tl] * LOG2E) : 0.f;
+      const float e = wr[g] * fast_exp2(s[0][g] * c1 - lr[g] * LOG2E);
+      const bool dead = (!nlive) | (tl >= trem) | (((sr[g] >> r) & 1u) != 0u);
+      s[0][g] = dead ? 0.f : e;
     }
     bf16x8 g0, g1;
     pack_acc(s[0], g0, g1);   // G (tokens on rows) as the A operand: computes G^T . Qn
-#pragma unroll
-    for (int dc = 0; dc < ND; ++dc) {
-      dn[dc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g0, sg::read_tr_frag<NKS>(base, dc, 0, lane), dn[dc], 0, 0, 0);
-      dn[dc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g1, sg::read_tr_frag<NKS>(base, dc, 1, lane), dn[dc], 0, 0, 0);
-    }
+    sg::mma_tile_tr<NKS, ND>(base, g0, g1, dn, lane);
     cur = cur == 2 ? 0 : cur + 1;
     nxt = nxt == 2 ? 0 : nxt + 1;
   }

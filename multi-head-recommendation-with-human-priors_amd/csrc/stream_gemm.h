@@ -175,15 +175,63 @@ __device__ __forceinline__ void dma_words(const void* lane_src, unsigned char* l
   __builtin_amdgcn_global_load_lds((gptr_t)lane_src, (lptr_t)lds_wave_base, 4, 0, 0);
 }
 
-// acc[f] (+)= tile . frag[f]^T for the RF stationary fragments
-template <int NKS, int RF>
+// acc[f] (+)= tile . frag[f]^T for the RF stationary fragments.  The A fragments are read PF k-steps ahead of the
+// MFMAs that consume them (two register sets), so LDS latency hides under the matrix pipe instead of every MFMA
+// waiting for its own ds_read (what hipcc emits for the naive loop at one wave per SIMD).
+template <int NKS, int RF, int PF = 2>
 __device__ __forceinline__ void mma_tile(const unsigned char* tile, const bf16x8 (&frag)[RF][NKS], f32x16 (&acc)[RF], int r,
                                          int half) {
+  constexpr int P = PF < NKS ? PF : NKS;
+  constexpr int NB = (NKS + P - 1) / P;
+  bf16x8 a[2][P];
 #pragma unroll
-  for (int ks = 0; ks < NKS; ++ks) {
-    const bf16x8 a = Tile<NKS>::read_a(tile, r, half, ks);
+  for (int j = 0; j < P; ++j) a[0][j] = Tile<NKS>::read_a(tile, r, half, j);
 #pragma unroll
-    for (int f = 0; f < RF; ++f) acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, frag[f][ks], acc[f], 0, 0, 0);
+  for (int b = 0; b < NB; ++b) {
+    if (b + 1 < NB) {
+#pragma unroll
+      for (int j = 0; j < P; ++j)
+        if ((b + 1) * P + j < NKS) a[(b + 1) & 1][j] = Tile<NKS>::read_a(tile, r, half, (b + 1) * P + j);
+    }
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+      const int ks = b * P + j;
+      if (ks < NKS) {
+#pragma unroll
+        for (int f = 0; f < RF; ++f) acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[b & 1][j], frag[f][ks], acc[f], 0, 0, 0);
+      }
+    }
+  }
+}
+
+// out[dc] += A(g0,g1) . tile^T-fragments: the second product of the backward kernels (sums over the tile's 32 rows).
+// g0/g1 are the two k-step fragments of the gated tile; B fragments come from read_tr_frag, read one dc ahead.
+template <int NKS, int ND>
+__device__ __forceinline__ void mma_tile_tr(const unsigned char* tile, bf16x8 g0, bf16x8 g1, f32x16 (&out)[ND], int lane) {
+  bf16x8 b[2][2];
+  b[0][0] = read_tr_frag<NKS>(tile, 0, 0, lane);
+  b[0][1] = read_tr_frag<NKS>(tile, 0, 1, lane);
+#pragma unroll
+  for (int dc = 0; dc < ND; ++dc) {
+    if (dc + 1 < ND) {
+      b[(dc + 1) & 1][0] = read_tr_frag<NKS>(tile, dc + 1, 0, lane);
+      b[(dc + 1) & 1][1] = read_tr_frag<NKS>(tile, dc + 1, 1, lane);
+    }
+    out[dc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g0, b[dc & 1][0], out[dc], 0, 0, 0);
+    out[dc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g1, b[dc & 1][1], out[dc], 0, 0, 0);
+  }
+}
+
+// Scheduling hint for a region that holds one 16-MFMA product (with its transposed LDS reads) and an independent
+// VALU epilogue: ask hipcc to emit them as 16 x {1 MFMA, 2 DS reads, `valu` VALU} so the epilogue runs in the issue
+// slots the matrix pipe leaves free (cdna guide T19; at one wave per SIMD nothing else can fill those slots).
+template <int VALU_PER_MFMA>
+__device__ __forceinline__ void interleave_mfma_valu_16() {
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);              // MFMA
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);              // DS read
+    __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER_MFMA, 0);  // VALU
   }
 }
 

@@ -79,7 +79,7 @@ def test_segment_sum_and_adam_rows(ops):
     N, D, B, L, P, nneg = 400, 256, 6, 10, 2, 50
     W = L + P
     ids_a = torch.randint(1, N, (B * W,), generator=g)
-    ids_a[:20] = 5
+    ids_a[:50] = 5                                        # a hot row spanning several 32-row chunks
     ids_b = torch.randint(1, N, (nneg,), generator=g)
     ga = bf(torch.randn(B * W, D, generator=g))
     gb = torch.randn(nneg, D, generator=g)
@@ -99,12 +99,13 @@ def test_segment_sum_and_adam_rows(ops):
     assert set(torch.nonzero(slot >= 0).flatten().tolist()) == set(touched.tolist())
     got = torch.zeros(N, D)
     got[touched] = out_rows.cpu()[slot[touched].long()]
-    np.testing.assert_allclose(got.numpy(), dense.numpy(), rtol=1e-5, atol=1e-5)
-    # determinism: a second run gives the same bits
+    np.testing.assert_allclose(got.numpy(), dense.numpy(), rtol=1e-5, atol=2e-5)
+    # rows whose segment fits one chunk are bitwise reproducible (only chunk-spanning hot rows use atomics)
     out2 = torch.zeros_like(out_rows)
     slot2 = torch.full((N,), -1, dtype=torch.int32).cuda()
     ops.sparse_rows_segment_sum(dev(sorted_ids), dev(perm), dev(ga), dev(gb), dev(xg), L, W, out2, slot2)
-    assert torch.equal(out2.cpu()[slot[touched].long()], out_rows.cpu()[slot[touched].long()])
+    cold = touched[touched != 5]
+    assert torch.equal(out2.cpu()[slot[cold].long()], out_rows.cpu()[slot[cold].long()])
     # AdamW over the table, two steps, untouched rows move too (dense semantics)
     w = torch.randn(N, D, generator=g)
     m = torch.zeros(N, D)
