@@ -88,11 +88,13 @@ __global__ __launch_bounds__(256, 2) void catalog_emit_kernel(
       return items + (n < n_items ? n : n_items - 1) * T::DIM;
     };
   };
+  sg::LaneAddr<NKS> la;
+  la.init(lane);
   const int n_loc = t1 - t0;
   D::issue(tiles, row_ptr_for(t0), wv, lane);
   if (n_loc > 1) D::issue(tiles + T::BYTES, row_ptr_for(t0 + 1), wv, lane);
-  int cur = 0, nxt = 2;
-  for (int i = 0; i < n_loc; ++i) {
+  sg::ring_loop<3>(n_loc, [&](auto slot_c, int i) {
+    constexpr int cur = decltype(slot_c)::value, nxt = (cur + 2) % 3;
     const int t = t0 + i;
     if (i + 1 < n_loc) sg::wait_vmcnt<D::PW>(); else sg::wait_vmcnt<0>();
     sg::ring_barrier();
@@ -100,7 +102,7 @@ __global__ __launch_bounds__(256, 2) void catalog_emit_kernel(
     f32x16 acc[RF];
 #pragma unroll
     for (int f = 0; f < RF; ++f) acc[f] = sg::zero16();
-    sg::mma_tile<NKS, RF>(tiles + cur * T::BYTES, frag, acc, r, half);
+    sg::mma_tile<NKS, RF>(tiles + cur * T::BYTES, la, frag, acc);
 
 #pragma unroll
     for (int f = 0; f < RF; ++f) {
@@ -133,9 +135,7 @@ __global__ __launch_bounds__(256, 2) void catalog_emit_kernel(
         }
       }
     }
-    cur = cur == 2 ? 0 : cur + 1;
-    nxt = nxt == 2 ? 0 : nxt + 1;
-  }
+  });
 }
 
 // ------------------------------------------------------------------------------------------

@@ -168,17 +168,19 @@ __global__ __launch_bounds__(256, 2) void nce_fwd_kernel(const IT* __restrict__ 
   auto row_ptr_for = [&](int tile) {
     return [=](int rr) -> const bf16_t* { return negs + (int64_t)min(tile * 32 + rr, n_neg - 1) * T::DIM; };
   };
+  sg::LaneAddr<NKS> la;
+  la.init(lane);
   const int n_loc = t_end - t_begin;
   D::issue(smem, row_ptr_for(t_begin), wv, lane);
   if (n_loc > 1) D::issue(smem + T::BYTES, row_ptr_for(t_begin + 1), wv, lane);
-  int cur = 0, nxt = 2;
-  for (int i = 0; i < n_loc; ++i) {
+  sg::ring_loop<3>(n_loc, [&](auto slot_c, int i) {
+    constexpr int cur = decltype(slot_c)::value, nxt = (cur + 2) % 3;
     const int t = t_begin + i;
     if (i + 1 < n_loc) sg::wait_vmcnt<D::PW>(); else sg::wait_vmcnt<0>();
     sg::ring_barrier();
     if (i + 2 < n_loc) D::issue(smem + nxt * T::BYTES, row_ptr_for(t + 2), wv, lane);
     f32x16 acc[2] = {sg::zero16(), sg::zero16()};
-    sg::mma_tile<NKS, 2>(smem + cur * T::BYTES, frag, acc, r, half);
+    sg::mma_tile<NKS, 2>(smem + cur * T::BYTES, la, frag, acc);
     const int rem = n_neg - t * 32;
     uint32_t sbits = 0;
 #pragma unroll
@@ -197,9 +199,7 @@ __global__ __launch_bounds__(256, 2) void nce_fwd_kernel(const IT* __restrict__ 
       sbits |= __shfl_xor(sbits, 32, 64);
       if (live && half == 0) supp_out[(int64_t)t * tok_cap + tok] = sbits;
     }
-    cur = cur == 2 ? 0 : cur + 1;
-    nxt = nxt == 2 ? 0 : nxt + 1;
-  }
+  });
   sum += __shfl_xor(sum, 32, 64);
   if (LOGS) {
     nv += __shfl_xor(nv, 32, 64);
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256, 1) void nce_bwd_q_kernel(const bf16_t* qn, con
   using T = sg::Tile<NKS>;
   constexpr int ND = (NKS + 1) / 2;          // 32-column chunks of the feature dim
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* tiles = smem;               // 3 x T::BYTES, then 3 x 1 KiB of suppression words
+  unsigned char* tiles = smem;               // 4 x T::BYTES, then 4 x 1 KiB of suppression words
   {
     const int64_t grp = blockIdx.z, to = grp * tok_cap;
     qn += to * T::DIM; pn += to * T::DIM; negs += grp * (int64_t)n_neg * T::DIM;
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256, 1) void nce_bwd_q_kernel(const bf16_t* qn, con
   // negative tiles + this wave's 32 suppression words per tile stream through a 3-deep LDS-DMA ring
   using D = sg::Dma<NKS>;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  unsigned char* words = smem + 3 * T::BYTES;                       // 3 x [4 waves][64] uint32
+  unsigned char* words = smem + 4 * T::BYTES;                       // 4 x [4 waves][64] uint32
   auto row_ptr_for = [&](int tile) {
     return [=](int rr) -> const bf16_t* { return negs + (int64_t)min(tile * 32 + rr, n_neg - 1) * T::DIM; };
   };
@@ -309,38 +309,47 @@ __global__ __launch_bounds__(256, 1) void nce_bwd_q_kernel(const bf16_t* qn, con
     D::issue(tiles + buf * T::BYTES, row_ptr_for(tile), wv, lane);
     sg::dma_words(supp + (int64_t)tile * tok_cap + tokc, words + buf * 1024 + wv * 256);
   };
-  // (A one-tile software skew - dQ += G(t-1).N(t-1) issued beside the VALU epilogue of tile t with
-  // sched_group_barrier hints - was measured 5-15 % SLOWER here: hipcc shuffles the 128 accumulators between the VGPR
-  // and AGPR halves of the register file around the interleaved region.  The straight order below is what ships.)
+  // Software pipeline, one-tile skew, 4-slot ring: the 16 MFMAs of S(t) are issued with the VALU epilogue of S(t-1)
+  // placed element by element in their gaps (mma_tile_epi), then dQ += G(t-1) . N(t-1) runs on tile t-1, which is
+  // still resident.  (Letting hipcc interleave with sched_group_barrier hints, or pairing the product with the
+  // epilogue of the same iteration, measured 5-15 % slower than no skew at all.)
+  sg::LaneAddr<NKS> la;
+  la.init(lane);
   const int n_loc = t_end - t_begin;
   issue_all(0, t_begin);
   if (n_loc > 1) issue_all(1, t_begin + 1);
-  int cur = 0, nxt = 2;
-  for (int i = 0; i < n_loc; ++i) {
+  f32x16 s_prev = sg::zero16();          // S of the previous tile
+  uint32_t dead_prev = 0xFFFFFFFFu;      // ... and its dead-row mask (all dead before the first tile: G = 0)
+  // one extra iteration drains the pipeline (its MFMAs run on a stale but finite tile and are discarded)
+  sg::ring_loop<4>(n_loc + 1, [&](auto slot_c, int i) {
+    constexpr int cur = decltype(slot_c)::value, nxt = (cur + 2) % 4, prv = (cur + 3) % 4;
     const int t = t_begin + i;
-    if (i + 1 < n_loc) sg::wait_vmcnt<D::PW + 1>(); else sg::wait_vmcnt<0>();
+    const bool has_tile = i < n_loc;
+    if (has_tile) {
+      if (i + 1 < n_loc) sg::wait_vmcnt<D::PW + 1>(); else sg::wait_vmcnt<0>();
+    }
     sg::ring_barrier();
     if (i + 2 < n_loc) issue_all(nxt, t + 2);
     const unsigned char* tile = tiles + cur * T::BYTES;
-    const uint32_t sw = live ? reinterpret_cast<const uint32_t*>(words + cur * 1024 + wv * 256)[lane] : 0u;
-    f32x16 acc[1] = {sg::zero16()};
-    sg::mma_tile<NKS, 1, 4>(tile, frag, acc, r, half);     // S^T: rows = negatives, cols = tokens
+    const uint32_t sw = (live && has_tile) ? reinterpret_cast<const uint32_t*>(words + cur * 1024 + wv * 256)[lane] : 0u;
     const int rem = n_neg - t * 32;
     // rows past n_neg and suppressed pairs: one 32-bit "dead" mask per lane, tested branch-free
-    const uint32_t dead = sw | (rem >= 32 ? 0u : (0xFFFFFFFFu << (rem > 0 ? rem : 0)));
-#pragma unroll
-    for (int g = 0; g < 16; ++g) {
-      const float e = my_w * fast_exp2(acc[0][g] * c1 - my_l2);
-      const float gij = ((dead >> sg::crow(g, half)) & 1u) ? 0.f : e;
-      dsc += gij * acc[0][g];
-      acc[0][g] = gij;
-    }
+    const uint32_t dead = has_tile ? (sw | (rem >= 32 ? 0u : (0xFFFFFFFFu << (rem > 0 ? rem : 0)))) : 0xFFFFFFFFu;
+    f32x16 acc = sg::zero16();
+    f32x16 gacc;
+    sg::mma_tile_epi<NKS, 4>(tile, la, frag, acc, [&](int g) {
+      const float e = my_w * fast_exp2(s_prev[g] * c1 - my_l2);
+      const float gij = ((dead_prev >> sg::crow(g, half)) & 1u) ? 0.f : e;
+      dsc += gij * s_prev[g];
+      gacc[g] = gij;
+    });
     bf16x8 g0, g1;
-    pack_acc(acc[0], g0, g1);   // G^T (negatives on rows) as the A operand: computes G . N
-    sg::mma_tile_tr<NKS, ND>(tile, g0, g1, dq, lane);
-    cur = cur == 2 ? 0 : cur + 1;
-    nxt = nxt == 2 ? 0 : nxt + 1;
-  }
+    pack_acc(gacc, g0, g1);   // G^T of tile t-1 (negatives on rows) as the A operand: computes G . N
+    // (first iteration: prv holds nothing yet, so the product runs on the current tile with G = 0)
+    sg::mma_tile_tr<NKS, ND>(i == 0 ? tile : tiles + prv * T::BYTES, la, g0, g1, dq);
+    s_prev = acc;
+    dead_prev = dead;
+  });
 
   // ---- finish: positive term, L2-normalisation chain rule, accumulation into the source rows -------
   // dq[dc][g]: row (reg) = token wave*32 + crow(g,half), column (lane) = feature dc*32 + r
@@ -452,27 +461,35 @@ __global__ __launch_bounds__(256, 1) void nce_bwd_n_kernel(const bf16_t* qn, con
     if (half == 1 && wv == 1) src = lse + tk;
     sg::dma_words(src, base + T::BYTES + wv * 256);
   };
+  // one-tile skew as in nce_bwd_q: S(t) MFMAs with the epilogue of S(t-1) in their gaps, then dN += G(t-1)^T . Q(t-1)
+  sg::LaneAddr<NKS> la;
+  la.init(lane);
   const int n_loc = (tt1 - tt0 + tstep - 1) / tstep;
   issue_all(0, tt0);
   if (n_loc > 1) issue_all(1, tt0 + tstep);
-  int cur = 0, nxt = 2;
-  for (int i = 0; i < n_loc; ++i) {
+  f32x16 s_prev = sg::zero16();
+  int trem_prev = 0;                     // 0 live tokens before the first tile: G = 0
+  sg::ring_loop<4>(n_loc + 1, [&](auto slot_c, int i) {
+    constexpr int cur = decltype(slot_c)::value, nxt = (cur + 2) % 4, prv = (cur + 3) % 4;
     const int t = tt0 + i * tstep;
-    if (i + 1 < n_loc) sg::wait_vmcnt<D::PW + 1>(); else sg::wait_vmcnt<0>();
+    const bool has_tile = i < n_loc;
+    if (has_tile) {
+      if (i + 1 < n_loc) sg::wait_vmcnt<D::PW + 1>(); else sg::wait_vmcnt<0>();
+    }
     sg::ring_barrier();
     if (i + 2 < n_loc) issue_all(nxt, t + 2 * tstep);
     const unsigned char* base = smem + cur * BUF;
-    f32x16 s[1] = {sg::zero16()};
-    sg::mma_tile<NKS, 1, 4>(base, frag, s, r, half);              // rows = tokens, cols = negatives
-    const uint32_t* wd = reinterpret_cast<const uint32_t*>(base + T::BYTES);
-    const uint32_t* swd = wd + wv * 64;                              // suppression words of my wave's negative tile
-    const float* wsc = reinterpret_cast<const float*>(wd + 32);      // w      of the tile's 32 tokens (wave 0, upper half)
-    const float* lsc = reinterpret_cast<const float*>(wd + 64 + 32); // lse    of the tile's 32 tokens (wave 1, upper half)
-    const int trem = n_tok - t * 32;                                 // tokens past n_tok contribute nothing
-    // per-token scalars of my 16 accumulator rows: 4 runs of 4 consecutive tokens -> 16-byte LDS reads, no branches
+    const unsigned char* pbase = i == 0 ? base : smem + prv * BUF;    // first iteration: G = 0 against the current tile
+    // per-token scalars of the PREVIOUS tile: suppression words of my wave's negative tile, w, lse
+    const uint32_t* wd = reinterpret_cast<const uint32_t*>(pbase + T::BYTES);
+    const uint32_t* swd = wd + wv * 64;
+    const float* wsc = reinterpret_cast<const float*>(wd + 32);
+    const float* lsc = reinterpret_cast<const float*>(wd + 64 + 32);
+    // my 16 accumulator rows are 4 runs of 4 consecutive tokens: their scalars come in as 16-byte LDS reads BEFORE the
+    // MFMA batch (scalar-sized LDS reads inside the MFMA gaps put an LDS round trip into every gap: measured +25 %)
     const int tb = 4 * half;
     float wr[16], lr[16];
-    uint32_t sr[16];
+    uint32_t dm = 0;                                   // bit g set: row g contributes nothing
 #pragma unroll
     for (int q4 = 0; q4 < 4; ++q4) {
       const f32x4 w4 = *reinterpret_cast<const f32x4*>(wsc + 8 * q4 + tb);
@@ -481,24 +498,25 @@ __global__ __launch_bounds__(256, 1) void nce_bwd_n_kernel(const bf16_t* qn, con
           *reinterpret_cast<const __attribute__((ext_vector_type(4))) uint32_t*>(swd + 8 * q4 + tb);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        wr[4 * q4 + e] = w4[e];
-        lr[4 * q4 + e] = l4[e];
-        sr[4 * q4 + e] = s4[e];
+        const int g = 4 * q4 + e;
+        wr[g] = w4[e];
+        lr[g] = l4[e] * LOG2E;
+        const bool dead = (!nlive) | (sg::crow(g, half) >= trem_prev) | (((s4[e] >> r) & 1u) != 0u);
+        dm |= dead ? (1u << g) : 0u;
       }
     }
-#pragma unroll
-    for (int g = 0; g < 16; ++g) {
-      const int tl = sg::crow(g, half);
-      const float e = wr[g] * fast_exp2(s[0][g] * c1 - lr[g] * LOG2E);
-      const bool dead = (!nlive) | (tl >= trem) | (((sr[g] >> r) & 1u) != 0u);
-      s[0][g] = dead ? 0.f : e;
-    }
+    f32x16 acc = sg::zero16();
+    f32x16 gacc;
+    sg::mma_tile_epi<NKS, 4>(base, la, frag, acc, [&](int g) {
+      const float ex = wr[g] * fast_exp2(s_prev[g] * c1 - lr[g]);
+      gacc[g] = ((dm >> g) & 1u) ? 0.f : ex;
+    });
     bf16x8 g0, g1;
-    pack_acc(s[0], g0, g1);   // G (tokens on rows) as the A operand: computes G^T . Qn
-    sg::mma_tile_tr<NKS, ND>(base, g0, g1, dn, lane);
-    cur = cur == 2 ? 0 : cur + 1;
-    nxt = nxt == 2 ? 0 : nxt + 1;
-  }
+    pack_acc(gacc, g0, g1);   // G of tile t-1 (tokens on rows) as the A operand: computes G^T . Qn
+    sg::mma_tile_tr<NKS, ND>(pbase, la, g0, g1, dn);
+    s_prev = acc;
+    trem_prev = has_tile ? n_tok - t * 32 : 0;
+  });
   // dn[dc][g]: row (reg) = negative neg0 + wave*32 + crow(g,half), column (lane) = feature dc*32 + r
 #pragma unroll
   for (int g = 0; g < 16; ++g) {
@@ -608,7 +626,7 @@ extern "C" int mhr_nce_bwd_tokens(const void* qn, const void* pn, const void* ne
   const dim3 grid_q((tok_cap + 127) / 128, splits, n_groups);
 #define L_(NKS)                                                                                                          \
   {                                                                                                                      \
-    size_t lds_q = 3 * sg::Tile<NKS>::BYTES + 3 * 1024;                                                                  \
+    size_t lds_q = 4 * sg::Tile<NKS>::BYTES + 4 * 1024;                                                                  \
     hipLaunchKernelGGL((nce_bwd_q_kernel<NKS>), grid_q, dim3(256), lds_q, s, (const bf16_t*)qn, (const bf16_t*)pn,       \
                        (const bf16_t*)negs, supp, n_neg, n_tok_dev, tok_cap, tps, logit_scale_dev, lse, w, q_inv, p_inv, \
                        s_pos, q_idx, p_idx, dq_rows, dp_rows, d_logit_scale);                                            \
@@ -634,7 +652,7 @@ extern "C" int mhr_nce_bwd_negs(const void* qn, const void* negs, const uint32_t
   if (splits < 1) splits = 1;
 #define L_(NKS)                                                                                                        \
   {                                                                                                                    \
-    size_t lds_n = 3 * (sg::Tile<NKS>::BYTES + 1024);                                                                  \
+    size_t lds_n = 4 * (sg::Tile<NKS>::BYTES + 1024);                                                                  \
     hipLaunchKernelGGL((nce_bwd_n_kernel<NKS>), dim3(neg_groups, splits, n_groups), dim3(256), lds_n, s, (const bf16_t*)qn,      \
                        (const bf16_t*)negs, supp, n_neg, n_tok_dev, tok_cap, logit_scale_dev, lse, w, d_negs);          \
   }

@@ -13,6 +13,8 @@
 //   A: lane l holds A[row l&31][k = 8*(l>>5) + j];  B: lane l holds B[k = 8*(l>>5) + j][col l&31]
 //   C: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5)
 #pragma once
+#include <type_traits>
+
 #include "mhr_common.h"
 
 namespace sg {
@@ -89,27 +91,58 @@ struct Stage {
   }
 };
 
-// Transposed fragment straight from the row-major swizzled tile with ds_read_b64_tr_b16 (cdna guide T10): the
-// B operand of a product that sums over the ROW index of an accumulator tile (rows = this tile's 32 rows):
-// element j of lane half h must be tile[row 16*s + 8*(j>>2) + 4*h + (j&3)][col dc*32 + (lane&31)].
-// Per 16-lane group the instruction reads a 4-row x 16-column block: lane 4q+p supplies the address of row q,
-// columns 4p..4p+3, and lane i receives column i of the 4 rows.  Two reads (rows +0 and +8) make one fragment.
-// EXEC must be all ones.  Columns beyond DIM (only when DIM < 32) read neighbouring rows / zeros: callers mask them.
-// (The _v4i16 form of the builtin followed by per-element bit casts is mis-optimised by hipcc 7.2 - all four
-// elements collapse to element 0 - so the _v4bf16 form and a whole-vector shuffle are used.)
+// Per-lane LDS byte offsets of every fragment read, computed ONCE per kernel.  The swizzle is an XOR on the low four
+// chunk bits, so all reads of a tile are `lane offset + compile-time immediate`:
+//   row read of k-step ks      : a[ks & 7] + 256*(ks >> 3)
+//   transposed read (dc, s, hi) : t[hi][dc & 3] + 256*(dc >> 2) + 16*s*ROW_BYTES        (hi = rows +8)
+// With the ring slot a compile-time constant too (tile loops are unrolled by the ring depth) the main loops carry no
+// address arithmetic at all; recomputing the XORs per read cost 150-200 VALU instructions per 32-MFMA tile.
+template <int NKS>
+struct LaneAddr {
+  using T = Tile<NKS>;
+  static constexpr int NA = NKS < 8 ? NKS : 8;
+  int a[NA];
+  int t[2][4];
+  __device__ __forceinline__ void init(int lane) {
+    const int r = lane & 31, half = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < NA; ++j) a[j] = T::off(r, 2 * j + half);
+    const int i = lane & 15, q = i >> 2, p = i & 3, g1 = (lane >> 4) & 1;
+    const int cl = 2 * g1 + (p >> 1), bo = (p & 1) * 8;
+    const int row0 = 4 * half + q;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      t[0][d] = T::off(row0, d * 4 + cl) + bo;
+      t[1][d] = T::off(row0 + 8, d * 4 + cl) + bo;
+    }
+  }
+  __device__ __forceinline__ bf16x8 read_a(const unsigned char* tile, int ks) const {
+    return *reinterpret_cast<const bf16x8*>(tile + a[ks & 7] + 256 * (ks >> 3));
+  }
+  // Transposed fragment straight from the row-major swizzled tile with ds_read_b64_tr_b16 (cdna guide T10): the
+  // B operand of a product that sums over the ROW index of an accumulator tile (rows = this tile's 32 rows):
+  // element j of lane half h must be tile[row 16*s + 8*(j>>2) + 4*h + (j&3)][col dc*32 + (lane&31)].
+  // Per 16-lane group the instruction reads a 4-row x 16-column block: lane 4q+p supplies the address of row q,
+  // columns 4p..4p+3, and lane i receives column i of the 4 rows (probed on gfx950: tools/probe_tr.hip).  Two reads
+  // (rows +0 and +8) make one fragment.  EXEC must be all ones.  Columns beyond DIM (only when DIM < 32) read
+  // neighbouring rows / zeros: callers mask them.
+  // (The _v4i16 form of the builtin followed by per-element bit casts is mis-optimised by hipcc 7.2 - all four
+  // elements collapse to element 0 - so the _v4bf16 form and a whole-vector shuffle are used.)
+  __device__ __forceinline__ bf16x8 read_tr(const unsigned char* tile, int dc, int s) const {
+    typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+    const int imm = 256 * (dc >> 2) + 16 * s * T::ROW_BYTES;
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + t[0][dc & 3] + imm));
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + t[1][dc & 3] + imm));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  }
+};
+
+// stand-alone form (tests / probes): same result as LaneAddr::read_tr
 template <int NKS>
 __device__ __forceinline__ bf16x8 read_tr_frag(const unsigned char* tile, int dc, int s, int lane) {
-  using T = Tile<NKS>;
-  typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
-  const int i = lane & 15, q = i >> 2, p = i & 3, g1 = (lane >> 4) & 1, half = lane >> 5;
-  const int col = dc * 32 + 16 * g1 + 4 * p;
-  const int c = col >> 3, bo = (col & 7) * 2;
-  const int row0 = 16 * s + 4 * half + q, row1 = row0 + 8;
-  const unsigned char* a0 = tile + T::off(row0, c) + bo;
-  const unsigned char* a1 = tile + T::off(row1, c) + bo;
-  bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(a0));
-  bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(a1));
-  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  LaneAddr<NKS> la;
+  la.init(lane);
+  return la.read_tr(tile, dc, s);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -179,19 +212,19 @@ __device__ __forceinline__ void dma_words(const void* lane_src, unsigned char* l
 // MFMAs that consume them (two register sets), so LDS latency hides under the matrix pipe instead of every MFMA
 // waiting for its own ds_read (what hipcc emits for the naive loop at one wave per SIMD).
 template <int NKS, int RF, int PF = 2>
-__device__ __forceinline__ void mma_tile(const unsigned char* tile, const bf16x8 (&frag)[RF][NKS], f32x16 (&acc)[RF], int r,
-                                         int half) {
+__device__ __forceinline__ void mma_tile(const unsigned char* tile, const LaneAddr<NKS>& la, const bf16x8 (&frag)[RF][NKS],
+                                         f32x16 (&acc)[RF]) {
   constexpr int P = PF < NKS ? PF : NKS;
   constexpr int NB = (NKS + P - 1) / P;
   bf16x8 a[2][P];
 #pragma unroll
-  for (int j = 0; j < P; ++j) a[0][j] = Tile<NKS>::read_a(tile, r, half, j);
+  for (int j = 0; j < P; ++j) a[0][j] = la.read_a(tile, j);
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
     if (b + 1 < NB) {
 #pragma unroll
       for (int j = 0; j < P; ++j)
-        if ((b + 1) * P + j < NKS) a[(b + 1) & 1][j] = Tile<NKS>::read_a(tile, r, half, (b + 1) * P + j);
+        if ((b + 1) * P + j < NKS) a[(b + 1) & 1][j] = la.read_a(tile, (b + 1) * P + j);
     }
 #pragma unroll
     for (int j = 0; j < P; ++j) {
@@ -204,21 +237,69 @@ __device__ __forceinline__ void mma_tile(const unsigned char* tile, const bf16x8
   }
 }
 
+// Same product with an independent VALU job pinned into the MFMA gaps: after the MFMA of k-step ks the caller's
+// epi(e) runs for accumulator elements e = ks*EPK .. ks*EPK+EPK-1 of ANOTHER (already complete) accumulator, and a
+// sched_barrier fixes that order.  At one wave per SIMD the in-order issue stage cannot overlap a batch of MFMAs with
+// VALU work that follows the batch in program order; placing one element's epilogue (~8 VALU, one v_exp) in each
+// 32-cycle MFMA gap hides it behind the matrix pipe (cdna guide: "budget every MFMA gap ... and place them").
+template <int NKS, int PF, typename Epi>
+__device__ __forceinline__ void mma_tile_epi(const unsigned char* tile, const LaneAddr<NKS>& la, const bf16x8 (&frag)[1][NKS],
+                                             f32x16& acc, Epi epi) {
+  constexpr int P = PF < NKS ? PF : NKS;
+  constexpr int NB = (NKS + P - 1) / P;
+  constexpr int EPK = (16 + NKS - 1) / NKS;                // accumulator elements handled per k-step
+  bf16x8 a[2][P];
+#pragma unroll
+  for (int j = 0; j < P; ++j) a[0][j] = la.read_a(tile, j);
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    if (b + 1 < NB) {
+#pragma unroll
+      for (int j = 0; j < P; ++j)
+        if ((b + 1) * P + j < NKS) a[(b + 1) & 1][j] = la.read_a(tile, (b + 1) * P + j);
+    }
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+      const int ks = b * P + j;
+      if (ks < NKS) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[b & 1][j], frag[0][ks], acc, 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < EPK; ++e)
+          if (ks * EPK + e < 16) epi(ks * EPK + e);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+}
+
 // out[dc] += A(g0,g1) . tile^T-fragments: the second product of the backward kernels (sums over the tile's 32 rows).
-// g0/g1 are the two k-step fragments of the gated tile; B fragments come from read_tr_frag, read one dc ahead.
+// g0/g1 are the two k-step fragments of the gated tile; B fragments come from LaneAddr::read_tr, read one dc ahead.
 template <int NKS, int ND>
-__device__ __forceinline__ void mma_tile_tr(const unsigned char* tile, bf16x8 g0, bf16x8 g1, f32x16 (&out)[ND], int lane) {
+__device__ __forceinline__ void mma_tile_tr(const unsigned char* tile, const LaneAddr<NKS>& la, bf16x8 g0, bf16x8 g1,
+                                            f32x16 (&out)[ND]) {
   bf16x8 b[2][2];
-  b[0][0] = read_tr_frag<NKS>(tile, 0, 0, lane);
-  b[0][1] = read_tr_frag<NKS>(tile, 0, 1, lane);
+  b[0][0] = la.read_tr(tile, 0, 0);
+  b[0][1] = la.read_tr(tile, 0, 1);
 #pragma unroll
   for (int dc = 0; dc < ND; ++dc) {
     if (dc + 1 < ND) {
-      b[(dc + 1) & 1][0] = read_tr_frag<NKS>(tile, dc + 1, 0, lane);
-      b[(dc + 1) & 1][1] = read_tr_frag<NKS>(tile, dc + 1, 1, lane);
+      b[(dc + 1) & 1][0] = la.read_tr(tile, dc + 1, 0);
+      b[(dc + 1) & 1][1] = la.read_tr(tile, dc + 1, 1);
     }
     out[dc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g0, b[dc & 1][0], out[dc], 0, 0, 0);
     out[dc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g1, b[dc & 1][1], out[dc], 0, 0, 0);
+  }
+}
+
+// Runs body(slot_constant, i) for i = 0..n-1 with slot = i % DEPTH as a COMPILE-TIME constant (the loop is unrolled
+// by the ring depth), so ring-slot bases fold into the immediate offset field of the LDS instructions.
+template <int DEPTH, typename Body>
+__device__ __forceinline__ void ring_loop(int n, Body body) {
+  for (int i0 = 0; i0 < n; i0 += DEPTH) {
+    body(std::integral_constant<int, 0>{}, i0);
+    if constexpr (DEPTH > 1) { if (i0 + 1 < n) body(std::integral_constant<int, 1>{}, i0 + 1); }
+    if constexpr (DEPTH > 2) { if (i0 + 2 < n) body(std::integral_constant<int, 2>{}, i0 + 2); }
+    if constexpr (DEPTH > 3) { if (i0 + 3 < n) body(std::integral_constant<int, 3>{}, i0 + 3); }
   }
 }
 

@@ -1,6 +1,7 @@
 // In-situ check of sg::read_tr_frag against its contract on the swizzled tile image.
 #include "../multi-head-recommendation-with-human-priors_amd/csrc/stream_gemm.h"
 #include <vector>
+#include <stdio.h>
 void mhr_set_error(const char*, ...) {}
 template <int NKS>
 __global__ void k(const bf16_t* src, float* out, int dc, int s) {
