@@ -50,7 +50,13 @@ def cpu_baseline_train(cfgd, item_num, seconds=20.0):
     import mhr_amd.synth as synth
     from REC.config.configurator import Config
     from REC.utils import get_model
-    cores = os.cpu_count() or 1
+    # the GPU box grants a CPU share (16 cores for one GPU) although os.cpu_count() reports the whole host:
+    # oversubscribing 256 threads made one oracle step take minutes
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))
     torch.set_num_threads(cores)
     cfg = Config(config_dict=dict(cfgd, device="cpu"))
     data = synth.SyntheticData(cfg, item_num, "cpu")
@@ -70,7 +76,7 @@ def cpu_baseline_train(cfgd, item_num, seconds=20.0):
     n, t_used = 0, 0.0
     # negatives per sample sized as on the GPU (ceil(num_negatives / B_gpu)); the sample is B=4 windows per step
     n_neg_gpu = data.n_neg(cfgd["train_batch_size"])
-    while t_used < seconds and n < 50:
+    while t_used < seconds and n < 40:
         batch = data.train_batch(B)
         batch = (batch[0], batch[1][:, :, :n_neg_gpu].contiguous(), batch[2], batch[3])
         t0 = time.time()

@@ -37,12 +37,15 @@ class DataStruct(object):
         self._data_dict[name] = value
 
     def update_tensor(self, name, value):
-        self._tensor_lists.setdefault(name, []).append(value.detach().cpu().clone())
+        # per-batch results stay where they were produced (the device); the reference's `.cpu().clone()` per batch
+        # (collector.py:48-54) would serialise the host against the GPU once per batch.
+        self._tensor_lists.setdefault(name, []).append(value.detach())
 
     def finalize_tensors(self):
+        # one concatenation and one device->host copy per key for the whole evaluation
         for name, lst in self._tensor_lists.items():
             if lst:
-                self._data_dict[name] = torch.cat(lst, dim=0)
+                self._data_dict[name] = torch.cat(lst, dim=0).cpu()
         self._tensor_lists.clear()
 
 

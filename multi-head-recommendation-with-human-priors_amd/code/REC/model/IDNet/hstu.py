@@ -205,6 +205,8 @@ class HSTU(BaseModel):
         self._pending_rows = None
         self._tok_cache = {}
         self._item_cache = None
+        self._bf16_cache = {}
+        self._row_bits_cache = {}
         self._step_seed = 0
 
     # ------------------------------------------------------------------------------------------
@@ -225,18 +227,41 @@ class HSTU(BaseModel):
     # ------------------------------------------------------------------------------------------
     # encoder + heads
     # ------------------------------------------------------------------------------------------
-    def _encode(self, x, key_valid):
+    def _layer_weights_bf16(self, i, layer):
+        """bf16 operands of layer i's two GEMMs.  While the module is in eval mode the casts are done once and kept
+        (weights do not move between `eval()` and the next `train()` / `load_state_dict`, which drop the cache)."""
+        if not self.training:
+            hit = self._bf16_cache.get(i)
+            if hit is not None:
+                return hit
+        w = (layer._uvqk.to(torch.bfloat16), layer._o.weight.to(torch.bfloat16), layer._o.bias.to(torch.bfloat16))
+        if not self.training and not torch.is_grad_enabled():
+            self._bf16_cache[i] = w
+        return w
+
+    def train(self, mode=True):
+        self._bf16_cache = {}
+        return super().train(mode)
+
+    def load_state_dict(self, *args, **kwargs):
+        self._bf16_cache = {}
+        self._item_cache = None
+        return super().load_state_dict(*args, **kwargs)
+
+    def _encode(self, x, key_valid, training=None):
         """x [B,L,D] fp32, key_valid [B,L] uint8 -> [B,L,D] fp32 (reference hstu.py:221-328)."""
         from REC.model.hstu_functional import HSTUCoreFn, LayerNormFn
         B, L, D = x.shape
         x2 = x.reshape(B * L, D)
-        p = self._linear_dropout_rate if self.training else 0.0
+        training = self.training if training is None else training
+        p = self._linear_dropout_rate if training else 0.0
         for i, layer in enumerate(self._hstu._attention_layers):
             xn = LayerNormFn.apply(x2, layer._eps)
-            h = xn @ layer._uvqk.to(torch.bfloat16)
+            w_uvqk, w_o, b_o = self._layer_weights_bf16(i, layer)
+            h = xn @ w_uvqk
             seed = (self._step_seed * 1000003 + i * 7919 + self.rank * 104729) & 0x7FFFFFFFFFFFFFFF
             o = HSTUCoreFn.apply(h, key_valid, B, L, self._num_heads, self._dqk, layer._eps, p, seed)
-            y = F.linear(o, layer._o.weight.to(torch.bfloat16), layer._o.bias.to(torch.bfloat16))
+            y = F.linear(o, w_o, b_o)
             x2 = x2 + y.float()
         return x2.view(B, L, D)
 
@@ -437,10 +462,7 @@ class HSTU(BaseModel):
         else:
             rows, _ = ops.embedding_gather(self.item_embedding.weight, item_seq.contiguous(), torch.float32)
             x = self.item_id_proj_tower(rows) + self.position_embedding.weight[:L][None]
-        was_training = self.training
-        self.eval()
-        out = self._encode(x, (item_seq != 0).to(torch.uint8).contiguous())
-        self.train(was_training)
+        out = self._encode(x, (item_seq != 0).to(torch.uint8).contiguous(), training=False)   # dropout off, like .eval()
         heads = self._heads(out[:, -1])                                   # [B,H,D]
         return ops.l2norm_rows(heads.contiguous(), torch.float32)
 
@@ -448,8 +470,13 @@ class HSTU(BaseModel):
         """Per (user, head) admissible-category bit (int32 bit pattern): bit c for prior heads, bit 31 for
         unconstrained heads, 0 for heads switched off by `prior_given_at_test` (reference hstu.py:982-999)."""
         S, C, H = self.num_segment_head, self.num_prior_head, self.medusa_num_heads
+        static = self.loss != 'prior' or not self.prior_given_at_test
+        if static and (B, device) in self._row_bits_cache:
+            return self._row_bits_cache[(B, device)]
         if self.loss != 'prior':
-            return torch.full((B * H,), -(1 << 31), dtype=torch.int32, device=device)
+            bits = torch.full((B * H,), -(1 << 31), dtype=torch.int32, device=device)
+            self._row_bits_cache[(B, device)] = bits
+            return bits
         additive = self.head_interaction == 'additive'
         cat_of_head = torch.tensor([(h - S if h >= S else -1) if additive else h % C for h in range(H)], device=device)
         bits = torch.where(cat_of_head >= 0, torch.ones_like(cat_of_head) << cat_of_head.clamp_min(0),
@@ -459,7 +486,10 @@ class HSTU(BaseModel):
             given = target_tags[:, :self.given_prior_len].bool().any(dim=1)                       # [B,C]
             on = torch.where(cat_of_head[None, :] >= 0, given[:, cat_of_head.clamp_min(0)], torch.ones_like(bits, dtype=torch.bool))
             bits = torch.where(on, bits, torch.zeros_like(bits))
-        return bits.reshape(-1).to(torch.int32)
+        bits = bits.reshape(-1).to(torch.int32)
+        if static:
+            self._row_bits_cache[(B, device)] = bits
+        return bits
 
     @staticmethod
     def pack_item_tags(all_item_tags):
@@ -491,8 +521,8 @@ class HSTU(BaseModel):
             hu, hi = history[0].to(dev), history[1].to(dev)
             order = torch.argsort(hu * self.item_num + hi)
             hist_items = hi[order].contiguous()
-            hist_ptr = torch.zeros(B + 1, dtype=torch.int32, device=dev)
-            hist_ptr[1:] = torch.cumsum(torch.bincount(hu, minlength=B), 0).int()
+            # CSR offsets by binary search on the sorted user column (torch.bincount would sync the host)
+            hist_ptr = torch.searchsorted(hu[order].contiguous(), torch.arange(B + 1, device=dev)).int()
         vals, idx = ops.catalog_topk(users, H, items_bf, tag_bits, row_bits, hist_ptr, hist_items, k, stats=stats)
         return FusedTopK(vals.view(B, H, k), idx.view(B, H, k))
 

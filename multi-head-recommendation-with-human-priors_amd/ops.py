@@ -49,7 +49,7 @@ def _ptr(t):
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
 
 
 def _chk(t, name, dtype=None):
