@@ -235,6 +235,18 @@ def main():
                     out["roofline"] = {"bound": "hbm", "kernel": name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                                        "launch_ms": round(mean_ms, 4)}
+            # HBM bytes per launch of that kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE run on this same
+            # command and condensed by tools/summarize_profiles.py; counters cannot be read from inside the process)
+            if "roofline" in out and args.config == "cfg1" and not args.batch:
+                kname = {"mhr_nce_bwd_tokens": "nce_bwd_q_kernel", "mhr_nce_bwd_negs": "nce_bwd_n_kernel", "mhr_nce_fwd": "nce_fwd_kernel",
+                         "mhr_catalog_score_emit": "catalog_emit_kernel", "mhr_adam_rows": "adam_rows_kernel"}.get(name)
+                import glob
+                files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_hbm_traffic{'_eval' if args.mode == 'eval' else ''}.json")))
+                if kname and files:
+                    rec = json.load(open(files[-1]))["kernels"].get(kname)
+                    if rec:
+                        out["roofline"]["traffic"] = rec["hbm_bytes_per_launch"]
+                        out["roofline"]["traffic_source"] = os.path.relpath(files[-1], ROOT)
             out["kernel_ms_per_step"] = per_step
             if "mhr_adam_rows" in prof:
                 ms = prof["mhr_adam_rows"][1]

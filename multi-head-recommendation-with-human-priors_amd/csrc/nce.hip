@@ -8,16 +8,25 @@
 //   keep_ij = !(f_ij > thres);   lse_i = log( exp(scale*s_i+) + sum_j keep_ij exp(scale*s_ij) );   loss_i = lse_i - scale*s_i+
 //
 // Three kernels on the row-stationary streaming GEMM core (stream_gemm.h), all with S^T orientation
-// (streamed rows on accumulator registers, stationary rows on lanes):
-//   nce_fwd    : tokens stationary (normalised Q and P fragments in registers, 32 tokens per wave), negatives
-//                streamed; two MFMAs per LDS fragment read (s and f share the negative operand); running sums
-//                are one VGPR per lane because |logit| <= scale bounds the exponent (no running max);
-//                also stores the normalised token rows (and Q^T) for the backward.
-//   nce_bwd_q  : tokens stationary; recomputes s,f; G_ij = w_i keep_ij exp(scale*s_ij - lse_i) converted to
-//                bf16 in registers is the A operand of dQn += G . N (N^T tiles streamed from a transposed
-//                copy); finishes with the L2-normalisation chain rule and writes per-token rows (no atomics).
-//   nce_bwd_n  : negatives stationary (32 per wave), token tiles streamed; dN += G^T . Qn accumulated in
-//                registers across all tokens of the workgroup's token split, then one float-atomic pass.
+// (streamed rows on accumulator registers, stationary rows on lanes).  One launch serves every prior category
+// (grid.z = group): per-group token lists (q_idx/p_idx into the shared head / target row matrices), per-group
+// negative pools, per-group live counts read from device memory (no host sync).
+//   nce_fwd    : tokens stationary (rows gathered through the index lists, L2-normalised in registers, kept as
+//                MFMA B fragments, 32 tokens per wave), 32-negative tiles streamed through a 3-slot LDS ring
+//                filled by LDS-DMA (global_load_lds_dwordx4); two MFMAs per LDS fragment read (s and f share
+//                the negative operand); running sums are one VGPR per lane because |logit| <= scale bounds the
+//                exponent (no running max).  Stores the normalised bf16 token rows, 1/||q||, 1/||p||, s+ and the
+//                false-negative suppression BITS (one bit per (token, negative)) for the backward.
+//   nce_finalize: per-token lse / loss / rank across the negative splits, per-group means.
+//   nce_bwd_q  : tokens stationary; recomputes s only (suppression comes from the saved bits);
+//                G_ij = w_i keep_ij exp(scale*s_ij - lse_i) in bf16 is the A operand of dQn += G . N, where the
+//                N^T fragments come from the SAME LDS tile via ds_read_b64_tr_b16 (no transposed copy).  The
+//                S(t) MFMAs carry the exp/convert epilogue of S(t-1) in their issue gaps (one-tile skew).
+//                Finishes with the L2-normalisation chain rule and adds dq/dp rows straight into the head /
+//                target row gradients with 256-B-shaped float atomics.
+//   nce_bwd_n  : negatives stationary (32 per wave), token tiles streamed (Qn tile + its w/lse/supp words by
+//                LDS-DMA); dN += G^T . Qn with Qn^T fragments from ds_read_b64_tr_b16; accumulated in registers
+//                across the workgroup's token share, then one float-atomic pass.
 #include "mhr_common.h"
 #include "stream_gemm.h"
 
