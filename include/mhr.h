@@ -145,8 +145,9 @@ int mhr_hstu_attn_bwd(const void* q_pre, const void* k_pre, const void* v_pre, i
  * so data-dependent token counts need no host sync; `tok_cap` bounds the grid.  dim in {16,32,64,128,256}.
  * GROUPS: one launch serves n_groups independent (token list, negative pool) problems - the prior categories of a
  * step - laid out along a leading axis: q_idx/p_idx/w/lse/loss/... [n_groups, tok_cap], n_tok_dev [n_groups],
- * negs [n_groups, n_neg, dim], qn/pn [n_groups, tok_cap, dim], supp [n_groups, ceil(n_neg/32), tok_cap],
- * d_negs [n_groups, n_neg, dim]; q_rows / p_rows / dq_rows / dp_rows are shared row spaces.
+ * negs [n_groups, round_up(n_neg, 32), dim] (each pool padded to whole 32-row tiles with finite rows, e.g. zeros; the
+ * padding rows never contribute), qn/pn [n_groups, tok_cap, dim], supp [n_groups, ceil(n_neg/32), tok_cap],
+ * d_negs [n_groups, n_neg, dim] (unpadded); q_rows / p_rows / dq_rows / dp_rows are shared row spaces.
  *   logit_pos = s*cos(q,p); logit_j = s*cos(q,neg_j), dropped when cos(p,neg_j) > thres; s = exp(clamp(logit_scale,0,ln 100))
  *   loss[t] = logsumexp(logits) - logit_pos;  lse[t] saved for backward (both written by mhr_nce_finalize).
  * Optional logs (may be NULL): n_valid[t] = 1 + #kept negatives; rank[t] = #kept negatives with logit > logit_pos
@@ -172,17 +173,21 @@ int mhr_nce_finalize(const float* sum, const float* s_pos, int n_groups, const i
  * mhr_nce_bwd_tokens: token-stationary; accumulates the gradient w.r.t. the RAW query / positive rows
  *   (normalisation chain rule included) into dq_rows[q_idx[t], :] / dp_rows[p_idx[t], :] (f32, same row spaces as the
  *   forward's q_rows / p_rows; float atomics because several tokens share a row; caller zeroes) and atomically adds
- *   d(logit_scale parameter) into *d_logit_scale (may be NULL).
+ *   d(logit_scale parameter) into *d_logit_scale (may be NULL).  It also writes lw_out[t] = lse[t] log2(e) - log2(w[t])
+ *   ([n_groups, tok_cap] f32, may be NULL), the per-token exponent offset mhr_nce_bwd_negs consumes:
+ *   w exp(scale s - lse) = exp2(scale log2(e) s - lw).
  * mhr_nce_bwd_negs: negative-stationary; accumulates d_negs ([n_neg, dim] f32, float atomics across token splits;
- *   caller zeroes) w.r.t. the normalised negatives. */
+ *   caller zeroes) w.r.t. the normalised negatives.  `lw` is the array mhr_nce_bwd_tokens wrote (launch that first).
+ * Both require tok_cap % 32 == 0: the forward pads the last live 32-token tile of the saved state (zero qn / pn rows,
+ * all-ones suppression words) so that whole token tiles stream without clamping. */
 int mhr_nce_bwd_tokens(const void* qn, const void* pn, const void* negs, const uint32_t* supp, int n_neg, int dim,
                        int n_groups, const int32_t* n_tok_dev, int tok_cap, const float* logit_scale_dev,
                        const float* lse, const float* w, const float* q_inv, const float* p_inv, const float* s_pos,
                        const int32_t* q_idx, const int32_t* p_idx,
-                       float* dq_rows, float* dp_rows, float* d_logit_scale, void* stream);
+                       float* dq_rows, float* dp_rows, float* d_logit_scale, float* lw_out, void* stream);
 int mhr_nce_bwd_negs(const void* qn, const void* negs, const uint32_t* supp, int n_neg, int dim, int n_groups,
                      const int32_t* n_tok_dev, int tok_cap, const float* logit_scale_dev,
-                     const float* lse, const float* w, float* d_negs, void* stream);
+                     const float* lw, float* d_negs, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Full-catalog multi-head scoring + top-k + cross-head merge

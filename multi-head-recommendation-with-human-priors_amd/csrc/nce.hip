@@ -34,6 +34,35 @@ namespace {
 
 constexpr float LOG2E = 1.4426950408889634f;
 
+// In-kernel phase timing (cdna guide section 7, "stamp before you restructure"): only in -DMHR_STAMP builds made by
+// tools/stamp_nce.py; the product library carries none of it.
+#ifdef MHR_STAMP
+__device__ unsigned long long g_stamps[16];
+#define STAMP_DECL unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tp_ = 0; \
+  const bool st_on_ = blockIdx.x == 3 && blockIdx.y == 0 && blockIdx.z == 0;
+#ifdef STAMP_COARSE
+#define STAMP_SKIP(k) ((k) != 5 && (k) != -1)
+#else
+#define STAMP_SKIP(k) false
+#endif
+#define STAMP(k)                                                                             \
+  if constexpr (!STAMP_SKIP(k)) {                                                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+    unsigned long long t_;                                                                   \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");               \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+    if ((k) >= 0) st_[(k) < 0 ? 0 : (k)] += t_ - tp_;                                        \
+    tp_ = t_;                                                                                \
+  }
+#define STAMP_FLUSH                                                            \
+  if (st_on_ && threadIdx.x == 0)                                              \
+    for (int k_ = 0; k_ < 8; ++k_) g_stamps[k_] = st_[k_];
+#else
+#define STAMP_DECL
+#define STAMP(k)
+#define STAMP_FLUSH
+#endif
+
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 __device__ __forceinline__ float clamp_scale(const float* logit_scale_dev) {
@@ -112,7 +141,7 @@ __global__ __launch_bounds__(256, 2) void nce_fwd_kernel(const IT* __restrict__ 
   // negatives are [groups, n_neg, D]; query / positive source rows are shared.
   {
     const int64_t grp = blockIdx.z, to = grp * tok_cap;
-    q_idx += to; p_idx += to; n_tok_dev += grp; negs += grp * (int64_t)n_neg * T::DIM; sum_out += to;
+    q_idx += to; p_idx += to; n_tok_dev += grp; negs += grp * (int64_t)((n_neg + 31) & ~31) * T::DIM; sum_out += to;
     if (n_valid) n_valid += to;
     if (rank) rank += to;
     if (qn_out) qn_out += to * T::DIM;
@@ -152,14 +181,18 @@ __global__ __launch_bounds__(256, 2) void nce_fwd_kernel(const IT* __restrict__ 
 #pragma unroll
     for (int i = 0; i < 8; ++i) spos += (float)frag[0][ks][i] * (float)frag[1][ks][i];
   spos += __shfl_xor(spos, 32, 64);
-  if (live && first_split) {
+  // Saved state for the backward.  Lanes past n_tok inside a processed block (tok < tok_cap) are written too - zero
+  // rows here and all-ones suppression words below - so that the backward can stream whole 32-token tiles without
+  // clamping: a padded token contributes exactly nothing.
+  const bool in_cap = tok < tok_cap;
+  if (in_cap && first_split) {
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
       const int k0 = ks * 16 + 8 * half;
       if (qn_out) *reinterpret_cast<bf16x8*>(qn_out + (int64_t)tok * T::DIM + k0) = frag[0][ks];
       if (pn_out) *reinterpret_cast<bf16x8*>(pn_out + (int64_t)tok * T::DIM + k0) = frag[1][ks];
     }
-    if (half == 0) {
+    if (live && half == 0) {
       if (q_inv) q_inv[tok] = qi;
       if (p_inv) p_inv[tok] = pi;
       if (s_pos_out) s_pos_out[tok] = spos;
@@ -206,7 +239,7 @@ __global__ __launch_bounds__(256, 2) void nce_fwd_kernel(const IT* __restrict__ 
     }
     if (supp_out) {                                       // one word per (negative tile, token): bit j = negative t*32+j suppressed
       sbits |= __shfl_xor(sbits, 32, 64);
-      if (live && half == 0) supp_out[(int64_t)t * tok_cap + tok] = sbits;
+      if (in_cap && half == 0) supp_out[(int64_t)t * tok_cap + tok] = live ? sbits : 0xFFFFFFFFu;
     }
   });
   sum += __shfl_xor(sum, 32, 64);
@@ -261,6 +294,29 @@ __device__ __forceinline__ float half_sum(float v) {   // sum over the 32 lanes 
   return v;
 }
 
+// exp2 of the gated logit with the per-token weight folded into the exponent, then masked BITWISE (dead rows may hold
+// NaN / garbage: x & 0 is 0 where 0.0f * NaN is not).  The bit tests are spelled as v_bfe_i32 + v_and / v_bfi: hipcc turns
+// the C form into v_lshlrev + v_cmp + s_nop + v_cndmask, which overflows the 32-cycle MFMA gap the epilogue lives in.
+// One asm block per element, with the bit extract BETWEEN v_exp_f32 and its consumer: on gfx940+ a VALU instruction
+// reading a transcendental result needs one instruction in between (hipcc inserts that for code it can see, not for
+// inline asm - back to back, the first lanes read the register before v_exp has written it).
+__device__ __forceinline__ float gate_alive(float s, float c1, float c0, uint32_t alive_bits, int pos) {   // bit = 1: keep
+  const float x = s * c1 - c0;
+  float g;
+  int m;
+  asm("v_exp_f32 %0, %2\n\tv_bfe_i32 %1, %3, %4, 1\n\tv_and_b32 %0, %0, %1"
+      : "=&v"(g), "=&v"(m) : "v"(x), "v"(alive_bits), "v"(pos));
+  return g;
+}
+__device__ __forceinline__ float gate_dead(float s, float c1, float c0, uint32_t dead_bits, int pos) {     // bit = 1: drop
+  const float x = s * c1 - c0;
+  float g;
+  int m;
+  asm("v_exp_f32 %0, %2\n\tv_bfe_i32 %1, %3, %4, 1\n\tv_bfi_b32 %0, %1, 0, %0"                          // (m & 0) | (~m & e)
+      : "=&v"(g), "=&v"(m) : "v"(x), "v"(dead_bits), "v"(pos));
+  return g;
+}
+
 template <int NKS>
 __global__ __launch_bounds__(256, 1) void nce_bwd_q_kernel(const bf16_t* qn, const bf16_t* pn,
                                                            const bf16_t* negs, const uint32_t* supp,
@@ -270,16 +326,18 @@ __global__ __launch_bounds__(256, 1) void nce_bwd_q_kernel(const bf16_t* qn, con
                                                            const float* q_inv, const float* p_inv,
                                                            const float* s_pos, const int32_t* q_idx,
                                                            const int32_t* p_idx, float* __restrict__ dq_rows,
-                                                           float* __restrict__ dp_rows, float* __restrict__ d_logit_scale) {
+                                                           float* __restrict__ dp_rows, float* __restrict__ d_logit_scale,
+                                                           float* __restrict__ lw_out) {
   using T = sg::Tile<NKS>;
   constexpr int ND = (NKS + 1) / 2;          // 32-column chunks of the feature dim
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* tiles = smem;               // 4 x T::BYTES, then 4 x 1 KiB of suppression words
   {
     const int64_t grp = blockIdx.z, to = grp * tok_cap;
-    qn += to * T::DIM; pn += to * T::DIM; negs += grp * (int64_t)n_neg * T::DIM;
+    qn += to * T::DIM; pn += to * T::DIM; negs += grp * (int64_t)((n_neg + 31) & ~31) * T::DIM;
     supp += grp * (int64_t)((n_neg + 31) >> 5) * tok_cap;
     n_tok_dev += grp; lse += to; w += to; q_inv += to; p_inv += to; s_pos += to; q_idx += to; p_idx += to;
+    if (lw_out) lw_out += to;
   }
   const int n_tok = min(*n_tok_dev, tok_cap);
   const int tok0 = blockIdx.x * 128;
@@ -298,79 +356,83 @@ __global__ __launch_bounds__(256, 1) void nce_bwd_q_kernel(const bf16_t* qn, con
     frag[0][ks] = live ? *reinterpret_cast<const bf16x8*>(qn + (int64_t)tok * T::DIM + ks * 16 + 8 * half) : sg::zero8();
   const float scale = clamp_scale(logit_scale_dev);
   const float c1 = scale * LOG2E;
-  const float my_w = live ? w[tok] : 0.f;
-  const float my_l2 = live ? lse[tok] * LOG2E : 0.f;
+  // g_ij = w_i exp(scale s_ij - lse_i) = exp2(c1 s_ij - c0_i),  c0 = lse log2(e) - log2(w)   (w = 0 -> c0 = +inf -> g = 0)
+  const float c0 = live ? lse[tok] * LOG2E - __log2f(w[tok]) : 0.f;
+  if (lw_out && live && first_split && half == 0) lw_out[tok] = c0;
 
   f32x16 dq[ND];
 #pragma unroll
   for (int dc = 0; dc < ND; ++dc) dq[dc] = sg::zero16();
-  float dsc = 0.f;   // sum_j g_ij * s_ij for my token (my half's rows)
 
-  // negative tiles + this wave's 32 suppression words per tile stream through a 3-deep LDS-DMA ring
-  using D = sg::Dma<NKS>;
+  // Negative tiles + this wave's 32 suppression words per tile stream through a 4-slot LDS-DMA ring.  Steady state is
+  // branch-free: every iteration waits `vmcnt(PW+1)` (tile i landed, tile i+1 may be in flight), issues the PW+1 DMA
+  // instructions of tile min(i+2, last) - redundant copies of the last tile at the tail keep the count uniform - and
+  // runs one sg::bwd_tile step: S(t) MFMAs with the epilogue of S(t-1) in their gaps, then dQ += G(t-1) . N(t-1) on
+  // the previous slot with the DMA instructions in ITS gaps.
+  using P = sg::DmaPieces<NKS>;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   unsigned char* words = smem + 4 * T::BYTES;                       // 4 x [4 waves][64] uint32
-  auto row_ptr_for = [&](int tile) {
-    return [=](int rr) -> const bf16_t* { return negs + (int64_t)min(tile * 32 + rr, n_neg - 1) * T::DIM; };
+  P dp;
+  dp.init(wv, lane);
+  const uint32_t tok_off = (uint32_t)min(tok, tok_cap - 1) * 4u;
+  const int t_last = t_end - 1;
+  auto dma_k = [&](auto k_c, auto slot_c, int tn) {
+    constexpr int k = decltype(k_c)::value, slot = decltype(slot_c)::value;
+    if constexpr (k < P::PW) {   // rows past n_neg are the pool's padding rows (finite); their columns are masked by the tail bits
+      dp.template piece<k>(tiles + slot * T::BYTES, reinterpret_cast<const char*>(negs) + (int64_t)tn * (32 * T::ROW_BYTES));
+    } else {
+      sg::dma_words(reinterpret_cast<const char*>(supp) + (int64_t)tn * tok_cap * 4 + tok_off, words + slot * 1024 + wv * 256);
+    }
   };
-  const int tokc = min(tok, tok_cap - 1);
-  auto issue_all = [&](int buf, int tile) {
-    D::issue(tiles + buf * T::BYTES, row_ptr_for(tile), wv, lane);
-    sg::dma_words(supp + (int64_t)tile * tok_cap + tokc, words + buf * 1024 + wv * 256);
+  auto dma_all = [&](auto slot_c, int tn) {
+    auto f = [&](auto k_c) { dma_k(k_c, slot_c, tn); };
+    sg::static_for<P::PW + 1>(f);
   };
-  // Software pipeline, one-tile skew, 4-slot ring: the 16 MFMAs of S(t) are issued with the VALU epilogue of S(t-1)
-  // placed element by element in their gaps (mma_tile_epi), then dQ += G(t-1) . N(t-1) runs on tile t-1, which is
-  // still resident.  (Letting hipcc interleave with sched_group_barrier hints, or pairing the product with the
-  // epilogue of the same iteration, measured 5-15 % slower than no skew at all.)
   sg::LaneAddr<NKS> la;
   la.init(lane);
+  sg::TrAddr<NKS> ta;
+  ta.init(la, tiles);
+  sg::RowAddr<NKS> ra;
+  ra.init(la, tiles);
+  const uint32_t sw_addr = sg::lds_addr(words) + wv * 256 + lane * 4;
+  // slot 3 is the "previous tile" of the first iteration (G = 0 there): make it finite
+  for (int o = threadIdx.x * 16; o < T::BYTES; o += 256 * 16) *reinterpret_cast<f32x4*>(tiles + 3 * T::BYTES + o) = f32x4{0.f, 0.f, 0.f, 0.f};
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // published by the first ring barrier
   const int n_loc = t_end - t_begin;
-  issue_all(0, t_begin);
-  if (n_loc > 1) issue_all(1, t_begin + 1);
+  dma_all(std::integral_constant<int, 0>{}, t_begin);
+  dma_all(std::integral_constant<int, 1>{}, min(t_begin + 1, t_last));
   f32x16 s_prev = sg::zero16();          // S of the previous tile
-  uint32_t dead_prev = 0xFFFFFFFFu;      // ... and its dead-row mask (all dead before the first tile: G = 0)
-  // one extra iteration drains the pipeline (its MFMAs run on a stale but finite tile and are discarded)
+  uint32_t alive_prev = 0;               // its live-row bits, pre-shifted by 4*half (none before the first tile: G = 0)
+  STAMP_DECL
+  STAMP(-1)
+  // one extra iteration drains the pipeline (its S runs on a redundant copy of the last tile and is discarded)
   sg::ring_loop<4>(n_loc + 1, [&](auto slot_c, int i) {
     constexpr int cur = decltype(slot_c)::value, nxt = (cur + 2) % 4, prv = (cur + 3) % 4;
     const int t = t_begin + i;
-    const bool has_tile = i < n_loc;
-    if (has_tile) {
-      if (i + 1 < n_loc) sg::wait_vmcnt<D::PW + 1>(); else sg::wait_vmcnt<0>();
-    }
+    STAMP(5)
+    sg::wait_vmcnt<P::PW + 1>();
     sg::ring_barrier();
-    if (i + 2 < n_loc) issue_all(nxt, t + 2);
-    const unsigned char* tile = tiles + cur * T::BYTES;
-    const uint32_t sw = (live && has_tile) ? reinterpret_cast<const uint32_t*>(words + cur * 1024 + wv * 256)[lane] : 0u;
-    const int rem = n_neg - t * 32;
-    // rows past n_neg and suppressed pairs: one 32-bit "dead" mask per lane, tested branch-free
-    const uint32_t dead = has_tile ? (sw | (rem >= 32 ? 0u : (0xFFFFFFFFu << (rem > 0 ? rem : 0)))) : 0xFFFFFFFFu;
+    uint32_t sw;
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(sw) : "v"(sw_addr), "n"(cur * 1024));   // done before bwd_tile's first wait
+    const int tn = min(t + 2, t_last);
     f32x16 acc = sg::zero16();
-    f32x16 gacc;
-    sg::mma_tile_epi<NKS, 4>(tile, la, frag, acc, [&](int g) {
-      const float e = my_w * fast_exp2(s_prev[g] * c1 - my_l2);
-      const float gij = ((dead_prev >> sg::crow(g, half)) & 1u) ? 0.f : e;
-      dsc += gij * s_prev[g];
-      gacc[g] = gij;
-    });
-    bf16x8 g0, g1;
-    pack_acc(gacc, g0, g1);   // G^T of tile t-1 (negatives on rows) as the A operand: computes G . N
-    // (first iteration: prv holds nothing yet, so the product runs on the current tile with G = 0)
-    sg::mma_tile_tr<NKS, ND>(i == 0 ? tile : tiles + prv * T::BYTES, la, g0, g1, dq);
+    sg::bwd_tile<NKS, ND, cur * T::BYTES, prv * T::BYTES, P::PW + 1>(
+        ra, ta, frag, acc, dq, [&](auto n_c) { sg::wait_lgkm_values<decltype(n_c)::value>(sw); },
+        [&](int g) { return gate_alive(s_prev[g], c1, c0, alive_prev, (g & 3) + 8 * (g >> 2)); },
+        [&](auto k_c) { dma_k(k_c, std::integral_constant<int, nxt>{}, tn); });
+    // rows past n_neg and suppressed pairs are dead; so is everything of a dead token or of the drain iteration
+    const int rem = n_neg - t * 32;
+    const uint32_t dead = sw | (rem >= 32 ? 0u : (0xFFFFFFFFu << (rem > 0 ? rem : 0)));
+    alive_prev = (live && i < n_loc) ? (~dead >> (4 * half)) : 0u;
     s_prev = acc;
-    dead_prev = dead;
   });
+  STAMP(5)
+  sg::wait_vmcnt<0>();
 
+  STAMP_FLUSH
   // ---- finish: positive term, L2-normalisation chain rule, accumulation into the source rows -------
   // dq[dc][g]: row (reg) = token wave*32 + crow(g,half), column (lane) = feature dc*32 + r
-  float dls = 0.f;
-  dsc += __shfl_xor(dsc, 32, 64);   // both halves hold rows of the same token column -> full sum per token (lane r)
-  if (live && half == 0) {
-    const float ppos = __expf(scale * s_pos[tok] - lse[tok]);
-    dls = dsc + (first_split ? my_w * (ppos - 1.0f) * s_pos[tok] : 0.f);
-  }
-  dls = wave_sum(dls);
-  if (lane == 0 && d_logit_scale) atomicAdd(d_logit_scale, dls * scale);   // d/d(param) with scale = exp(param)
-
+  float dls = 0.f;   // d(loss)/d(scale) of my half's 16 tokens: sum_j g_ij s_ij = qn_i . dQn_i, plus the positive term
 #pragma unroll
   for (int g = 0; g < 16; ++g) {
     const int tk = tok0 + wave * 32 + sg::crow(g, half);
@@ -379,7 +441,7 @@ __global__ __launch_bounds__(256, 1) void nce_bwd_q_kernel(const bf16_t* qn, con
     const float sp = tl ? s_pos[tk] : 0.f;
     const float coef = (tl && first_split) ? wi * (__expf(scale * sp - lse[tk]) - 1.0f) : 0.f;   // w (p_pos - 1)
     float qv[ND], pv[ND], dqn[ND], dpn[ND];
-    float dot_q = 0.f, dot_p = 0.f;
+    float dot_q = 0.f, dot_p = 0.f, dot_raw = 0.f;
 #pragma unroll
     for (int dc = 0; dc < ND; ++dc) {
       const int d = dc * 32 + r;
@@ -388,11 +450,13 @@ __global__ __launch_bounds__(256, 1) void nce_bwd_q_kernel(const bf16_t* qn, con
       pv[dc] = ok ? (float)pn[(int64_t)tk * T::DIM + d] : 0.f;
       dqn[dc] = ok ? scale * (dq[dc][g] + coef * pv[dc]) : 0.f;
       dpn[dc] = scale * coef * qv[dc];
+      dot_raw += ok ? qv[dc] * dq[dc][g] : 0.f;
       dot_q += qv[dc] * dqn[dc];
       dot_p += pv[dc] * dpn[dc];
     }
     dot_q = half_sum(dot_q);
     dot_p = half_sum(dot_p);
+    dls += half_sum(dot_raw) + coef * sp;
     if (tl) {
       // several tokens share a head row (offsets p of one segment) or a target row (l + 1 + p = const): accumulate
       // with float atomics, one 128-byte segment per wave half per instruction (full-rate shape)
@@ -409,6 +473,8 @@ __global__ __launch_bounds__(256, 1) void nce_bwd_q_kernel(const bf16_t* qn, con
       }
     }
   }
+  dls += __shfl_xor(dls, 32, 64);   // the two halves hold different tokens
+  if (lane == 0 && d_logit_scale) atomicAdd(d_logit_scale, dls * scale);   // d/d(param) with scale = exp(param)
 }
 
 // ------------------------------------------------------------------------------------------
@@ -419,19 +485,18 @@ __global__ __launch_bounds__(256, 1) void nce_bwd_n_kernel(const bf16_t* qn, con
                                                            const uint32_t* supp, int n_neg,
                                                            const int32_t* n_tok_dev, int tok_cap,
                                                            const float* __restrict__ logit_scale_dev,
-                                                           const float* lse, const float* w,
-                                                           float* d_negs) {
+                                                           const float* lw, float* d_negs) {
   using T = sg::Tile<NKS>;
   constexpr int ND = (NKS + 1) / 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // per ring slot: Q tile | [4 waves][64] words: lanes 0-31 = suppression words of that wave's negative tile for the
-  // 32 tokens, lanes 32-63 = w (wave 0) / lse (wave 1) of the 32 tokens
+  // 32 tokens, lanes 32-63 = lw (= lse log2e - log2 w, written by nce_bwd_q) of the 32 tokens
   constexpr int BUF = T::BYTES + 1024;
-  using D = sg::Dma<NKS>;
+  using P = sg::DmaPieces<NKS>;
   {
     const int64_t grp = blockIdx.z, to = grp * tok_cap;
-    qn += to * T::DIM; negs += grp * (int64_t)n_neg * T::DIM; supp += grp * (int64_t)((n_neg + 31) >> 5) * tok_cap;
-    n_tok_dev += grp; lse += to; w += to; d_negs += grp * (int64_t)n_neg * T::DIM;
+    qn += to * T::DIM; negs += grp * (int64_t)((n_neg + 31) & ~31) * T::DIM; supp += grp * (int64_t)((n_neg + 31) >> 5) * tok_cap;
+    n_tok_dev += grp; lw += to; d_negs += grp * (int64_t)n_neg * T::DIM;
   }
   const int n_tok = min(*n_tok_dev, tok_cap);
   const int n_tok_tiles = (n_tok + 31) >> 5;
@@ -443,7 +508,7 @@ __global__ __launch_bounds__(256, 1) void nce_bwd_n_kernel(const bf16_t* qn, con
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, half = lane >> 5;
   const int wv = __builtin_amdgcn_readfirstlane(wave);
   const int neg = neg0 + wave * 32 + r;                 // my stationary negative (lane column)
-  const bool nlive = neg < n_neg;
+  const bool nlive = neg < n_neg;                       // dead negatives keep a zero fragment; their dN rows are not written
   const int n_neg_tiles = (n_neg + 31) >> 5;
 
   bf16x8 frag[1][NKS];
@@ -457,75 +522,69 @@ __global__ __launch_bounds__(256, 1) void nce_bwd_n_kernel(const bf16_t* qn, con
 #pragma unroll
   for (int dc = 0; dc < ND; ++dc) dn[dc] = sg::zero16();
 
-  auto qrow_for = [&](int tile) {
-    return [=](int rr) -> const bf16_t* { return qn + (int64_t)min(tile * 32 + rr, n_tok - 1) * T::DIM; };
-  };
+  // Token tiles stream like the negative tiles of nce_bwd_q (same branch-free ring).  tok_cap is a multiple of 32 and
+  // the forward pads the last live 32-token tile (zero Qn rows, all-ones suppression words), so no row is ever
+  // clamped and a padded token contributes exactly nothing.
+  P dp;
+  dp.init(wv, lane);
   const int my_nt = min((neg0 >> 5) + wv, n_neg_tiles - 1);
-  auto issue_all = [&](int buf, int tile) {
-    unsigned char* base = smem + buf * BUF;
-    D::issue(base, qrow_for(tile), wv, lane);
-    const int tk = min(tile * 32 + r, tok_cap - 1);
-    const void* src = supp + (int64_t)my_nt * tok_cap + tk;
-    if (half == 1 && wv == 0) src = w + tk;
-    if (half == 1 && wv == 1) src = lse + tk;
-    sg::dma_words(src, base + T::BYTES + wv * 256);
+  // my word of a token tile: lanes 0-31 the suppression word of (my negative tile, token r), lanes 32-63 lw of token r
+  const char* word_base = half == 0 ? reinterpret_cast<const char*>(supp + (int64_t)my_nt * tok_cap + r)
+                                    : reinterpret_cast<const char*>(lw + r);
+  const int n_loc = (tt1 - tt0 + tstep - 1) / tstep;
+  const int tt_last = tt0 + (n_loc - 1) * tstep;
+  auto dma_k = [&](auto k_c, auto slot_c, int tn) {
+    constexpr int k = decltype(k_c)::value, slot = decltype(slot_c)::value;
+    unsigned char* base = smem + slot * BUF;
+    if constexpr (k < P::PW) dp.template piece<k>(base, reinterpret_cast<const char*>(qn) + (int64_t)tn * (32 * T::ROW_BYTES));
+    else sg::dma_words(word_base + (int64_t)tn * 128, base + T::BYTES + wv * 256);
   };
-  // one-tile skew as in nce_bwd_q: S(t) MFMAs with the epilogue of S(t-1) in their gaps, then dN += G(t-1)^T . Q(t-1)
+  auto dma_all = [&](auto slot_c, int tn) {
+    auto f = [&](auto k_c) { dma_k(k_c, slot_c, tn); };
+    sg::static_for<P::PW + 1>(f);
+  };
   sg::LaneAddr<NKS> la;
   la.init(lane);
-  const int n_loc = (tt1 - tt0 + tstep - 1) / tstep;
-  issue_all(0, tt0);
-  if (n_loc > 1) issue_all(1, tt0 + tstep);
+  sg::TrAddr<NKS> ta;
+  ta.init(la, smem);
+  sg::RowAddr<NKS> ra;
+  ra.init(la, smem);
+  // my 16 accumulator rows are 4 runs of 4 consecutive tokens (8 q4 + 4 half + 0..3): their words come as 16-byte reads
+  const uint32_t wd_addr = sg::lds_addr(smem) + T::BYTES + wv * 256 + 16 * half;
+  // slot 3 is the "previous tile" of the first iteration: zero rows, all-ones suppression words (G = 0)
+  for (int o = threadIdx.x * 16; o < T::BYTES; o += 256 * 16) *reinterpret_cast<f32x4*>(smem + 3 * BUF + o) = f32x4{0.f, 0.f, 0.f, 0.f};
+  reinterpret_cast<uint32_t*>(smem + 3 * BUF + T::BYTES)[threadIdx.x] = 0xFFFFFFFFu;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // published by the first ring barrier
+  dma_all(std::integral_constant<int, 0>{}, tt0);
+  dma_all(std::integral_constant<int, 1>{}, min(tt0 + tstep, tt_last));
   f32x16 s_prev = sg::zero16();
-  int trem_prev = 0;                     // 0 live tokens before the first tile: G = 0
   sg::ring_loop<4>(n_loc + 1, [&](auto slot_c, int i) {
     constexpr int cur = decltype(slot_c)::value, nxt = (cur + 2) % 4, prv = (cur + 3) % 4;
-    const int t = tt0 + i * tstep;
-    const bool has_tile = i < n_loc;
-    if (has_tile) {
-      if (i + 1 < n_loc) sg::wait_vmcnt<D::PW + 1>(); else sg::wait_vmcnt<0>();
-    }
+    sg::wait_vmcnt<P::PW + 1>();
     sg::ring_barrier();
-    if (i + 2 < n_loc) issue_all(nxt, t + 2 * tstep);
-    const unsigned char* base = smem + cur * BUF;
-    const unsigned char* pbase = i == 0 ? base : smem + prv * BUF;    // first iteration: G = 0 against the current tile
-    // per-token scalars of the PREVIOUS tile: suppression words of my wave's negative tile, w, lse
-    const uint32_t* wd = reinterpret_cast<const uint32_t*>(pbase + T::BYTES);
-    const uint32_t* swd = wd + wv * 64;
-    const float* wsc = reinterpret_cast<const float*>(wd + 32);
-    const float* lsc = reinterpret_cast<const float*>(wd + 64 + 32);
-    // my 16 accumulator rows are 4 runs of 4 consecutive tokens: their scalars come in as 16-byte LDS reads BEFORE the
-    // MFMA batch (scalar-sized LDS reads inside the MFMA gaps put an LDS round trip into every gap: measured +25 %)
-    const int tb = 4 * half;
-    float wr[16], lr[16];
-    uint32_t dm = 0;                                   // bit g set: row g contributes nothing
-#pragma unroll
-    for (int q4 = 0; q4 < 4; ++q4) {
-      const f32x4 w4 = *reinterpret_cast<const f32x4*>(wsc + 8 * q4 + tb);
-      const f32x4 l4 = *reinterpret_cast<const f32x4*>(lsc + 8 * q4 + tb);
-      const __attribute__((ext_vector_type(4))) uint32_t s4 =
-          *reinterpret_cast<const __attribute__((ext_vector_type(4))) uint32_t*>(swd + 8 * q4 + tb);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int g = 4 * q4 + e;
-        wr[g] = w4[e];
-        lr[g] = l4[e] * LOG2E;
-        const bool dead = (!nlive) | (sg::crow(g, half) >= trem_prev) | (((s4[e] >> r) & 1u) != 0u);
-        dm |= dead ? (1u << g) : 0u;
-      }
-    }
+    // per-token words of the PREVIOUS tile (requested first: complete before bwd_tile's first counted wait)
+    sg::u32x4 s4[4], l4[4];
+    auto rd = [&](auto q_c) {
+      constexpr int q4 = decltype(q_c)::value;
+      s4[q4] = sg::ds_read_b128_asm<prv * BUF + 32 * q4>(wd_addr);
+      l4[q4] = sg::ds_read_b128_asm<prv * BUF + 128 + 32 * q4>(wd_addr);
+    };
+    sg::static_for<4>(rd);
+    const int tn = min(tt0 + (i + 2) * tstep, tt_last);
     f32x16 acc = sg::zero16();
-    f32x16 gacc;
-    sg::mma_tile_epi<NKS, 4>(base, la, frag, acc, [&](int g) {
-      const float ex = wr[g] * fast_exp2(s_prev[g] * c1 - lr[g]);
-      gacc[g] = ((dm >> g) & 1u) ? 0.f : ex;
-    });
-    bf16x8 g0, g1;
-    pack_acc(gacc, g0, g1);   // G of tile t-1 (tokens on rows) as the A operand: computes G^T . Qn
-    sg::mma_tile_tr<NKS, ND>(pbase, la, g0, g1, dn);
+    sg::bwd_tile<NKS, ND, cur * BUF, prv * BUF, P::PW + 1>(
+        ra, ta, frag, acc, dn,
+        [&](auto n_c) { sg::wait_lgkm_values<decltype(n_c)::value>(s4[0], s4[1], s4[2], s4[3], l4[0], l4[1], l4[2], l4[3]); },
+        [&](int g) {   // bit r (my negative) of the token's suppression word
+          // (whole-vector bit cast, then element: hipcc 7.2 folds element-extract + scalar bit cast of an asm result to
+          //  element 0 - the same bug as the ds_read_tr builtin note in stream_gemm.h)
+          const f32x4 lf = __builtin_bit_cast(f32x4, l4[g >> 2]);
+          return gate_dead(s_prev[g], c1, lf[g & 3], s4[g >> 2][g & 3], r);
+        },
+        [&](auto k_c) { dma_k(k_c, std::integral_constant<int, nxt>{}, tn); });
     s_prev = acc;
-    trem_prev = has_tile ? n_tok - t * 32 : 0;
   });
+  sg::wait_vmcnt<0>();
   // dn[dc][g]: row (reg) = negative neg0 + wave*32 + crow(g,half), column (lane) = feature dc*32 + r
 #pragma unroll
   for (int g = 0; g < 16; ++g) {
@@ -622,13 +681,14 @@ extern "C" int mhr_nce_bwd_tokens(const void* qn, const void* pn, const void* ne
                                   int n_groups, const int32_t* n_tok_dev, int tok_cap, const float* logit_scale_dev, const float* lse,
                                   const float* w, const float* q_inv, const float* p_inv, const float* s_pos,
                                   const int32_t* q_idx, const int32_t* p_idx, float* dq_rows, float* dp_rows,
-                                  float* d_logit_scale, void* stream) {
+                                  float* d_logit_scale, float* lw_out, void* stream) {
   MHR_REQUIRE(qn && pn && negs && supp && n_tok_dev && logit_scale_dev && lse && w && q_inv && p_inv && s_pos,
               "nce_bwd_tokens: null input pointer");
   MHR_REQUIRE(q_idx && p_idx && dq_rows && dp_rows, "nce_bwd_tokens: null index/output pointer");
   int nks;
   MHR_REQUIRE(nks_for(dim, nks), "nce_bwd_tokens: dim=%d unsupported (16/32/64/128/256)", dim);
   MHR_REQUIRE(n_neg > 0 && tok_cap > 0 && n_groups >= 1 && n_groups <= 65535, "nce_bwd_tokens: bad sizes");
+  MHR_REQUIRE(tok_cap % 32 == 0, "nce_bwd_tokens: tok_cap=%d must be a multiple of 32", tok_cap);
   hipStream_t s = (hipStream_t)stream;
   int tps;
   const int splits = nce_splits((n_neg + 31) / 32, n_groups, 2, tps);   // every range repeats the atomic epilogue
@@ -638,7 +698,7 @@ extern "C" int mhr_nce_bwd_tokens(const void* qn, const void* pn, const void* ne
     size_t lds_q = 4 * sg::Tile<NKS>::BYTES + 4 * 1024;                                                                  \
     hipLaunchKernelGGL((nce_bwd_q_kernel<NKS>), grid_q, dim3(256), lds_q, s, (const bf16_t*)qn, (const bf16_t*)pn,       \
                        (const bf16_t*)negs, supp, n_neg, n_tok_dev, tok_cap, tps, logit_scale_dev, lse, w, q_inv, p_inv, \
-                       s_pos, q_idx, p_idx, dq_rows, dp_rows, d_logit_scale);                                            \
+                       s_pos, q_idx, p_idx, dq_rows, dp_rows, d_logit_scale, lw_out);                                    \
   }
   NKS_SWITCH(nks, L_);
 #undef L_
@@ -647,9 +707,10 @@ extern "C" int mhr_nce_bwd_tokens(const void* qn, const void* pn, const void* ne
 }
 
 extern "C" int mhr_nce_bwd_negs(const void* qn, const void* negs, const uint32_t* supp, int n_neg, int dim, int n_groups,
-                                const int32_t* n_tok_dev, int tok_cap, const float* logit_scale_dev, const float* lse,
-                                const float* w, float* d_negs, void* stream) {
-  MHR_REQUIRE(qn && negs && supp && n_tok_dev && logit_scale_dev && lse && w && d_negs, "nce_bwd_negs: null pointer");
+                                const int32_t* n_tok_dev, int tok_cap, const float* logit_scale_dev, const float* lw,
+                                float* d_negs, void* stream) {
+  MHR_REQUIRE(qn && negs && supp && n_tok_dev && logit_scale_dev && lw && d_negs, "nce_bwd_negs: null pointer");
+  MHR_REQUIRE(tok_cap % 32 == 0, "nce_bwd_negs: tok_cap=%d must be a multiple of 32", tok_cap);
   int nks;
   MHR_REQUIRE(nks_for(dim, nks), "nce_bwd_negs: dim=%d unsupported (16/32/64/128/256)", dim);
   MHR_REQUIRE(n_neg > 0 && tok_cap > 0 && n_groups >= 1 && n_groups <= 65535, "nce_bwd_negs: bad sizes");
@@ -663,10 +724,16 @@ extern "C" int mhr_nce_bwd_negs(const void* qn, const void* negs, const uint32_t
   {                                                                                                                    \
     size_t lds_n = 4 * (sg::Tile<NKS>::BYTES + 1024);                                                                  \
     hipLaunchKernelGGL((nce_bwd_n_kernel<NKS>), dim3(neg_groups, splits, n_groups), dim3(256), lds_n, s, (const bf16_t*)qn,      \
-                       (const bf16_t*)negs, supp, n_neg, n_tok_dev, tok_cap, logit_scale_dev, lse, w, d_negs);          \
+                       (const bf16_t*)negs, supp, n_neg, n_tok_dev, tok_cap, logit_scale_dev, lw, d_negs);          \
   }
   NKS_SWITCH(nks, L_);
 #undef L_
   MHR_CHECK_LAUNCH("nce_bwd_negs");
   return MHR_OK;
 }
+
+#ifdef MHR_STAMP
+extern "C" int mhr_debug_read_stamps(unsigned long long* host16) {
+  return (int)hipMemcpyFromSymbol(host16, HIP_SYMBOL(g_stamps), 16 * sizeof(unsigned long long));
+}
+#endif

@@ -13,7 +13,9 @@
 //   A: lane l holds A[row l&31][k = 8*(l>>5) + j];  B: lane l holds B[k = 8*(l>>5) + j][col l&31]
 //   C: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5)
 #pragma once
+#include <initializer_list>
 #include <type_traits>
+#include <utility>
 
 #include "mhr_common.h"
 
@@ -97,6 +99,7 @@ struct Stage {
 //   transposed read (dc, s, hi) : t[hi][dc & 3] + 256*(dc >> 2) + 16*s*ROW_BYTES        (hi = rows +8)
 // With the ring slot a compile-time constant too (tile loops are unrolled by the ring depth) the main loops carry no
 // address arithmetic at all; recomputing the XORs per read cost 150-200 VALU instructions per 32-MFMA tile.
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 template <int NKS>
 struct LaneAddr {
   using T = Tile<NKS>;
@@ -117,7 +120,14 @@ struct LaneAddr {
     }
   }
   __device__ __forceinline__ bf16x8 read_a(const unsigned char* tile, int ks) const {
+#ifdef EXP_NOSREAD
+    u32x4_t c;   // volatile moves: not hoistable, so the register pressure matches the real kernel
+    asm volatile("v_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %4\n\tv_mov_b32 %3, %5"
+                 : "=&v"(c.x), "=&v"(c.y), "=&v"(c.z), "=&v"(c.w) : "v"(a[ks & 7]), "v"(t[0][ks & 3]));
+    return __builtin_bit_cast(bf16x8, c);
+#else
     return *reinterpret_cast<const bf16x8*>(tile + a[ks & 7] + 256 * (ks >> 3));
+#endif
   }
   // Transposed fragment straight from the row-major swizzled tile with ds_read_b64_tr_b16 (cdna guide T10): the
   // B operand of a product that sums over the ROW index of an accumulator tile (rows = this tile's 32 rows):
@@ -200,6 +210,41 @@ struct Dma {
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(tile + pc * 1024), 16, 0, 0);
       }
     }
+  }
+};
+
+// Per-piece form for loops that place single DMA instructions into MFMA gaps.  Every wave issues exactly PW pieces
+// per tile (waves beyond the tile's piece count repeat an earlier piece: same bytes to the same LDS address), so one
+// compile-time `s_waitcnt vmcnt(n)` is right for all four waves.
+//   Fast path: source rows contiguous (row stride = DIM): address = wave-uniform tile base (SGPR pair) + a per-lane
+//   32-bit offset computed once per kernel -> `global_load_lds_dwordx4 v_off, s[base]`, no per-tile address VALU.
+template <int NKS>
+struct DmaPieces {
+  using T = Tile<NKS>;
+  static constexpr int PIECES = T::BYTES / 1024;
+  static constexpr int PW = (PIECES + 3) / 4;
+  uint32_t off[PW];        // byte offset of my 16 bytes inside the (unswizzled) source tile, per piece
+  int pc[PW];              // piece index (wave-uniform)
+  __device__ __forceinline__ void init(int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < PW; ++i) {
+      pc[i] = (wave * PW + i) % PIECES;
+      const int pos = pc[i] * 1024 + lane * 16;
+      const int row = pos / T::ROW_BYTES, slot = (pos % T::ROW_BYTES) >> 4;
+      off[i] = (uint32_t)(row * T::ROW_BYTES + ((slot ^ T::key(row)) << 4));
+    }
+  }
+  template <int K>
+  __device__ __forceinline__ void piece(unsigned char* tile_lds, const char* tile_src) const {
+    __builtin_amdgcn_global_load_lds((gptr_t)(tile_src + off[K]), (lptr_t)(tile_lds + pc[K] * 1024), 16, 0, 0);
+  }
+  // rows through a callback (clamped / gathered rows): per-piece address arithmetic, same instruction count
+  template <int K, typename RowPtr>
+  __device__ __forceinline__ void piece_rows(unsigned char* tile_lds, RowPtr row_ptr, int lane) const {
+    const int pos = pc[K] * 1024 + lane * 16;
+    const int row = pos / T::ROW_BYTES, slot = (pos % T::ROW_BYTES) >> 4;
+    const bf16_t* src = row_ptr(row) + ((slot ^ T::key(row)) << 3);
+    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(tile_lds + pc[K] * 1024), 16, 0, 0);
   }
 };
 
@@ -289,6 +334,223 @@ __device__ __forceinline__ void mma_tile_tr(const unsigned char* tile, const Lan
     out[dc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g0, b[dc & 1][0], out[dc], 0, 0, 0);
     out[dc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g1, b[dc & 1][1], out[dc], 0, 0, 0);
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// The same product with the transposed reads emitted as inline asm.  hipcc 7.2 guards every
+// __builtin_amdgcn_ds_read_tr16_b64 with `s_waitcnt vmcnt(0)` when LDS-DMA loads are in flight (it cannot prove the
+// read does not alias the DMA destination), which drains the whole prefetch ring once per tile - in the
+// sampled-softmax backward kernels that exposed a full L2/HBM round trip per 32 MFMAs.  The asm form carries no
+// memory operand, so only the counted waits of the ring remain.  The price is doing the LDS wait counting by hand:
+// reads are issued PD column chunks ahead and `s_waitcnt lgkmcnt(4*PD)` (4 reads per chunk) precedes each MFMA pair;
+// the waited registers are threaded through the wait statement as "+v" operands so the MFMAs cannot be hoisted
+// above it.  LDS instructions hipcc adds on its own only make the counted wait stricter, never weaker.
+//   lds_base : LDS byte address of the ring (see lds_addr()), OFF: compile-time byte offset of the tile in the ring.
+// ---------------------------------------------------------------------------------------------------------
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+
+template <int IMM>
+__device__ __forceinline__ u32x2 ds_read_tr_asm(uint32_t addr) {
+  static_assert(IMM >= 0 && IMM < 65536, "LDS offset field is 16 bits");
+  u32x2 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(IMM));
+  return v;
+}
+
+template <int N>
+__device__ __forceinline__ void wait_lgkm(u32x2& a, u32x2& b, u32x2& c, u32x2& d) {
+  static_assert(N >= 0 && N <= 15, "lgkmcnt is 4 bits");
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
+}
+
+template <int NKS>
+struct TrAddr {           // per-lane LDS byte ADDRESSES (ring base included) of the transposed reads
+  uint32_t t[2][4];
+  __device__ __forceinline__ void init(const LaneAddr<NKS>& la, const void* ring) {
+    const uint32_t b = lds_addr(ring);
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int d = 0; d < 4; ++d) t[h][d] = b + (uint32_t)la.t[h][d];
+  }
+};
+
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+template <int NKS, int ND, int OFF, int PD = 2>
+__device__ __forceinline__ void mma_tile_tr_asm(const TrAddr<NKS>& ta, bf16x8 g0, bf16x8 g1, f32x16 (&out)[ND]) {
+  using T = Tile<NKS>;
+  constexpr int P = PD < ND ? PD : ND;
+  u32x2 r[P + 1][4];      // [.][0,1] = rows +0/+8 of k-step 0, [.][2,3] = of k-step 1
+  auto issue = [&](auto dc_c) {
+    constexpr int dc = decltype(dc_c)::value;
+    constexpr int imm = OFF + 256 * (dc >> 2), s1 = 16 * T::ROW_BYTES;
+    u32x2* q = r[dc % (P + 1)];
+#ifdef EXP_NOTR
+    q[0] = q[1] = q[2] = q[3] = u32x2{ta.t[0][dc & 3], ta.t[1][dc & 3]};
+#else
+    q[0] = ds_read_tr_asm<imm>(ta.t[0][dc & 3]);
+    q[1] = ds_read_tr_asm<imm>(ta.t[1][dc & 3]);
+    q[2] = ds_read_tr_asm<imm + s1>(ta.t[0][dc & 3]);
+    q[3] = ds_read_tr_asm<imm + s1>(ta.t[1][dc & 3]);
+#endif
+  };
+  auto step = [&](auto dc_c) {
+    constexpr int dc = decltype(dc_c)::value;
+    if constexpr (dc + P < ND) issue(std::integral_constant<int, dc + P>{});
+    constexpr int ahead = (ND - 1 - dc) < P ? (ND - 1 - dc) : P;     // chunks issued after this one
+    u32x2* q = r[dc % (P + 1)];
+#ifndef EXP_NOTRWAIT
+    wait_lgkm<4 * ahead>(q[0], q[1], q[2], q[3]);
+#endif
+    const u32x4 b0 = {q[0].x, q[0].y, q[1].x, q[1].y}, b1 = {q[2].x, q[2].y, q[3].x, q[3].y};
+    out[dc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g0, __builtin_bit_cast(bf16x8, b0), out[dc], 0, 0, 0);
+    out[dc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g1, __builtin_bit_cast(bf16x8, b1), out[dc], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  static_for<P>(issue);
+  static_for<ND>(step);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// One tile step of the backward kernels, hand-ordered (everything that touches LDS is inline asm, so the only waits
+// are the counted ones written here):
+//     S(t)   = tile_cur . frag^T            NKS chained MFMAs, row fragments read PA k-steps ahead,
+//     epi(e)                                 the caller's per-element epilogue of S(t-1), EPK elements per MFMA gap,
+//     out   += G(t-1) . tile_prv             ND x 2 MFMAs, transposed fragments read PT chunks ahead - the first PT
+//                                            chunks are already requested during the last S gaps, so the second
+//                                            product starts without an LDS round trip.
+// `mid()` runs after the first PA row reads are in flight (the place for the next tile's DMA issue: its issue cost
+// overlaps the LDS latency).  `pack(g0, g1)` converts the finished epilogue into the two A fragments of G(t-1).
+// LDS return order is issue order, so `s_waitcnt lgkmcnt(n)` with n = reads issued after the one needed is exact.
+// ---------------------------------------------------------------------------------------------------------
+template <int IMM>
+__device__ __forceinline__ u32x4 ds_read_b128_asm(uint32_t addr) {
+  static_assert(IMM >= 0 && IMM < 65536, "LDS offset field is 16 bits");
+  u32x4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(IMM));
+  return v;
+}
+template <int N>
+__device__ __forceinline__ void wait_lgkm1(u32x4& a) {
+  static_assert(N >= 0 && N <= 15, "lgkmcnt is 4 bits");
+  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(N));
+}
+
+template <int NKS>
+struct RowAddr {          // per-lane LDS byte ADDRESSES (ring base included) of the row-fragment reads
+  static constexpr int NA = NKS < 8 ? NKS : 8;
+  uint32_t a[NA];
+  __device__ __forceinline__ void init(const LaneAddr<NKS>& la, const void* ring) {
+    const uint32_t b = lds_addr(ring);
+#pragma unroll
+    for (int j = 0; j < NA; ++j) a[j] = b + (uint32_t)la.a[j];
+  }
+};
+
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
+
+// epi(e) -> float : element e (accumulator register index) of the gated previous tile, already masked.
+// dma(k)          : k = 0..NDMA-1, the next tile's LDS-DMA instructions, one per gap of the second product (those
+//                   gaps carry only two transposed reads, the S gaps are full of epilogue).
+// Values read from LDS by the caller's own inline-asm reads (issued BEFORE bwd_tile) must be passed through this after
+// the wait that covers them: an asm output looks "ready" to hipcc at the read itself, so ordinary code or non-volatile
+// asm consuming it could otherwise be scheduled above the wait.  `ready(n)` in bwd_tile is the place: n = LDS reads
+// issued after the caller's.
+template <typename V>
+__device__ __forceinline__ void redefine(V& v) {
+  asm volatile("" : "+v"(v));
+}
+template <int N, typename... V>
+__device__ __forceinline__ void wait_lgkm_values(V&... v) {
+  static_assert(N >= 0 && N <= 15, "lgkmcnt is 4 bits");
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N));
+  (redefine(v), ...);
+}
+
+template <int NKS, int ND, int OFF_CUR, int OFF_PRV, int NDMA, typename Ready, typename Epi, typename DmaFn>
+__device__ __forceinline__ void bwd_tile(const RowAddr<NKS>& ra, const TrAddr<NKS>& ta, const bf16x8 (&frag)[1][NKS],
+                                         f32x16& acc, f32x16 (&out)[ND], Ready ready, Epi epi, DmaFn dma) {
+  using T = Tile<NKS>;
+  constexpr int PA = NKS < 4 ? NKS : 4;
+  constexpr int PT = ND < 2 ? ND : 2;
+  constexpr int EPK = (16 + NKS - 1) / NKS;
+  constexpr int T0 = NKS - PT;             // S step after which transposed chunk 0 is requested
+  u32x4 a[PA + 1];
+  u32x2 r[PT + 1][4];
+  uint32_t pk[8];                          // bf16 pairs of the gated tile: pk[0..3] = k-step 0, pk[4..7] = k-step 1
+  float even = 0.f;
+  auto issue_a = [&](auto ks_c) {
+    constexpr int ks = decltype(ks_c)::value;
+    a[ks % (PA + 1)] = ds_read_b128_asm<OFF_CUR + 256 * (ks >> 3)>(ra.a[ks & 7]);
+  };
+  auto issue_t = [&](auto dc_c) {
+    constexpr int dc = decltype(dc_c)::value;
+    constexpr int imm = OFF_PRV + 256 * (dc >> 2), s1 = 16 * T::ROW_BYTES;
+    u32x2* q = r[dc % (PT + 1)];
+    q[0] = ds_read_tr_asm<imm>(ta.t[0][dc & 3]);
+    q[1] = ds_read_tr_asm<imm>(ta.t[1][dc & 3]);
+    q[2] = ds_read_tr_asm<imm + s1>(ta.t[0][dc & 3]);
+    q[3] = ds_read_tr_asm<imm + s1>(ta.t[1][dc & 3]);
+  };
+  static_for<PA>(issue_a);
+  ready(std::integral_constant<int, PA>{});
+  auto s_step = [&](auto ks_c) {
+    constexpr int ks = decltype(ks_c)::value;
+    if constexpr (ks + PA < NKS) issue_a(std::integral_constant<int, ks + PA>{});
+    constexpr int a_after = (ks + PA < NKS ? ks + PA : NKS - 1) - ks;
+    constexpr int t_chunks = ks > T0 ? ks - T0 : 0;
+    wait_lgkm1<a_after + 4 * t_chunks>(a[ks % (PA + 1)]);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[ks % (PA + 1)]), frag[0][ks], acc, 0, 0, 0);
+#pragma unroll
+    for (int e = ks * EPK; e < ks * EPK + EPK && e < 16; ++e) {
+      const float g = epi(e);
+      if (e & 1) pk[e >> 1] = cvt_pk_bf16(even, g); else even = g;
+    }
+    if constexpr (ks >= T0) issue_t(std::integral_constant<int, ks - T0>{});
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  static_for<NKS>(s_step);
+  const u32x4 g0v = {pk[0], pk[1], pk[2], pk[3]}, g1v = {pk[4], pk[5], pk[6], pk[7]};
+  const bf16x8 g0 = __builtin_bit_cast(bf16x8, g0v), g1 = __builtin_bit_cast(bf16x8, g1v);
+  auto t_step = [&](auto dc_c) {
+    constexpr int dc = decltype(dc_c)::value;
+    if constexpr (dc + PT < ND) issue_t(std::integral_constant<int, dc + PT>{});
+    constexpr int ahead = (ND - 1 - dc) < PT ? (ND - 1 - dc) : PT;
+    u32x2* q = r[dc % (PT + 1)];
+    wait_lgkm<4 * ahead>(q[0], q[1], q[2], q[3]);
+    const u32x4 b0 = {q[0].x, q[0].y, q[1].x, q[1].y}, b1 = {q[2].x, q[2].y, q[3].x, q[3].y};
+    out[dc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g0, __builtin_bit_cast(bf16x8, b0), out[dc], 0, 0, 0);
+    if constexpr (2 * dc < NDMA) dma(std::integral_constant<int, 2 * dc>{});
+    __builtin_amdgcn_sched_barrier(0);
+    out[dc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g1, __builtin_bit_cast(bf16x8, b1), out[dc], 0, 0, 0);
+    if constexpr (2 * dc + 1 < NDMA) dma(std::integral_constant<int, 2 * dc + 1>{});
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  static_for<ND>(t_step);
+  // DMA pieces that did not fit a gap (narrow feature dims have few gaps)
+  auto rest = [&](auto k_c) {
+    constexpr int k = decltype(k_c)::value;
+    if constexpr (k >= 2 * ND) dma(k_c);
+  };
+  static_for<NDMA>(rest);
 }
 
 // Runs body(slot_constant, i) for i = 0..n-1 with slot = i % DEPTH as a COMPILE-TIME constant (the loop is unrolled

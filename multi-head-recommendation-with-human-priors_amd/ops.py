@@ -209,7 +209,7 @@ def hstu_attn_bwd(h, act, key_valid, d_out, dh, B, L, n_heads, head_dim, apply_s
 class NceSaved:
     """Tensors the forward keeps for the backward (all preallocated at token capacity)."""
     __slots__ = ("qn", "pn", "supp", "q_inv", "p_inv", "s_pos", "lse", "loss", "n_valid", "rank", "negs",
-                 "n_tok_dev", "tok_cap", "thres", "dim", "n_neg", "groups")
+                 "n_tok_dev", "tok_cap", "cap", "thres", "dim", "n_neg", "groups", "q_idx", "p_idx")
 
 
 def nce_fwd(q_rows, q_idx, p_rows, p_idx, negs, n_tok_dev, tok_cap, logit_scale, thres=0.99, want_logs=False,
@@ -228,54 +228,70 @@ def nce_fwd(q_rows, q_idx, p_rows, p_idx, negs, n_tok_dev, tok_cap, logit_scale,
     dev = negs.device
     G, n_neg, D = negs.shape
     assert q_idx.shape == (G, tok_cap) and p_idx.shape == (G, tok_cap) and n_tok_dev.numel() == G
+    if n_neg % 32:                                    # pools are stored [G, round_up(n_neg, 32), D]: whole tiles stream unclamped
+        negs = torch.nn.functional.pad(negs, (0, 0, 0, 32 - n_neg % 32)).contiguous()
+    # the kernels stream whole 32-token tiles: capacities are rounded up (production shapes already are multiples of 32)
+    cap = (tok_cap + 31) // 32 * 32
+    if cap != tok_cap:
+        q_idx = torch.nn.functional.pad(q_idx, (0, cap - tok_cap)).contiguous()
+        p_idx = torch.nn.functional.pad(p_idx, (0, cap - tok_cap)).contiguous()
     sv = NceSaved()
-    sv.loss = torch.zeros(G, tok_cap, dtype=torch.float32, device=dev)
-    sv.lse = torch.zeros(G, tok_cap, dtype=torch.float32, device=dev)
-    sv.n_valid = torch.zeros(G, tok_cap, dtype=torch.int32, device=dev) if want_logs else None
-    sv.rank = torch.zeros(G, tok_cap, dtype=torch.int32, device=dev) if want_logs else None
-    sv.s_pos = torch.empty(G, tok_cap, dtype=torch.float32, device=dev)
+    sv.q_idx, sv.p_idx = q_idx, p_idx
+    loss = torch.zeros(G, cap, dtype=torch.float32, device=dev)
+    sv.lse = torch.zeros(G, cap, dtype=torch.float32, device=dev)
+    n_valid = torch.zeros(G, cap, dtype=torch.int32, device=dev) if want_logs else None
+    rank = torch.zeros(G, cap, dtype=torch.int32, device=dev) if want_logs else None
+    sv.s_pos = torch.empty(G, cap, dtype=torch.float32, device=dev)
     if for_backward:
-        sv.qn = torch.empty(G, tok_cap, D, dtype=torch.bfloat16, device=dev)
-        sv.pn = torch.empty(G, tok_cap, D, dtype=torch.bfloat16, device=dev)
-        sv.supp = torch.empty(G, (n_neg + 31) // 32, tok_cap, dtype=torch.int32, device=dev)
-        sv.q_inv = torch.empty(G, tok_cap, dtype=torch.float32, device=dev)
-        sv.p_inv = torch.empty(G, tok_cap, dtype=torch.float32, device=dev)
+        sv.qn = torch.empty(G, cap, D, dtype=torch.bfloat16, device=dev)
+        sv.pn = torch.empty(G, cap, D, dtype=torch.bfloat16, device=dev)
+        sv.supp = torch.empty(G, (n_neg + 31) // 32, cap, dtype=torch.int32, device=dev)
+        sv.q_inv = torch.empty(G, cap, dtype=torch.float32, device=dev)
+        sv.p_inv = torch.empty(G, cap, dtype=torch.float32, device=dev)
     else:
         sv.qn = sv.pn = sv.supp = sv.q_inv = sv.p_inv = None
     sv.negs = negs
-    sv.n_tok_dev, sv.tok_cap, sv.thres, sv.dim, sv.n_neg, sv.groups = n_tok_dev, tok_cap, float(thres), D, n_neg, G
-    ssum = torch.zeros(G, tok_cap, dtype=torch.float32, device=dev)
+    sv.n_tok_dev, sv.tok_cap, sv.cap, sv.thres, sv.dim, sv.n_neg, sv.groups = n_tok_dev, tok_cap, cap, float(thres), D, n_neg, G
+    ssum = torch.zeros(G, cap, dtype=torch.float32, device=dev)
     st = _stream()
     _timed_call("mhr_nce_fwd", q_rows.data_ptr(), q_idx.data_ptr(), p_rows.data_ptr(), p_idx.data_ptr(), _dt(q_rows),
-                negs.data_ptr(), n_neg, D, G, n_tok_dev.data_ptr(), tok_cap, logit_scale.data_ptr(), float(thres),
-                ssum.data_ptr(), _ptr(sv.n_valid), _ptr(sv.rank), _ptr(sv.qn), _ptr(sv.pn),
+                negs.data_ptr(), n_neg, D, G, n_tok_dev.data_ptr(), cap, logit_scale.data_ptr(), float(thres),
+                ssum.data_ptr(), _ptr(n_valid), _ptr(rank), _ptr(sv.qn), _ptr(sv.pn),
                 _ptr(sv.supp), _ptr(sv.q_inv), _ptr(sv.p_inv), _ptr(sv.s_pos), st)
-    lib.call("mhr_nce_finalize", ssum.data_ptr(), sv.s_pos.data_ptr(), G, n_tok_dev.data_ptr(), tok_cap,
-             logit_scale.data_ptr(), sv.loss.data_ptr(), sv.lse.data_ptr(), _ptr(sv.n_valid), st)
+    lib.call("mhr_nce_finalize", ssum.data_ptr(), sv.s_pos.data_ptr(), G, n_tok_dev.data_ptr(), cap,
+             logit_scale.data_ptr(), loss.data_ptr(), sv.lse.data_ptr(), _ptr(n_valid), st)
+    sv.loss = loss[:, :tok_cap]
+    sv.n_valid = None if n_valid is None else n_valid[:, :tok_cap]
+    sv.rank = None if rank is None else rank[:, :tok_cap]
     return sv
 
 
 def nce_bwd(sv, w, logit_scale, q_idx, p_idx, dq_rows, dp_rows, d_negs=None, d_logit_scale=None):
     """w [G, tok_cap] f32 = dLoss/dloss[g, t].  Accumulates into dq_rows [Rq, D] / dp_rows [Rp, D] (f32, the
-    forward's shared row spaces); returns (d_negs [G, n_neg, D] f32, d_logit_scale [1])."""
+    forward's shared row spaces); returns (d_negs [G, n_neg, D] f32, d_logit_scale [1]).  q_idx / p_idx are the
+    forward's index lists (the padded copies saved by nce_fwd are what the kernels read)."""
     dev = sv.negs.device
-    D, cap, G = sv.dim, sv.tok_cap, sv.groups
-    if q_idx.dim() == 1:
-        q_idx, p_idx, w = q_idx[None], p_idx[None], w[None]
+    D, cap, G = sv.dim, sv.cap, sv.groups
+    if w.dim() == 1:
+        w = w[None]
     if d_negs is None:
         d_negs = torch.zeros(G, sv.n_neg, D, dtype=torch.float32, device=dev)
     if d_logit_scale is None:
         d_logit_scale = torch.zeros(1, dtype=torch.float32, device=dev)
+    if cap != sv.tok_cap:
+        w = torch.nn.functional.pad(w, (0, cap - sv.tok_cap))
+    w = w.contiguous()
     _chk(w, "w", torch.float32)
     _chk(dq_rows, "dq_rows", torch.float32)
     _chk(dp_rows, "dp_rows", torch.float32)
+    lw = torch.empty(G, cap, dtype=torch.float32, device=dev)     # lse log2e - log2 w: written by bwd_tokens, read by bwd_negs
     st = _stream()
     _timed_call("mhr_nce_bwd_tokens", sv.qn.data_ptr(), sv.pn.data_ptr(), sv.negs.data_ptr(), sv.supp.data_ptr(), sv.n_neg, D,
                 G, sv.n_tok_dev.data_ptr(), cap, logit_scale.data_ptr(), sv.lse.data_ptr(), w.data_ptr(), sv.q_inv.data_ptr(),
-                sv.p_inv.data_ptr(), sv.s_pos.data_ptr(), q_idx.data_ptr(), p_idx.data_ptr(), dq_rows.data_ptr(),
-                dp_rows.data_ptr(), d_logit_scale.data_ptr(), st)
+                sv.p_inv.data_ptr(), sv.s_pos.data_ptr(), sv.q_idx.data_ptr(), sv.p_idx.data_ptr(), dq_rows.data_ptr(),
+                dp_rows.data_ptr(), d_logit_scale.data_ptr(), lw.data_ptr(), st)
     _timed_call("mhr_nce_bwd_negs", sv.qn.data_ptr(), sv.negs.data_ptr(), sv.supp.data_ptr(), sv.n_neg, D, G,
-                sv.n_tok_dev.data_ptr(), cap, logit_scale.data_ptr(), sv.lse.data_ptr(), w.data_ptr(), d_negs.data_ptr(), st)
+                sv.n_tok_dev.data_ptr(), cap, logit_scale.data_ptr(), lw.data_ptr(), d_negs.data_ptr(), st)
     return d_negs, d_logit_scale
 
 
