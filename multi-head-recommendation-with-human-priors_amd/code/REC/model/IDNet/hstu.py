@@ -230,14 +230,13 @@ class HSTU(BaseModel):
     def _layer_weights_bf16(self, i, layer):
         """bf16 operands of layer i's two GEMMs.  While the module is in eval mode the casts are done once and kept
         (weights do not move between `eval()` and the next `train()` / `load_state_dict`, which drop the cache)."""
-        if not self.training:
-            hit = self._bf16_cache.get(i)
-            if hit is not None:
-                return hit
-        w = (layer._uvqk.to(torch.bfloat16), layer._o.weight.to(torch.bfloat16), layer._o.bias.to(torch.bfloat16))
-        if not self.training and not torch.is_grad_enabled():
-            self._bf16_cache[i] = w
-        return w
+        if self.training or torch.is_grad_enabled():
+            return None                                   # SplitKLinearFn casts (and differentiates through) the masters
+        hit = self._bf16_cache.get(i)
+        if hit is None:
+            hit = self._bf16_cache[i] = (layer._uvqk.to(torch.bfloat16), layer._o.weight.to(torch.bfloat16),
+                                         layer._o.bias.to(torch.bfloat16))
+        return hit
 
     def train(self, mode=True):
         self._bf16_cache = {}
@@ -250,18 +249,23 @@ class HSTU(BaseModel):
 
     def _encode(self, x, key_valid, training=None):
         """x [B,L,D] fp32, key_valid [B,L] uint8 -> [B,L,D] fp32 (reference hstu.py:221-328)."""
-        from REC.model.hstu_functional import HSTUCoreFn, LayerNormFn
+        from REC.model.hstu_functional import HSTUCoreFn, LayerNormFn, SplitKLinearFn
         B, L, D = x.shape
         x2 = x.reshape(B * L, D)
         training = self.training if training is None else training
         p = self._linear_dropout_rate if training else 0.0
         for i, layer in enumerate(self._hstu._attention_layers):
             xn = LayerNormFn.apply(x2, layer._eps)
-            w_uvqk, w_o, b_o = self._layer_weights_bf16(i, layer)
-            h = xn @ w_uvqk
+            cached = self._layer_weights_bf16(i, layer)
             seed = (self._step_seed * 1000003 + i * 7919 + self.rank * 104729) & 0x7FFFFFFFFFFFFFFF
-            o = HSTUCoreFn.apply(h, key_valid, B, L, self._num_heads, self._dqk, layer._eps, p, seed)
-            y = F.linear(o, w_o, b_o)
+            if cached is None:
+                h = SplitKLinearFn.apply(xn, layer._uvqk, None, False, None)
+                o = HSTUCoreFn.apply(h, key_valid, B, L, self._num_heads, self._dqk, layer._eps, p, seed)
+                y = SplitKLinearFn.apply(o, layer._o.weight, layer._o.bias, True, None)
+            else:
+                h = xn @ cached[0]
+                o = HSTUCoreFn.apply(h, key_valid, B, L, self._num_heads, self._dqk, layer._eps, p, seed)
+                y = F.linear(o, cached[1], cached[2])
             x2 = x2 + y.float()
         return x2.view(B, L, D)
 

@@ -26,6 +26,39 @@ class LayerNormFn(Function):
         return ops.layernorm_bwd(dy.contiguous(), x, mean, rstd, dx_dtype=torch.float32), None
 
 
+class SplitKLinearFn(Function):
+    """y = x @ W (w_is_nk=False, W [K, N]) or x @ W.T + b (w_is_nk=True, W [N, K], the nn.Linear layout), bf16 GEMMs on
+    fp32 master weights (reference hstu.py:236-239 under bf16-mixed autocast).
+
+    The weight gradient contracts over all B*L tokens into a 256 x 1024 (or 256 x 256) result: as one GEMM that is 64
+    output tiles on a 256-CU part (measured 94-137 us per call, ~2.2 ms per step at cfg1).  It is issued as a
+    split-K batched GEMM instead - S slices of the token axis, S x more tiles - and the S partials are summed in fp32."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, w_is_nk, w_bf16):
+        wb = w.to(torch.bfloat16) if w_bf16 is None else w_bf16
+        y = torch.nn.functional.linear(x, wb, None if b is None else b.to(torch.bfloat16)) if w_is_nk else x @ wb
+        ctx.save_for_backward(x, wb)
+        ctx.w_is_nk, ctx.has_bias = w_is_nk, b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wb = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = dy @ wb if ctx.w_is_nk else dy @ wb.t()
+        R = x.shape[0]
+        S = next((s for s in (16, 8, 4, 2) if R % s == 0 and R // s >= 256), 1)
+        xs, dys = x.view(S, R // S, -1), dy.view(S, R // S, -1)
+        if ctx.w_is_nk:
+            dw = torch.bmm(dys.transpose(1, 2), xs)               # [S, N, K]
+        else:
+            dw = torch.bmm(xs.transpose(1, 2), dys)               # [S, K, N]
+        dw = dw.float().sum(0) if S > 1 else dw[0].float()
+        db = dy.float().sum(0) if ctx.has_bias else None
+        return dx, dw, db, None, None
+
+
 class HSTUCoreFn(Function):
     """h = LN(x) @ W_uvqk (pre-activation, [B*L, 4D] bf16)  ->  o = silu(u) * LN(attn(silu(q), silu(k), silu(v))) * drop.
 

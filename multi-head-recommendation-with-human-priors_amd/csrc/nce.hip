@@ -411,7 +411,9 @@ __global__ __launch_bounds__(256, 1) void nce_bwd_q_kernel(const bf16_t* qn, con
     const int t = t_begin + i;
     STAMP(5)
     sg::wait_vmcnt<P::PW + 1>();
+#if !(defined(MHR_STAMP) && defined(EXP_NOBAR))
     sg::ring_barrier();
+#endif
     uint32_t sw;
     asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(sw) : "v"(sw_addr), "n"(cur * 1024));   // done before bwd_tile's first wait
     const int tn = min(t + 2, t_last);
@@ -419,7 +421,12 @@ __global__ __launch_bounds__(256, 1) void nce_bwd_q_kernel(const bf16_t* qn, con
     sg::bwd_tile<NKS, ND, cur * T::BYTES, prv * T::BYTES, P::PW + 1>(
         ra, ta, frag, acc, dq, [&](auto n_c) { sg::wait_lgkm_values<decltype(n_c)::value>(sw); },
         [&](int g) { return gate_alive(s_prev[g], c1, c0, alive_prev, (g & 3) + 8 * (g >> 2)); },
+#if defined(MHR_STAMP) && defined(EXP_NODMA)
+        [&](auto) {});
+    (void)tn;
+#else
         [&](auto k_c) { dma_k(k_c, std::integral_constant<int, nxt>{}, tn); });
+#endif
     // rows past n_neg and suppressed pairs are dead; so is everything of a dead token or of the drain iteration
     const int rem = n_neg - t * 32;
     const uint32_t dead = sw | (rem >= 32 ? 0u : (0xFFFFFFFFu << (rem > 0 ? rem : 0)));
@@ -432,43 +439,66 @@ __global__ __launch_bounds__(256, 1) void nce_bwd_q_kernel(const bf16_t* qn, con
   STAMP_FLUSH
   // ---- finish: positive term, L2-normalisation chain rule, accumulation into the source rows -------
   // dq[dc][g]: row (reg) = token wave*32 + crow(g,half), column (lane) = feature dc*32 + r
+  // Memory latency is taken in batches: lane j < 16 of each half fetches the per-token scalars of accumulator row j
+  // (7 loads per lane, broadcast by shuffles), and the normalised rows are loaded four tokens at a time before any of
+  // them is used - the row-by-row form spent ~40 % of the kernel waiting on 48 dependent round trips.
   float dls = 0.f;   // d(loss)/d(scale) of my half's 16 tokens: sum_j g_ij s_ij = qn_i . dQn_i, plus the positive term
+  const int my_row = tok0 + wave * 32 + sg::crow(lane & 15, half);
+  const bool my_live = my_row < n_tok;
+  const float r_w = my_live ? w[my_row] : 0.f, r_sp = my_live ? s_pos[my_row] : 0.f, r_lse = my_live ? lse[my_row] : 0.f;
+  const float r_iq = my_live ? q_inv[my_row] : 0.f, r_ip = my_live ? p_inv[my_row] : 0.f;
+  const int r_qi = my_live ? q_idx[my_row] : 0, r_pi = my_live ? p_idx[my_row] : 0;
+  const float r_coef = (my_live && first_split) ? r_w * (__expf(scale * r_sp - r_lse) - 1.0f) : 0.f;   // w (p_pos - 1)
+  const int src0 = lane & 32;
 #pragma unroll
-  for (int g = 0; g < 16; ++g) {
-    const int tk = tok0 + wave * 32 + sg::crow(g, half);
-    const bool tl = tk < n_tok;
-    const float wi = tl ? w[tk] : 0.f;
-    const float sp = tl ? s_pos[tk] : 0.f;
-    const float coef = (tl && first_split) ? wi * (__expf(scale * sp - lse[tk]) - 1.0f) : 0.f;   // w (p_pos - 1)
-    float qv[ND], pv[ND], dqn[ND], dpn[ND];
-    float dot_q = 0.f, dot_p = 0.f, dot_raw = 0.f;
+  for (int g0 = 0; g0 < 16; g0 += 4) {
+    float qv[4][ND], pv[4][ND];
 #pragma unroll
-    for (int dc = 0; dc < ND; ++dc) {
-      const int d = dc * 32 + r;
-      const bool ok = tl && d < T::DIM;
-      qv[dc] = ok ? (float)qn[(int64_t)tk * T::DIM + d] : 0.f;
-      pv[dc] = ok ? (float)pn[(int64_t)tk * T::DIM + d] : 0.f;
-      dqn[dc] = ok ? scale * (dq[dc][g] + coef * pv[dc]) : 0.f;
-      dpn[dc] = scale * coef * qv[dc];
-      dot_raw += ok ? qv[dc] * dq[dc][g] : 0.f;
-      dot_q += qv[dc] * dqn[dc];
-      dot_p += pv[dc] * dpn[dc];
-    }
-    dot_q = half_sum(dot_q);
-    dot_p = half_sum(dot_p);
-    dls += half_sum(dot_raw) + coef * sp;
-    if (tl) {
-      // several tokens share a head row (offsets p of one segment) or a target row (l + 1 + p = const): accumulate
-      // with float atomics, one 128-byte segment per wave half per instruction (full-rate shape)
-      const float iq = q_inv[tk], ip = p_inv[tk];
-      float* qdst = dq_rows + (int64_t)q_idx[tk] * T::DIM;
-      float* pdst = dp_rows + (int64_t)p_idx[tk] * T::DIM;
+    for (int gi = 0; gi < 4; ++gi) {
+      const int tk = tok0 + wave * 32 + sg::crow(g0 + gi, half);
+      const bool tl = tk < n_tok;
 #pragma unroll
       for (int dc = 0; dc < ND; ++dc) {
         const int d = dc * 32 + r;
-        if (d < T::DIM) {
-          atomicAdd(qdst + d, (dqn[dc] - qv[dc] * dot_q) * iq);
-          if (first_split) atomicAdd(pdst + d, (dpn[dc] - pv[dc] * dot_p) * ip);
+        const bool ok = tl && d < T::DIM;
+        qv[gi][dc] = ok ? (float)qn[(int64_t)tk * T::DIM + d] : 0.f;
+        pv[gi][dc] = ok ? (float)pn[(int64_t)tk * T::DIM + d] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int gi = 0; gi < 4; ++gi) {
+      const int g = g0 + gi;
+      const int tk = tok0 + wave * 32 + sg::crow(g, half);
+      const bool tl = tk < n_tok;
+      const float coef = __shfl(r_coef, src0 + g, 64), sp = __shfl(r_sp, src0 + g, 64);
+      float dqn[ND], dpn[ND];
+      float dot_q = 0.f, dot_p = 0.f, dot_raw = 0.f;
+#pragma unroll
+      for (int dc = 0; dc < ND; ++dc) {
+        const bool ok = tl && dc * 32 + r < T::DIM;
+        dqn[dc] = ok ? scale * (dq[dc][g] + coef * pv[gi][dc]) : 0.f;
+        dpn[dc] = scale * coef * qv[gi][dc];
+        dot_raw += ok ? qv[gi][dc] * dq[dc][g] : 0.f;
+        dot_q += qv[gi][dc] * dqn[dc];
+        dot_p += pv[gi][dc] * dpn[dc];
+      }
+      dot_q = half_sum(dot_q);
+      dot_p = half_sum(dot_p);
+      dls += half_sum(dot_raw) + coef * sp;
+      const float iq = __shfl(r_iq, src0 + g, 64), ip = __shfl(r_ip, src0 + g, 64);
+      const int qi = __shfl(r_qi, src0 + g, 64), pi = __shfl(r_pi, src0 + g, 64);
+      if (tl) {
+        // several tokens share a head row (offsets p of one segment) or a target row (l + 1 + p = const): accumulate
+        // with float atomics, one 128-byte segment per wave half per instruction (full-rate shape)
+        float* qdst = dq_rows + (int64_t)qi * T::DIM;
+        float* pdst = dp_rows + (int64_t)pi * T::DIM;
+#pragma unroll
+        for (int dc = 0; dc < ND; ++dc) {
+          const int d = dc * 32 + r;
+          if (d < T::DIM) {
+            atomicAdd(qdst + d, (dqn[dc] - qv[gi][dc] * dot_q) * iq);
+            if (first_split) atomicAdd(pdst + d, (dpn[dc] - pv[gi][dc] * dot_p) * ip);
+          }
         }
       }
     }
