@@ -138,6 +138,18 @@ int mhr_hstu_attn_bwd(const void* q_pre, const void* k_pre, const void* v_pre, i
                       int B, int L, int n_heads, int head_dim, int apply_silu, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Token compaction (replaces the boolean-mask indexing of model/IDNet/hstu.py:688-690, 814-829 and its host-side
+ * `mask.sum() == 0` branch).  mask [n_groups, n_slots] uint8 (0/1) marks the live (group, slot) pairs; q_all
+ * [n_groups, n_slots], p_all / o_all [n_slots] int32 are static tables (query row, target row, prediction offset
+ * of a slot).  For every group the live slots are written in ascending slot order:
+ *   q_idx / p_idx / o_idx [n_groups, tok_cap][j] = table value of the j-th live slot,  n_tok[g] = min(#live, tok_cap)
+ * (entries >= n_tok[g] are left untouched).  scratch: [n_groups, ceil(n_slots / 4096)] int32.  Two launches.
+ * ---------------------------------------------------------------------------------------- */
+int mhr_token_compact(const uint8_t* mask, const int32_t* q_all, const int32_t* p_all, const int32_t* o_all,
+                      int n_groups, int n_slots, int tok_cap, int32_t* q_idx, int32_t* p_idx, int32_t* o_idx,
+                      int32_t* n_tok, int32_t* scratch, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Sampled softmax with false-negative suppression (model/IDNet/hstu.py:600-619 + F.cross_entropy 697/833).
  * Tokens are described by row indices instead of compacted copies: token t uses query row
  * q_rows[q_idx[t]] and positive row p_rows[p_idx[t]] (both raw, L2-normalised inside; io_dtype f32/bf16).
@@ -166,7 +178,12 @@ int mhr_nce_fwd(const void* q_rows, const int32_t* q_idx, const void* p_rows, co
  * n_valid / rank) with atomics - the caller zeroes sum_out, n_valid, rank - and mhr_nce_finalize produces
  * lse[t] = scale + log(sum[t] + exp(scale*(s_pos[t]-1))), loss[t] = lse[t] - scale*s_pos[t], n_valid[t] += 1. */
 int mhr_nce_finalize(const float* sum, const float* s_pos, int n_groups, const int32_t* n_tok_dev, int tok_cap,
-                     const float* logit_scale_dev, float* loss, float* lse, int32_t* n_valid, void* stream);
+                     const float* logit_scale_dev, float* loss, float* lse, int32_t* n_valid,
+                     const int32_t* bucket_idx, int n_buckets, float* bucket_sum, float* bucket_cnt, void* stream);
+/* Optional bucket sums (bucket_idx may be NULL): bucket_idx [n_groups, tok_cap] int32 in [0, n_buckets) names the
+ * prediction offset of each token; bucket_sum / bucket_cnt [n_groups, n_buckets] f32 (caller zeroes) receive
+ * sum(loss) and the token count per (group, offset) - the reference takes the MEAN loss per offset before weighting
+ * (hstu.py:697-700, 833-836), so no per-token tensor has to go back through an index_add. */
 /* Backward, two kernels (one launch each).  w[t] = d(total loss)/d(loss[t]) (0 for unused slots).  Inputs are the
  * forward's saved tensors; the false-negative decisions are replayed from `supp` instead of recomputing cos(p, neg),
  * and the transposed operands are read from the streamed tiles with ds_read_b64_tr_b16 (no transposed copies).
@@ -184,7 +201,10 @@ int mhr_nce_bwd_tokens(const void* qn, const void* pn, const void* negs, const u
                        int n_groups, const int32_t* n_tok_dev, int tok_cap, const float* logit_scale_dev,
                        const float* lse, const float* w, const float* q_inv, const float* p_inv, const float* s_pos,
                        const int32_t* q_idx, const int32_t* p_idx,
-                       float* dq_rows, float* dp_rows, float* d_logit_scale, float* lw_out, void* stream);
+                       float* dq_rows, float* dp_rows, float* d_logit_scale, float* lw_out,
+                       const int32_t* w_bucket, int n_buckets, void* stream);
+/* w: per-token [n_groups, tok_cap] when w_bucket is NULL; otherwise w is [n_groups, n_buckets] and token t of group g
+ * weighs w[g, w_bucket[g, t]] (the gradient of a per-offset mean is constant inside a bucket). */
 int mhr_nce_bwd_negs(const void* qn, const void* negs, const uint32_t* supp, int n_neg, int dim, int n_groups,
                      const int32_t* n_tok_dev, int tok_cap, const float* logit_scale_dev,
                      const float* lw, float* d_negs, void* stream);

@@ -266,7 +266,7 @@ class HSTU(BaseModel):
                 h = xn @ cached[0]
                 o = HSTUCoreFn.apply(h, key_valid, B, L, self._num_heads, self._dqk, layer._eps, p, seed)
                 y = F.linear(o, cached[1], cached[2])
-            x2 = x2 + y.float()
+            x2 = torch.add(x2, y)                              # fp32 + bf16 -> fp32 in one kernel (no separate cast)
         return x2.view(B, L, D)
 
     def _heads(self, x):
@@ -301,8 +301,8 @@ class HSTU(BaseModel):
             hp = head_for_p.to(device)[:, None, :, None]                                        # [G,1,P,1]
             G = hp.shape[0]
             q_all = ((b * H + hp) * L + l).expand(G, B, P, L).reshape(G, -1).int().contiguous()
-            p_all = (b * (L + P) + l + 1 + p).expand(1, B, P, L).reshape(-1).int()
-            o_all = p.expand(1, B, P, L).reshape(-1).long()
+            p_all = (b * (L + P) + l + 1 + p).expand(1, B, P, L).reshape(-1).int().contiguous()
+            o_all = p.expand(1, B, P, L).reshape(-1).int().contiguous()
             self._tok_cache[key] = (q_all, p_all, o_all)
         return self._tok_cache[key]
 
@@ -315,24 +315,16 @@ class HSTU(BaseModel):
         from REC.model.hstu_functional import NceLossFn
         G, B, P, L = valid_g.shape
         dev = valid_g.device
-        cap = B * P * L
+        n_slots = B * P * L
         q_all, p_all, o_all = self._token_tables(B, dev, head_for_p)
-        m = valid_g.reshape(G, cap)
-        pos = torch.cumsum(m, 1) - 1
-        n_tok = m.sum(1).to(torch.int32)
-        tgt = torch.where(m, pos, torch.full_like(pos, cap))
-        q_idx = torch.zeros(G, cap + 1, dtype=torch.int32, device=dev).scatter_(1, tgt, q_all)[:, :cap].contiguous()
-        p_idx = torch.zeros(G, cap + 1, dtype=torch.int32, device=dev).scatter_(1, tgt, p_all.expand(G, cap))[:, :cap].contiguous()
-        o_idx = torch.zeros(G, cap + 1, dtype=torch.long, device=dev).scatter_(1, tgt, o_all.expand(G, cap))[:, :cap]
+        from mhr_amd import ops
+        q_idx, p_idx, o_idx, n_tok = ops.token_compact(valid_g.reshape(G, n_slots), q_all, p_all, o_all)
+        cap = q_idx.shape[1]
         want_logs = log_group is not None
         logs = {} if want_logs else None
-        loss_tok = NceLossFn.apply(head_rows, e_rows, negs_g, self.logit_scale, q_idx, p_idx, n_tok, cap,
-                                   float(self.nce_thres), want_logs, logs)                          # [G, cap]
-        live = (torch.arange(cap, device=dev)[None, :] < n_tok[:, None]).float()
-        flat = (torch.arange(G, device=dev)[:, None] * P + o_idx).reshape(-1)
-        sum_p = torch.zeros(G * P, dtype=torch.float32, device=dev).index_add_(0, flat, loss_tok.reshape(-1))
-        cnt_p = torch.zeros(G * P, dtype=torch.float32, device=dev).index_add_(0, flat, live.reshape(-1))
-        mean_p = (sum_p / cnt_p.clamp_min(1.0)).view(G, P)
+        mean_p = NceLossFn.apply(head_rows, e_rows, negs_g, self.logit_scale, q_idx, p_idx, n_tok, cap,
+                                 float(self.nce_thres), want_logs, logs, o_idx, P)                  # [G, P]
+        live = (torch.arange(cap, device=dev)[None, :] < n_tok[:, None]).float() if want_logs else None
         out_logs = None
         if want_logs:
             g = log_group

@@ -200,32 +200,43 @@ class L2NormFn(Function):
 
 
 class NceLossFn(Function):
-    """Per-token sampled-softmax loss of G groups (negative pools / prior categories) in one launch per kernel
+    """Sampled-softmax loss of G groups (negative pools / prior categories) in one launch per kernel
     (reference hstu.py:600-619 + cross_entropy, called once per prior head there).
 
     q_rows [Rq, D] / p_rows [Rp, D] fp32 (raw head embeddings / target embeddings, shared by the groups); token t of
-    group g pairs q_rows[q_idx[g,t]] with p_rows[p_idx[g,t]]; negs [G, n_neg, D] bf16 normalised.  Returns loss
-    [G, tok_cap] fp32 (zeros beyond n_tok[g]).  No [N_tok, n_neg] tensor is ever materialised.
+    group g pairs q_rows[q_idx[g,t]] with p_rows[p_idx[g,t]]; negs [G, n_neg, D] bf16 normalised.
+    Without buckets: returns the per-token loss [G, tok_cap] fp32 (zeros beyond n_tok[g]).
+    With bucket_idx [G, tok_cap] int32 / n_buckets: returns the MEAN loss per (group, bucket) [G, n_buckets] - the
+    reference's per-offset mean (hstu.py:697-700) - straight from the finalize kernel; the backward turns d(mean) into
+    per-bucket token weights, so no per-token tensor passes through torch.  No [N_tok, n_neg] tensor is ever materialised.
     """
 
     @staticmethod
-    def forward(ctx, q_rows, p_rows, negs, logit_scale, q_idx, p_idx, n_tok_dev, tok_cap, thres, want_logs, logs_out):
+    def forward(ctx, q_rows, p_rows, negs, logit_scale, q_idx, p_idx, n_tok_dev, tok_cap, thres, want_logs, logs_out,
+                bucket_idx=None, n_buckets=0):
         sv = ops.nce_fwd(q_rows, q_idx, p_rows, p_idx, negs, n_tok_dev, tok_cap, logit_scale.detach().view(1), thres,
-                         want_logs=want_logs, for_backward=True)
+                         want_logs=want_logs, for_backward=True, bucket_idx=bucket_idx, n_buckets=n_buckets)
         ctx.sv = sv
         ctx.save_for_backward(q_idx, p_idx, logit_scale)
         ctx.shapes = (q_rows.shape, p_rows.shape)
         if want_logs and logs_out is not None:
             logs_out["n_valid"], logs_out["rank"] = sv.n_valid, sv.rank
-        return sv.loss
+        if bucket_idx is None:
+            return sv.loss
+        if logs_out is not None:
+            logs_out["bucket_cnt"] = sv.bucket_cnt
+        return sv.bucket_sum / sv.bucket_cnt.clamp_min(1.0)
 
     @staticmethod
-    def backward(ctx, d_loss):
+    def backward(ctx, d_out):
         q_idx, p_idx, logit_scale = ctx.saved_tensors
         sv = ctx.sv
         q_shape, p_shape = ctx.shapes
-        dq = torch.zeros(q_shape, dtype=torch.float32, device=d_loss.device)
-        dp = torch.zeros(p_shape, dtype=torch.float32, device=d_loss.device)
-        d_negs, d_ls = ops.nce_bwd(sv, d_loss.contiguous().float(), logit_scale.detach().view(1), q_idx, p_idx, dq, dp)
+        dq = torch.zeros(q_shape, dtype=torch.float32, device=d_out.device)
+        dp = torch.zeros(p_shape, dtype=torch.float32, device=d_out.device)
+        w = d_out.contiguous().float()
+        if sv.bucket_idx is not None:
+            w = w / sv.bucket_cnt.clamp_min(1.0)                      # d(mean)/d(loss_t) = 1 / count of the bucket
+        d_negs, d_ls = ops.nce_bwd(sv, w, logit_scale.detach().view(1), q_idx, p_idx, dq, dp)
         ctx.sv = None
-        return dq, dp, d_negs, d_ls.view(logit_scale.shape), None, None, None, None, None, None, None
+        return dq, dp, d_negs, d_ls.view(logit_scale.shape), None, None, None, None, None, None, None, None, None

@@ -257,24 +257,48 @@ __global__ __launch_bounds__(256, 2) void nce_fwd_kernel(const IT* __restrict__ 
 }
 
 // lse / loss from the partial sums of all negative ranges
+constexpr int MAX_BUCKETS = 64;
 __global__ __launch_bounds__(256) void nce_finalize_kernel(const float* sum, const float* s_pos,
                                                            const int32_t* __restrict__ n_tok_dev, int tok_cap,
                                                            const float* __restrict__ logit_scale_dev,
-                                                           float* loss, float* lse, int32_t* n_valid) {
+                                                           float* loss, float* lse, int32_t* n_valid,
+                                                           const int32_t* __restrict__ bucket_idx, int n_buckets,
+                                                           float* __restrict__ bucket_sum, float* __restrict__ bucket_cnt) {
   const int64_t to = (int64_t)blockIdx.y * tok_cap;
   sum += to; s_pos += to; loss += to; lse += to;
   if (n_valid) n_valid += to;
+  __shared__ float s_sum[MAX_BUCKETS], s_cnt[MAX_BUCKETS];
+  if (bucket_idx) {
+    for (int b = threadIdx.x; b < n_buckets; b += blockDim.x) s_sum[b] = s_cnt[b] = 0.f;
+    __syncthreads();
+  }
   const int n_tok = min(n_tok_dev[blockIdx.y], tok_cap);
   const int tok = blockIdx.x * blockDim.x + threadIdx.x;
-  if (tok >= n_tok) return;
-  const float scale = clamp_scale(logit_scale_dev);
-  const float c1 = scale * LOG2E;
-  const float sp = s_pos[tok];
-  const float total = sum[tok] + fast_exp2(sp * c1 - c1);
-  const float l = scale + __logf(total);
-  lse[tok] = l;
-  loss[tok] = l - scale * sp;
-  if (n_valid) n_valid[tok] += 1;        // the positive itself (hstu.py:622: logits > finfo.min / 100)
+  if (tok < n_tok) {
+    const float scale = clamp_scale(logit_scale_dev);
+    const float c1 = scale * LOG2E;
+    const float sp = s_pos[tok];
+    const float total = sum[tok] + fast_exp2(sp * c1 - c1);
+    const float l = scale + __logf(total);
+    lse[tok] = l;
+    loss[tok] = l - scale * sp;
+    if (n_valid) n_valid[tok] += 1;        // the positive itself (hstu.py:622: logits > finfo.min / 100)
+    if (bucket_idx) {                      // per-(group, prediction offset) sums: the loss is a mean per offset (hstu.py:697-700)
+      const int b = bucket_idx[to + tok];
+      if (b >= 0 && b < n_buckets) {
+        atomicAdd(&s_sum[b], l - scale * sp);
+        atomicAdd(&s_cnt[b], 1.0f);
+      }
+    }
+  }
+  if (bucket_idx) {
+    __syncthreads();
+    for (int b = threadIdx.x; b < n_buckets; b += blockDim.x)
+      if (s_cnt[b] != 0.f) {
+        atomicAdd(bucket_sum + blockIdx.y * n_buckets + b, s_sum[b]);
+        atomicAdd(bucket_cnt + blockIdx.y * n_buckets + b, s_cnt[b]);
+      }
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -327,7 +351,8 @@ __global__ __launch_bounds__(256, 1) void nce_bwd_q_kernel(const bf16_t* qn, con
                                                            const float* s_pos, const int32_t* q_idx,
                                                            const int32_t* p_idx, float* __restrict__ dq_rows,
                                                            float* __restrict__ dp_rows, float* __restrict__ d_logit_scale,
-                                                           float* __restrict__ lw_out) {
+                                                           float* __restrict__ lw_out, const int32_t* __restrict__ w_bucket,
+                                                           int n_buckets) {
   using T = sg::Tile<NKS>;
   constexpr int ND = (NKS + 1) / 2;          // 32-column chunks of the feature dim
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -336,9 +361,12 @@ __global__ __launch_bounds__(256, 1) void nce_bwd_q_kernel(const bf16_t* qn, con
     const int64_t grp = blockIdx.z, to = grp * tok_cap;
     qn += to * T::DIM; pn += to * T::DIM; negs += grp * (int64_t)((n_neg + 31) & ~31) * T::DIM;
     supp += grp * (int64_t)((n_neg + 31) >> 5) * tok_cap;
-    n_tok_dev += grp; lse += to; w += to; q_inv += to; p_inv += to; s_pos += to; q_idx += to; p_idx += to;
+    n_tok_dev += grp; lse += to; q_inv += to; p_inv += to; s_pos += to; q_idx += to; p_idx += to;
     if (lw_out) lw_out += to;
+    if (w_bucket) { w_bucket += to; w += grp * n_buckets; } else { w += to; }
   }
+  // loss weight of a token: its own entry, or its bucket's (the loss is a mean per (group, prediction offset))
+  auto w_of = [&](int t) { return w_bucket ? w[w_bucket[t]] : w[t]; };
   const int n_tok = min(*n_tok_dev, tok_cap);
   const int tok0 = blockIdx.x * 128;
   if (tok0 >= n_tok) return;
@@ -357,7 +385,7 @@ __global__ __launch_bounds__(256, 1) void nce_bwd_q_kernel(const bf16_t* qn, con
   const float scale = clamp_scale(logit_scale_dev);
   const float c1 = scale * LOG2E;
   // g_ij = w_i exp(scale s_ij - lse_i) = exp2(c1 s_ij - c0_i),  c0 = lse log2(e) - log2(w)   (w = 0 -> c0 = +inf -> g = 0)
-  const float c0 = live ? lse[tok] * LOG2E - __log2f(w[tok]) : 0.f;
+  const float c0 = live ? lse[tok] * LOG2E - __log2f(w_of(tok)) : 0.f;
   if (lw_out && live && first_split && half == 0) lw_out[tok] = c0;
 
   f32x16 dq[ND];
@@ -445,7 +473,7 @@ __global__ __launch_bounds__(256, 1) void nce_bwd_q_kernel(const bf16_t* qn, con
   float dls = 0.f;   // d(loss)/d(scale) of my half's 16 tokens: sum_j g_ij s_ij = qn_i . dQn_i, plus the positive term
   const int my_row = tok0 + wave * 32 + sg::crow(lane & 15, half);
   const bool my_live = my_row < n_tok;
-  const float r_w = my_live ? w[my_row] : 0.f, r_sp = my_live ? s_pos[my_row] : 0.f, r_lse = my_live ? lse[my_row] : 0.f;
+  const float r_w = my_live ? w_of(my_row) : 0.f, r_sp = my_live ? s_pos[my_row] : 0.f, r_lse = my_live ? lse[my_row] : 0.f;
   const float r_iq = my_live ? q_inv[my_row] : 0.f, r_ip = my_live ? p_inv[my_row] : 0.f;
   const int r_qi = my_live ? q_idx[my_row] : 0, r_pi = my_live ? p_idx[my_row] : 0;
   const float r_coef = (my_live && first_split) ? r_w * (__expf(scale * r_sp - r_lse) - 1.0f) : 0.f;   // w (p_pos - 1)
@@ -698,11 +726,14 @@ extern "C" int mhr_nce_fwd(const void* q_rows, const int32_t* q_idx, const void*
 }
 
 extern "C" int mhr_nce_finalize(const float* sum, const float* s_pos, int n_groups, const int32_t* n_tok_dev, int tok_cap,
-                                const float* logit_scale_dev, float* loss, float* lse, int32_t* n_valid, void* stream) {
+                                const float* logit_scale_dev, float* loss, float* lse, int32_t* n_valid,
+                                const int32_t* bucket_idx, int n_buckets, float* bucket_sum, float* bucket_cnt, void* stream) {
   MHR_REQUIRE(sum && s_pos && n_tok_dev && logit_scale_dev && loss && lse, "nce_finalize: null pointer");
   MHR_REQUIRE(tok_cap > 0 && n_groups >= 1 && n_groups <= 65535, "nce_finalize: bad sizes");
+  MHR_REQUIRE(!bucket_idx || (bucket_sum && bucket_cnt && n_buckets >= 1 && n_buckets <= MAX_BUCKETS),
+              "nce_finalize: bucket sums need bucket_sum, bucket_cnt and 1 <= n_buckets <= %d", MAX_BUCKETS);
   hipLaunchKernelGGL(nce_finalize_kernel, dim3((tok_cap + 255) / 256, n_groups), dim3(256), 0, (hipStream_t)stream, sum, s_pos,
-                     n_tok_dev, tok_cap, logit_scale_dev, loss, lse, n_valid);
+                     n_tok_dev, tok_cap, logit_scale_dev, loss, lse, n_valid, bucket_idx, n_buckets, bucket_sum, bucket_cnt);
   MHR_CHECK_LAUNCH("nce_finalize");
   return MHR_OK;
 }
@@ -711,7 +742,7 @@ extern "C" int mhr_nce_bwd_tokens(const void* qn, const void* pn, const void* ne
                                   int n_groups, const int32_t* n_tok_dev, int tok_cap, const float* logit_scale_dev, const float* lse,
                                   const float* w, const float* q_inv, const float* p_inv, const float* s_pos,
                                   const int32_t* q_idx, const int32_t* p_idx, float* dq_rows, float* dp_rows,
-                                  float* d_logit_scale, float* lw_out, void* stream) {
+                                  float* d_logit_scale, float* lw_out, const int32_t* w_bucket, int n_buckets, void* stream) {
   MHR_REQUIRE(qn && pn && negs && supp && n_tok_dev && logit_scale_dev && lse && w && q_inv && p_inv && s_pos,
               "nce_bwd_tokens: null input pointer");
   MHR_REQUIRE(q_idx && p_idx && dq_rows && dp_rows, "nce_bwd_tokens: null index/output pointer");
@@ -728,7 +759,7 @@ extern "C" int mhr_nce_bwd_tokens(const void* qn, const void* pn, const void* ne
     size_t lds_q = 4 * sg::Tile<NKS>::BYTES + 4 * 1024;                                                                  \
     hipLaunchKernelGGL((nce_bwd_q_kernel<NKS>), grid_q, dim3(256), lds_q, s, (const bf16_t*)qn, (const bf16_t*)pn,       \
                        (const bf16_t*)negs, supp, n_neg, n_tok_dev, tok_cap, tps, logit_scale_dev, lse, w, q_inv, p_inv, \
-                       s_pos, q_idx, p_idx, dq_rows, dp_rows, d_logit_scale, lw_out);                                    \
+                       s_pos, q_idx, p_idx, dq_rows, dp_rows, d_logit_scale, lw_out, w_bucket, n_buckets);               \
   }
   NKS_SWITCH(nks, L_);
 #undef L_

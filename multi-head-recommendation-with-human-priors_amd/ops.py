@@ -206,14 +206,39 @@ def hstu_attn_bwd(h, act, key_valid, d_out, dh, B, L, n_heads, head_dim, apply_s
 # ------------------------------------------------------------------------------------------------
 # sampled softmax
 # ------------------------------------------------------------------------------------------------
+def token_compact(mask, q_all, p_all, o_all, tok_cap=None):
+    """Ordered compaction of live (group, slot) pairs.  mask [G, n_slots] bool/uint8; q_all [G, n_slots] int32;
+    p_all, o_all [n_slots] int32.  Returns (q_idx, p_idx, o_idx [G, cap] int32 - entries beyond n_tok undefined -,
+    n_tok [G] int32) with cap = tok_cap (default n_slots) rounded up to a multiple of 32.  No host sync."""
+    if mask.dtype == torch.bool:
+        mask = mask.view(torch.uint8)
+    _chk(mask, "mask", torch.uint8)
+    _chk(q_all, "q_all", torch.int32)
+    _chk(p_all, "p_all", torch.int32)
+    _chk(o_all, "o_all", torch.int32)
+    G, n_slots = mask.shape
+    assert q_all.shape == (G, n_slots) and p_all.numel() == n_slots and o_all.numel() == n_slots
+    cap = ((n_slots if tok_cap is None else tok_cap) + 31) // 32 * 32
+    dev = mask.device
+    q_idx = torch.empty(G, cap, dtype=torch.int32, device=dev)
+    p_idx = torch.empty(G, cap, dtype=torch.int32, device=dev)
+    o_idx = torch.empty(G, cap, dtype=torch.int32, device=dev)
+    n_tok = torch.empty(G, dtype=torch.int32, device=dev)
+    scratch = torch.empty(G, (n_slots + 4095) // 4096, dtype=torch.int32, device=dev)
+    lib.call("mhr_token_compact", mask.data_ptr(), q_all.data_ptr(), p_all.data_ptr(), o_all.data_ptr(), G, n_slots, cap,
+             q_idx.data_ptr(), p_idx.data_ptr(), o_idx.data_ptr(), n_tok.data_ptr(), scratch.data_ptr(), _stream())
+    return q_idx, p_idx, o_idx, n_tok
+
+
 class NceSaved:
     """Tensors the forward keeps for the backward (all preallocated at token capacity)."""
     __slots__ = ("qn", "pn", "supp", "q_inv", "p_inv", "s_pos", "lse", "loss", "n_valid", "rank", "negs",
-                 "n_tok_dev", "tok_cap", "cap", "thres", "dim", "n_neg", "groups", "q_idx", "p_idx")
+                 "n_tok_dev", "tok_cap", "cap", "thres", "dim", "n_neg", "groups", "q_idx", "p_idx", "bucket_idx", "n_buckets",
+                 "bucket_sum", "bucket_cnt")
 
 
 def nce_fwd(q_rows, q_idx, p_rows, p_idx, negs, n_tok_dev, tok_cap, logit_scale, thres=0.99, want_logs=False,
-            for_backward=True):
+            for_backward=True, bucket_idx=None, n_buckets=0):
     """Grouped sampled softmax.  q_rows/p_rows [*, D] (bf16 or f32, same dtype, shared by all groups);
     q_idx/p_idx [G, tok_cap] int32; negs [G, n_neg, D] bf16 normalised; n_tok_dev [G] int32.
     (1-D q_idx / 2-D negs are accepted as a single group.)  Saved tensors carry the leading group axis."""
@@ -235,8 +260,16 @@ def nce_fwd(q_rows, q_idx, p_rows, p_idx, negs, n_tok_dev, tok_cap, logit_scale,
     if cap != tok_cap:
         q_idx = torch.nn.functional.pad(q_idx, (0, cap - tok_cap)).contiguous()
         p_idx = torch.nn.functional.pad(p_idx, (0, cap - tok_cap)).contiguous()
+        if bucket_idx is not None:
+            bucket_idx = torch.nn.functional.pad(bucket_idx, (0, cap - tok_cap)).contiguous()
     sv = NceSaved()
     sv.q_idx, sv.p_idx = q_idx, p_idx
+    sv.bucket_idx, sv.n_buckets, sv.bucket_sum, sv.bucket_cnt = bucket_idx, int(n_buckets), None, None
+    if bucket_idx is not None:       # per-(group, bucket) loss sums and token counts come out of the finalize kernel
+        _chk(bucket_idx, "bucket_idx", torch.int32)
+        assert bucket_idx.shape == (G, cap)
+        sums = torch.zeros(2, G, n_buckets, dtype=torch.float32, device=dev)
+        sv.bucket_sum, sv.bucket_cnt = sums[0], sums[1]
     loss = torch.zeros(G, cap, dtype=torch.float32, device=dev)
     sv.lse = torch.zeros(G, cap, dtype=torch.float32, device=dev)
     n_valid = torch.zeros(G, cap, dtype=torch.int32, device=dev) if want_logs else None
@@ -259,7 +292,8 @@ def nce_fwd(q_rows, q_idx, p_rows, p_idx, negs, n_tok_dev, tok_cap, logit_scale,
                 ssum.data_ptr(), _ptr(n_valid), _ptr(rank), _ptr(sv.qn), _ptr(sv.pn),
                 _ptr(sv.supp), _ptr(sv.q_inv), _ptr(sv.p_inv), _ptr(sv.s_pos), st)
     lib.call("mhr_nce_finalize", ssum.data_ptr(), sv.s_pos.data_ptr(), G, n_tok_dev.data_ptr(), cap,
-             logit_scale.data_ptr(), loss.data_ptr(), sv.lse.data_ptr(), _ptr(n_valid), st)
+             logit_scale.data_ptr(), loss.data_ptr(), sv.lse.data_ptr(), _ptr(n_valid), _ptr(bucket_idx), int(n_buckets),
+             _ptr(sv.bucket_sum), _ptr(sv.bucket_cnt), st)
     sv.loss = loss[:, :tok_cap]
     sv.n_valid = None if n_valid is None else n_valid[:, :tok_cap]
     sv.rank = None if rank is None else rank[:, :tok_cap]
@@ -267,18 +301,20 @@ def nce_fwd(q_rows, q_idx, p_rows, p_idx, negs, n_tok_dev, tok_cap, logit_scale,
 
 
 def nce_bwd(sv, w, logit_scale, q_idx, p_idx, dq_rows, dp_rows, d_negs=None, d_logit_scale=None):
-    """w [G, tok_cap] f32 = dLoss/dloss[g, t].  Accumulates into dq_rows [Rq, D] / dp_rows [Rp, D] (f32, the
+    """w [G, tok_cap] f32 = dLoss/dloss[g, t] - or [G, n_buckets] when the forward was given bucket_idx (every token
+    of a bucket then has the same weight).  Accumulates into dq_rows [Rq, D] / dp_rows [Rp, D] (f32, the
     forward's shared row spaces); returns (d_negs [G, n_neg, D] f32, d_logit_scale [1]).  q_idx / p_idx are the
     forward's index lists (the padded copies saved by nce_fwd are what the kernels read)."""
     dev = sv.negs.device
     D, cap, G = sv.dim, sv.cap, sv.groups
     if w.dim() == 1:
         w = w[None]
+    bucketed = sv.bucket_idx is not None and w.shape == (G, sv.n_buckets) and sv.n_buckets != sv.tok_cap
     if d_negs is None:
         d_negs = torch.zeros(G, sv.n_neg, D, dtype=torch.float32, device=dev)
     if d_logit_scale is None:
         d_logit_scale = torch.zeros(1, dtype=torch.float32, device=dev)
-    if cap != sv.tok_cap:
+    if cap != sv.tok_cap and not bucketed:
         w = torch.nn.functional.pad(w, (0, cap - sv.tok_cap))
     w = w.contiguous()
     _chk(w, "w", torch.float32)
@@ -289,7 +325,8 @@ def nce_bwd(sv, w, logit_scale, q_idx, p_idx, dq_rows, dp_rows, d_negs=None, d_l
     _timed_call("mhr_nce_bwd_tokens", sv.qn.data_ptr(), sv.pn.data_ptr(), sv.negs.data_ptr(), sv.supp.data_ptr(), sv.n_neg, D,
                 G, sv.n_tok_dev.data_ptr(), cap, logit_scale.data_ptr(), sv.lse.data_ptr(), w.data_ptr(), sv.q_inv.data_ptr(),
                 sv.p_inv.data_ptr(), sv.s_pos.data_ptr(), sv.q_idx.data_ptr(), sv.p_idx.data_ptr(), dq_rows.data_ptr(),
-                dp_rows.data_ptr(), d_logit_scale.data_ptr(), lw.data_ptr(), st)
+                dp_rows.data_ptr(), d_logit_scale.data_ptr(), lw.data_ptr(), sv.bucket_idx.data_ptr() if bucketed else 0,
+                sv.n_buckets if bucketed else 0, st)
     _timed_call("mhr_nce_bwd_negs", sv.qn.data_ptr(), sv.negs.data_ptr(), sv.supp.data_ptr(), sv.n_neg, D, G,
                 sv.n_tok_dev.data_ptr(), cap, logit_scale.data_ptr(), lw.data_ptr(), d_negs.data_ptr(), st)
     return d_negs, d_logit_scale

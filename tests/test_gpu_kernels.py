@@ -334,6 +334,57 @@ def test_nce_fwd_bwd(ops, D, n_tok, n_neg, dtype):
     assert abs(float(dls.cpu()) - float(lsr.grad)) < 2e-2 * abs(float(lsr.grad)) + 1e-4
 
 
+@pytest.mark.parametrize("G,n_slots,density", [(1, 37, 0.5), (3, 4096, 0.3), (4, 9000, 0.33), (2, 5000, 0.0), (2, 300, 1.0)])
+def test_token_compact_matches_boolean_mask_indexing(ops, G, n_slots, density):
+    """mhr_token_compact vs the reference's `x[mask]` (hstu.py:688-690): same values, same (ascending) order; bit-exact."""
+    g = torch.Generator().manual_seed(n_slots + G)
+    mask = torch.rand(G, n_slots, generator=g) < density
+    q_all = torch.randint(0, 1 << 20, (G, n_slots), generator=g).int()
+    p_all = torch.randint(0, 1 << 20, (n_slots,), generator=g).int()
+    o_all = torch.randint(0, 8, (n_slots,), generator=g).int()
+    q_idx, p_idx, o_idx, n_tok = ops.token_compact(dev(mask), dev(q_all), dev(p_all), dev(o_all))
+    assert q_idx.shape[1] % 32 == 0 and q_idx.shape[1] >= n_slots
+    for gi in range(G):
+        n = int(mask[gi].sum())
+        assert int(n_tok[gi]) == n
+        np.testing.assert_array_equal(q_idx[gi, :n].cpu().numpy(), q_all[gi][mask[gi]].numpy())
+        np.testing.assert_array_equal(p_idx[gi, :n].cpu().numpy(), p_all[mask[gi]].numpy())
+        np.testing.assert_array_equal(o_idx[gi, :n].cpu().numpy(), o_all[mask[gi]].numpy())
+
+
+def test_nce_bucket_means_equal_per_token_path(ops):
+    """Per-(group, offset) mean losses from the finalize kernel, and the backward driven by per-bucket weights, equal
+    the per-token path with the same weights expanded by hand (losses 1e-5 relative; gradients: same kernels, 1e-5)."""
+    g = torch.Generator().manual_seed(7)
+    D, n_src, n_neg, cap, G, P = 64, 200, 96, 160, 2, 5
+    q_rows, p_rows = torch.randn(n_src, D, generator=g), torch.randn(n_src, D, generator=g)
+    n_toks = [150, 33]
+    qi = torch.randint(0, n_src, (G, cap), generator=g).int()
+    pi = torch.randint(0, n_src, (G, cap), generator=g).int()
+    oi = torch.randint(0, P, (G, cap), generator=g).int()
+    negs = bf(HO.l2n(torch.randn(G, n_neg, D, generator=g)))
+    ls = torch.tensor([math.log(20.0)]).cuda()
+    ntd = torch.tensor(n_toks, dtype=torch.int32).cuda()
+    sv = ops.nce_fwd(dev(q_rows), dev(qi), dev(p_rows), dev(pi), dev(negs), ntd, cap, ls, 0.99, bucket_idx=dev(oi), n_buckets=P)
+    loss = sv.loss.cpu()
+    w_gp = torch.rand(G, P, generator=g)
+    w_tok = torch.zeros(G, cap)
+    for gi in range(G):
+        n = n_toks[gi]
+        for o in range(P):
+            sel = oi[gi, :n] == o
+            assert float(sv.bucket_cnt[gi, o]) == float(sel.sum())
+            np.testing.assert_allclose(float(sv.bucket_sum[gi, o]), float(loss[gi, :n][sel].sum()), rtol=1e-5, atol=1e-5)
+        w_tok[gi, :n] = w_gp[gi][oi[gi, :n].long()]
+    dq1, dp1 = torch.zeros(n_src, D).cuda(), torch.zeros(n_src, D).cuda()
+    dn1, dls1 = ops.nce_bwd(sv, dev(w_gp), ls, dev(qi), dev(pi), dq1, dp1)
+    sv2 = ops.nce_fwd(dev(q_rows), dev(qi), dev(p_rows), dev(pi), dev(negs), ntd, cap, ls, 0.99)
+    dq2, dp2 = torch.zeros(n_src, D).cuda(), torch.zeros(n_src, D).cuda()
+    dn2, dls2 = ops.nce_bwd(sv2, dev(w_tok), ls, dev(qi), dev(pi), dq2, dp2)
+    for a, b in ((dq1, dq2), (dp1, dp2), (dn1, dn2), (dls1, dls2)):
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-7
+
+
 def test_nce_grouped_launch_equals_per_group(ops):
     """Three groups (different token lists, negative pools and live counts, one of them EMPTY) in one launch."""
     g = torch.Generator().manual_seed(99)
