@@ -172,7 +172,9 @@ int mhr_nce_fwd(const void* q_rows, const int32_t* q_idx, const void* p_rows, co
                 const void* negs, int n_neg, int dim, int n_groups, const int32_t* n_tok_dev, int tok_cap,
                 const float* logit_scale_dev, float thres,
                 float* sum_out, int32_t* n_valid, int32_t* rank,
-                void* qn_out, void* pn_out, uint32_t* supp_out, float* q_inv, float* p_inv, float* s_pos, void* stream);
+                void* qn_out, void* pn_out, uint32_t* supp_out, float* q_inv, float* p_inv, float* s_pos,
+                int log_group, void* stream);
+/* log_group: the one group whose n_valid / rank are wanted (-1 = every group); the other groups skip the counting. */
 /* The forward is split over negative ranges (grid.y) so that (token block, negative range) units fill the chip
  * without a tail: each unit adds its partial sum_j keep*exp(scale*(s_j - 1)) into sum_out[t] (and its counts into
  * n_valid / rank) with atomics - the caller zeroes sum_out, n_valid, rank - and mhr_nce_finalize produces

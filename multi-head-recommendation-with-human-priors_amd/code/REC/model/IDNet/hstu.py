@@ -323,7 +323,8 @@ class HSTU(BaseModel):
         want_logs = log_group is not None
         logs = {} if want_logs else None
         mean_p = NceLossFn.apply(head_rows, e_rows, negs_g, self.logit_scale, q_idx, p_idx, n_tok, cap,
-                                 float(self.nce_thres), want_logs, logs, o_idx, P)                  # [G, P]
+                                 float(self.nce_thres), want_logs, logs, o_idx, P,
+                                 log_group if want_logs else -1)                                     # [G, P]
         live = (torch.arange(cap, device=dev)[None, :] < n_tok[:, None]).float() if want_logs else None
         out_logs = None
         if want_logs:

@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256, 2) void nce_fwd_kernel(const IT* __restrict__ 
                                                          int32_t* n_valid, int32_t* rank,
                                                          bf16_t* qn_out, bf16_t* pn_out,
                                                          uint32_t* supp_out, float* q_inv,
-                                                         float* p_inv, float* s_pos_out) {
+                                                         float* p_inv, float* s_pos_out, int log_group) {
   using T = sg::Tile<NKS>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // blockIdx.z selects the group (negative pool / prior category): every per-token array is [groups, tok_cap(, D)],
@@ -204,44 +204,69 @@ __global__ __launch_bounds__(256, 2) void nce_fwd_kernel(const IT* __restrict__ 
   float sum = 0.f;
   int nv = 0, rk = 0;
 
-  // negative tiles stream through a 3-deep LDS-DMA ring (stream_gemm.h); rows past n_neg are clamped (masked by `rem`)
-  using D = sg::Dma<NKS>;
+  // Negative tiles stream through a 3-slot LDS-DMA ring (stream_gemm.h), branch-free: every iteration waits
+  // `vmcnt(PW)` (tile i landed, tile i+1 may be in flight) and issues the PW pieces of tile min(i+2, last) with
+  // SGPR-base addressing; the pool is padded to whole tiles, rows past n_neg are masked by `rem`.
+  using P = sg::DmaPieces<NKS>;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  auto row_ptr_for = [&](int tile) {
-    return [=](int rr) -> const bf16_t* { return negs + (int64_t)min(tile * 32 + rr, n_neg - 1) * T::DIM; };
+  P dp;
+  dp.init(wv, lane);
+  auto dma_tile = [&](auto slot_c, int tn) {
+    auto f = [&](auto k_c) {
+      dp.template piece<decltype(k_c)::value>(smem + decltype(slot_c)::value * T::BYTES,
+                                               reinterpret_cast<const char*>(negs) + (int64_t)tn * (32 * T::ROW_BYTES));
+    };
+    sg::static_for<P::PW>(f);
   };
   sg::LaneAddr<NKS> la;
   la.init(lane);
-  const int n_loc = t_end - t_begin;
-  D::issue(smem, row_ptr_for(t_begin), wv, lane);
-  if (n_loc > 1) D::issue(smem + T::BYTES, row_ptr_for(t_begin + 1), wv, lane);
+  const int n_loc = t_end - t_begin, t_last = t_end - 1;
+  const bool do_logs = LOGS && (log_group < 0 || (int)blockIdx.z == log_group);
+  dma_tile(std::integral_constant<int, 0>{}, t_begin);
+  dma_tile(std::integral_constant<int, 1>{}, min(t_begin + 1, t_last));
   sg::ring_loop<3>(n_loc, [&](auto slot_c, int i) {
     constexpr int cur = decltype(slot_c)::value, nxt = (cur + 2) % 3;
     const int t = t_begin + i;
-    if (i + 1 < n_loc) sg::wait_vmcnt<D::PW>(); else sg::wait_vmcnt<0>();
+    sg::wait_vmcnt<P::PW>();
     sg::ring_barrier();
-    if (i + 2 < n_loc) D::issue(smem + nxt * T::BYTES, row_ptr_for(t + 2), wv, lane);
+    dma_tile(std::integral_constant<int, nxt>{}, min(t + 2, t_last));
     f32x16 acc[2] = {sg::zero16(), sg::zero16()};
     sg::mma_tile<NKS, 2>(smem + cur * T::BYTES, la, frag, acc);
     const int rem = n_neg - t * 32;
-    uint32_t sbits = 0;
+    // False negatives (cos(positive, negative) > thres) are rare: one max over the tile's 16 values per lane and a
+    // wave-wide vote select the common path, which is exp + add per logit and nothing else.
+    float fmax = acc[1][0];
 #pragma unroll
-    for (int g = 0; g < 16; ++g) {
-      const bool supp = acc[1][g] > thres;               // false negative: cos(positive, negative) > thres
-      const bool keep = (sg::crow(g, half) < rem) && !supp;
-      const float e = fast_exp2(acc[0][g] * c1 - c1);
-      sum += keep ? e : 0.f;
-      sbits |= supp ? (1u << sg::crow(g, half)) : 0u;
-      if (LOGS) {
-        nv += keep ? 1 : 0;
-        rk += (keep && acc[0][g] > spos) ? 1 : 0;
+    for (int g = 1; g < 16; g += 3) fmax = fmaxf(fmaxf(fmax, acc[1][g]), fmaxf(acc[1][g + 1], acc[1][g + 2]));
+    const bool plain = rem >= 32 && __builtin_amdgcn_ballot_w64(fmax > thres) == 0;
+    uint32_t sbits = 0;
+    if (plain) {
+#pragma unroll
+      for (int g = 0; g < 16; ++g) sum += fast_exp2(acc[0][g] * c1 - c1);
+      if (do_logs) {
+        nv += 16;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) rk += acc[0][g] > spos ? 1 : 0;
       }
-    }
-    if (supp_out) {                                       // one word per (negative tile, token): bit j = negative t*32+j suppressed
+    } else {
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        const bool supp = acc[1][g] > thres;               // false negative: cos(positive, negative) > thres
+        const bool keep = (sg::crow(g, half) < rem) && !supp;
+        const float e = fast_exp2(acc[0][g] * c1 - c1);
+        sum += keep ? e : 0.f;
+        sbits |= supp ? (1u << sg::crow(g, half)) : 0u;
+        if (do_logs) {
+          nv += keep ? 1 : 0;
+          rk += (keep && acc[0][g] > spos) ? 1 : 0;
+        }
+      }
       sbits |= __shfl_xor(sbits, 32, 64);
-      if (in_cap && half == 0) supp_out[(int64_t)t * tok_cap + tok] = live ? sbits : 0xFFFFFFFFu;
     }
+    // one word per (negative tile, token): bit j = negative t*32+j suppressed
+    if (supp_out && in_cap && half == 0) supp_out[(int64_t)t * tok_cap + tok] = live ? sbits : 0xFFFFFFFFu;
   });
+  sg::wait_vmcnt<0>();
   sum += __shfl_xor(sum, 32, 64);
   if (LOGS) {
     nv += __shfl_xor(nv, 32, 64);
@@ -693,7 +718,7 @@ extern "C" int mhr_nce_fwd(const void* q_rows, const int32_t* q_idx, const void*
                            const void* negs, int n_neg, int dim, int n_groups, const int32_t* n_tok_dev, int tok_cap,
                            const float* logit_scale_dev, float thres, float* sum_out, int32_t* n_valid, int32_t* rank,
                            void* qn_out, void* pn_out, uint32_t* supp_out, float* q_inv, float* p_inv, float* s_pos,
-                           void* stream) {
+                           int log_group, void* stream) {
   MHR_REQUIRE(q_rows && q_idx && p_rows && p_idx && negs && n_tok_dev && logit_scale_dev && sum_out && s_pos,
               "nce_fwd: null pointer");
   int nks;
@@ -706,7 +731,7 @@ extern "C" int mhr_nce_fwd(const void* q_rows, const int32_t* q_idx, const void*
   const bool logs = n_valid != nullptr || rank != nullptr;
 #define ARGS(IT)                                                                                                         \
   (const IT*)q_rows, q_idx, (const IT*)p_rows, p_idx, (const bf16_t*)negs, n_neg, n_tok_dev, tok_cap, logit_scale_dev,   \
-      thres, tps, sum_out, n_valid, rank, (bf16_t*)qn_out, (bf16_t*)pn_out, supp_out, q_inv, p_inv, s_pos
+      thres, tps, sum_out, n_valid, rank, (bf16_t*)qn_out, (bf16_t*)pn_out, supp_out, q_inv, p_inv, s_pos, log_group
 #define L_(NKS)                                                                                                          \
   {                                                                                                                      \
     size_t lds = 3 * sg::Tile<NKS>::BYTES;                                                                               \

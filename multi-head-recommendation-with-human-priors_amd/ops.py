@@ -238,7 +238,7 @@ class NceSaved:
 
 
 def nce_fwd(q_rows, q_idx, p_rows, p_idx, negs, n_tok_dev, tok_cap, logit_scale, thres=0.99, want_logs=False,
-            for_backward=True, bucket_idx=None, n_buckets=0):
+            for_backward=True, bucket_idx=None, n_buckets=0, log_group=-1):
     """Grouped sampled softmax.  q_rows/p_rows [*, D] (bf16 or f32, same dtype, shared by all groups);
     q_idx/p_idx [G, tok_cap] int32; negs [G, n_neg, D] bf16 normalised; n_tok_dev [G] int32.
     (1-D q_idx / 2-D negs are accepted as a single group.)  Saved tensors carry the leading group axis."""
@@ -290,7 +290,7 @@ def nce_fwd(q_rows, q_idx, p_rows, p_idx, negs, n_tok_dev, tok_cap, logit_scale,
     _timed_call("mhr_nce_fwd", q_rows.data_ptr(), q_idx.data_ptr(), p_rows.data_ptr(), p_idx.data_ptr(), _dt(q_rows),
                 negs.data_ptr(), n_neg, D, G, n_tok_dev.data_ptr(), cap, logit_scale.data_ptr(), float(thres),
                 ssum.data_ptr(), _ptr(n_valid), _ptr(rank), _ptr(sv.qn), _ptr(sv.pn),
-                _ptr(sv.supp), _ptr(sv.q_inv), _ptr(sv.p_inv), _ptr(sv.s_pos), st)
+                _ptr(sv.supp), _ptr(sv.q_inv), _ptr(sv.p_inv), _ptr(sv.s_pos), int(log_group), st)
     lib.call("mhr_nce_finalize", ssum.data_ptr(), sv.s_pos.data_ptr(), G, n_tok_dev.data_ptr(), cap,
              logit_scale.data_ptr(), loss.data_ptr(), sv.lse.data_ptr(), _ptr(n_valid), _ptr(bucket_idx), int(n_buckets),
              _ptr(sv.bucket_sum), _ptr(sv.bucket_cnt), st)
