@@ -273,6 +273,17 @@ class HSTU(BaseModel):
         """x [..., D] fp32 -> [..., H, D] fp32 (reference hstu.py:652-667, 915-931).  bf16 GEMMs, fp32 residual,
         like the reference under bf16-mixed autocast."""
         S, C = self.num_segment_head, self.num_prior_head
+        heads = getattr(self, 'medusa_head', None)
+        if (x.is_cuda and heads is not None and self.medusa_num_layers == 1 and self.head_interaction != 'hierarchical'
+                and all(isinstance(h, nn.Sequential) and len(h) == 1 and not h[0].use_norm for h in heads)):
+            # one-ResBlock heads: all H projections as ONE GEMM on concatenated weights (x is read once, the weight
+            # gradient is one split-K GEMM), SiLU + residual in two elementwise kernels, no stack
+            from REC.model.hstu_functional import SplitKLinearFn
+            H, D = len(heads), x.shape[-1]
+            w = torch.cat([h[0].linear.weight for h in heads], 0)
+            b = torch.cat([h[0].linear.bias for h in heads], 0)
+            z = SplitKLinearFn.apply(x.reshape(-1, D).to(torch.bfloat16), w, b, True, None)
+            return torch.add(x.unsqueeze(-2), F.silu(z.view(*x.shape[:-1], H, D)))
         with torch.autocast(device_type=x.device.type, dtype=torch.bfloat16, enabled=x.is_cuda):
             if self.medusa_num_layers > 0 and self.head_interaction == 'hierarchical':
                 cat = [self.medusa_cat_head[c](x) for c in range(C)]
