@@ -96,6 +96,13 @@ int mhr_layernorm_fwd(const void* x, int x_dtype, void* y, int y_dtype, float* m
 /* dx (+)= rstd * (dy - mean(dy) - xhat * mean(dy*xhat));  accumulate != 0 adds into dx (f32 only). */
 int mhr_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* mean, const float* rstd,
                       void* dx, int dx_dtype, int accumulate, int64_t rows, int dim, void* stream);
+/* Residual add fused with the next layer's LayerNorm (model/IDNet/hstu.py:286-287 then 241):
+ *   x_out = x + y,  xn = LN(x_out)      x, x_out f32 [rows, dim]; y, xn bf16; mean / rstd [rows] saved for the backward.
+ * Backward: total = d_xout + LN'(d_xn)  written as dx (f32, gradient of x) and dy (bf16, gradient of y). */
+int mhr_add_layernorm_fwd(const float* x, const void* y_bf16, float* x_out, void* xn_bf16, float* mean, float* rstd,
+                          int64_t rows, int dim, float eps, void* stream);
+int mhr_add_layernorm_bwd(const void* d_xn_bf16, const float* x_out, const float* mean, const float* rstd,
+                          const float* d_xout, float* dx, void* dy_bf16, int64_t rows, int dim, void* stream);
 
 /* o = silu(u) * LayerNorm(a) * dropmask   (hstu.py:277-285).  u is a column block of the uvqk GEMM
  * output: u[r,c] = u_base[r*u_stride + c] (pre-activation; SiLU applied here).  a [rows, dim].

@@ -249,13 +249,14 @@ class HSTU(BaseModel):
 
     def _encode(self, x, key_valid, training=None):
         """x [B,L,D] fp32, key_valid [B,L] uint8 -> [B,L,D] fp32 (reference hstu.py:221-328)."""
-        from REC.model.hstu_functional import HSTUCoreFn, LayerNormFn, SplitKLinearFn
+        from REC.model.hstu_functional import AddLayerNormFn, HSTUCoreFn, LayerNormFn, SplitKLinearFn
         B, L, D = x.shape
         x2 = x.reshape(B * L, D)
         training = self.training if training is None else training
         p = self._linear_dropout_rate if training else 0.0
-        for i, layer in enumerate(self._hstu._attention_layers):
-            xn = LayerNormFn.apply(x2, layer._eps)
+        layers = self._hstu._attention_layers
+        xn = LayerNormFn.apply(x2, layers[0]._eps)
+        for i, layer in enumerate(layers):
             cached = self._layer_weights_bf16(i, layer)
             seed = (self._step_seed * 1000003 + i * 7919 + self.rank * 104729) & 0x7FFFFFFFFFFFFFFF
             if cached is None:
@@ -266,7 +267,10 @@ class HSTU(BaseModel):
                 h = xn @ cached[0]
                 o = HSTUCoreFn.apply(h, key_valid, B, L, self._num_heads, self._dqk, layer._eps, p, seed)
                 y = F.linear(o, cached[1], cached[2])
-            x2 = torch.add(x2, y)                              # fp32 + bf16 -> fp32 in one kernel (no separate cast)
+            if i + 1 < len(layers):            # residual add + the next layer's LayerNorm in one pass
+                x2, xn = AddLayerNormFn.apply(x2, y, layers[i + 1]._eps)
+            else:
+                x2 = torch.add(x2, y)           # fp32 + bf16 -> fp32 in one kernel
         return x2.view(B, L, D)
 
     def _heads(self, x):

@@ -26,6 +26,27 @@ class LayerNormFn(Function):
         return ops.layernorm_bwd(dy.contiguous(), x, mean, rstd, dx_dtype=torch.float32), None
 
 
+class AddLayerNormFn(Function):
+    """(x, y) -> (x + y, LN(x + y)): the residual add of one HSTU layer fused with the LayerNorm of the next
+    (reference hstu.py:286-287, 241).  x fp32, y bf16 -> x_out fp32, xn bf16."""
+
+    @staticmethod
+    def forward(ctx, x, y, eps):
+        x_out, xn, mean, rstd = ops.add_layernorm_fwd(x.contiguous(), y.contiguous(), eps)
+        ctx.save_for_backward(x_out, mean, rstd)
+        return x_out, xn
+
+    @staticmethod
+    def backward(ctx, d_xout, d_xn):
+        x_out, mean, rstd = ctx.saved_tensors
+        if d_xout is None:
+            d_xout = torch.zeros_like(x_out)
+        if d_xn is None:
+            d_xn = torch.zeros(x_out.shape, dtype=torch.bfloat16, device=x_out.device)
+        dx, dy = ops.add_layernorm_bwd(d_xn.contiguous(), x_out, mean, rstd, d_xout.contiguous().float())
+        return dx, dy, None
+
+
 class SplitKLinearFn(Function):
     """y = x @ W (w_is_nk=False, W [K, N]) or x @ W.T + b (w_is_nk=True, W [N, K], the nn.Linear layout), bf16 GEMMs on
     fp32 master weights (reference hstu.py:236-239 under bf16-mixed autocast).

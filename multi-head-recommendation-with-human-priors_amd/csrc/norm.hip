@@ -189,6 +189,106 @@ extern "C" int mhr_layernorm_bwd(const void* dy, int dy_dtype, const void* x, in
 }
 
 // ------------------------------------------------------------------------------------------
+// Residual add fused with the NEXT layer's LayerNorm (reference hstu.py:286-287 `output + x`, then 241 of the next
+// layer): x_out = x + y (fp32 stream + bf16 branch), xn = LN(x_out).  12 B per element instead of 16 for the two
+// separate kernels; the backward returns the total gradient of x_out once in fp32 (residual path) and once in bf16
+// (the branch's GEMM input), which also removes the autograd add and the cast.
+// ------------------------------------------------------------------------------------------
+template <int NC>
+__global__ __launch_bounds__(256) void add_ln_fwd_kernel(const float* __restrict__ x, const bf16_t* __restrict__ y,
+                                                         float* __restrict__ x_out, bf16_t* __restrict__ xn,
+                                                         float* __restrict__ mean_o, float* __restrict__ rstd_o,
+                                                         int64_t rows, int dim, float eps) {
+  WAVE_ROW_LOOP(rows) {
+    RowRegs<NC> r, b;
+    load_row<float, NC>(x + row * dim, dim, lane, r);
+    load_row<bf16_t, NC>(y + row * dim, dim, lane, b);
+#pragma unroll
+    for (int i = 0; i < NC; ++i)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) r.v[i][k] += b.v[i][k];
+    store_row<float, NC>(x_out + row * dim, dim, lane, r);
+    float mean, rstd;
+    row_stats<NC>(r, dim, lane, eps, mean, rstd);
+#pragma unroll
+    for (int i = 0; i < NC; ++i)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) r.v[i][k] = (r.v[i][k] - mean) * rstd;
+    store_row<bf16_t, NC>(xn + row * dim, dim, lane, r);
+    if (lane == 0) {
+      mean_o[row] = mean;
+      rstd_o[row] = rstd;
+    }
+  }
+}
+
+template <int NC>
+__global__ __launch_bounds__(256) void add_ln_bwd_kernel(const bf16_t* __restrict__ d_xn, const float* __restrict__ x_out,
+                                                         const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
+                                                         const float* __restrict__ d_xout, float* __restrict__ dx,
+                                                         bf16_t* __restrict__ dy, int64_t rows, int dim) {
+  WAVE_ROW_LOOP(rows) {
+    RowRegs<NC> g, xv, o;
+    load_row<bf16_t, NC>(d_xn + row * dim, dim, lane, g);
+    load_row<float, NC>(x_out + row * dim, dim, lane, xv);
+    load_row<float, NC>(d_xout + row * dim, dim, lane, o);
+    const float mean = mean_i[row], rstd = rstd_i[row];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      int c = lane * 4 + i * 256;
+      if (c < dim) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float xh = (xv.v[i][k] - mean) * rstd;
+          xv.v[i][k] = xh;
+          s1 += g.v[i][k];
+          s2 += g.v[i][k] * xh;
+        }
+      }
+    }
+    s1 = wave_sum(s1) / (float)dim;
+    s2 = wave_sum(s2) / (float)dim;
+#pragma unroll
+    for (int i = 0; i < NC; ++i)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o.v[i][k] += rstd * (g.v[i][k] - s1 - xv.v[i][k] * s2);
+    store_row<float, NC>(dx + row * dim, dim, lane, o);
+    store_row<bf16_t, NC>(dy + row * dim, dim, lane, o);
+  }
+}
+
+extern "C" int mhr_add_layernorm_fwd(const float* x, const void* y_bf16, float* x_out, void* xn_bf16, float* mean, float* rstd,
+                                     int64_t rows, int dim, float eps, void* stream) {
+  MHR_REQUIRE(x && y_bf16 && x_out && xn_bf16 && mean && rstd, "add_layernorm_fwd: null pointer");
+  MHR_REQUIRE(dim > 0 && dim % 4 == 0 && dim <= 2048, "add_layernorm_fwd: dim=%d unsupported", dim);
+  if (rows <= 0) return MHR_OK;
+  const int grid = mhr_grid_for(rows, 4);
+#define L(NC)                                                                                                          \
+  hipLaunchKernelGGL((add_ln_fwd_kernel<NC>), dim3(grid), dim3(256), 0, (hipStream_t)stream, x, (const bf16_t*)y_bf16, \
+                     x_out, (bf16_t*)xn_bf16, mean, rstd, rows, dim, eps)
+  DISPATCH_NC(dim, L);
+#undef L
+  MHR_CHECK_LAUNCH("add_layernorm_fwd");
+  return MHR_OK;
+}
+
+extern "C" int mhr_add_layernorm_bwd(const void* d_xn_bf16, const float* x_out, const float* mean, const float* rstd,
+                                     const float* d_xout, float* dx, void* dy_bf16, int64_t rows, int dim, void* stream) {
+  MHR_REQUIRE(d_xn_bf16 && x_out && mean && rstd && d_xout && dx && dy_bf16, "add_layernorm_bwd: null pointer");
+  MHR_REQUIRE(dim > 0 && dim % 4 == 0 && dim <= 2048, "add_layernorm_bwd: dim=%d unsupported", dim);
+  if (rows <= 0) return MHR_OK;
+  const int grid = mhr_grid_for(rows, 4);
+#define L(NC)                                                                                                              \
+  hipLaunchKernelGGL((add_ln_bwd_kernel<NC>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)d_xn_bf16, x_out, \
+                     mean, rstd, d_xout, dx, (bf16_t*)dy_bf16, rows, dim)
+  DISPATCH_NC(dim, L);
+#undef L
+  MHR_CHECK_LAUNCH("add_layernorm_bwd");
+  return MHR_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // o = silu(u) * LN(a) * dropmask
 // ------------------------------------------------------------------------------------------
 template <typename T, typename OT, int NC>

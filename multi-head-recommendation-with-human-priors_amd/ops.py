@@ -139,6 +139,34 @@ def layernorm_bwd(dy, x, mean, rstd, dx=None, accumulate=False, dx_dtype=torch.f
     return dx
 
 
+def add_layernorm_fwd(x, y, eps=1e-6):
+    """x_out = x + y (fp32 + bf16), xn = LN(x_out) bf16.  Returns (x_out, xn, mean, rstd)."""
+    _chk(x, "x", torch.float32)
+    _chk(y, "y", torch.bfloat16)
+    D = x.shape[-1]
+    rows = x.numel() // D
+    x_out = torch.empty_like(x)
+    xn = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    lib.call("mhr_add_layernorm_fwd", x.data_ptr(), y.data_ptr(), x_out.data_ptr(), xn.data_ptr(), mean.data_ptr(),
+             rstd.data_ptr(), rows, D, eps, _stream())
+    return x_out, xn, mean, rstd
+
+
+def add_layernorm_bwd(d_xn, x_out, mean, rstd, d_xout):
+    """-> (dx f32, dy bf16), both = d_xout + LN'(d_xn)."""
+    _chk(d_xn, "d_xn", torch.bfloat16)
+    _chk(d_xout, "d_xout", torch.float32)
+    D = x_out.shape[-1]
+    rows = x_out.numel() // D
+    dx = torch.empty_like(x_out)
+    dy = torch.empty(x_out.shape, dtype=torch.bfloat16, device=x_out.device)
+    lib.call("mhr_add_layernorm_bwd", d_xn.data_ptr(), x_out.data_ptr(), mean.data_ptr(), rstd.data_ptr(), d_xout.data_ptr(),
+             dx.data_ptr(), dy.data_ptr(), rows, D, _stream())
+    return dx, dy
+
+
 def ln_gate_fwd(h, a, dim, out_dtype=None, eps=1e-6, dropout_p=0.0, seed=0):
     """o = silu(h[:, :dim]) * LN(a) * dropmask.  h [rows, stride] pre-activation, a [rows, dim]."""
     rows = a.numel() // dim

@@ -334,6 +334,27 @@ def test_nce_fwd_bwd(ops, D, n_tok, n_neg, dtype):
     assert abs(float(dls.cpu()) - float(lsr.grad)) < 2e-2 * abs(float(lsr.grad)) + 1e-4
 
 
+@pytest.mark.parametrize("rows,D", [(7, 64), (300, 256), (33, 1024)])
+def test_add_layernorm_fwd_bwd(ops, rows, D):
+    """Fused residual add + LayerNorm vs torch fp32 on the same bf16-rounded branch: x_out exact (fp32 add), xn and
+    the bf16 gradient within one bf16 rounding of the row scale, the fp32 gradient 1e-5 relative."""
+    g = torch.Generator().manual_seed(rows)
+    x = torch.randn(rows, D, generator=g)
+    y = bf(torch.randn(rows, D, generator=g))
+    x_out, xn, mean, rstd = ops.add_layernorm_fwd(dev(x), dev(y), 1e-6)
+    xr = (x + y.float()).requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xr, (D,), eps=1e-6)
+    np.testing.assert_array_equal(x_out.cpu().numpy(), xr.detach().numpy())
+    assert float((xn.float().cpu() - ref.detach()).abs().max()) <= 2 ** -7 * float(ref.abs().max())
+    d_xn = bf(torch.randn(rows, D, generator=g))
+    d_xout = torch.randn(rows, D, generator=g)
+    dx, dy = ops.add_layernorm_bwd(dev(d_xn), x_out, mean, rstd, dev(d_xout))
+    ref.backward(d_xn.float())
+    want = d_xout + xr.grad
+    assert rel_err(dx.cpu(), want) < 1e-5
+    assert float((dy.float().cpu() - want).abs().max()) <= 2 ** -7 * float(want.abs().max())
+
+
 @pytest.mark.parametrize("G,n_slots,density", [(1, 37, 0.5), (3, 4096, 0.3), (4, 9000, 0.33), (2, 5000, 0.0), (2, 300, 1.0)])
 def test_token_compact_matches_boolean_mask_indexing(ops, G, n_slots, density):
     """mhr_token_compact vs the reference's `x[mask]` (hstu.py:688-690): same values, same (ascending) order; bit-exact."""
