@@ -10,21 +10,26 @@
 // 32 keys on v_mfma_f32_32x32x16_bf16.  Scores are computed TRANSPOSED (keys on the accumulator rows,
 // queries on the lanes) so that the gated tile, converted to bf16 in registers, is directly the B operand
 // of the second product O^T = V^T . P^T (summing over the accumulator's row index needs no lane
-// movement, cdna guide section 3).  K (row-major) and V^T are staged once per workgroup in LDS with the
-// load-time SiLU of hstu.py:244-245 applied.  The backward runs two passes per workgroup (dK/dV per key
-// block, then dQ per query block) so that no cross-wave reduction or atomic is needed and the result is
-// bitwise reproducible.
+// movement, cdna guide section 3).  K and V are staged once per workgroup in LDS as swizzled 32-row tile images
+// (stream_gemm.h) with the load-time SiLU of hstu.py:244-245 applied; the second product reads V^T fragments
+// from the same image with ds_read_b64_tr_b16.  The backward runs two passes per workgroup (dK/dV per key block
+// with Q and dO resident, then dQ per query block with K and V resident) so that no cross-wave reduction or
+// atomic is needed and the result is bitwise reproducible; every inner-loop operand comes from LDS.
 #include "mhr_common.h"
+#include "stream_gemm.h"
 
 namespace {
 
-__device__ __forceinline__ int crow(int g, int half) { return (g & 3) + 8 * (g >> 2) + 4 * half; }
+using sg::crow;
+using sg::zero16;
+using sg::zero8;
 
-__device__ __forceinline__ bf16x8 zero8() {
-  bf16x8 z;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) z[i] = (bf16_t)0.0f;
-  return z;
+constexpr float LOG2E_F = 1.4426950408889634f;
+
+// sigmoid with one v_exp and one v_rcp (the division form costs a Newton step per element; every score tile applies it
+// to 16 values per lane, which is where these kernels spend their VALU time)
+__device__ __forceinline__ float fast_sigmoid(float x) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-x * LOG2E_F));
 }
 
 __device__ __forceinline__ bf16x8 silu8(bf16x8 x) {
@@ -40,17 +45,6 @@ __device__ __forceinline__ bf16x8 load_frag(const bf16_t* base, int64_t stride, 
   return zero8();
 }
 
-// Fragment for a product that sums over the ROW index of an accumulator tile: element j of lane half h
-// must come from k = base + 16*s + 8*(j>>2) + 4*h + (j&3) (cdna guide section 3, "accumulator tile as
-// the next MFMA's operand").  T is a transposed LDS image [idx][ld] with the summed index contiguous.
-__device__ __forceinline__ bf16x8 read_T_frag(const bf16_t* T, int ld, int idx, int base, int s, int half) {
-  const bf16_t* p = T + idx * ld + base + 16 * s + 4 * half;
-  bf16x4 lo = *reinterpret_cast<const bf16x4*>(p);
-  bf16x4 hi = *reinterpret_cast<const bf16x4*>(p + 8);
-  bf16x8 f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-  return f;
-}
-
 __device__ __forceinline__ void pack_acc(const f32x16& x, bf16x8& f0, bf16x8& f1) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -59,28 +53,23 @@ __device__ __forceinline__ void pack_acc(const f32x16& x, bf16x8& f0, bf16x8& f1
   }
 }
 
-__device__ __forceinline__ f32x16 zero16() {
-  f32x16 z;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) z[i] = 0.f;
-  return z;
-}
-
-// stage a [L, hd] row-major global block transposed into T[HC][ld] (zeros for m >= L or col >= hd)
-template <int HC>
-__device__ __forceinline__ void stage_transposed(bf16_t* T, int ld, const bf16_t* src, int64_t stride, int L, int Lp, int hd,
-                                                 bool do_silu, bf16_t* act, int64_t act_stride) {
-  constexpr int chunks = HC / 8;
-  for (int c = threadIdx.x; c < Lp * chunks; c += blockDim.x) {
-    const int m = c / chunks, d0 = (c % chunks) * 8;
+// Stage a [L, hd] row-major global block as ceil(L/32) swizzled 32-row tile images (stream_gemm.h Tile<NKS>, feature
+// dim padded to 16*NKS with zeros, rows >= L zero).  One image serves BOTH access shapes the kernels need: row
+// fragments (ds_read_b128: operand rows on the lanes, features on the vector) and transposed fragments
+// (ds_read_b64_tr_b16: operand summed over the ROW index) - so no transposed copy is ever built.
+template <int NKS>
+__device__ __forceinline__ void stage_tiles(unsigned char* dst, const bf16_t* src, int64_t stride, int L, int Lp, int hd,
+                                            bool do_silu, bf16_t* act, int64_t act_stride) {
+  using T = sg::Tile<NKS>;
+  for (int c = threadIdx.x; c < Lp * T::CH; c += blockDim.x) {
+    const int m = c / T::CH, j = c % T::CH;
     bf16x8 val = zero8();
-    if (m < L && d0 < hd) {
-      val = *reinterpret_cast<const bf16x8*>(src + (int64_t)m * stride + d0);
+    if (m < L && j * 8 < hd) {
+      val = *reinterpret_cast<const bf16x8*>(src + (int64_t)m * stride + j * 8);
       if (do_silu) val = silu8(val);
-      if (act) *reinterpret_cast<bf16x8*>(act + (int64_t)m * act_stride + d0) = val;
+      if (act) *reinterpret_cast<bf16x8*>(act + (int64_t)m * act_stride + j * 8) = val;
     }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) T[(d0 + i) * ld + m] = val[i];
+    *reinterpret_cast<bf16x8*>(dst + (m >> 5) * T::BYTES + T::off(m & 31, j)) = val;
   }
 }
 
@@ -105,13 +94,12 @@ __global__ __launch_bounds__(256) void hstu_attn_fwd_kernel(const bf16_t* __rest
                                                             int64_t out_stride, bf16_t* act_q, bf16_t* act_k, bf16_t* act_v,
                                                             int64_t act_stride, int L, int n_heads, int hd, int apply_silu,
                                                             float inv_n) {
+  using T = sg::Tile<NKS>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int HK = NKS * 16, HC = ND * 32;
   const int Lp = (L + 31) & ~31, nb = Lp >> 5;
-  const int ldk = HK + 8, ldv = Lp + 8;
-  bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);   // [Lp][ldk]
-  bf16_t* VTs = Ks + Lp * ldk;                    // [HC][ldv]
-  uint32_t* vmask = reinterpret_cast<uint32_t*>(VTs + HC * ldv);
+  unsigned char* Kt = smem;                       // nb tiles: activated K
+  unsigned char* Vt = smem + nb * T::BYTES;       // nb tiles: activated V
+  uint32_t* vmask = reinterpret_cast<uint32_t*>(Vt + nb * T::BYTES);
 
   const int b = blockIdx.x / n_heads, head = blockIdx.x % n_heads;
   const int64_t row0 = (int64_t)b * L;
@@ -123,25 +111,14 @@ __global__ __launch_bounds__(256) void hstu_attn_fwd_kernel(const bf16_t* __rest
   bf16_t* av = act_v ? act_v + row0 * act_stride + head * hd : nullptr;
   const bool do_silu = apply_silu != 0;
 
-  // K row-major with SiLU applied
-  {
-    constexpr int chunks = HK / 8;
-    for (int c = threadIdx.x; c < Lp * chunks; c += 256) {
-      const int m = c / chunks, k0 = (c % chunks) * 8;
-      bf16x8 val = zero8();
-      if (m < L && k0 < hd) {
-        val = *reinterpret_cast<const bf16x8*>(kp + (int64_t)m * stride + k0);
-        if (do_silu) val = silu8(val);
-        if (ak) *reinterpret_cast<bf16x8*>(ak + (int64_t)m * act_stride + k0) = val;
-      }
-      *reinterpret_cast<bf16x8*>(Ks + m * ldk + k0) = val;
-    }
-  }
-  stage_transposed<HC>(VTs, ldv, vp, stride, L, Lp, hd, do_silu, av, act_stride);
+  stage_tiles<NKS>(Kt, kp, stride, L, Lp, hd, do_silu, ak, act_stride);
+  stage_tiles<NKS>(Vt, vp, stride, L, Lp, hd, do_silu, av, act_stride);
   build_valid_mask(vmask, key_valid + row0, L, nb);
   __syncthreads();
 
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, half = lane >> 5;
+  sg::LaneAddr<NKS> la;
+  la.init(lane);
   for (int it = 0; it * 4 < nb; ++it) {
     const int qb = (it & 1) ? it * 4 + (3 - wave) : it * 4 + wave;   // zig-zag: balances the causal triangle
     if (qb >= nb) continue;
@@ -159,27 +136,25 @@ __global__ __launch_bounds__(256) void hstu_attn_fwd_kernel(const bf16_t* __rest
     for (int dc = 0; dc < ND; ++dc) o[dc] = zero16();
 
     for (int kb = 0; kb <= qb; ++kb) {
+      const unsigned char* kt = Kt + kb * T::BYTES;
+      const unsigned char* vt = Vt + kb * T::BYTES;
       f32x16 s = zero16();
 #pragma unroll
-      for (int ks = 0; ks < NKS; ++ks) {
-        bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (kb * 32 + r) * ldk + ks * 16 + 8 * half);
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);   // S^T: rows = keys, cols = queries
-      }
+      for (int ks = 0; ks < NKS; ++ks)
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(la.read_a(kt, ks), qf[ks], s, 0, 0, 0);   // S^T: rows = keys, cols = queries
       const uint32_t vm = vmask[kb];
 #pragma unroll
       for (int g = 0; g < 16; ++g) {
         const int kl = crow(g, half);
         const bool ok = ((vm >> kl) & 1u) && (kb * 32 + kl <= qrow);
-        s[g] = ok ? silu_f(s[g]) * inv_n : 0.f;
+        s[g] = ok ? s[g] * fast_sigmoid(s[g]) * inv_n : 0.f;
       }
       bf16x8 p0, p1;
       pack_acc(s, p0, p1);
 #pragma unroll
       for (int dc = 0; dc < ND; ++dc) {
-        bf16x8 vt0 = read_T_frag(VTs, ldv, dc * 32 + r, kb * 32, 0, half);
-        o[dc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vt0, p0, o[dc], 0, 0, 0);   // O^T += V^T . P^T
-        bf16x8 vt1 = read_T_frag(VTs, ldv, dc * 32 + r, kb * 32, 1, half);
-        o[dc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vt1, p1, o[dc], 0, 0, 0);
+        o[dc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(la.read_tr(vt, dc, 0), p0, o[dc], 0, 0, 0);   // O^T += V^T . P^T
+        o[dc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(la.read_tr(vt, dc, 1), p1, o[dc], 0, 0, 0);
       }
     }
     if (qrow < L) {
@@ -208,13 +183,12 @@ __global__ __launch_bounds__(256) void hstu_attn_bwd_kernel(
     const uint8_t* __restrict__ key_valid, const bf16_t* __restrict__ d_out, int64_t do_stride, bf16_t* __restrict__ dq,
     bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, int64_t d_stride, int L, int n_heads, int hd, int apply_silu,
     float inv_n) {
+  using T = sg::Tile<NKS>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int HC = ND * 32;
   const int Lp = (L + 31) & ~31, nb = Lp >> 5;
-  const int ldt = Lp + 8;
-  bf16_t* T0 = reinterpret_cast<bf16_t*>(smem);   // Q^T in pass A, K^T in pass B   [HC][ldt]
-  bf16_t* T1 = T0 + HC * ldt;                     // dO^T                            [HC][ldt]
-  uint32_t* vmask = reinterpret_cast<uint32_t*>(T1 + HC * ldt);
+  unsigned char* T0 = smem;                      // Q tiles in pass A, K tiles in pass B
+  unsigned char* T1 = smem + nb * T::BYTES;      // dO tiles in pass A, V tiles in pass B
+  uint32_t* vmask = reinterpret_cast<uint32_t*>(T1 + nb * T::BYTES);
 
   const int b = blockIdx.x / n_heads, head = blockIdx.x % n_heads;
   const int64_t row0 = (int64_t)b * L;
@@ -225,12 +199,17 @@ __global__ __launch_bounds__(256) void hstu_attn_bwd_kernel(
   const bf16_t* dop = d_out + row0 * do_stride + hoff;
   const bool chain = apply_silu != 0;
 
-  stage_transposed<HC>(T0, ldt, aq, act_stride, L, Lp, hd, false, nullptr, 0);
-  stage_transposed<HC>(T1, ldt, dop, do_stride, L, Lp, hd, false, nullptr, 0);
+  // Everything the inner loops touch lives in LDS: the per-(query block, key block) work used to fetch its Q / dO (or
+  // K / V) fragments straight from global memory, one dependent L2 round trip per 8 MFMAs (386 MB of traffic per
+  // launch against 65 MB of operands, 176 us per layer at cfg1).
+  stage_tiles<NKS>(T0, aq, act_stride, L, Lp, hd, false, nullptr, 0);
+  stage_tiles<NKS>(T1, dop, do_stride, L, Lp, hd, false, nullptr, 0);
   build_valid_mask(vmask, key_valid + row0, L, nb);
   __syncthreads();
 
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, half = lane >> 5;
+  sg::LaneAddr<NKS> la;
+  la.init(lane);
 
   // ---- pass A: dK, dV for key block kb (keys on the lanes) -----------------------------------------
   for (int it = 0; it * 4 < nb; ++it) {
@@ -251,20 +230,20 @@ __global__ __launch_bounds__(256) void hstu_attn_bwd_kernel(
       dkacc[dc] = zero16();
     }
     for (int qb = kb; qb < nb; ++qb) {
+      const unsigned char* qt = T0 + qb * T::BYTES;
+      const unsigned char* dot = T1 + qb * T::BYTES;
       f32x16 s = zero16(), dp = zero16();
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) {
-        bf16x8 qf = load_frag(aq, act_stride, qb * 32 + r, L, ks * 16 + 8 * half, hd);
-        bf16x8 dof = load_frag(dop, do_stride, qb * 32 + r, L, ks * 16 + 8 * half, hd);
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, kf[ks], s, 0, 0, 0);      // S: rows = queries, cols = keys
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof, vf[ks], dp, 0, 0, 0);   // dP = dO . V^T
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(la.read_a(qt, ks), kf[ks], s, 0, 0, 0);      // S: rows = queries, cols = keys
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(la.read_a(dot, ks), vf[ks], dp, 0, 0, 0);   // dP = dO . V^T
       }
 #pragma unroll
       for (int g = 0; g < 16; ++g) {
         const int qi = qb * 32 + crow(g, half);
         const bool ok = kvalid && key <= qi;
         const float x = s[g];
-        const float sig = 1.0f / (1.0f + __expf(-x));
+        const float sig = fast_sigmoid(x);
         s[g] = ok ? x * sig * inv_n : 0.f;                                           // P
         dp[g] = ok ? dp[g] * inv_n * sig * (1.0f + x * (1.0f - sig)) : 0.f;          // dS
       }
@@ -273,15 +252,10 @@ __global__ __launch_bounds__(256) void hstu_attn_bwd_kernel(
       pack_acc(dp, da0, da1);
 #pragma unroll
       for (int dc = 0; dc < ND; ++dc) {
-        bf16x8 t;
-        t = read_T_frag(T1, ldt, dc * 32 + r, qb * 32, 0, half);
-        dvacc[dc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa0, t, dvacc[dc], 0, 0, 0);   // dV += P^T . dO
-        t = read_T_frag(T1, ldt, dc * 32 + r, qb * 32, 1, half);
-        dvacc[dc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa1, t, dvacc[dc], 0, 0, 0);
-        t = read_T_frag(T0, ldt, dc * 32 + r, qb * 32, 0, half);
-        dkacc[dc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da0, t, dkacc[dc], 0, 0, 0);   // dK += dS^T . Q
-        t = read_T_frag(T0, ldt, dc * 32 + r, qb * 32, 1, half);
-        dkacc[dc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da1, t, dkacc[dc], 0, 0, 0);
+        dvacc[dc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa0, la.read_tr(dot, dc, 0), dvacc[dc], 0, 0, 0);   // dV += P^T . dO
+        dvacc[dc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa1, la.read_tr(dot, dc, 1), dvacc[dc], 0, 0, 0);
+        dkacc[dc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da0, la.read_tr(qt, dc, 0), dkacc[dc], 0, 0, 0);    // dK += dS^T . Q
+        dkacc[dc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da1, la.read_tr(qt, dc, 1), dkacc[dc], 0, 0, 0);
       }
     }
     // results: rows (regs) = keys, cols (lanes) = feature
@@ -307,8 +281,9 @@ __global__ __launch_bounds__(256) void hstu_attn_bwd_kernel(
   }
 
   // ---- pass B: dQ for query block qb (queries on the lanes) ----------------------------------------
-  __syncthreads();                      // everyone is done reading Q^T
-  stage_transposed<HC>(T0, ldt, ak, act_stride, L, Lp, hd, false, nullptr, 0);   // K^T
+  __syncthreads();                      // everyone is done reading the Q / dO tiles
+  stage_tiles<NKS>(T0, ak, act_stride, L, Lp, hd, false, nullptr, 0);
+  stage_tiles<NKS>(T1, av, act_stride, L, Lp, hd, false, nullptr, 0);
   __syncthreads();
   for (int it = 0; it * 4 < nb; ++it) {
     const int qb = (it & 1) ? it * 4 + (3 - wave) : it * 4 + wave;
@@ -324,13 +299,13 @@ __global__ __launch_bounds__(256) void hstu_attn_bwd_kernel(
 #pragma unroll
     for (int dc = 0; dc < ND; ++dc) dqacc[dc] = zero16();
     for (int kb = 0; kb <= qb; ++kb) {
+      const unsigned char* kt = T0 + kb * T::BYTES;
+      const unsigned char* vt = T1 + kb * T::BYTES;
       f32x16 s = zero16(), dp = zero16();
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) {
-        bf16x8 kf = load_frag(ak, act_stride, kb * 32 + r, L, ks * 16 + 8 * half, hd);
-        bf16x8 vf = load_frag(av, act_stride, kb * 32 + r, L, ks * 16 + 8 * half, hd);
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);      // S^T: rows = keys, cols = queries
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[ks], dp, 0, 0, 0);   // dP^T = V . dO^T
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(la.read_a(kt, ks), qf[ks], s, 0, 0, 0);      // S^T: rows = keys, cols = queries
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(la.read_a(vt, ks), dof[ks], dp, 0, 0, 0);   // dP^T = V . dO^T
       }
       const uint32_t vm = vmask[kb];
 #pragma unroll
@@ -338,17 +313,15 @@ __global__ __launch_bounds__(256) void hstu_attn_bwd_kernel(
         const int kl = crow(g, half);
         const bool ok = ((vm >> kl) & 1u) && (kb * 32 + kl <= qcol);
         const float x = s[g];
-        const float sig = 1.0f / (1.0f + __expf(-x));
+        const float sig = fast_sigmoid(x);
         dp[g] = ok ? dp[g] * inv_n * sig * (1.0f + x * (1.0f - sig)) : 0.f;          // dS^T
       }
       bf16x8 a0, a1;
       pack_acc(dp, a0, a1);
 #pragma unroll
       for (int dc = 0; dc < ND; ++dc) {
-        bf16x8 t = read_T_frag(T0, ldt, dc * 32 + r, kb * 32, 0, half);
-        dqacc[dc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, t, dqacc[dc], 0, 0, 0);   // dQ += dS . K
-        t = read_T_frag(T0, ldt, dc * 32 + r, kb * 32, 1, half);
-        dqacc[dc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, t, dqacc[dc], 0, 0, 0);
+        dqacc[dc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, la.read_tr(kt, dc, 0), dqacc[dc], 0, 0, 0);   // dQ += dS . K
+        dqacc[dc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, la.read_tr(kt, dc, 1), dqacc[dc], 0, 0, 0);
       }
     }
 #pragma unroll
@@ -400,8 +373,7 @@ extern "C" int mhr_hstu_attn_fwd(const void* q, const void* k, const void* v, in
   MHR_REQUIRE((act_q != nullptr) == (act_k != nullptr) && (act_k != nullptr) == (act_v != nullptr),
               "hstu_attn_fwd: act_q/act_k/act_v must be all set or all null");
   const int Lp = (L + 31) & ~31, nb = Lp / 32;
-  const int HK = sh.nks * 16, HC = sh.nd * 32;
-  size_t lds = (size_t)Lp * (HK + 8) * 2 + (size_t)HC * (Lp + 8) * 2 + (size_t)nb * 4 + 16;
+  size_t lds = (size_t)2 * nb * (32 * sh.nks * 32) + (size_t)nb * 4 + 16;     // K and V tile images + validity words
   MHR_REQUIRE(lds <= 160 * 1024 && nb <= 256, "hstu_attn_fwd: L=%d head_dim=%d needs %zu B of LDS (> 160 KiB)", L, head_dim, lds);
   const float inv_n = 1.0f / (float)L;
   const int64_t out_stride = (int64_t)n_heads * head_dim;
@@ -431,8 +403,7 @@ extern "C" int mhr_hstu_attn_bwd(const void* q_pre, const void* k_pre, const voi
   MHR_REQUIRE(B > 0 && L > 0 && n_heads > 0, "hstu_attn_bwd: bad sizes");
   MHR_REQUIRE(act_stride % 8 == 0 && ((int64_t)n_heads * head_dim) % 8 == 0, "hstu_attn_bwd: strides must be multiples of 8");
   const int Lp = (L + 31) & ~31, nb = Lp / 32;
-  const int HC = sh.nd * 32;
-  size_t lds = (size_t)2 * HC * (Lp + 8) * 2 + (size_t)nb * 4 + 16;
+  size_t lds = (size_t)2 * nb * (32 * sh.nks * 32) + (size_t)nb * 4 + 16;     // two tensors' tile images at a time
   MHR_REQUIRE(lds <= 160 * 1024 && nb <= 256, "hstu_attn_bwd: L=%d head_dim=%d needs %zu B of LDS (> 160 KiB)", L, head_dim, lds);
   const float inv_n = 1.0f / (float)L;
   const int64_t do_stride = (int64_t)n_heads * head_dim;
