@@ -26,6 +26,20 @@ using sg::zero8;
 
 constexpr float LOG2E_F = 1.4426950408889634f;
 
+#ifdef MHR_STAMP   // in-kernel phase timing, only in the builds tools/stamp_nce.py makes
+__device__ unsigned long long g_attn_stamps[16];
+#define ASTAMP(k)                                                                       \
+  {                                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                  \
+    unsigned long long t_;                                                              \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");          \
+    __builtin_amdgcn_sched_barrier(0);                                                  \
+    if (blockIdx.x == 37 && threadIdx.x == 0) g_attn_stamps[k] = t_;                    \
+  }
+#else
+#define ASTAMP(k)
+#endif
+
 // sigmoid with one v_exp and one v_rcp (the division form costs a Newton step per element; every score tile applies it
 // to 16 values per lane, which is where these kernels spend their VALU time)
 __device__ __forceinline__ float fast_sigmoid(float x) {
@@ -136,18 +150,25 @@ __global__ __launch_bounds__(256) void hstu_attn_fwd_kernel(const bf16_t* __rest
     for (int dc = 0; dc < ND; ++dc) o[dc] = zero16();
 
     for (int kb = 0; kb <= qb; ++kb) {
+      const uint32_t vm = vmask[kb];
+      if (vm == 0) continue;                       // a block of padding keys contributes exactly nothing
       const unsigned char* kt = Kt + kb * T::BYTES;
       const unsigned char* vt = Vt + kb * T::BYTES;
       f32x16 s = zero16();
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks)
         s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(la.read_a(kt, ks), qf[ks], s, 0, 0, 0);   // S^T: rows = keys, cols = queries
-      const uint32_t vm = vmask[kb];
+      // off-diagonal tiles of fully valid key blocks need no mask at all (1/L is applied once, at the store)
+      if (kb < qb && vm == 0xFFFFFFFFu) {
 #pragma unroll
-      for (int g = 0; g < 16; ++g) {
-        const int kl = crow(g, half);
-        const bool ok = ((vm >> kl) & 1u) && (kb * 32 + kl <= qrow);
-        s[g] = ok ? s[g] * fast_sigmoid(s[g]) * inv_n : 0.f;
+        for (int g = 0; g < 16; ++g) s[g] *= fast_sigmoid(s[g]);
+      } else {
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+          const int kl = crow(g, half);
+          const bool ok = ((vm >> kl) & 1u) && (kb * 32 + kl <= qrow);
+          s[g] = ok ? s[g] * fast_sigmoid(s[g]) : 0.f;
+        }
       }
       bf16x8 p0, p1;
       pack_acc(s, p0, p1);
@@ -165,7 +186,8 @@ __global__ __launch_bounds__(256) void hstu_attn_fwd_kernel(const bf16_t* __rest
         for (int g4 = 0; g4 < 4; ++g4) {
           const int d0 = dc * 32 + 8 * g4 + 4 * half;
           if (d0 < hd) {
-            bf16x4 w = {(bf16_t)o[dc][4 * g4], (bf16_t)o[dc][4 * g4 + 1], (bf16_t)o[dc][4 * g4 + 2], (bf16_t)o[dc][4 * g4 + 3]};
+            bf16x4 w = {(bf16_t)(o[dc][4 * g4] * inv_n), (bf16_t)(o[dc][4 * g4 + 1] * inv_n), (bf16_t)(o[dc][4 * g4 + 2] * inv_n),
+                        (bf16_t)(o[dc][4 * g4 + 3] * inv_n)};
             *reinterpret_cast<bf16x4*>(orow + d0) = w;
           }
         }
@@ -202,10 +224,12 @@ __global__ __launch_bounds__(256) void hstu_attn_bwd_kernel(
   // Everything the inner loops touch lives in LDS: the per-(query block, key block) work used to fetch its Q / dO (or
   // K / V) fragments straight from global memory, one dependent L2 round trip per 8 MFMAs (386 MB of traffic per
   // launch against 65 MB of operands, 176 us per layer at cfg1).
+  ASTAMP(0)
   stage_tiles<NKS>(T0, aq, act_stride, L, Lp, hd, false, nullptr, 0);
   stage_tiles<NKS>(T1, dop, do_stride, L, Lp, hd, false, nullptr, 0);
   build_valid_mask(vmask, key_valid + row0, L, nb);
   __syncthreads();
+  ASTAMP(1)
 
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, half = lane >> 5;
   sg::LaneAddr<NKS> la;
@@ -229,7 +253,8 @@ __global__ __launch_bounds__(256) void hstu_attn_bwd_kernel(
       dvacc[dc] = zero16();
       dkacc[dc] = zero16();
     }
-    for (int qb = kb; qb < nb; ++qb) {
+    const uint32_t vm_kb = vmask[kb];
+    for (int qb = kb; qb < nb && vm_kb != 0; ++qb) {     // a block of padding keys gets zero gradients
       const unsigned char* qt = T0 + qb * T::BYTES;
       const unsigned char* dot = T1 + qb * T::BYTES;
       f32x16 s = zero16(), dp = zero16();
@@ -238,14 +263,26 @@ __global__ __launch_bounds__(256) void hstu_attn_bwd_kernel(
         s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(la.read_a(qt, ks), kf[ks], s, 0, 0, 0);      // S: rows = queries, cols = keys
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(la.read_a(dot, ks), vf[ks], dp, 0, 0, 0);   // dP = dO . V^T
       }
+      // P = silu(S), dS = dP silu'(S); the 1/L of both is applied once, when dV / dK are stored.  Off-diagonal tiles of
+      // fully valid key blocks skip the mask arithmetic.
+      if (qb > kb && vm_kb == 0xFFFFFFFFu) {
 #pragma unroll
-      for (int g = 0; g < 16; ++g) {
-        const int qi = qb * 32 + crow(g, half);
-        const bool ok = kvalid && key <= qi;
-        const float x = s[g];
-        const float sig = fast_sigmoid(x);
-        s[g] = ok ? x * sig * inv_n : 0.f;                                           // P
-        dp[g] = ok ? dp[g] * inv_n * sig * (1.0f + x * (1.0f - sig)) : 0.f;          // dS
+        for (int g = 0; g < 16; ++g) {
+          const float x = s[g];
+          const float sig = fast_sigmoid(x);
+          s[g] = x * sig;
+          dp[g] = dp[g] * sig * (1.0f + x * (1.0f - sig));
+        }
+      } else {
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+          const int qi = qb * 32 + crow(g, half);
+          const bool ok = kvalid && key <= qi;
+          const float x = s[g];
+          const float sig = fast_sigmoid(x);
+          s[g] = ok ? x * sig : 0.f;                                           // P
+          dp[g] = ok ? dp[g] * sig * (1.0f + x * (1.0f - sig)) : 0.f;          // dS
+        }
       }
       bf16x8 pa0, pa1, da0, da1;
       pack_acc(s, pa0, pa1);
@@ -267,7 +304,7 @@ __global__ __launch_bounds__(256) void hstu_attn_bwd_kernel(
         for (int g = 0; g < 16; ++g) {
           const int m = kb * 32 + crow(g, half);
           if (m < L) {
-            float gv = dvacc[dc][g], gk = dkacc[dc][g];
+            float gv = dvacc[dc][g] * inv_n, gk = dkacc[dc][g] * inv_n;
             if (chain) {
               gv *= dsilu_f((float)v_pre[(row0 + m) * stride + hoff + d]);
               gk *= dsilu_f((float)k_pre[(row0 + m) * stride + hoff + d]);
@@ -281,10 +318,13 @@ __global__ __launch_bounds__(256) void hstu_attn_bwd_kernel(
   }
 
   // ---- pass B: dQ for query block qb (queries on the lanes) ----------------------------------------
+  ASTAMP(2)
   __syncthreads();                      // everyone is done reading the Q / dO tiles
+  ASTAMP(3)
   stage_tiles<NKS>(T0, ak, act_stride, L, Lp, hd, false, nullptr, 0);
   stage_tiles<NKS>(T1, av, act_stride, L, Lp, hd, false, nullptr, 0);
   __syncthreads();
+  ASTAMP(4)
   for (int it = 0; it * 4 < nb; ++it) {
     const int qb = (it & 1) ? it * 4 + (3 - wave) : it * 4 + wave;
     if (qb >= nb) continue;
@@ -299,6 +339,8 @@ __global__ __launch_bounds__(256) void hstu_attn_bwd_kernel(
 #pragma unroll
     for (int dc = 0; dc < ND; ++dc) dqacc[dc] = zero16();
     for (int kb = 0; kb <= qb; ++kb) {
+      const uint32_t vm = vmask[kb];
+      if (vm == 0) continue;
       const unsigned char* kt = T0 + kb * T::BYTES;
       const unsigned char* vt = T1 + kb * T::BYTES;
       f32x16 s = zero16(), dp = zero16();
@@ -307,14 +349,22 @@ __global__ __launch_bounds__(256) void hstu_attn_bwd_kernel(
         s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(la.read_a(kt, ks), qf[ks], s, 0, 0, 0);      // S^T: rows = keys, cols = queries
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(la.read_a(vt, ks), dof[ks], dp, 0, 0, 0);   // dP^T = V . dO^T
       }
-      const uint32_t vm = vmask[kb];
+      if (kb < qb && vm == 0xFFFFFFFFu) {
 #pragma unroll
-      for (int g = 0; g < 16; ++g) {
-        const int kl = crow(g, half);
-        const bool ok = ((vm >> kl) & 1u) && (kb * 32 + kl <= qcol);
-        const float x = s[g];
-        const float sig = fast_sigmoid(x);
-        dp[g] = ok ? dp[g] * inv_n * sig * (1.0f + x * (1.0f - sig)) : 0.f;          // dS^T
+        for (int g = 0; g < 16; ++g) {
+          const float x = s[g];
+          const float sig = fast_sigmoid(x);
+          dp[g] = dp[g] * sig * (1.0f + x * (1.0f - sig));
+        }
+      } else {
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+          const int kl = crow(g, half);
+          const bool ok = ((vm >> kl) & 1u) && (kb * 32 + kl <= qcol);
+          const float x = s[g];
+          const float sig = fast_sigmoid(x);
+          dp[g] = ok ? dp[g] * sig * (1.0f + x * (1.0f - sig)) : 0.f;          // dS^T
+        }
       }
       bf16x8 a0, a1;
       pack_acc(dp, a0, a1);
@@ -332,7 +382,7 @@ __global__ __launch_bounds__(256) void hstu_attn_bwd_kernel(
         for (int g = 0; g < 16; ++g) {
           const int n = qb * 32 + crow(g, half);
           if (n < L) {
-            float gq = dqacc[dc][g];
+            float gq = dqacc[dc][g] * inv_n;
             if (chain) gq *= dsilu_f((float)q_pre[(row0 + n) * stride + hoff + d]);
             dq[(row0 + n) * d_stride + hoff + d] = (bf16_t)gq;
           }
@@ -340,6 +390,7 @@ __global__ __launch_bounds__(256) void hstu_attn_bwd_kernel(
       }
     }
   }
+  ASTAMP(5)
 }
 
 struct AttnShape {
@@ -422,3 +473,9 @@ extern "C" int mhr_hstu_attn_bwd(const void* q_pre, const void* k_pre, const voi
   MHR_CHECK_LAUNCH("hstu_attn_bwd");
   return MHR_OK;
 }
+
+#ifdef MHR_STAMP
+extern "C" int mhr_debug_read_attn_stamps(unsigned long long* host16) {
+  return (int)hipMemcpyFromSymbol(host16, HIP_SYMBOL(g_attn_stamps), 16 * sizeof(unsigned long long));
+}
+#endif

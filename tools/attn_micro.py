@@ -1,0 +1,31 @@
+"""Micro-driver: HSTU attention fwd/bwd at the cfg1 shape (B=128, L=200, 8 heads x 32), with phase stamps when the
+stamped library (tools/stamp_nce.py build) is loaded via STAMP=1."""
+import ctypes, os, sys, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import mhr_amd.lib as L_
+if os.environ.get("STAMP"):
+    L_.LIB_PATH = os.path.join(ROOT, "tools", "_stamp", "libmhr_hip.so")
+from mhr_amd import ops
+B, L, H, hd = 128, 200, 8, 32
+D = H * hd
+g = torch.Generator(device="cuda").manual_seed(0)
+h = (torch.randn(B * L, 4 * D, device="cuda", generator=g) * 0.5).bfloat16()
+lens = torch.randint(L // 4, L + 1, (B,), device="cuda", generator=g)
+if os.environ.get("FULL"): lens[:] = L
+kv = (torch.arange(L, device="cuda")[None, :] >= (L - lens)[:, None]).to(torch.uint8).contiguous()   # front padded
+d_out = (torch.randn(B * L, D, device="cuda", generator=g) * 0.1).bfloat16()
+dh = torch.zeros_like(h)
+for _ in range(3):
+    out, act = ops.hstu_attn_fwd(h, kv, B, L, H, hd)
+    ops.hstu_attn_bwd(h, act, kv, d_out, dh, B, L, H, hd)
+torch.cuda.synchronize()
+ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+ev[0].record(); out, act = ops.hstu_attn_fwd(h, kv, B, L, H, hd); ev[1].record()
+ops.hstu_attn_bwd(h, act, kv, d_out, dh, B, L, H, hd); ev[2].record(); torch.cuda.synchronize()
+print(f"attn fwd {ev[0].elapsed_time(ev[1])*1e3:.1f} us  bwd {ev[1].elapsed_time(ev[2])*1e3:.1f} us  mean len {float(lens.float().mean()):.0f}")
+if os.environ.get("STAMP"):
+    dll = ctypes.CDLL(L_.LIB_PATH); buf = (ctypes.c_ulonglong * 16)()
+    assert dll.mhr_debug_read_attn_stamps(buf) == 0
+    names = ["stage Q,dO + sync", "pass A (dK,dV) incl. stores", "sync", "restage K,V + sync", "pass B (dQ) incl. stores"]
+    for i, nm in enumerate(names): print(f"  {nm:32s} {buf[i+1]-buf[i]:8d} cycles")
