@@ -180,8 +180,13 @@ int mhr_nce_fwd(const void* q_rows, const int32_t* q_idx, const void* p_rows, co
                 const float* logit_scale_dev, float thres,
                 float* sum_out, int32_t* n_valid, int32_t* rank,
                 void* qn_out, void* pn_out, uint32_t* supp_out, float* q_inv, float* p_inv, float* s_pos,
-                int log_group, void* stream);
-/* log_group: the one group whose n_valid / rank are wanted (-1 = every group); the other groups skip the counting. */
+                int log_group, float* u_out, void* stream);
+/* log_group: the one group whose n_valid / rank are wanted (-1 = every group); the other groups skip the counting.
+ * u_out (may be NULL; needs every saved tensor and tok_cap % 32 == 0): the TRAINING path.  [n_groups, tok_cap, dim] f32,
+ *   u_out[g, t, :] = sum_j keep_tj exp(scale (s_tj - 1)) negs[g, j, :]
+ * the unnormalised token-side gradient: d(loss_t)/d(qn_t) restricted to the negatives is exp(scale - lse_t) * scale *
+ * u_out[t].  It is accumulated by the forward itself (the gated tile goes straight back into the matrix pipe against
+ * the LDS-resident negatives), so the backward needs no second pass over the negatives for the token side. */
 /* The forward is split over negative ranges (grid.y) so that (token block, negative range) units fill the chip
  * without a tail: each unit adds its partial sum_j keep*exp(scale*(s_j - 1)) into sum_out[t] (and its counts into
  * n_valid / rank) with atomics - the caller zeroes sum_out, n_valid, rank - and mhr_nce_finalize produces
@@ -193,27 +198,27 @@ int mhr_nce_finalize(const float* sum, const float* s_pos, int n_groups, const i
  * prediction offset of each token; bucket_sum / bucket_cnt [n_groups, n_buckets] f32 (caller zeroes) receive
  * sum(loss) and the token count per (group, offset) - the reference takes the MEAN loss per offset before weighting
  * (hstu.py:697-700, 833-836), so no per-token tensor has to go back through an index_add. */
-/* Backward, two kernels (one launch each).  w[t] = d(total loss)/d(loss[t]) (0 for unused slots).  Inputs are the
- * forward's saved tensors; the false-negative decisions are replayed from `supp` instead of recomputing cos(p, neg),
- * and the transposed operands are read from the streamed tiles with ds_read_b64_tr_b16 (no transposed copies).
- * mhr_nce_bwd_tokens: token-stationary; accumulates the gradient w.r.t. the RAW query / positive rows
- *   (normalisation chain rule included) into dq_rows[q_idx[t], :] / dp_rows[p_idx[t], :] (f32, same row spaces as the
- *   forward's q_rows / p_rows; float atomics because several tokens share a row; caller zeroes) and atomically adds
- *   d(logit_scale parameter) into *d_logit_scale (may be NULL).  It also writes lw_out[t] = lse[t] log2(e) - log2(w[t])
- *   ([n_groups, tok_cap] f32, may be NULL), the per-token exponent offset mhr_nce_bwd_negs consumes:
- *   w exp(scale s - lse) = exp2(scale log2(e) s - lw).
- * mhr_nce_bwd_negs: negative-stationary; accumulates d_negs ([n_neg, dim] f32, float atomics across token splits;
- *   caller zeroes) w.r.t. the normalised negatives.  `lw` is the array mhr_nce_bwd_tokens wrote (launch that first).
- * Both require tok_cap % 32 == 0: the forward pads the last live 32-token tile of the saved state (zero qn / pn rows,
- * all-ones suppression words) so that whole token tiles stream without clamping. */
-int mhr_nce_bwd_tokens(const void* qn, const void* pn, const void* negs, const uint32_t* supp, int n_neg, int dim,
-                       int n_groups, const int32_t* n_tok_dev, int tok_cap, const float* logit_scale_dev,
+/* Backward, two kernels (one launch each).  w[t] = d(total loss)/d(loss[t]) (0 for unused slots); inputs are the
+ * forward's saved tensors.
+ * mhr_nce_bwd_tokens: row-wise.  From u (mhr_nce_fwd's u_out) it forms dQn_t = w_t exp(scale - lse_t) u_t, adds the
+ *   positive-pair term, applies the L2-normalisation chain rule and accumulates the gradient w.r.t. the RAW query /
+ *   positive rows into dq_rows[q_idx[t], :] / dp_rows[p_idx[t], :] (f32, same row spaces as the forward's q_rows /
+ *   p_rows; float atomics because several tokens share a row; caller zeroes); atomically adds d(logit_scale parameter)
+ *   into *d_logit_scale (may be NULL); writes lw_out[t] = lse[t] log2(e) - log2(w[t]) ([n_groups, tok_cap] f32, may be
+ *   NULL), the per-token exponent offset mhr_nce_bwd_negs consumes: w exp(scale s - lse) = exp2(scale log2(e) s - lw).
+ *   w: per-token [n_groups, tok_cap] when w_bucket is NULL; otherwise w is [n_groups, n_buckets] and token t of group g
+ *   weighs w[g, w_bucket[g, t]] (the gradient of a per-offset mean is constant inside a bucket).
+ * mhr_nce_bwd_negs: negative-stationary streaming GEMM; recomputes the logits, replays the false-negative decisions
+ *   from `supp`, and accumulates d_negs ([n_neg, dim] f32, float atomics across token splits; caller zeroes) w.r.t.
+ *   the normalised negatives.  `lw` is the array mhr_nce_bwd_tokens wrote (launch that first).  Requires
+ *   tok_cap % 32 == 0: the forward pads the last live 32-token tile of the saved state (zero qn / pn rows, all-ones
+ *   suppression words) so that whole token tiles stream without clamping. */
+int mhr_nce_bwd_tokens(const void* qn, const void* pn, const float* u, int dim, int n_groups,
+                       const int32_t* n_tok_dev, int tok_cap, const float* logit_scale_dev,
                        const float* lse, const float* w, const float* q_inv, const float* p_inv, const float* s_pos,
                        const int32_t* q_idx, const int32_t* p_idx,
                        float* dq_rows, float* dp_rows, float* d_logit_scale, float* lw_out,
                        const int32_t* w_bucket, int n_buckets, void* stream);
-/* w: per-token [n_groups, tok_cap] when w_bucket is NULL; otherwise w is [n_groups, n_buckets] and token t of group g
- * weighs w[g, w_bucket[g, t]] (the gradient of a per-offset mean is constant inside a bucket). */
 int mhr_nce_bwd_negs(const void* qn, const void* negs, const uint32_t* supp, int n_neg, int dim, int n_groups,
                      const int32_t* n_tok_dev, int tok_cap, const float* logit_scale_dev,
                      const float* lw, float* d_negs, void* stream);

@@ -121,6 +121,29 @@ __device__ __forceinline__ void load_norm_frags(const IT* src, bool live, int ha
   }
 }
 
+// exp2 of the gated logit with the per-token weight folded into the exponent, then masked BITWISE (dead rows may hold
+// NaN / garbage: x & 0 is 0 where 0.0f * NaN is not).  The bit tests are spelled as v_bfe_i32 + v_and / v_bfi: hipcc turns
+// the C form into v_lshlrev + v_cmp + s_nop + v_cndmask, which overflows the 32-cycle MFMA gap the epilogue lives in.
+// One asm block per element, with the bit extract BETWEEN v_exp_f32 and its consumer: on gfx940+ a VALU instruction
+// reading a transcendental result needs one instruction in between (hipcc inserts that for code it can see, not for
+// inline asm - back to back, the first lanes read the register before v_exp has written it).
+__device__ __forceinline__ float gate_alive(float s, float c1, float c0, uint32_t alive_bits, int pos) {   // bit = 1: keep
+  const float x = s * c1 - c0;
+  float g;
+  int m;
+  asm("v_exp_f32 %0, %2\n\tv_bfe_i32 %1, %3, %4, 1\n\tv_and_b32 %0, %0, %1"
+      : "=&v"(g), "=&v"(m) : "v"(x), "v"(alive_bits), "v"(pos));
+  return g;
+}
+__device__ __forceinline__ float gate_dead(float s, float c1, float c0, uint32_t dead_bits, int pos) {     // bit = 1: drop
+  const float x = s * c1 - c0;
+  float g;
+  int m;
+  asm("v_exp_f32 %0, %2\n\tv_bfe_i32 %1, %3, %4, 1\n\tv_bfi_b32 %0, %1, 0, %0"                          // (m & 0) | (~m & e)
+      : "=&v"(g), "=&v"(m) : "v"(x), "v"(dead_bits), "v"(pos));
+  return g;
+}
+
 // ------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------
@@ -281,6 +304,190 @@ __global__ __launch_bounds__(256, 2) void nce_fwd_kernel(const IT* __restrict__ 
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// forward fused with the token-side backward product (training path)
+// ------------------------------------------------------------------------------------------
+// dQn_i = sum_j G_ij n_j with G_ij = w_i keep_ij exp(scale s_ij - lse_i) factorises as
+//     dQn_i = w_i exp(scale - lse_i) * U_i,     U_i = sum_j keep_ij exp(scale (s_ij - 1)) n_j ,
+// and U_i needs neither lse nor w: it is the numerator that goes with the softmax denominator the forward already
+// accumulates (the flash-attention output accumulator without the running max - |logit| <= scale bounds the
+// exponent).  So the forward keeps a second accumulator U [32 tokens x D] per wave and feeds the gated tile
+// E = keep * exp(scale (s - 1)) (bf16, in registers) straight back into the matrix pipe against the SAME LDS tile
+// (transposed fragments).  The separate token-stationary backward kernel - a second full pass over the negatives
+// that recomputed every logit - disappears; what is left of it is a row-wise kernel (nce_bwd_rows_kernel below).
+// One wave per SIMD (U is 128 accumulator registers), 4-slot DMA ring, hand-ordered tile step (sg::tile_step, RF = 2):
+// the s and f MFMAs of tile t carry the exp / suppression epilogue of tile t-1 in their gaps.
+template <int NKS, typename IT, bool LOGS>
+__global__ __launch_bounds__(256, 1) void nce_fwd_u_kernel(const IT* __restrict__ q_rows, const int32_t* q_idx,
+                                                           const IT* __restrict__ p_rows, const int32_t* p_idx,
+                                                           const bf16_t* negs, int n_neg,
+                                                           const int32_t* n_tok_dev, int tok_cap,
+                                                           const float* __restrict__ logit_scale_dev, float thres,
+                                                           float* sum_out, int32_t* n_valid, int32_t* rank,
+                                                           bf16_t* qn_out, bf16_t* pn_out,
+                                                           uint32_t* supp_out, float* q_inv,
+                                                           float* p_inv, float* s_pos_out, int log_group,
+                                                           float* __restrict__ u_out) {
+  using T = sg::Tile<NKS>;
+  constexpr int ND = (NKS + 1) / 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  {
+    const int64_t grp = blockIdx.z, to = grp * tok_cap;
+    q_idx += to; p_idx += to; n_tok_dev += grp; negs += grp * (int64_t)((n_neg + 31) & ~31) * T::DIM; sum_out += to;
+    if (n_valid) n_valid += to;
+    if (rank) rank += to;
+    qn_out += to * T::DIM; pn_out += to * T::DIM; u_out += to * T::DIM;
+    supp_out += grp * (int64_t)((n_neg + 31) >> 5) * tok_cap;
+    q_inv += to; p_inv += to; s_pos_out += to;
+  }
+  const int n_tok = min(*n_tok_dev, tok_cap);
+  const int tok0 = blockIdx.x * 128;
+  if (tok0 >= n_tok) return;
+  const int n_tiles = (n_neg + 31) >> 5;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, half = lane >> 5;
+  const int tok = tok0 + wave * 32 + r;
+  const bool live = tok < n_tok;
+  const bool in_cap = tok < tok_cap;
+
+  bf16x8 frag[2][NKS];   // [0] = normalised query, [1] = normalised positive
+  float qi = 0.f, pi = 0.f;
+  {
+    const IT* qs = q_rows + (live ? (int64_t)q_idx[tok] * T::DIM : 0);
+    const IT* ps = p_rows + (live ? (int64_t)p_idx[tok] * T::DIM : 0);
+    qi = row_inv_norm<NKS, IT>(qs, live, half);
+    pi = row_inv_norm<NKS, IT>(ps, live, half);
+    load_norm_frags<NKS, IT>(qs, live, half, qi, frag[0]);
+    load_norm_frags<NKS, IT>(ps, live, half, pi, frag[1]);
+  }
+  float spos = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) spos += (float)frag[0][ks][i] * (float)frag[1][ks][i];
+  spos += __shfl_xor(spos, 32, 64);
+  // saved state; lanes past n_tok inside the block write zero rows / all-ones suppression words (see nce_fwd_kernel)
+  if (in_cap) {
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      const int k0 = ks * 16 + 8 * half;
+      *reinterpret_cast<bf16x8*>(qn_out + (int64_t)tok * T::DIM + k0) = frag[0][ks];
+      *reinterpret_cast<bf16x8*>(pn_out + (int64_t)tok * T::DIM + k0) = frag[1][ks];
+    }
+    if (live && half == 0) {
+      q_inv[tok] = qi;
+      p_inv[tok] = pi;
+      s_pos_out[tok] = spos;
+    }
+  }
+  const float scale = clamp_scale(logit_scale_dev);
+  const float c1 = scale * LOG2E;
+  const bool do_logs = LOGS && (log_group < 0 || (int)blockIdx.z == log_group);
+
+  f32x16 u[ND];
+#pragma unroll
+  for (int dc = 0; dc < ND; ++dc) u[dc] = sg::zero16();
+  float sum = 0.f;
+  int nv = 0, rk = 0;
+
+  using P = sg::DmaPieces<NKS>;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  P dp;
+  dp.init(wv, lane);
+  const int t_last = n_tiles - 1;
+  auto dma_k = [&](auto k_c, auto slot_c, int tn) {
+    dp.template piece<decltype(k_c)::value>(smem + decltype(slot_c)::value * T::BYTES,
+                                             reinterpret_cast<const char*>(negs) + (int64_t)tn * (32 * T::ROW_BYTES));
+  };
+  auto dma_all = [&](auto slot_c, int tn) {
+    auto f = [&](auto k_c) { dma_k(k_c, slot_c, tn); };
+    sg::static_for<P::PW>(f);
+  };
+  sg::LaneAddr<NKS> la;
+  la.init(lane);
+  sg::TrAddr<NKS> ta;
+  ta.init(la, smem);
+  sg::RowAddr<NKS> ra;
+  ra.init(la, smem);
+  // slot 3 is the "previous tile" of the first iteration (E = 0 there): make it finite
+  for (int o = threadIdx.x * 16; o < T::BYTES; o += 256 * 16) *reinterpret_cast<f32x4*>(smem + 3 * T::BYTES + o) = f32x4{0.f, 0.f, 0.f, 0.f};
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // published by the first ring barrier
+  dma_all(std::integral_constant<int, 0>{}, 0);
+  dma_all(std::integral_constant<int, 1>{}, min(1, t_last));
+  // S / f accumulators ping-pong by tile parity: tile t's epilogue runs one iteration later, straight from the other set
+  f32x16 sf[2][2] = {{sg::zero16(), sg::zero16()}, {sg::zero16(), sg::zero16()}};
+  uint32_t alive_prev = 0;               // live-row bits of the previous tile, pre-shifted by 4*half
+  // the loop exists twice (with / without the rank + n_valid counting of the logged group): a per-element runtime test
+  // would put a branch into every MFMA gap
+  auto run = [&](auto logs_c) {
+    constexpr bool WITH_LOGS = decltype(logs_c)::value;
+    sg::ring_loop<4>(n_tiles + 1, [&](auto slot_c, int i) {
+      constexpr int cur = decltype(slot_c)::value, nxt = (cur + 2) % 4, prv = (cur + 3) % 4, par = cur & 1;
+      sg::wait_vmcnt<P::PW>();
+      sg::ring_barrier();
+      const int tn = min(i + 2, t_last);
+      sf[par][0] = sg::zero16();
+      sf[par][1] = sg::zero16();
+      const f32x16& s_prev = sf[par ^ 1][0];
+      const f32x16& f_prev = sf[par ^ 1][1];
+      uint32_t sbits = 0;
+      sg::tile_step<NKS, ND, cur * T::BYTES, prv * T::BYTES, P::PW, 2>(
+          ra, ta, frag, sf[par], u, [](auto) {},
+          [&](int g) { return gate_alive(s_prev[g], c1, c1, alive_prev, (g & 3) + 8 * (g >> 2)); },
+          [&](auto k_c) { dma_k(k_c, std::integral_constant<int, nxt>{}, tn); },
+          [&](int g, float e) {
+            const int pos = (g & 3) + 8 * (g >> 2);
+            const int sm = f_prev[g] > thres ? -1 : 0;          // false negative: cos(positive, negative) > thres
+            const float ek = __builtin_bit_cast(float, __builtin_bit_cast(int, e) & ~sm);
+            sum += ek;
+            sbits = ((uint32_t)sm & (1u << pos)) | sbits;       // v_and_or_b32
+            if constexpr (WITH_LOGS) {
+              const int km = (((int)(alive_prev << (31 - pos))) >> 31) & ~sm;      // -1: a kept, live logit
+              nv -= km;
+              rk -= s_prev[g] > spos ? km : 0;
+            }
+            return ek;
+          });
+      // suppression word of the tile whose epilogue just ran (bit j = negative 32(t-1)+j suppressed for my token)
+      if (i > 0) {
+        uint32_t word = sbits << (4 * half);
+        word |= __shfl_xor(word, 32, 64);
+        if (in_cap && half == 0) supp_out[(int64_t)(i - 1) * tok_cap + tok] = live ? word : 0xFFFFFFFFu;
+      }
+      const int rem = n_neg - i * 32;
+      const uint32_t tail = rem >= 32 ? 0xFFFFFFFFu : (rem > 0 ? ~(0xFFFFFFFFu << rem) : 0u);
+      alive_prev = (live && i < n_tiles) ? (tail >> (4 * half)) : 0u;
+    });
+  };
+  if (do_logs) run(std::true_type{});
+  else run(std::false_type{});
+  sg::wait_vmcnt<0>();
+
+  sum += __shfl_xor(sum, 32, 64);
+  if (LOGS) {
+    nv += __shfl_xor(nv, 32, 64);
+    rk += __shfl_xor(rk, 32, 64);
+  }
+  if (live && half == 0) {
+    atomicAdd(sum_out + tok, sum);
+    if (do_logs) {
+      if (n_valid) atomicAdd(n_valid + tok, nv);
+      if (rank) atomicAdd(rank + tok, rk);
+    }
+  }
+  // U: rows (regs) = tokens wave*32 + crow(g, half), columns (lanes) = features dc*32 + r
+#pragma unroll
+  for (int g = 0; g < 16; ++g) {
+    const int tk = tok0 + wave * 32 + sg::crow(g, half);
+    if (tk < n_tok) {
+#pragma unroll
+      for (int dc = 0; dc < ND; ++dc) {
+        const int d = dc * 32 + r;
+        if (d < T::DIM) u_out[(int64_t)tk * T::DIM + d] = u[dc][g];
+      }
+    }
+  }
+}
+
 // lse / loss from the partial sums of all negative ranges
 constexpr int MAX_BUCKETS = 64;
 __global__ __launch_bounds__(256) void nce_finalize_kernel(const float* sum, const float* s_pos,
@@ -343,34 +550,13 @@ __device__ __forceinline__ float half_sum(float v) {   // sum over the 32 lanes 
   return v;
 }
 
-// exp2 of the gated logit with the per-token weight folded into the exponent, then masked BITWISE (dead rows may hold
-// NaN / garbage: x & 0 is 0 where 0.0f * NaN is not).  The bit tests are spelled as v_bfe_i32 + v_and / v_bfi: hipcc turns
-// the C form into v_lshlrev + v_cmp + s_nop + v_cndmask, which overflows the 32-cycle MFMA gap the epilogue lives in.
-// One asm block per element, with the bit extract BETWEEN v_exp_f32 and its consumer: on gfx940+ a VALU instruction
-// reading a transcendental result needs one instruction in between (hipcc inserts that for code it can see, not for
-// inline asm - back to back, the first lanes read the register before v_exp has written it).
-__device__ __forceinline__ float gate_alive(float s, float c1, float c0, uint32_t alive_bits, int pos) {   // bit = 1: keep
-  const float x = s * c1 - c0;
-  float g;
-  int m;
-  asm("v_exp_f32 %0, %2\n\tv_bfe_i32 %1, %3, %4, 1\n\tv_and_b32 %0, %0, %1"
-      : "=&v"(g), "=&v"(m) : "v"(x), "v"(alive_bits), "v"(pos));
-  return g;
-}
-__device__ __forceinline__ float gate_dead(float s, float c1, float c0, uint32_t dead_bits, int pos) {     // bit = 1: drop
-  const float x = s * c1 - c0;
-  float g;
-  int m;
-  asm("v_exp_f32 %0, %2\n\tv_bfe_i32 %1, %3, %4, 1\n\tv_bfi_b32 %0, %1, 0, %0"                          // (m & 0) | (~m & e)
-      : "=&v"(g), "=&v"(m) : "v"(x), "v"(dead_bits), "v"(pos));
-  return g;
-}
-
-template <int NKS>
-__global__ __launch_bounds__(256, 1) void nce_bwd_q_kernel(const bf16_t* qn, const bf16_t* pn,
-                                                           const bf16_t* negs, const uint32_t* supp,
-                                                           int n_neg, const int32_t* n_tok_dev, int tok_cap,
-                                                           int tiles_per_split, const float* __restrict__ logit_scale_dev,
+// Row-wise remainder of the token-side backward: dQn_i = w_i exp(scale - lse_i) U_i (U from nce_fwd_u_kernel), the
+// positive-pair term, the L2-normalisation chain rule, d(logit_scale), and the accumulation into the shared source
+// rows.  One wave per token, four tokens in flight per wave; lanes cover the feature dim 64 at a time (256-B float
+// atomic segments).  Also writes lw = lse log2(e) - log2(w) for nce_bwd_n.
+__global__ __launch_bounds__(256) void nce_bwd_rows_kernel(const bf16_t* qn, const bf16_t* pn, const float* u, int dim,
+                                                           const int32_t* n_tok_dev, int tok_cap,
+                                                           const float* __restrict__ logit_scale_dev,
                                                            const float* lse, const float* w,
                                                            const float* q_inv, const float* p_inv,
                                                            const float* s_pos, const int32_t* q_idx,
@@ -378,186 +564,79 @@ __global__ __launch_bounds__(256, 1) void nce_bwd_q_kernel(const bf16_t* qn, con
                                                            float* __restrict__ dp_rows, float* __restrict__ d_logit_scale,
                                                            float* __restrict__ lw_out, const int32_t* __restrict__ w_bucket,
                                                            int n_buckets) {
-  using T = sg::Tile<NKS>;
-  constexpr int ND = (NKS + 1) / 2;          // 32-column chunks of the feature dim
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* tiles = smem;               // 4 x T::BYTES, then 4 x 1 KiB of suppression words
+  constexpr int TB = 4;            // tokens in flight per wave
+  constexpr int NC = 4;            // 64-column chunks (dim <= 256)
   {
     const int64_t grp = blockIdx.z, to = grp * tok_cap;
-    qn += to * T::DIM; pn += to * T::DIM; negs += grp * (int64_t)((n_neg + 31) & ~31) * T::DIM;
-    supp += grp * (int64_t)((n_neg + 31) >> 5) * tok_cap;
+    qn += to * dim; pn += to * dim; u += to * dim;
     n_tok_dev += grp; lse += to; q_inv += to; p_inv += to; s_pos += to; q_idx += to; p_idx += to;
     if (lw_out) lw_out += to;
     if (w_bucket) { w_bucket += to; w += grp * n_buckets; } else { w += to; }
   }
-  // loss weight of a token: its own entry, or its bucket's (the loss is a mean per (group, prediction offset))
-  auto w_of = [&](int t) { return w_bucket ? w[w_bucket[t]] : w[t]; };
   const int n_tok = min(*n_tok_dev, tok_cap);
-  const int tok0 = blockIdx.x * 128;
-  if (tok0 >= n_tok) return;
-  const int n_tiles = (n_neg + 31) >> 5;
-  const int t_begin = blockIdx.y * tiles_per_split, t_end = min(n_tiles, t_begin + tiles_per_split);
-  if (t_begin >= t_end) return;
-  const bool first_split = blockIdx.y == 0;       // owns the positive-pair terms
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, half = lane >> 5;
-  const int tok = tok0 + wave * 32 + r;
-  const bool live = tok < n_tok;
-
-  bf16x8 frag[1][NKS];
-#pragma unroll
-  for (int ks = 0; ks < NKS; ++ks)
-    frag[0][ks] = live ? *reinterpret_cast<const bf16x8*>(qn + (int64_t)tok * T::DIM + ks * 16 + 8 * half) : sg::zero8();
+  const int lane = threadIdx.x & 63;
+  const int wave_g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), n_waves = gridDim.x * (blockDim.x >> 6);
   const float scale = clamp_scale(logit_scale_dev);
-  const float c1 = scale * LOG2E;
-  // g_ij = w_i exp(scale s_ij - lse_i) = exp2(c1 s_ij - c0_i),  c0 = lse log2(e) - log2(w)   (w = 0 -> c0 = +inf -> g = 0)
-  const float c0 = live ? lse[tok] * LOG2E - __log2f(w_of(tok)) : 0.f;
-  if (lw_out && live && first_split && half == 0) lw_out[tok] = c0;
-
-  f32x16 dq[ND];
+  float dls = 0.f;
+  for (int t0 = wave_g * TB; t0 < n_tok; t0 += n_waves * TB) {
+    float qv[TB][NC], pv[TB][NC], uv[TB][NC];
+    float wi[TB], sp[TB], ls[TB], iq[TB], ip[TB];
+    int qi[TB], pi[TB];
 #pragma unroll
-  for (int dc = 0; dc < ND; ++dc) dq[dc] = sg::zero16();
-
-  // Negative tiles + this wave's 32 suppression words per tile stream through a 4-slot LDS-DMA ring.  Steady state is
-  // branch-free: every iteration waits `vmcnt(PW+1)` (tile i landed, tile i+1 may be in flight), issues the PW+1 DMA
-  // instructions of tile min(i+2, last) - redundant copies of the last tile at the tail keep the count uniform - and
-  // runs one sg::bwd_tile step: S(t) MFMAs with the epilogue of S(t-1) in their gaps, then dQ += G(t-1) . N(t-1) on
-  // the previous slot with the DMA instructions in ITS gaps.
-  using P = sg::DmaPieces<NKS>;
-  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  unsigned char* words = smem + 4 * T::BYTES;                       // 4 x [4 waves][64] uint32
-  P dp;
-  dp.init(wv, lane);
-  const uint32_t tok_off = (uint32_t)min(tok, tok_cap - 1) * 4u;
-  const int t_last = t_end - 1;
-  auto dma_k = [&](auto k_c, auto slot_c, int tn) {
-    constexpr int k = decltype(k_c)::value, slot = decltype(slot_c)::value;
-    if constexpr (k < P::PW) {   // rows past n_neg are the pool's padding rows (finite); their columns are masked by the tail bits
-      dp.template piece<k>(tiles + slot * T::BYTES, reinterpret_cast<const char*>(negs) + (int64_t)tn * (32 * T::ROW_BYTES));
-    } else {
-      sg::dma_words(reinterpret_cast<const char*>(supp) + (int64_t)tn * tok_cap * 4 + tok_off, words + slot * 1024 + wv * 256);
-    }
-  };
-  auto dma_all = [&](auto slot_c, int tn) {
-    auto f = [&](auto k_c) { dma_k(k_c, slot_c, tn); };
-    sg::static_for<P::PW + 1>(f);
-  };
-  sg::LaneAddr<NKS> la;
-  la.init(lane);
-  sg::TrAddr<NKS> ta;
-  ta.init(la, tiles);
-  sg::RowAddr<NKS> ra;
-  ra.init(la, tiles);
-  const uint32_t sw_addr = sg::lds_addr(words) + wv * 256 + lane * 4;
-  // slot 3 is the "previous tile" of the first iteration (G = 0 there): make it finite
-  for (int o = threadIdx.x * 16; o < T::BYTES; o += 256 * 16) *reinterpret_cast<f32x4*>(tiles + 3 * T::BYTES + o) = f32x4{0.f, 0.f, 0.f, 0.f};
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // published by the first ring barrier
-  const int n_loc = t_end - t_begin;
-  dma_all(std::integral_constant<int, 0>{}, t_begin);
-  dma_all(std::integral_constant<int, 1>{}, min(t_begin + 1, t_last));
-  f32x16 s_prev = sg::zero16();          // S of the previous tile
-  uint32_t alive_prev = 0;               // its live-row bits, pre-shifted by 4*half (none before the first tile: G = 0)
-  STAMP_DECL
-  STAMP(-1)
-  // one extra iteration drains the pipeline (its S runs on a redundant copy of the last tile and is discarded)
-  sg::ring_loop<4>(n_loc + 1, [&](auto slot_c, int i) {
-    constexpr int cur = decltype(slot_c)::value, nxt = (cur + 2) % 4, prv = (cur + 3) % 4;
-    const int t = t_begin + i;
-    STAMP(5)
-    sg::wait_vmcnt<P::PW + 1>();
-#if !(defined(MHR_STAMP) && defined(EXP_NOBAR))
-    sg::ring_barrier();
-#endif
-    uint32_t sw;
-    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(sw) : "v"(sw_addr), "n"(cur * 1024));   // done before bwd_tile's first wait
-    const int tn = min(t + 2, t_last);
-    f32x16 acc = sg::zero16();
-    sg::bwd_tile<NKS, ND, cur * T::BYTES, prv * T::BYTES, P::PW + 1>(
-        ra, ta, frag, acc, dq, [&](auto n_c) { sg::wait_lgkm_values<decltype(n_c)::value>(sw); },
-        [&](int g) { return gate_alive(s_prev[g], c1, c0, alive_prev, (g & 3) + 8 * (g >> 2)); },
-#if defined(MHR_STAMP) && defined(EXP_NODMA)
-        [&](auto) {});
-    (void)tn;
-#else
-        [&](auto k_c) { dma_k(k_c, std::integral_constant<int, nxt>{}, tn); });
-#endif
-    // rows past n_neg and suppressed pairs are dead; so is everything of a dead token or of the drain iteration
-    const int rem = n_neg - t * 32;
-    const uint32_t dead = sw | (rem >= 32 ? 0u : (0xFFFFFFFFu << (rem > 0 ? rem : 0)));
-    alive_prev = (live && i < n_loc) ? (~dead >> (4 * half)) : 0u;
-    s_prev = acc;
-  });
-  STAMP(5)
-  sg::wait_vmcnt<0>();
-
-  STAMP_FLUSH
-  // ---- finish: positive term, L2-normalisation chain rule, accumulation into the source rows -------
-  // dq[dc][g]: row (reg) = token wave*32 + crow(g,half), column (lane) = feature dc*32 + r
-  // Memory latency is taken in batches: lane j < 16 of each half fetches the per-token scalars of accumulator row j
-  // (7 loads per lane, broadcast by shuffles), and the normalised rows are loaded four tokens at a time before any of
-  // them is used - the row-by-row form spent ~40 % of the kernel waiting on 48 dependent round trips.
-  float dls = 0.f;   // d(loss)/d(scale) of my half's 16 tokens: sum_j g_ij s_ij = qn_i . dQn_i, plus the positive term
-  const int my_row = tok0 + wave * 32 + sg::crow(lane & 15, half);
-  const bool my_live = my_row < n_tok;
-  const float r_w = my_live ? w_of(my_row) : 0.f, r_sp = my_live ? s_pos[my_row] : 0.f, r_lse = my_live ? lse[my_row] : 0.f;
-  const float r_iq = my_live ? q_inv[my_row] : 0.f, r_ip = my_live ? p_inv[my_row] : 0.f;
-  const int r_qi = my_live ? q_idx[my_row] : 0, r_pi = my_live ? p_idx[my_row] : 0;
-  const float r_coef = (my_live && first_split) ? r_w * (__expf(scale * r_sp - r_lse) - 1.0f) : 0.f;   // w (p_pos - 1)
-  const int src0 = lane & 32;
-#pragma unroll
-  for (int g0 = 0; g0 < 16; g0 += 4) {
-    float qv[4][ND], pv[4][ND];
-#pragma unroll
-    for (int gi = 0; gi < 4; ++gi) {
-      const int tk = tok0 + wave * 32 + sg::crow(g0 + gi, half);
+    for (int b = 0; b < TB; ++b) {
+      const int tk = t0 + b;
       const bool tl = tk < n_tok;
+      wi[b] = tl ? (w_bucket ? w[w_bucket[tk]] : w[tk]) : 0.f;
+      sp[b] = tl ? s_pos[tk] : 0.f;
+      ls[b] = tl ? lse[tk] : 0.f;
+      iq[b] = tl ? q_inv[tk] : 0.f;
+      ip[b] = tl ? p_inv[tk] : 0.f;
+      qi[b] = tl ? q_idx[tk] : 0;
+      pi[b] = tl ? p_idx[tk] : 0;
 #pragma unroll
-      for (int dc = 0; dc < ND; ++dc) {
-        const int d = dc * 32 + r;
-        const bool ok = tl && d < T::DIM;
-        qv[gi][dc] = ok ? (float)qn[(int64_t)tk * T::DIM + d] : 0.f;
-        pv[gi][dc] = ok ? (float)pn[(int64_t)tk * T::DIM + d] : 0.f;
+      for (int c = 0; c < NC; ++c) {
+        const int d = c * 64 + lane;
+        const bool ok = tl && d < dim;
+        qv[b][c] = ok ? (float)qn[(int64_t)tk * dim + d] : 0.f;
+        pv[b][c] = ok ? (float)pn[(int64_t)tk * dim + d] : 0.f;
+        uv[b][c] = ok ? u[(int64_t)tk * dim + d] : 0.f;
       }
     }
 #pragma unroll
-    for (int gi = 0; gi < 4; ++gi) {
-      const int g = g0 + gi;
-      const int tk = tok0 + wave * 32 + sg::crow(g, half);
-      const bool tl = tk < n_tok;
-      const float coef = __shfl(r_coef, src0 + g, 64), sp = __shfl(r_sp, src0 + g, 64);
-      float dqn[ND], dpn[ND];
+    for (int b = 0; b < TB; ++b) {
+      const int tk = t0 + b;
+      if (tk >= n_tok) break;
+      const float a = wi[b] * __expf(scale - ls[b]);                          // G_ij = a * E_ij
+      const float coef = wi[b] * (__expf(scale * sp[b] - ls[b]) - 1.0f);     // w (p_pos - 1)
+      if (lw_out && lane == 0) lw_out[tk] = ls[b] * LOG2E - __log2f(wi[b]);
+      float dqn[NC], dpn[NC];
       float dot_q = 0.f, dot_p = 0.f, dot_raw = 0.f;
 #pragma unroll
-      for (int dc = 0; dc < ND; ++dc) {
-        const bool ok = tl && dc * 32 + r < T::DIM;
-        dqn[dc] = ok ? scale * (dq[dc][g] + coef * pv[gi][dc]) : 0.f;
-        dpn[dc] = scale * coef * qv[gi][dc];
-        dot_raw += ok ? qv[gi][dc] * dq[dc][g] : 0.f;
-        dot_q += qv[gi][dc] * dqn[dc];
-        dot_p += pv[gi][dc] * dpn[dc];
+      for (int c = 0; c < NC; ++c) {
+        const float raw = a * uv[b][c];
+        dqn[c] = scale * (raw + coef * pv[b][c]);
+        dpn[c] = scale * coef * qv[b][c];
+        dot_raw += qv[b][c] * raw;
+        dot_q += qv[b][c] * dqn[c];
+        dot_p += pv[b][c] * dpn[c];
       }
-      dot_q = half_sum(dot_q);
-      dot_p = half_sum(dot_p);
-      dls += half_sum(dot_raw) + coef * sp;
-      const float iq = __shfl(r_iq, src0 + g, 64), ip = __shfl(r_ip, src0 + g, 64);
-      const int qi = __shfl(r_qi, src0 + g, 64), pi = __shfl(r_pi, src0 + g, 64);
-      if (tl) {
-        // several tokens share a head row (offsets p of one segment) or a target row (l + 1 + p = const): accumulate
-        // with float atomics, one 128-byte segment per wave half per instruction (full-rate shape)
-        float* qdst = dq_rows + (int64_t)qi * T::DIM;
-        float* pdst = dp_rows + (int64_t)pi * T::DIM;
+      dot_q = wave_sum(dot_q);
+      dot_p = wave_sum(dot_p);
+      dls += wave_sum(dot_raw) + coef * sp[b];      // sum_j g_ij s_ij = qn_i . dQn_i, plus the positive term
+      // several tokens share a head row (offsets p of one segment) or a target row (l + 1 + p = const): float atomics
+      float* qdst = dq_rows + (int64_t)qi[b] * dim;
+      float* pdst = dp_rows + (int64_t)pi[b] * dim;
 #pragma unroll
-        for (int dc = 0; dc < ND; ++dc) {
-          const int d = dc * 32 + r;
-          if (d < T::DIM) {
-            atomicAdd(qdst + d, (dqn[dc] - qv[gi][dc] * dot_q) * iq);
-            if (first_split) atomicAdd(pdst + d, (dpn[dc] - pv[gi][dc] * dot_p) * ip);
-          }
+      for (int c = 0; c < NC; ++c) {
+        const int d = c * 64 + lane;
+        if (d < dim) {
+          atomicAdd(qdst + d, (dqn[c] - qv[b][c] * dot_q) * iq[b]);
+          atomicAdd(pdst + d, (dpn[c] - pv[b][c] * dot_p) * ip[b]);
         }
       }
     }
   }
-  dls += __shfl_xor(dls, 32, 64);   // the two halves hold different tokens
-  if (lane == 0 && d_logit_scale) atomicAdd(d_logit_scale, dls * scale);   // d/d(param) with scale = exp(param)
+  if (lane == 0 && d_logit_scale && dls != 0.f) atomicAdd(d_logit_scale, dls * scale);   // d/d(param), scale = exp(param)
 }
 
 // ------------------------------------------------------------------------------------------
@@ -718,9 +797,11 @@ extern "C" int mhr_nce_fwd(const void* q_rows, const int32_t* q_idx, const void*
                            const void* negs, int n_neg, int dim, int n_groups, const int32_t* n_tok_dev, int tok_cap,
                            const float* logit_scale_dev, float thres, float* sum_out, int32_t* n_valid, int32_t* rank,
                            void* qn_out, void* pn_out, uint32_t* supp_out, float* q_inv, float* p_inv, float* s_pos,
-                           int log_group, void* stream) {
+                           int log_group, float* u_out, void* stream) {
   MHR_REQUIRE(q_rows && q_idx && p_rows && p_idx && negs && n_tok_dev && logit_scale_dev && sum_out && s_pos,
               "nce_fwd: null pointer");
+  MHR_REQUIRE(!u_out || (qn_out && pn_out && supp_out && q_inv && p_inv && tok_cap % 32 == 0),
+              "nce_fwd: u_out (fused training path) needs every saved tensor and tok_cap %% 32 == 0");
   int nks;
   MHR_REQUIRE(nks_for(dim, nks), "nce_fwd: dim=%d unsupported (16/32/64/128/256)", dim);
   MHR_REQUIRE(n_neg > 0 && tok_cap > 0 && n_groups >= 1 && n_groups <= 65535, "nce_fwd: bad sizes");
@@ -732,6 +813,26 @@ extern "C" int mhr_nce_fwd(const void* q_rows, const int32_t* q_idx, const void*
 #define ARGS(IT)                                                                                                         \
   (const IT*)q_rows, q_idx, (const IT*)p_rows, p_idx, (const bf16_t*)negs, n_neg, n_tok_dev, tok_cap, logit_scale_dev,   \
       thres, tps, sum_out, n_valid, rank, (bf16_t*)qn_out, (bf16_t*)pn_out, supp_out, q_inv, p_inv, s_pos, log_group
+#define LU_(NKS)                                                                                                         \
+  {                                                                                                                      \
+    size_t lds = 4 * sg::Tile<NKS>::BYTES;                                                                               \
+    const dim3 gu((tok_cap + 127) / 128, 1, n_groups);                                                                   \
+    if (io_dtype == MHR_BF16) {                                                                                          \
+      if (logs) hipLaunchKernelGGL((nce_fwd_u_kernel<NKS, bf16_t, true>), gu, dim3(256), lds, s, UARGS(bf16_t));         \
+      else hipLaunchKernelGGL((nce_fwd_u_kernel<NKS, bf16_t, false>), gu, dim3(256), lds, s, UARGS(bf16_t));             \
+    } else {                                                                                                             \
+      if (logs) hipLaunchKernelGGL((nce_fwd_u_kernel<NKS, float, true>), gu, dim3(256), lds, s, UARGS(float));           \
+      else hipLaunchKernelGGL((nce_fwd_u_kernel<NKS, float, false>), gu, dim3(256), lds, s, UARGS(float));               \
+    }                                                                                                                    \
+  }
+#define UARGS(IT)                                                                                                        \
+  (const IT*)q_rows, q_idx, (const IT*)p_rows, p_idx, (const bf16_t*)negs, n_neg, n_tok_dev, tok_cap, logit_scale_dev,   \
+      thres, sum_out, n_valid, rank, (bf16_t*)qn_out, (bf16_t*)pn_out, supp_out, q_inv, p_inv, s_pos, log_group, u_out
+  if (u_out) {
+    NKS_SWITCH(nks, LU_);
+    MHR_CHECK_LAUNCH("nce_fwd (fused)");
+    return MHR_OK;
+  }
 #define L_(NKS)                                                                                                          \
   {                                                                                                                      \
     size_t lds = 3 * sg::Tile<NKS>::BYTES;                                                                               \
@@ -745,7 +846,9 @@ extern "C" int mhr_nce_fwd(const void* q_rows, const int32_t* q_idx, const void*
   }
   NKS_SWITCH(nks, L_);
 #undef L_
+#undef LU_
 #undef ARGS
+#undef UARGS
   MHR_CHECK_LAUNCH("nce_fwd");
   return MHR_OK;
 }
@@ -763,31 +866,21 @@ extern "C" int mhr_nce_finalize(const float* sum, const float* s_pos, int n_grou
   return MHR_OK;
 }
 
-extern "C" int mhr_nce_bwd_tokens(const void* qn, const void* pn, const void* negs, const uint32_t* supp, int n_neg, int dim,
-                                  int n_groups, const int32_t* n_tok_dev, int tok_cap, const float* logit_scale_dev, const float* lse,
+extern "C" int mhr_nce_bwd_tokens(const void* qn, const void* pn, const float* u, int dim, int n_groups,
+                                  const int32_t* n_tok_dev, int tok_cap, const float* logit_scale_dev, const float* lse,
                                   const float* w, const float* q_inv, const float* p_inv, const float* s_pos,
                                   const int32_t* q_idx, const int32_t* p_idx, float* dq_rows, float* dp_rows,
                                   float* d_logit_scale, float* lw_out, const int32_t* w_bucket, int n_buckets, void* stream) {
-  MHR_REQUIRE(qn && pn && negs && supp && n_tok_dev && logit_scale_dev && lse && w && q_inv && p_inv && s_pos,
+  MHR_REQUIRE(qn && pn && u && n_tok_dev && logit_scale_dev && lse && w && q_inv && p_inv && s_pos,
               "nce_bwd_tokens: null input pointer");
   MHR_REQUIRE(q_idx && p_idx && dq_rows && dp_rows, "nce_bwd_tokens: null index/output pointer");
-  int nks;
-  MHR_REQUIRE(nks_for(dim, nks), "nce_bwd_tokens: dim=%d unsupported (16/32/64/128/256)", dim);
-  MHR_REQUIRE(n_neg > 0 && tok_cap > 0 && n_groups >= 1 && n_groups <= 65535, "nce_bwd_tokens: bad sizes");
-  MHR_REQUIRE(tok_cap % 32 == 0, "nce_bwd_tokens: tok_cap=%d must be a multiple of 32", tok_cap);
-  hipStream_t s = (hipStream_t)stream;
-  int tps;
-  const int splits = nce_splits((n_neg + 31) / 32, n_groups, 2, tps);   // every range repeats the atomic epilogue
-  const dim3 grid_q((tok_cap + 127) / 128, splits, n_groups);
-#define L_(NKS)                                                                                                          \
-  {                                                                                                                      \
-    size_t lds_q = 4 * sg::Tile<NKS>::BYTES + 4 * 1024;                                                                  \
-    hipLaunchKernelGGL((nce_bwd_q_kernel<NKS>), grid_q, dim3(256), lds_q, s, (const bf16_t*)qn, (const bf16_t*)pn,       \
-                       (const bf16_t*)negs, supp, n_neg, n_tok_dev, tok_cap, tps, logit_scale_dev, lse, w, q_inv, p_inv, \
-                       s_pos, q_idx, p_idx, dq_rows, dp_rows, d_logit_scale, lw_out, w_bucket, n_buckets);               \
-  }
-  NKS_SWITCH(nks, L_);
-#undef L_
+  MHR_REQUIRE(dim > 0 && dim <= 256, "nce_bwd_tokens: dim=%d unsupported (<= 256)", dim);
+  MHR_REQUIRE(tok_cap > 0 && n_groups >= 1 && n_groups <= 65535, "nce_bwd_tokens: bad sizes");
+  int blocks = (tok_cap + 15) / 16;                 // 4 waves x 4 tokens per pass
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(nce_bwd_rows_kernel, dim3(blocks, 1, n_groups), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qn,
+                     (const bf16_t*)pn, u, dim, n_tok_dev, tok_cap, logit_scale_dev, lse, w, q_inv, p_inv, s_pos, q_idx, p_idx,
+                     dq_rows, dp_rows, d_logit_scale, lw_out, w_bucket, n_buckets);
   MHR_CHECK_LAUNCH("nce_bwd_tokens");
   return MHR_OK;
 }

@@ -485,9 +485,18 @@ __device__ __forceinline__ void wait_lgkm_values(V&... v) {
   (redefine(v), ...);
 }
 
-template <int NKS, int ND, int OFF_CUR, int OFF_PRV, int NDMA, typename Ready, typename Epi, typename DmaFn>
-__device__ __forceinline__ void bwd_tile(const RowAddr<NKS>& ra, const TrAddr<NKS>& ta, const bf16x8 (&frag)[1][NKS],
-                                         f32x16& acc, f32x16 (&out)[ND], Ready ready, Epi epi, DmaFn dma) {
+struct EpiIdentity {
+  __device__ __forceinline__ float operator()(int, float g) const { return g; }
+};
+
+// RF = 1: one stationary fragment set (the backward kernels).  RF = 2: two sets sharing every row-fragment read (the
+// fused forward: s = q.n and f = p.n); the per-element epilogue is then split over the two MFMA gaps of a k-step:
+// epi(e) after the first MFMA, epi2(e, value) after the second.
+template <int NKS, int ND, int OFF_CUR, int OFF_PRV, int NDMA, int RF, typename Ready, typename Epi, typename DmaFn,
+          typename Epi2 = EpiIdentity>
+__device__ __forceinline__ void tile_step(const RowAddr<NKS>& ra, const TrAddr<NKS>& ta, const bf16x8 (&frag)[RF][NKS],
+                                          f32x16 (&accs)[RF], f32x16 (&out)[ND], Ready ready, Epi epi, DmaFn dma,
+                                          Epi2 epi2 = Epi2{}) {
   using T = Tile<NKS>;
   constexpr int PA = NKS < 4 ? NKS : 4;
   constexpr int PT = ND < 2 ? ND : 2;
@@ -518,11 +527,25 @@ __device__ __forceinline__ void bwd_tile(const RowAddr<NKS>& ra, const TrAddr<NK
     constexpr int a_after = (ks + PA < NKS ? ks + PA : NKS - 1) - ks;
     constexpr int t_chunks = ks > T0 ? ks - T0 : 0;
     wait_lgkm1<a_after + 4 * t_chunks>(a[ks % (PA + 1)]);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[ks % (PA + 1)]), frag[0][ks], acc, 0, 0, 0);
+    const bf16x8 av = __builtin_bit_cast(bf16x8, a[ks % (PA + 1)]);
+    accs[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, frag[0][ks], accs[0], 0, 0, 0);
+    if constexpr (RF == 1) {
 #pragma unroll
-    for (int e = ks * EPK; e < ks * EPK + EPK && e < 16; ++e) {
-      const float g = epi(e);
-      if (e & 1) pk[e >> 1] = cvt_pk_bf16(even, g); else even = g;
+      for (int e = ks * EPK; e < ks * EPK + EPK && e < 16; ++e) {
+        const float g = epi(e);
+        if (e & 1) pk[e >> 1] = cvt_pk_bf16(even, g); else even = g;
+      }
+    } else {
+      float half_done[EPK];
+#pragma unroll
+      for (int e = ks * EPK; e < ks * EPK + EPK && e < 16; ++e) half_done[e - ks * EPK] = epi(e);
+      __builtin_amdgcn_sched_barrier(0);
+      accs[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, frag[1][ks], accs[1], 0, 0, 0);
+#pragma unroll
+      for (int e = ks * EPK; e < ks * EPK + EPK && e < 16; ++e) {
+        const float g = epi2(e, half_done[e - ks * EPK]);
+        if (e & 1) pk[e >> 1] = cvt_pk_bf16(even, g); else even = g;
+      }
     }
     if constexpr (ks >= T0) issue_t(std::integral_constant<int, ks - T0>{});
     __builtin_amdgcn_sched_barrier(0);
@@ -551,6 +574,14 @@ __device__ __forceinline__ void bwd_tile(const RowAddr<NKS>& ra, const TrAddr<NK
     if constexpr (k >= 2 * ND) dma(k_c);
   };
   static_for<NDMA>(rest);
+}
+
+template <int NKS, int ND, int OFF_CUR, int OFF_PRV, int NDMA, typename Ready, typename Epi, typename DmaFn>
+__device__ __forceinline__ void bwd_tile(const RowAddr<NKS>& ra, const TrAddr<NKS>& ta, const bf16x8 (&frag)[1][NKS],
+                                         f32x16& acc, f32x16 (&out)[ND], Ready ready, Epi epi, DmaFn dma) {
+  f32x16 accs[1] = {acc};
+  tile_step<NKS, ND, OFF_CUR, OFF_PRV, NDMA, 1>(ra, ta, frag, accs, out, ready, epi, dma);
+  acc = accs[0];
 }
 
 // Runs body(slot_constant, i) for i = 0..n-1 with slot = i % DEPTH as a COMPILE-TIME constant (the loop is unrolled

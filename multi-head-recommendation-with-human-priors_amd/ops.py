@@ -262,7 +262,7 @@ class NceSaved:
     """Tensors the forward keeps for the backward (all preallocated at token capacity)."""
     __slots__ = ("qn", "pn", "supp", "q_inv", "p_inv", "s_pos", "lse", "loss", "n_valid", "rank", "negs",
                  "n_tok_dev", "tok_cap", "cap", "thres", "dim", "n_neg", "groups", "q_idx", "p_idx", "bucket_idx", "n_buckets",
-                 "bucket_sum", "bucket_cnt")
+                 "bucket_sum", "bucket_cnt", "u")
 
 
 def nce_fwd(q_rows, q_idx, p_rows, p_idx, negs, n_tok_dev, tok_cap, logit_scale, thres=0.99, want_logs=False,
@@ -309,8 +309,9 @@ def nce_fwd(q_rows, q_idx, p_rows, p_idx, negs, n_tok_dev, tok_cap, logit_scale,
         sv.supp = torch.empty(G, (n_neg + 31) // 32, cap, dtype=torch.int32, device=dev)
         sv.q_inv = torch.empty(G, cap, dtype=torch.float32, device=dev)
         sv.p_inv = torch.empty(G, cap, dtype=torch.float32, device=dev)
+        sv.u = torch.empty(G, cap, D, dtype=torch.float32, device=dev)      # unnormalised token-side gradient (fused forward)
     else:
-        sv.qn = sv.pn = sv.supp = sv.q_inv = sv.p_inv = None
+        sv.qn = sv.pn = sv.supp = sv.q_inv = sv.p_inv = sv.u = None
     sv.negs = negs
     sv.n_tok_dev, sv.tok_cap, sv.cap, sv.thres, sv.dim, sv.n_neg, sv.groups = n_tok_dev, tok_cap, cap, float(thres), D, n_neg, G
     ssum = torch.zeros(G, cap, dtype=torch.float32, device=dev)
@@ -318,7 +319,7 @@ def nce_fwd(q_rows, q_idx, p_rows, p_idx, negs, n_tok_dev, tok_cap, logit_scale,
     _timed_call("mhr_nce_fwd", q_rows.data_ptr(), q_idx.data_ptr(), p_rows.data_ptr(), p_idx.data_ptr(), _dt(q_rows),
                 negs.data_ptr(), n_neg, D, G, n_tok_dev.data_ptr(), cap, logit_scale.data_ptr(), float(thres),
                 ssum.data_ptr(), _ptr(n_valid), _ptr(rank), _ptr(sv.qn), _ptr(sv.pn),
-                _ptr(sv.supp), _ptr(sv.q_inv), _ptr(sv.p_inv), _ptr(sv.s_pos), int(log_group), st)
+                _ptr(sv.supp), _ptr(sv.q_inv), _ptr(sv.p_inv), _ptr(sv.s_pos), int(log_group), _ptr(sv.u), st)
     lib.call("mhr_nce_finalize", ssum.data_ptr(), sv.s_pos.data_ptr(), G, n_tok_dev.data_ptr(), cap,
              logit_scale.data_ptr(), loss.data_ptr(), sv.lse.data_ptr(), _ptr(n_valid), _ptr(bucket_idx), int(n_buckets),
              _ptr(sv.bucket_sum), _ptr(sv.bucket_cnt), st)
@@ -350,7 +351,7 @@ def nce_bwd(sv, w, logit_scale, q_idx, p_idx, dq_rows, dp_rows, d_negs=None, d_l
     _chk(dp_rows, "dp_rows", torch.float32)
     lw = torch.empty(G, cap, dtype=torch.float32, device=dev)     # lse log2e - log2 w: written by bwd_tokens, read by bwd_negs
     st = _stream()
-    _timed_call("mhr_nce_bwd_tokens", sv.qn.data_ptr(), sv.pn.data_ptr(), sv.negs.data_ptr(), sv.supp.data_ptr(), sv.n_neg, D,
+    _timed_call("mhr_nce_bwd_tokens", sv.qn.data_ptr(), sv.pn.data_ptr(), sv.u.data_ptr(), D,
                 G, sv.n_tok_dev.data_ptr(), cap, logit_scale.data_ptr(), sv.lse.data_ptr(), w.data_ptr(), sv.q_inv.data_ptr(),
                 sv.p_inv.data_ptr(), sv.s_pos.data_ptr(), sv.q_idx.data_ptr(), sv.p_idx.data_ptr(), dq_rows.data_ptr(),
                 dp_rows.data_ptr(), d_logit_scale.data_ptr(), lw.data_ptr(), sv.bucket_idx.data_ptr() if bucketed else 0,
