@@ -208,9 +208,9 @@ def main():
                     n_tok = float(valid.sum())
                     n_groups = 1
                 n_neg = world * B * data.n_neg(B)
-                mult = 4.0                                    # fwd: neg + fix logits = 2 x 2 N_tok N_neg D
-                if name != "mhr_nce_fwd":
-                    mult = 2.0                                # each backward kernel: one of dQ / dN (recompute not counted)
+                # fused forward: neg logits + false-negative logits + the token-side gradient product = 3 x 2 N_tok N_neg D;
+                # negative-side backward: dN only (its logit recompute is not counted)
+                mult = 6.0 if name == "mhr_nce_fwd" else 2.0
                 flops = mult * n_tok * n_neg * D
                 ach = flops / (mean_ms * 1e-3) / 1e12
                 out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS,
@@ -219,8 +219,8 @@ def main():
                                    "algorithmic_flops_per_launch": flops, "tokens_per_launch": n_tok, "groups": n_groups,
                                    "negatives_per_group": n_neg}
                 # all three sampled-softmax kernels, same accounting (fwd 4x, bwd 2x each)
-                out["nce_kernels_TFLOPs"] = {k: round((4.0 if k == "mhr_nce_fwd" else 2.0) * n_tok * n_neg * D / (v[1] * 1e-3) / 1e12, 1)
-                                             for k, v in prof.items() if k.startswith("mhr_nce")}
+                out["nce_kernels_TFLOPs"] = {k: round((6.0 if k == "mhr_nce_fwd" else 2.0) * n_tok * n_neg * D / (v[1] * 1e-3) / 1e12, 1)
+                                             for k, v in prof.items() if k in ("mhr_nce_fwd", "mhr_nce_bwd_negs")}
             elif name == "mhr_catalog_score_emit":
                 flops = 2.0 * B * model.medusa_num_heads * D * N      # the full pass dominates; sample passes are 1/14 + 1/222 of it
                 ach = flops / (mean_ms * launches / (args.steps) * 1e-3) / 1e12
@@ -238,7 +238,7 @@ def main():
             # HBM bytes per launch of that kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE run on this same
             # command and condensed by tools/summarize_profiles.py; counters cannot be read from inside the process)
             if "roofline" in out and args.config == "cfg1" and not args.batch:
-                kname = {"mhr_nce_bwd_tokens": "nce_bwd_q_kernel", "mhr_nce_bwd_negs": "nce_bwd_n_kernel", "mhr_nce_fwd": "nce_fwd_kernel",
+                kname = {"mhr_nce_bwd_tokens": "nce_bwd_rows_kernel", "mhr_nce_bwd_negs": "nce_bwd_n_kernel", "mhr_nce_fwd": "nce_fwd_u_kernel",
                          "mhr_catalog_score_emit": "catalog_emit_kernel", "mhr_adam_rows": "adam_rows_kernel"}.get(name)
                 import glob
                 files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_hbm_traffic{'_eval' if args.mode == 'eval' else ''}.json")))
