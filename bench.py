@@ -107,10 +107,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one process per GPU (the driver's launch).  MHR_DIST_BACKEND=gloo with several ranks sharing one card is only for
+    # rehearsing the N > 1 code path on a single-GPU box.
+    n_dev = torch.cuda.device_count()
+    backend = os.environ.get("MHR_DIST_BACKEND", "nccl")
+    torch.cuda.set_device(local_rank % n_dev)
+    dev = torch.device("cuda", local_rank % n_dev)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     import mhr_amd.synth as synth
     from mhr_amd import ops
     from REC.config.configurator import Config, apply_run_fixups
