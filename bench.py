@@ -163,8 +163,9 @@ def main():
 
     for i in range(args.warmup):
         step(i)
-    kernels = ["mhr_nce_fwd", "mhr_nce_bwd_tokens", "mhr_nce_bwd_negs", "mhr_catalog_score_emit", "mhr_hstu_attn_fwd",
-               "mhr_hstu_attn_bwd", "mhr_adam_rows", "mhr_embedding_gather_fwd", "mhr_sparse_rows_segment_sum", "mhr_topk_select"]
+    kernels = ["mhr_nce_fwd", "mhr_nce_bwd_tokens", "mhr_nce_bwd_negs", "mhr_catalog_score_emit", "mhr_catalog_score_emit_sliced",
+               "mhr_hstu_attn_fwd", "mhr_hstu_attn_bwd", "mhr_adam_rows", "mhr_embedding_gather_fwd", "mhr_sparse_rows_segment_sum",
+               "mhr_topk_select", "mhr_topk_select_sliced"]
     if not args.no_kernel_events:
         ops.PROFILE = {k: [] for k in kernels}
     sync()
@@ -228,7 +229,7 @@ def main():
                 # all three sampled-softmax kernels, same accounting (fwd 4x, bwd 2x each)
                 out["nce_kernels_TFLOPs"] = {k: round((6.0 if k == "mhr_nce_fwd" else 2.0) * n_tok * n_neg * D / (v[1] * 1e-3) / 1e12, 1)
                                              for k, v in prof.items() if k in ("mhr_nce_fwd", "mhr_nce_bwd_negs")}
-            elif name == "mhr_catalog_score_emit":
+            elif name in ("mhr_catalog_score_emit", "mhr_catalog_score_emit_sliced"):
                 flops = 2.0 * B * model.medusa_num_heads * D * N      # the full pass dominates; sample passes are 1/14 + 1/222 of it
                 ach = flops / (mean_ms * launches / (args.steps) * 1e-3) / 1e12
                 out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS,
@@ -246,7 +247,8 @@ def main():
             # command and condensed by tools/summarize_profiles.py; counters cannot be read from inside the process)
             if "roofline" in out and args.config == "cfg1" and not args.batch:
                 kname = {"mhr_nce_bwd_tokens": "nce_bwd_rows_kernel", "mhr_nce_bwd_negs": "nce_bwd_n_kernel", "mhr_nce_fwd": "nce_fwd_u_kernel",
-                         "mhr_catalog_score_emit": "catalog_emit_kernel", "mhr_adam_rows": "adam_rows_kernel"}.get(name)
+                         "mhr_catalog_score_emit": "catalog_emit_kernel", "mhr_catalog_score_emit_sliced": "catalog_emit_sliced_kernel",
+                         "mhr_adam_rows": "adam_rows_kernel"}.get(name)
                 import glob
                 files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_hbm_traffic{'_eval' if args.mode == 'eval' else ''}.json")))
                 if kname and files:

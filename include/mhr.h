@@ -243,6 +243,25 @@ int mhr_catalog_score_emit(const void* users, int n_rows, int H, const void* ite
                            const int32_t* hist_ptr, const int64_t* hist_items,
                            float* cand_val, int32_t* cand_idx, int32_t* cand_cnt, int cap, void* stream);
 
+/* Fast path of the same scorer ("sliced lists").  Every (row, item slice, lane half) triple owns a short list
+ *   cand_val / cand_idx [n_rows, 2 n_slices, cap_s],  cand_cnt [n_rows, 2 n_slices] (written, no zeroing needed)
+ * whose fill count lives in a register of the lane that owns it (mhr_topk_select_sliced then takes 2 n_slices lists): a threshold hit costs two plain stores (no atomic,
+ * no global load - the tile's tag words travel to LDS with the tile).  The history filter is NOT applied here but in
+ * mhr_topk_select_sliced.  n_slices: positive multiple of 8 (item tiles are split evenly over the slices; grid =
+ * ceil(n_rows / 256) * n_slices workgroups).  items_alloc_rows: rows of `items` that may be read; when item_stride == 1
+ * and the catalog is readable to the end of its last 32-row tile the tiles stream unclamped. */
+int mhr_catalog_score_emit_sliced(const void* users, int n_rows, const void* items, int64_t n_items, int64_t items_alloc_rows,
+                                  int dim, int64_t item_begin, int64_t item_stride, const uint32_t* tag_bits,
+                                  const uint32_t* row_bits, const float* tau, float* cand_val, int32_t* cand_idx,
+                                  int32_t* cand_cnt, int n_slices, int cap_s, void* stream);
+/* Exact top-k over a row's sliced lists (same order and completion rule as mhr_topk_select), dropping the items of the
+ * user's history (CSR hist_ptr / hist_items as above, may be NULL; user = row / H).  count_out[row] = candidates left
+ * after the history filter; status[row] = 1 when a slice list (count > cap_s) or the on-chip array (8192 keys)
+ * overflowed - such rows must be re-run exactly by the caller. */
+int mhr_topk_select_sliced(const float* cand_val, const int32_t* cand_idx, const int32_t* cand_cnt, int n_slices, int cap_s,
+                           int n_rows, int H, const int32_t* hist_ptr, const int64_t* hist_items, int k,
+                           float* out_val, int64_t* out_idx, float* kth_val, int32_t* count_out, int32_t* status, void* stream);
+
 /* Per-row exact selection of the k best candidates: value descending, index ascending on ties.
  * Rows with fewer than k candidates are completed with (-inf, lowest item ids not in the list).
  * out_val/out_idx [n_rows, k]; kth_val [n_rows] (optional) receives the k-th value.

@@ -524,6 +524,8 @@ class HSTU(BaseModel):
         key = (all_item_feature.data_ptr(), all_item_feature._version, None if all_item_tags is None else all_item_tags.data_ptr())
         if self._item_cache is None or self._item_cache[0] != key:
             items_bf = ops.l2norm_rows(all_item_feature.float().contiguous(), torch.bfloat16)      # hstu.py:974-975
+            if items_bf.shape[0] % 32:      # whole 32-row tiles: the catalog scorer then streams it unclamped
+                items_bf = torch.cat([items_bf, items_bf.new_zeros(32 - items_bf.shape[0] % 32, items_bf.shape[1])]).contiguous()
             tag_bits = self.pack_item_tags(all_item_tags) if (all_item_tags is not None and self.loss == 'prior') else None
             self._item_cache = (key, items_bf, tag_bits)
         _, items_bf, tag_bits = self._item_cache
@@ -535,7 +537,8 @@ class HSTU(BaseModel):
             hist_items = hi[order].contiguous()
             # CSR offsets by binary search on the sorted user column (torch.bincount would sync the host)
             hist_ptr = torch.searchsorted(hu[order].contiguous(), torch.arange(B + 1, device=dev)).int()
-        vals, idx = ops.catalog_topk(users, H, items_bf, tag_bits, row_bits, hist_ptr, hist_items, k, stats=stats)
+        vals, idx = ops.catalog_topk(users, H, items_bf, tag_bits, row_bits, hist_ptr, hist_items, k, stats=stats,
+                                     n_items=all_item_feature.shape[0])
         return FusedTopK(vals.view(B, H, k), idx.view(B, H, k))
 
     @torch.no_grad()

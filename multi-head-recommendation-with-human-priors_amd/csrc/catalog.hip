@@ -139,6 +139,116 @@ __global__ __launch_bounds__(256, 2) void catalog_emit_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
+// emit, sliced lists: the fast path of ops.catalog_topk
+// ------------------------------------------------------------------------------------------
+// The kernel above serialises every threshold hit on global-memory round trips (tag word, history binary search, a
+// returning atomic for the list slot): at cfg1 about a million hits per batch, 1.3 ms for 95 us worth of MFMA work.
+// Here a hit costs two plain stores: every (row, item slice, lane half) triple has its OWN short list whose fill count
+// lives in a register of the lane that owns it (no atomics), the tag words of a tile arrive in LDS with the tile (LDS-DMA),
+// and the history filter moves to the select kernel, where one workgroup per row checks its few thousand candidates
+// in parallel.  The DMA ring is branch-free with SGPR-base addressing (catalog padded to whole tiles) as in nce_fwd.
+template <int NKS, bool STRIDED>
+__global__ __launch_bounds__(256, 2) void catalog_emit_sliced_kernel(
+    const bf16_t* __restrict__ users, int n_rows, const bf16_t* __restrict__ items, int64_t n_items, int64_t item_begin,
+    int64_t item_stride, int n_tiles, int R, int n_slices, const uint32_t* __restrict__ tag_bits,
+    const uint32_t* __restrict__ row_bits, const float* __restrict__ tau, float* __restrict__ cand_val,
+    int32_t* __restrict__ cand_idx, int32_t* __restrict__ cand_cnt, int cap_s) {
+  using T = sg::Tile<NKS>;
+  constexpr int RF = 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* tiles = smem;                              // 3 x T::BYTES (LDS-DMA ring)
+  unsigned char* words = smem + 3 * T::BYTES;               // 3 x [4 waves][64] tag words of the tile's 32 items
+
+  const int w = blockIdx.x, xcd = w & 7, j = w >> 3;        // XCD-aware decode, as above
+  const int rt = j % R, slice = (j / R) * 8 + xcd;
+  const int tps = (n_tiles + n_slices - 1) / n_slices;
+  const int t0 = slice * tps, t1 = min(n_tiles, t0 + tps);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, half = lane >> 5;
+
+  bf16x8 frag[RF][NKS];
+  int row[RF], cnt[RF] = {0, 0};
+  float my_tau[RF];
+  uint32_t my_bits[RF];
+#pragma unroll
+  for (int f = 0; f < RF; ++f) {
+    row[f] = rt * 256 + wave * 64 + f * 32 + r;
+    const bool live = row[f] < n_rows;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks)
+      frag[f][ks] = live ? *reinterpret_cast<const bf16x8*>(users + (int64_t)row[f] * T::DIM + ks * 16 + 8 * half) : sg::zero8();
+    my_bits[f] = live ? row_bits[row[f]] : 0u;
+    my_tau[f] = (live && my_bits[f] != 0u) ? tau[row[f]] : INFINITY;     // rows switched off never pass the threshold test
+  }
+  if (t0 < t1) {
+    using P = sg::DmaPieces<NKS>;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    P dp;
+    dp.init(wv, lane);
+    const uint32_t* tag_src = tag_bits ? tag_bits : row_bits;            // no tags: any readable word (never tested)
+    auto item_of = [&](int tile, int rr) -> int64_t { return item_begin + ((int64_t)tile * 32 + rr) * item_stride; };
+    auto dma_tile = [&](auto slot_c, int tn) {
+      constexpr int slot = decltype(slot_c)::value;
+      auto f = [&](auto k_c) {
+        constexpr int k = decltype(k_c)::value;
+        if constexpr (STRIDED) {
+          dp.template piece_rows<k>(tiles + slot * T::BYTES, [=](int rr) {
+            const int64_t n = item_begin + ((int64_t)tn * 32 + rr) * item_stride;
+            return items + (n < n_items ? n : n_items - 1) * T::DIM;
+          }, lane);
+        } else {
+          dp.template piece<k>(tiles + slot * T::BYTES, reinterpret_cast<const char*>(items) + (item_begin + (int64_t)tn * 32) * T::ROW_BYTES);
+        }
+      };
+      sg::static_for<P::PW>(f);
+      const int64_t n = item_of(tn, r);
+      sg::dma_words(tag_src + (tag_bits ? (n < n_items ? n : n_items - 1) : 0), words + slot * 1024 + wv * 256);
+    };
+    sg::LaneAddr<NKS> la;
+    la.init(lane);
+    const int n_loc = t1 - t0, t_last = t1 - 1;
+    dma_tile(std::integral_constant<int, 0>{}, t0);
+    dma_tile(std::integral_constant<int, 1>{}, min(t0 + 1, t_last));
+    sg::ring_loop<3>(n_loc, [&](auto slot_c, int i) {
+      constexpr int cur = decltype(slot_c)::value, nxt = (cur + 2) % 3;
+      const int t = t0 + i;
+      sg::wait_vmcnt<P::PW + 1>();
+      sg::ring_barrier();
+      dma_tile(std::integral_constant<int, nxt>{}, min(t + 2, t_last));
+      f32x16 acc[RF];
+#pragma unroll
+      for (int f = 0; f < RF; ++f) acc[f] = sg::zero16();
+      sg::mma_tile<NKS, RF>(tiles + cur * T::BYTES, la, frag, acc);
+      const uint32_t* tw = reinterpret_cast<const uint32_t*>(words + cur * 1024 + wv * 256);
+#pragma unroll
+      for (int f = 0; f < RF; ++f) {
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+          const float sc = acc[f][g];
+          if (sc >= my_tau[f]) {                               // a hit: two stores, no round trip
+            const int rr = sg::crow(g, half);
+            const int64_t n = item_of(t, rr);
+            const bool tag_ok = !tag_bits || (tw[rr] & my_bits[f]) != 0u;
+            if (n < n_items && n != 0 && tag_ok) {             // n == 0: the pad id (trainer.py:724)
+              const int pos = cnt[f]++;
+              if (pos < cap_s) {
+                const int64_t o = ((int64_t)row[f] * (2 * n_slices) + 2 * slice + half) * cap_s + pos;
+                cand_val[o] = sc;
+                cand_idx[o] = (int32_t)n;
+              }
+            }
+          }
+        }
+      }
+    });
+    sg::wait_vmcnt<0>();
+  }
+  // the two lane halves of a row see different items of every tile: each half owns its own list (2 lists per slice)
+#pragma unroll
+  for (int f = 0; f < RF; ++f)
+    if (row[f] < n_rows) cand_cnt[(int64_t)row[f] * (2 * n_slices) + 2 * slice + half] = cnt[f];
+}
+
+// ------------------------------------------------------------------------------------------
 // exact top-k of a candidate list: 8-pass radix select on (okey(value) << 32 | ~index), then bitonic sort
 // ------------------------------------------------------------------------------------------
 constexpr int SEL_MAX_K = 1024;
@@ -267,6 +377,151 @@ __global__ __launch_bounds__(256) void topk_select_kernel(const float* __restric
   if (threadIdx.x == 0) {
     if (kth_val) kth_val[row] = (n >= k) ? okey_inv((uint32_t)(sel[k - 1] >> 32)) : -INFINITY;
     if (status) status[row] = cnt > cap ? 1 : 0;
+  }
+}
+
+// exact top-k of a row's sliced candidate lists.  One workgroup per row: gather the slices' entries into an LDS key array
+// (dropping the user's own history items: trainer.py:725-726, one binary search per candidate, all in parallel), then the
+// same 8-pass radix select + bitonic sort, on LDS.  count_out = valid candidates gathered; status = 1 when a slice list
+// or the LDS array overflowed (the caller re-runs such rows exactly).
+constexpr int SEL_CAP = 8192;
+__global__ __launch_bounds__(256) void topk_select_sliced_kernel(const float* __restrict__ cand_val, const int32_t* __restrict__ cand_idx,
+                                                                 const int32_t* __restrict__ cand_cnt, int n_slices, int cap_s,
+                                                                 int H, const int32_t* __restrict__ hist_ptr,
+                                                                 const int64_t* __restrict__ hist_items, int k, int kp2,
+                                                                 float* __restrict__ out_val, int64_t* __restrict__ out_idx,
+                                                                 float* __restrict__ kth_val, int32_t* __restrict__ count_out,
+                                                                 int32_t* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint64_t* keys = reinterpret_cast<uint64_t*>(smem);            // [SEL_CAP]
+  uint64_t* sel = keys + SEL_CAP;                                // [kp2]
+  __shared__ uint32_t hist[256];
+  __shared__ uint64_t s_prefix;
+  __shared__ int s_kk, s_nsel, s_n, s_over;
+  __shared__ int s_scan[256];
+
+  const int row = blockIdx.x;
+  const int32_t* cc = cand_cnt + (int64_t)row * n_slices;
+  int hp0 = 0, hp1 = 0;
+  if (hist_ptr) {
+    hp0 = hist_ptr[row / H];
+    hp1 = hist_ptr[row / H + 1];
+  }
+  if (threadIdx.x == 0) s_n = s_over = 0;
+  __syncthreads();
+  // gather: thread <-> (slice, entry) pairs, slice-major
+  for (int e = threadIdx.x; e < n_slices * cap_s; e += 256) {
+    const int sl = e / cap_s, jj = e % cap_s;
+    const int c = cc[sl];
+    if (jj == 0 && c > cap_s) s_over = 1;
+    if (jj < min(c, cap_s)) {
+      const int64_t o = ((int64_t)row * n_slices + sl) * cap_s + jj;
+      const int32_t n = cand_idx[o];
+      bool ok = true;
+      if (hist_items) {
+        int lo = hp0, hi = hp1;
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (hist_items[mid] < (int64_t)n) lo = mid + 1;
+          else hi = mid;
+        }
+        ok = !(lo < hp1 && hist_items[lo] == (int64_t)n);
+      }
+      if (ok) {
+        const int pos = atomicAdd(&s_n, 1);
+        if (pos < SEL_CAP) keys[pos] = ((uint64_t)okey(cand_val[o]) << 32) | (uint32_t)(~(uint32_t)n);
+      }
+    }
+  }
+  __syncthreads();
+  const int cnt = s_n;
+  const int n = min(cnt, SEL_CAP);
+
+  uint64_t kth_key = 0;
+  if (n > k) {
+    if (threadIdx.x == 0) {
+      s_prefix = 0;
+      s_kk = k;
+    }
+    uint64_t mask = 0;
+    for (int p = 7; p >= 0; --p) {
+      hist[threadIdx.x] = 0;
+      __syncthreads();
+      const uint64_t prefix = s_prefix;
+      for (int i = threadIdx.x; i < n; i += 256) {
+        const uint64_t key = keys[i];
+        if ((key & mask) == prefix) atomicAdd(&hist[(key >> (8 * p)) & 255], 1u);
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        int kk = s_kk, d = 255;
+        for (; d > 0; --d) {
+          const int c = (int)hist[d];
+          if (c >= kk) break;
+          kk -= c;
+        }
+        s_kk = kk;
+        s_prefix = prefix | ((uint64_t)d << (8 * p));
+      }
+      mask |= (uint64_t)0xFF << (8 * p);
+      __syncthreads();
+    }
+    kth_key = s_prefix;
+  }
+  if (threadIdx.x == 0) s_nsel = 0;
+  for (int i = threadIdx.x; i < kp2; i += 256) sel[i] = 0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const uint64_t key = keys[i];
+    if (key >= kth_key) {
+      const int pos = atomicAdd(&s_nsel, 1);
+      if (pos < kp2) sel[pos] = key;
+    }
+  }
+  __syncthreads();
+  const int nsel = min(s_nsel, k);
+  bitonic_sort_desc(sel, kp2);
+  for (int i = threadIdx.x; i < nsel; i += 256) {
+    const uint64_t key = sel[i];
+    out_val[(int64_t)row * k + i] = okey_inv((uint32_t)(key >> 32));
+    out_idx[(int64_t)row * k + i] = (int64_t)(uint32_t)(~(uint32_t)key);
+  }
+  if (nsel < k) {
+    // complete with (-inf, lowest item ids not in the list): among ids [0, k) at most nsel are taken
+    const int need = k - nsel;
+    int filled = 0;
+    for (int id0 = 0; id0 < k && filled < need; id0 += 256) {
+      const int id = id0 + threadIdx.x;
+      int free_ = 0;
+      if (id < k) {
+        free_ = 1;
+        for (int q = 0; q < nsel; ++q)
+          if ((uint32_t)(~(uint32_t)sel[q]) == (uint32_t)id) {
+            free_ = 0;
+            break;
+          }
+      }
+      s_scan[threadIdx.x] = free_;
+      __syncthreads();
+      for (int o = 1; o < 256; o <<= 1) {   // inclusive Hillis-Steele scan
+        int add = threadIdx.x >= o ? s_scan[threadIdx.x - o] : 0;
+        __syncthreads();
+        s_scan[threadIdx.x] += add;
+        __syncthreads();
+      }
+      const int my = filled + s_scan[threadIdx.x] - free_;   // exclusive position
+      if (free_ && my < need) {
+        out_val[(int64_t)row * k + nsel + my] = -INFINITY;
+        out_idx[(int64_t)row * k + nsel + my] = id;
+      }
+      filled += s_scan[255];
+      __syncthreads();
+    }
+  }
+  if (threadIdx.x == 0) {
+    if (kth_val) kth_val[row] = (n >= k) ? okey_inv((uint32_t)(sel[k - 1] >> 32)) : -INFINITY;
+    if (count_out) count_out[row] = cnt;
+    if (status) status[row] = (s_over || cnt > SEL_CAP) ? 1 : 0;
   }
 }
 
@@ -399,6 +654,67 @@ extern "C" int mhr_catalog_score_emit(const void* users, int n_rows, int H, cons
   }
 #undef L_
   MHR_CHECK_LAUNCH("catalog_score_emit");
+  return MHR_OK;
+}
+
+extern "C" int mhr_catalog_score_emit_sliced(const void* users, int n_rows, const void* items, int64_t n_items,
+                                             int64_t items_alloc_rows, int dim, int64_t item_begin, int64_t item_stride,
+                                             const uint32_t* tag_bits, const uint32_t* row_bits, const float* tau,
+                                             float* cand_val, int32_t* cand_idx, int32_t* cand_cnt, int n_slices, int cap_s,
+                                             void* stream) {
+  MHR_REQUIRE(users && items && row_bits && tau && cand_val && cand_idx && cand_cnt, "catalog_score_emit_sliced: null pointer");
+  MHR_REQUIRE(dim == 16 || dim == 32 || dim == 64 || dim == 128 || dim == 256,
+              "catalog_score_emit_sliced: dim=%d unsupported (16/32/64/128/256)", dim);
+  MHR_REQUIRE(n_rows > 0 && n_items > 0 && n_items < (1ll << 31) && item_begin >= 0 && item_begin < n_items && item_stride >= 1,
+              "catalog_score_emit_sliced: bad item range");
+  MHR_REQUIRE(n_slices >= 8 && n_slices % 8 == 0 && cap_s >= 1, "catalog_score_emit_sliced: n_slices=%d must be a positive multiple of 8", n_slices);
+  const int64_t n_sel = (n_items - item_begin + item_stride - 1) / item_stride;
+  const int n_tiles = (int)((n_sel + 31) / 32);
+  const int R = (n_rows + 255) / 256;
+  const int grid = R * n_slices;
+  // contiguous whole-tile streaming needs the catalog readable up to the end of the last tile
+  const bool contiguous = item_stride == 1 && item_begin + (int64_t)n_tiles * 32 <= items_alloc_rows;
+  hipStream_t s = (hipStream_t)stream;
+#define L_(NKS)                                                                                                            \
+  {                                                                                                                        \
+    size_t lds = 3 * sg::Tile<NKS>::BYTES + 3 * 1024;                                                                      \
+    if (contiguous)                                                                                                        \
+      hipLaunchKernelGGL((catalog_emit_sliced_kernel<NKS, false>), dim3(grid), dim3(256), lds, s, (const bf16_t*)users,    \
+                         n_rows, (const bf16_t*)items, n_items, item_begin, item_stride, n_tiles, R, n_slices, tag_bits,   \
+                         row_bits, tau, cand_val, cand_idx, cand_cnt, cap_s);                                              \
+    else                                                                                                                   \
+      hipLaunchKernelGGL((catalog_emit_sliced_kernel<NKS, true>), dim3(grid), dim3(256), lds, s, (const bf16_t*)users,     \
+                         n_rows, (const bf16_t*)items, n_items, item_begin, item_stride, n_tiles, R, n_slices, tag_bits,   \
+                         row_bits, tau, cand_val, cand_idx, cand_cnt, cap_s);                                              \
+  }
+  switch (dim) {
+    case 16: L_(1); break;
+    case 32: L_(2); break;
+    case 64: L_(4); break;
+    case 128: L_(8); break;
+    default: L_(16); break;
+  }
+#undef L_
+  MHR_CHECK_LAUNCH("catalog_score_emit_sliced");
+  return MHR_OK;
+}
+
+extern "C" int mhr_topk_select_sliced(const float* cand_val, const int32_t* cand_idx, const int32_t* cand_cnt, int n_slices,
+                                      int cap_s, int n_rows, int H, const int32_t* hist_ptr, const int64_t* hist_items, int k,
+                                      float* out_val, int64_t* out_idx, float* kth_val, int32_t* count_out, int32_t* status,
+                                      void* stream) {
+  MHR_REQUIRE(cand_val && cand_idx && cand_cnt && out_val && out_idx, "topk_select_sliced: null pointer");
+  MHR_REQUIRE(k >= 1 && k <= SEL_MAX_K && n_slices >= 1 && cap_s >= 1 && n_rows >= 0 && H >= 1,
+              "topk_select_sliced: k=%d must be in [1,%d]", k, SEL_MAX_K);
+  MHR_REQUIRE((hist_ptr == nullptr) == (hist_items == nullptr), "topk_select_sliced: hist_ptr/hist_items must both be set or null");
+  if (n_rows == 0) return MHR_OK;
+  const int kp2 = next_pow2(k);
+  const size_t lds = (size_t)(SEL_CAP + kp2) * 8;
+  auto kern = topk_select_sliced_kernel;
+  (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(kern, dim3(n_rows), dim3(256), lds, (hipStream_t)stream, cand_val, cand_idx, cand_cnt, n_slices, cap_s, H,
+                     hist_ptr, hist_items, k, kp2, out_val, out_idx, kth_val, count_out, status);
+  MHR_CHECK_LAUNCH("topk_select_sliced");
   return MHR_OK;
 }
 

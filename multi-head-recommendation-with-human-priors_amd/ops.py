@@ -365,7 +365,7 @@ def nce_bwd(sv, w, logit_scale, q_idx, p_idx, dq_rows, dp_rows, d_negs=None, d_l
 # catalog scoring / top-k / merge
 # ------------------------------------------------------------------------------------------------
 def catalog_emit(users, H, items, tag_bits, row_bits, tau, hist_ptr, hist_items, cap, item_begin=0, item_stride=1,
-                 cand=None):
+                 cand=None, n_items=None):
     n_rows, D = users.shape
     dev = users.device
     if cand is None:
@@ -374,7 +374,8 @@ def catalog_emit(users, H, items, tag_bits, row_bits, tau, hist_ptr, hist_items,
                 torch.zeros(n_rows, dtype=torch.int32, device=dev))
     else:
         cand[2].zero_()
-    _timed_call("mhr_catalog_score_emit", users.data_ptr(), n_rows, H, items.data_ptr(), items.shape[0], D, item_begin,
+    _timed_call("mhr_catalog_score_emit", users.data_ptr(), n_rows, H, items.data_ptr(),
+                items.shape[0] if n_items is None else n_items, D, item_begin,
              item_stride, _ptr(tag_bits), row_bits.data_ptr(), tau.data_ptr(), _ptr(hist_ptr), _ptr(hist_items),
              cand[0].data_ptr(), cand[1].data_ptr(), cand[2].data_ptr(), cap, _stream())
     return cand
@@ -393,37 +394,82 @@ def topk_select(cand, cap, k):
     return out_val, out_idx, kth, status
 
 
-def catalog_topk(users, H, items, tag_bits, row_bits, hist_ptr, hist_items, k, cap=4096, target=1024, stats=None):
+def _slices_for(n_rows, n_tiles):
+    """item slices of the sliced emit: about 512 workgroups (2 per CU), a multiple of 8 (one per XCD), <= n_tiles."""
+    R = (n_rows + 255) // 256
+    SL = max(1, 64 // R)
+    while SL > 1 and 8 * (SL - 1) >= n_tiles:
+        SL -= 1
+    return 8 * SL
+
+
+def catalog_emit_sliced(users, items, n_items, tag_bits, row_bits, tau, cap_s, item_begin=0, item_stride=1):
+    """-> (cand_val, cand_idx [n_rows, n_lists, cap_s], cand_cnt [n_rows, n_lists], n_lists = 2 x item slices).
+    No history filter (topk_select_sliced applies it)."""
+    n_rows, D = users.shape
+    dev = users.device
+    n_sel = (n_items - item_begin + item_stride - 1) // item_stride
+    n_slices = _slices_for(n_rows, (n_sel + 31) // 32)
+    val = torch.empty(n_rows, 2 * n_slices, cap_s, dtype=torch.float32, device=dev)      # 2 lists per slice (one per wave half)
+    idx = torch.empty(n_rows, 2 * n_slices, cap_s, dtype=torch.int32, device=dev)
+    cnt = torch.empty(n_rows, 2 * n_slices, dtype=torch.int32, device=dev)
+    _timed_call("mhr_catalog_score_emit_sliced", users.data_ptr(), n_rows, items.data_ptr(), n_items, items.shape[0], D,
+                item_begin, item_stride, _ptr(tag_bits), row_bits.data_ptr(), tau.data_ptr(), val.data_ptr(), idx.data_ptr(),
+                cnt.data_ptr(), n_slices, cap_s, _stream())
+    return val, idx, cnt, 2 * n_slices
+
+
+def topk_select_sliced(cand, H, hist_ptr, hist_items, k):
+    """-> (values [n_rows,k], indices [n_rows,k], kth value, valid-candidate count, overflow status)."""
+    val, idx, cnt, n_slices = cand
+    n_rows, _, cap_s = val.shape
+    dev = val.device
+    out_val = torch.empty(n_rows, k, dtype=torch.float32, device=dev)
+    out_idx = torch.empty(n_rows, k, dtype=torch.int64, device=dev)
+    kth = torch.empty(n_rows, dtype=torch.float32, device=dev)
+    count = torch.empty(n_rows, dtype=torch.int32, device=dev)
+    status = torch.empty(n_rows, dtype=torch.int32, device=dev)
+    _timed_call("mhr_topk_select_sliced", val.data_ptr(), idx.data_ptr(), cnt.data_ptr(), n_slices, cap_s, n_rows, H,
+                _ptr(hist_ptr), _ptr(hist_items), k, out_val.data_ptr(), out_idx.data_ptr(), kth.data_ptr(), count.data_ptr(),
+                status.data_ptr(), _stream())
+    return out_val, out_idx, kth, count, status
+
+
+def catalog_topk(users, H, items, tag_bits, row_bits, hist_ptr, hist_items, k, cap=4096, target=1024, stats=None, n_items=None):
     """Exact per-row top-k over the whole catalog (value desc, index asc), rows = (user, head) pairs.
 
-    users [B*H, D] bf16 normalised, items [N, D] bf16 normalised.  Returns (values [B*H,k] f32, indices [B*H,k] i64).
-    Thresholds come from two strided sample passes; exactness is verified (k <= count <= cap per row) and
-    rows that fail are re-run with tau = -inf, so the sampling only affects speed.
+    users [B*H, D] bf16 normalised, items [>= N, D] bf16 normalised (rows beyond n_items = N are padding: give the
+    table round_up(N, 32) rows and the item tiles stream unclamped).  Returns (values [B*H,k] f32, indices [B*H,k] i64).
+    Thresholds come from two strided sample passes; the full pass emits the few scores above them into per-(row, item
+    slice) lists and an exact select picks the top k.  Exactness is verified (enough candidates, no list overflow, per
+    row) and rows that fail are re-run with tau = -inf, so the sampling only affects speed.
     """
     n_rows, D = users.shape
-    N = items.shape[0]
+    N = items.shape[0] if n_items is None else int(n_items)
     dev = users.device
     ninf = torch.full((n_rows,), float("-inf"), dtype=torch.float32, device=dev)
     if N <= cap:
-        cand = catalog_emit(users, H, items, tag_bits, row_bits, ninf, hist_ptr, hist_items, N)
+        cand = catalog_emit(users, H, items, tag_bits, row_bits, ninf, hist_ptr, hist_items, N, n_items=N)
         ov, oi, _, _ = topk_select(cand, N, k)
         return ov, oi
     s1 = max(1, -(-N // 2048))
     s2 = max(1, -(-N // 32768))
-    n1, n2 = -(-N // s1), -(-N // s2)
     t1 = 8
     t2 = max(k // s2 + 1, target // s2)
-    c1 = catalog_emit(users, H, items, tag_bits, row_bits, ninf, hist_ptr, hist_items, n1, 0, s1)
-    _, _, kth1, _ = topk_select(c1, n1, t1)
-    cap2 = min(n2, 8192)
-    c2 = catalog_emit(users, H, items, tag_bits, row_bits, kth1, hist_ptr, hist_items, cap2, 0, s2)
-    _, _, kth2, st2 = topk_select(c2, cap2, t2)
-    tau = torch.where(torch.isfinite(kth2) & (st2 == 0), kth2, torch.where(st2 == 0, kth1, ninf))
-    tau = torch.where((c2[2] > cap2), ninf, tau)        # truncated sample list: threshold unknown -> exact path decides
-    cand = catalog_emit(users, H, items, tag_bits, row_bits, tau, hist_ptr, hist_items, cap)
-    ov, oi, _, _ = topk_select(cand, cap, k)
-    cnt = cand[2]
-    flagged = (cnt > cap) | ((cnt < k) & (row_bits != 0) & torch.isfinite(tau))
+    # pass 1: every s1-th item, all scores -> the t1-th largest bounds the top ~0.4 %
+    nt1 = -(-(-(-N // s1)) // 32)                                      # tiles of the first sample
+    c1 = catalog_emit_sliced(users, items, N, tag_bits, row_bits, ninf, 32 * -(-nt1 // _slices_for(n_rows, nt1)), 0, s1)
+    _, _, kth1, _, st1 = topk_select_sliced(c1, H, hist_ptr, hist_items, t1)
+    # pass 2: every s2-th item above kth1 -> the t2-th largest estimates the score of rank ~target
+    c2 = catalog_emit_sliced(users, items, N, tag_bits, row_bits, kth1, 32, 0, s2)
+    _, _, kth2, _, st2 = topk_select_sliced(c2, H, hist_ptr, hist_items, t2)
+    ok2 = (st2 == 0) & (st1 == 0)
+    tau = torch.where(torch.isfinite(kth2) & ok2, kth2, torch.where(ok2, kth1, ninf))
+    n_sl = _slices_for(n_rows, -(-N // 32))
+    cap_s = max(32, 4 * -(-target // n_sl) + 16)
+    cand = catalog_emit_sliced(users, items, N, tag_bits, row_bits, tau, cap_s)
+    ov, oi, _, cnt, st = topk_select_sliced(cand, H, hist_ptr, hist_items, k)
+    flagged = (st != 0) | ((cnt < k) & (row_bits != 0) & torch.isfinite(tau))
     if stats is not None:
         stats["mean_candidates"] = float(cnt.float().mean())
         stats["flagged_rows"] = int(flagged.sum())
@@ -441,7 +487,7 @@ def catalog_topk(users, H, items, tag_bits, row_bits, hist_ptr, hist_items, k, c
         sub_users = users[rows_f].contiguous()
         sub_bits = row_bits[rows_f].contiguous()
         sub_tau = torch.full((rows_f.numel(),), float("-inf"), dtype=torch.float32, device=dev)
-        c3 = catalog_emit(sub_users, H, items, tag_bits, sub_bits, sub_tau, sub_ptr, sub_items, N)
+        c3 = catalog_emit(sub_users, H, items, tag_bits, sub_bits, sub_tau, sub_ptr, sub_items, N, n_items=N)
         fv, fi, _, _ = topk_select(c3, N, k)
         ov[rows_f] = fv
         oi[rows_f] = fi
