@@ -199,6 +199,11 @@ def main():
         # ---- roofline of the dominant kernel ----
         if prof:
             dom = max(prof.items(), key=lambda kv: kv[1][2])
+            if args.mode == "eval":      # the eval roofline is quoted on the catalog scorer (north star), whatever else is slow
+                for cand_name in ("mhr_catalog_score_emit_sliced", "mhr_catalog_score_emit"):
+                    if cand_name in prof and prof[cand_name][0] > 0:
+                        dom = (cand_name, prof[cand_name])
+                        break
             name, (launches, mean_ms, total_ms) = dom
             per_step = {k: round(v[2] / args.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][2])}
             n_tok_total = None

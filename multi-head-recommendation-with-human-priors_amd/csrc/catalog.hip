@@ -253,6 +253,31 @@ __global__ __launch_bounds__(256, 2) void catalog_emit_sliced_kernel(
 // ------------------------------------------------------------------------------------------
 constexpr int SEL_MAX_K = 1024;
 
+// One radix-select digit step, all 256 threads: thread d owns bin d of `hist`; picks the largest digit d with
+// suffix(d) = sum_{j >= d} hist[j] >= kk and returns it with kk - suffix(d + 1) (a serial scan of the 256 bins by one
+// thread cost ~100 cycles of LDS latency per bin, 8 times per select: most of the kernel).
+__device__ __forceinline__ void pick_digit(const uint32_t* hist, int kk, int* s_wave_tot /*[4]*/, int* s_digit, int* s_kk) {
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int v = (int)hist[t];
+  int suf = v;                                             // inclusive suffix sum inside the wave
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int x = __shfl_down(suf, o, 64);
+    if (lane + o < 64) suf += x;
+  }
+  if (lane == 0) s_wave_tot[wv] = suf;                     // the wave's total
+  __syncthreads();
+  int above = 0;                                           // bins of higher waves
+  for (int w2 = wv + 1; w2 < 4; ++w2) above += s_wave_tot[w2];
+  const int incl = suf + above, excl = incl - v;           // suffix(d), suffix(d + 1)
+  if (incl >= kk && excl < kk) {                           // exactly one thread (bin 0 catches kk > total: cannot happen, n > k)
+    *s_digit = t;
+    *s_kk = kk - excl;
+  }
+  __syncthreads();
+}
+
+
 __device__ __forceinline__ void bitonic_sort_desc(uint64_t* a, int n_pow2) {
   for (int size = 2; size <= n_pow2; size <<= 1) {
     for (int strd = size >> 1; strd > 0; strd >>= 1) {
@@ -279,7 +304,7 @@ __global__ __launch_bounds__(256) void topk_select_kernel(const float* __restric
   __shared__ uint32_t hist[256];
   __shared__ uint64_t sel[SEL_MAX_K];
   __shared__ uint64_t s_prefix;
-  __shared__ int s_kk, s_nsel;
+  __shared__ int s_kk, s_nsel, s_kk2, s_digit, s_wtot[4];
   __shared__ int s_scan[256];
 
   const int row = blockIdx.x;
@@ -305,15 +330,10 @@ __global__ __launch_bounds__(256) void topk_select_kernel(const float* __restric
         if ((key & mask) == prefix) atomicAdd(&hist[(key >> (8 * p)) & 255], 1u);
       }
       __syncthreads();
+      pick_digit(hist, s_kk, s_wtot, &s_digit, &s_kk2);
       if (threadIdx.x == 0) {
-        int kk = s_kk, d = 255;
-        for (; d > 0; --d) {
-          const int c = (int)hist[d];
-          if (c >= kk) break;
-          kk -= c;
-        }
-        s_kk = kk;
-        s_prefix = prefix | ((uint64_t)d << (8 * p));
+        s_kk = s_kk2;
+        s_prefix = prefix | ((uint64_t)s_digit << (8 * p));
       }
       mask |= (uint64_t)0xFF << (8 * p);
       __syncthreads();
@@ -385,6 +405,7 @@ __global__ __launch_bounds__(256) void topk_select_kernel(const float* __restric
 // same 8-pass radix select + bitonic sort, on LDS.  count_out = valid candidates gathered; status = 1 when a slice list
 // or the LDS array overflowed (the caller re-runs such rows exactly).
 constexpr int SEL_CAP = 8192;
+constexpr int HIST_LDS = 2048;   // history entries kept on chip per user (longer histories are searched in global memory)
 __global__ __launch_bounds__(256) void topk_select_sliced_kernel(const float* __restrict__ cand_val, const int32_t* __restrict__ cand_idx,
                                                                  const int32_t* __restrict__ cand_cnt, int n_slices, int cap_s,
                                                                  int H, const int32_t* __restrict__ hist_ptr,
@@ -397,7 +418,7 @@ __global__ __launch_bounds__(256) void topk_select_sliced_kernel(const float* __
   uint64_t* sel = keys + SEL_CAP;                                // [kp2]
   __shared__ uint32_t hist[256];
   __shared__ uint64_t s_prefix;
-  __shared__ int s_kk, s_nsel, s_n, s_over;
+  __shared__ int s_kk, s_nsel, s_n, s_over, s_kk2, s_digit, s_wtot[4];
   __shared__ int s_scan[256];
 
   const int row = blockIdx.x;
@@ -408,28 +429,45 @@ __global__ __launch_bounds__(256) void topk_select_sliced_kernel(const float* __
     hp1 = hist_ptr[row / H + 1];
   }
   if (threadIdx.x == 0) s_n = s_over = 0;
+  // the user's history goes to LDS once (sorted ascending): every candidate is then checked by an on-chip binary search
+  int32_t* s_hist = reinterpret_cast<int32_t*>(sel + kp2);        // [HIST_LDS]
+  const int nh = hp1 - hp0;
+  const bool hist_in_lds = nh <= HIST_LDS;
+  if (hist_items && hist_in_lds)
+    for (int i = threadIdx.x; i < nh; i += 256) s_hist[i] = (int32_t)hist_items[hp0 + i];
   __syncthreads();
-  // gather: thread <-> (slice, entry) pairs, slice-major
-  for (int e = threadIdx.x; e < n_slices * cap_s; e += 256) {
-    const int sl = e / cap_s, jj = e % cap_s;
-    const int c = cc[sl];
-    if (jj == 0 && c > cap_s) s_over = 1;
-    if (jj < min(c, cap_s)) {
-      const int64_t o = ((int64_t)row * n_slices + sl) * cap_s + jj;
-      const int32_t n = cand_idx[o];
+  // gather: one thread per list (lists are short: a few entries each)
+  for (int l = threadIdx.x; l < n_slices; l += 256) {
+    int c = cc[l];
+    if (c > cap_s) {
+      s_over = 1;
+      c = cap_s;
+    }
+    const int64_t base = ((int64_t)row * n_slices + l) * cap_s;
+    for (int jj = 0; jj < c; ++jj) {
+      const int32_t n = cand_idx[base + jj];
       bool ok = true;
       if (hist_items) {
-        int lo = hp0, hi = hp1;
-        while (lo < hi) {
-          const int mid = (lo + hi) >> 1;
-          if (hist_items[mid] < (int64_t)n) lo = mid + 1;
-          else hi = mid;
+        int lo = 0, hi = nh;
+        if (hist_in_lds) {
+          while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (s_hist[mid] < n) lo = mid + 1;
+            else hi = mid;
+          }
+          ok = !(lo < nh && s_hist[lo] == n);
+        } else {
+          while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (hist_items[hp0 + mid] < (int64_t)n) lo = mid + 1;
+            else hi = mid;
+          }
+          ok = !(lo < nh && hist_items[hp0 + lo] == (int64_t)n);
         }
-        ok = !(lo < hp1 && hist_items[lo] == (int64_t)n);
       }
       if (ok) {
         const int pos = atomicAdd(&s_n, 1);
-        if (pos < SEL_CAP) keys[pos] = ((uint64_t)okey(cand_val[o]) << 32) | (uint32_t)(~(uint32_t)n);
+        if (pos < SEL_CAP) keys[pos] = ((uint64_t)okey(cand_val[base + jj]) << 32) | (uint32_t)(~(uint32_t)n);
       }
     }
   }
@@ -453,15 +491,10 @@ __global__ __launch_bounds__(256) void topk_select_sliced_kernel(const float* __
         if ((key & mask) == prefix) atomicAdd(&hist[(key >> (8 * p)) & 255], 1u);
       }
       __syncthreads();
+      pick_digit(hist, s_kk, s_wtot, &s_digit, &s_kk2);
       if (threadIdx.x == 0) {
-        int kk = s_kk, d = 255;
-        for (; d > 0; --d) {
-          const int c = (int)hist[d];
-          if (c >= kk) break;
-          kk -= c;
-        }
-        s_kk = kk;
-        s_prefix = prefix | ((uint64_t)d << (8 * p));
+        s_kk = s_kk2;
+        s_prefix = prefix | ((uint64_t)s_digit << (8 * p));
       }
       mask |= (uint64_t)0xFF << (8 * p);
       __syncthreads();
@@ -709,7 +742,7 @@ extern "C" int mhr_topk_select_sliced(const float* cand_val, const int32_t* cand
   MHR_REQUIRE((hist_ptr == nullptr) == (hist_items == nullptr), "topk_select_sliced: hist_ptr/hist_items must both be set or null");
   if (n_rows == 0) return MHR_OK;
   const int kp2 = next_pow2(k);
-  const size_t lds = (size_t)(SEL_CAP + kp2) * 8;
+  const size_t lds = (size_t)(SEL_CAP + kp2) * 8 + (size_t)HIST_LDS * 4;
   auto kern = topk_select_sliced_kernel;
   (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(kern, dim3(n_rows), dim3(256), lds, (hipStream_t)stream, cand_val, cand_idx, cand_cnt, n_slices, cap_s, H,
