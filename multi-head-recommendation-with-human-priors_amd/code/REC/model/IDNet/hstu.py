@@ -75,10 +75,10 @@ class HSTUJagged(nn.Module):
 
 class FusedTopK:
     """Per-head top-k of one eval batch: values [B,H,K] fp32, indices [B,H,K] int64 (value desc, index asc)."""
-    __slots__ = ("values", "indices")
+    __slots__ = ("values", "indices", "logs")
 
-    def __init__(self, values, indices):
-        self.values, self.indices = values, indices
+    def __init__(self, values, indices, logs=None):
+        self.values, self.indices, self.logs = values, indices, logs
 
 
 class HSTU(BaseModel):
@@ -185,9 +185,31 @@ class HSTU(BaseModel):
                 self.prior_loss_weight[dataload.category_to_int[name]] = cnt / total
         else:
             self.prior_loss_weight = [1.0 / C] * C
-        if self.loss == 'prior' and config['prior_switch'] is not None and nl > 0:
-            raise NotImplementedError("prior_switch heads (reference hstu.py:512-544) are not built yet; set prior_switch: null")
+        # prior switch (reference hstu.py:512-544): one auxiliary "does category c occur in the next pred_len items" logit
+        # per prior head, trained with BCE / asymmetric loss and usable to switch heads off at test time
         self.prior_switch = None
+        if self.loss == 'prior' and config['prior_switch'] is not None and nl > 0:
+            self.use_asym_switch_loss = config.get('asym_switch_loss', False)
+            self.switch_last_only = config.get('switch_last_only', False)
+            self.asl_gamma_pos, self.asl_gamma_neg = config.get('gamma_pos', 4.0), config.get('gamma_neg', 0.0)
+            assert config['split_mode'] == 'combine'
+            self.master_switch = config.get('master_switch', False)
+            if config['prior_switch'] == 'in':
+                self.aux_cat_head = nn.ModuleList([nn.Linear(D, 1) for _ in range(C)])
+                self.prior_switch = 'in'
+            elif config['prior_switch'] == 'in_out':
+                if self.head_interaction == 'multiplicative':
+                    assert S == 1, 'multiplicative head interaction is not supported for prior_switch=in_out when num_segment_head > 1'
+                self.aux_cat_head = nn.ModuleList([nn.Linear(2 * D, 1) for _ in range(C)])
+                self.prior_switch = 'in_out'
+            if self.prior_switch is not None:
+                if self.master_switch:
+                    for i in range(1, C):
+                        for p_ in self.aux_cat_head[i].parameters():
+                            p_.requires_grad_(False)
+                self.prior_switch_loss_weight = config['prior_switch_loss_weight']
+        self.use_prior_switch_test = config.get('use_prior_switch_test', False)
+        self.detach_aux_in = config.get('detach_aux_in', False)
         self.eval_pred_len = config['eval_pred_len']
         self.prior_given_at_test = config.get('prior_given_at_test', False)
         self.given_prior_len = config.get('given_prior_len', self.eval_pred_len) if self.prior_given_at_test else self.eval_pred_len
@@ -300,6 +322,40 @@ class HSTU(BaseModel):
             else:
                 outs = [head(x) for head in self.medusa_head]
         return torch.stack([o.float() for o in outs], dim=-2)
+
+    def _switch_logits(self, out, head_out, c):
+        """aux_cat_head[c] on the encoder output ('in') or [encoder output | head c output] ('in_out'); out [..., D],
+        head_out [..., H, D] (reference hstu.py:770-784, 940-947).  A D -> 1 GEMV: library matmul, bf16 like the
+        reference under autocast."""
+        if self.prior_switch == 'in':
+            aux_in = out
+        else:
+            h = self.num_segment_head + c if self.head_interaction == 'additive' else c
+            aux_in = torch.cat([out, head_out[..., h, :]], dim=-1)
+        if self.detach_aux_in:
+            aux_in = aux_in.detach()
+        with torch.autocast(device_type=out.device.type, dtype=torch.bfloat16, enabled=out.is_cuda):
+            return self.aux_cat_head[c](aux_in).squeeze(-1).float()
+
+    def _switch_loss(self, out, head_out, tag_win, c):
+        """(loss, accuracy) of the category-c switch (reference hstu.py:757-805).  tag_win [B,P,L,C] future tags."""
+        target = tag_win[..., c].any(dim=1).float()                            # [B,L]
+        logits = self._switch_logits(out, head_out, c)                         # [B,L]
+        if self.switch_last_only:
+            target, logits = target[:, -1:], logits[:, -1:]
+        if self.use_asym_switch_loss:      # REC/model/layers.py:16-83, sum over the last dim, mean over the rest
+            xs_pos = torch.sigmoid(logits)
+            xs_neg = (1 - xs_pos + 0.05).clamp(max=1)
+            ls = target * torch.log(xs_pos.clamp(min=1e-8)) + (1 - target) * torch.log(xs_neg.clamp(min=1e-8))
+            if self.asl_gamma_neg > 0 or self.asl_gamma_pos > 0:
+                pt = xs_pos * target + xs_neg * (1 - target)
+                ls = ls * torch.pow(1 - pt, self.asl_gamma_pos * target + self.asl_gamma_neg * (1 - target))
+            loss = (-ls.sum(dim=-1)).mean()
+        else:
+            p = max(min(float(self.prior_loss_weight[c]), 1.0 - 1e-6), 1e-6)
+            loss = F.binary_cross_entropy_with_logits(logits, target, pos_weight=torch.tensor((1.0 - p) / p, device=logits.device))
+        acc = ((logits >= 0).int() == target.int()).float().mean()
+        return loss, acc.detach()
 
     # ------------------------------------------------------------------------------------------
     # training
@@ -440,6 +496,15 @@ class HSTU(BaseModel):
                     model_out[f"seg_{s_}_loss"] = model_out[f"seg_{s_}_loss"] + seg[s_]
             else:
                 total = total / 2
+        if self.prior_switch is not None:
+            head_out = head_embs.permute(0, 2, 1, 3)                               # [B,L,H,D]
+            for c in range(1 if self.master_switch else C):
+                sw_loss, sw_acc = self._switch_loss(out, head_out, tag_win, c)
+                name = self.int_to_category[c]
+                model_out[f'head_cat_{name}_acc'] = sw_acc
+                model_out[f'head_cat_{name}_loss'] = self.prior_switch_loss_weight * sw_loss.detach()
+                # (the reference adds it inside the category loop, i.e. before the additive mode's final halving, hstu.py:870)
+                total = total + self.prior_switch_loss_weight * sw_loss * (0.5 if additive else 1.0)
         model_out.update(logs)
         model_out["loss"] = total
         return model_out
@@ -463,7 +528,7 @@ class HSTU(BaseModel):
         return ops.l2norm_rows(w.contiguous(), torch.float32)
 
     @torch.no_grad()
-    def _user_heads(self, item_seq):
+    def _user_heads(self, item_seq, want_switch=False):
         """[B,L] ids (front zero padded) -> L2-normalised head embeddings [B,H,D] fp32 (reference hstu.py:879-966)."""
         from mhr_amd import ops
         B, L = item_seq.shape
@@ -475,14 +540,31 @@ class HSTU(BaseModel):
             rows, _ = ops.embedding_gather(self.item_embedding.weight, item_seq.contiguous(), torch.float32)
             x = self.item_id_proj_tower(rows) + self.position_embedding.weight[:L][None]
         out = self._encode(x, (item_seq != 0).to(torch.uint8).contiguous(), training=False)   # dropout off, like .eval()
-        heads = self._heads(out[:, -1])                                   # [B,H,D]
+        last = out[:, -1]
+        heads = self._heads(last)                                         # [B,H,D]
+        if want_switch:
+            # prior-switch decisions at the last position (reference hstu.py:935-956): [B, n] bool, n = 1 under master_switch
+            n = 1 if self.master_switch else self.num_prior_head
+            pred = torch.stack([self._switch_logits(last, heads, c) >= 0 for c in range(n)], dim=1)
+            return ops.l2norm_rows(heads.contiguous(), torch.float32), pred
         return ops.l2norm_rows(heads.contiguous(), torch.float32)
 
-    def _row_constraints(self, B, target_tags, device):
+    def _switched_off(self, pred):
+        """[B,C] bool: prior heads the switch turns off (reference hstu.py:1002-1011)."""
+        if self.master_switch:
+            return torch.cat([~pred[:, :1], pred[:, :1].expand(-1, self.num_prior_head - 1)], dim=1)
+        return ~pred
+
+    def _switch_logs(self, pred, target_tags, logs):
+        for c in range(pred.shape[1]):
+            label = target_tags[:, :, c].sum(dim=-1) > 0
+            logs[f'head_cat_{self.int_to_category[c]}_num_correct'] = torch.sum((label == pred[:, c]) * 1.0)
+
+    def _row_constraints(self, B, target_tags, device, switched_off=None):
         """Per (user, head) admissible-category bit (int32 bit pattern): bit c for prior heads, bit 31 for
         unconstrained heads, 0 for heads switched off by `prior_given_at_test` (reference hstu.py:982-999)."""
         S, C, H = self.num_segment_head, self.num_prior_head, self.medusa_num_heads
-        static = self.loss != 'prior' or not self.prior_given_at_test
+        static = (self.loss != 'prior' or not self.prior_given_at_test) and switched_off is None
         if static and (B, device) in self._row_bits_cache:
             return self._row_bits_cache[(B, device)]
         if self.loss != 'prior':
@@ -498,6 +580,9 @@ class HSTU(BaseModel):
             given = target_tags[:, :self.given_prior_len].bool().any(dim=1)                       # [B,C]
             on = torch.where(cat_of_head[None, :] >= 0, given[:, cat_of_head.clamp_min(0)], torch.ones_like(bits, dtype=torch.bool))
             bits = torch.where(on, bits, torch.zeros_like(bits))
+        if switched_off is not None:                                                              # hstu.py:1002-1015
+            off = torch.where(cat_of_head[None, :] >= 0, switched_off[:, cat_of_head.clamp_min(0)], torch.zeros_like(bits, dtype=torch.bool))
+            bits = torch.where(off, torch.zeros_like(bits), bits)
         bits = bits.reshape(-1).to(torch.int32)
         if static:
             self._row_bits_cache[(B, device)] = bits
@@ -520,7 +605,15 @@ class HSTU(BaseModel):
         B = item_seq.shape[0]
         H = self.medusa_num_heads
         dev = item_seq.device
-        users = self._user_heads(item_seq).to(torch.bfloat16).view(B * H, -1).contiguous()
+        switched_off, logs = None, {'num_samples': self.eval_pred_len * B}
+        if self.prior_switch is not None:
+            heads_n, pred = self._user_heads(item_seq, want_switch=True)
+            self._switch_logs(pred, target_tags, logs)
+            if self.use_prior_switch_test:
+                switched_off = self._switched_off(pred)
+        else:
+            heads_n = self._user_heads(item_seq)
+        users = heads_n.to(torch.bfloat16).view(B * H, -1).contiguous()
         key = (all_item_feature.data_ptr(), all_item_feature._version, None if all_item_tags is None else all_item_tags.data_ptr())
         if self._item_cache is None or self._item_cache[0] != key:
             items_bf = ops.l2norm_rows(all_item_feature.float().contiguous(), torch.bfloat16)      # hstu.py:974-975
@@ -529,7 +622,7 @@ class HSTU(BaseModel):
             tag_bits = self.pack_item_tags(all_item_tags) if (all_item_tags is not None and self.loss == 'prior') else None
             self._item_cache = (key, items_bf, tag_bits)
         _, items_bf, tag_bits = self._item_cache
-        row_bits = self._row_constraints(B, target_tags, dev)
+        row_bits = self._row_constraints(B, target_tags, dev, switched_off)
         hist_ptr = hist_items = None
         if suppress_history and history is not None and history[0].numel() > 0:
             hu, hi = history[0].to(dev), history[1].to(dev)
@@ -539,14 +632,20 @@ class HSTU(BaseModel):
             hist_ptr = torch.searchsorted(hu[order].contiguous(), torch.arange(B + 1, device=dev)).int()
         vals, idx = ops.catalog_topk(users, H, items_bf, tag_bits, row_bits, hist_ptr, hist_items, k, stats=stats,
                                      n_items=all_item_feature.shape[0])
-        return FusedTopK(vals.view(B, H, k), idx.view(B, H, k))
+        fused = FusedTopK(vals.view(B, H, k), idx.view(B, H, k))
+        fused.logs = logs
+        return fused
 
     @torch.no_grad()
     def predict(self, item_seq, time_seq, all_item_feature, all_item_tags, target_tags, save_for_eval=False):
         """Reference contract: dense scores [B,H,N] fp32 with -inf masks (hstu.py:874-1016).  Kept for callers
         written against the reference; the fused path is `predict_topk`."""
         S, C = self.num_segment_head, self.num_prior_head
-        heads = self._user_heads(item_seq)                                                          # [B,H,D] fp32
+        pred = None
+        if self.prior_switch is not None:
+            heads, pred = self._user_heads(item_seq, want_switch=True)                              # [B,H,D] fp32, [B,n] bool
+        else:
+            heads = self._user_heads(item_seq)
         feat = all_item_feature.float()
         feat = feat / feat.norm(dim=-1, keepdim=True)
         scores = torch.matmul(heads, feat.t())
@@ -563,7 +662,15 @@ class HSTU(BaseModel):
                 scores[:, S:].masked_fill_(~tagm.unsqueeze(0), float('-inf'))
             else:
                 scores.masked_fill_(~tagm.repeat(S, 1).unsqueeze(0), float('-inf'))
+            if pred is not None and self.use_prior_switch_test:
+                off = self._switched_off(pred)
+                if additive:
+                    scores[:, S:].masked_fill_(off.unsqueeze(-1), float('-inf'))
+                else:
+                    scores.masked_fill_(off.repeat(1, S).unsqueeze(-1), float('-inf'))
         wandb_logs = {'num_samples': self.eval_pred_len * item_seq.shape[0]}
+        if pred is not None:
+            self._switch_logs(pred, target_tags, wandb_logs)
         saved_user = saved_head = None
         if save_for_eval:
             saved_head = heads.float().cpu().numpy()

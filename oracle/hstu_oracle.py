@@ -273,6 +273,49 @@ def _per_offset_mean(tok_loss, p_of_tok, P):
     return s / n.clamp_min(1.0)
 
 
+def asymmetric_loss(x, y, gamma_pos, gamma_neg, clip=0.05, eps=1e-8):
+    """REC/model/layers.py:16-83 (ASL): summed over the last dim, mean over the rest."""
+    xs_pos = torch.sigmoid(x)
+    xs_neg = 1 - xs_pos
+    if clip is not None and clip > 0:
+        xs_neg = (xs_neg + clip).clamp(max=1)
+    loss = y * torch.log(xs_pos.clamp(min=eps)) + (1 - y) * torch.log(xs_neg.clamp(min=eps))
+    if gamma_neg > 0 or gamma_pos > 0:
+        pt = xs_pos * y + xs_neg * (1 - y)
+        loss = loss * torch.pow(1 - pt, gamma_pos * y + gamma_neg * (1 - y))
+    return (-loss.sum(dim=-1)).mean()
+
+
+def switch_logits(weights, cfg, out, head_out, c):
+    """aux_cat_head[c] on the encoder output ('in') or on [encoder output | head c output] ('in_out').
+    out [..., D]; head_out [..., H, D] (head axis second to last).  model/IDNet/hstu.py:770-784, 940-947."""
+    S = cfg["num_segment_head"]
+    if cfg["prior_switch"] == "in":
+        aux_in = out
+    else:
+        h = S + c if cfg["head_interaction"] == "additive" else c
+        aux_in = torch.cat([out, head_out[..., h, :]], dim=-1)
+    if cfg.get("detach_aux_in"):
+        aux_in = aux_in.detach()
+    return (aux_in @ weights[f"aux_cat_head.{c}.weight"].T + weights[f"aux_cat_head.{c}.bias"]).squeeze(-1)
+
+
+def prior_switch_loss(weights, cfg, out, heads, tg, c, w_c):
+    """Per-category auxiliary "will the next pred_len items contain category c" head.  model/IDNet/hstu.py:757-805.
+    out [B,L,D]; heads [B,H,L,D]; tg [B,P,L,C] future tags.  Returns (loss, accuracy)."""
+    target = tg[..., c].bool().any(dim=1).float()                      # [B,L]
+    logits = switch_logits(weights, cfg, out, heads.permute(0, 2, 1, 3), c)   # [B,L]
+    if cfg.get("switch_last_only"):
+        target, logits = target[:, -1:], logits[:, -1:]
+    if cfg.get("asym_switch_loss"):
+        loss = asymmetric_loss(logits, target, cfg.get("gamma_pos", 4.0), cfg.get("gamma_neg", 0.0))
+    else:
+        p = max(min(float(w_c[c]), 1.0 - 1e-6), 1e-6)
+        loss = torch.nn.functional.binary_cross_entropy_with_logits(logits, target, pos_weight=torch.tensor((1.0 - p) / p))
+    acc = ((logits >= 0).int() == target.int()).float().mean()
+    return loss, acc.detach()
+
+
 def gather_negatives(weights, neg_ids):
     """hstu.py:669-673 / 751-755 at world size 1: gather, L2-normalise, flatten."""
     n = item_tower(weights, weights["item_embedding.weight"][neg_ids])
@@ -342,6 +385,12 @@ def train_forward(weights, cfg, batch, extra_negs=None):
         for c in range(C):
             res[f"head_nce_{names[c]}_loss"] = 0
             negs = negs_for(c) if by_cat else shared
+            if cfg.get("prior_switch") in ("in", "in_out") and not (cfg.get("master_switch") and c > 0):
+                sw_loss, sw_acc = prior_switch_loss(weights, cfg, out, heads, tg, c, w_c)
+                wsw = cfg["prior_switch_loss_weight"]
+                res[f"head_cat_{names[c]}_acc"] = sw_acc
+                res["loss"] = res["loss"] + wsw * sw_loss
+                res[f"head_cat_{names[c]}_loss"] = wsw * sw_loss.detach()
             m = valid & tg[..., c].bool()
             if m.sum() == 0:            # hstu.py:815-839: head contributes nothing
                 continue
@@ -385,14 +434,35 @@ def user_head_embeddings(weights, cfg, item_seq):
     return l2n(decode_heads(weights, cfg, last).float())
 
 
-def predict_scores(weights, cfg, item_seq, item_feature, all_item_tags, target_tags):
-    """HSTU.predict without the prior switch. model/IDNet/hstu.py:874-1016.
+def predict_switch(weights, cfg, item_seq):
+    """Prior-switch decisions at the last position: pred [B, n] bool (n = 1 with master_switch, else C).
+    model/IDNet/hstu.py:935-956."""
+    _, x = embed_inputs(weights, cfg, item_seq)
+    last = hstu_encoder(x, weights, cfg, item_seq != 0)[:, -1]             # [B,D]
+    head_out = decode_heads(weights, cfg, last)                            # [B,H,D] (not normalised)
+    n = 1 if cfg.get("master_switch") else cfg["num_prior_head"]
+    return torch.stack([switch_logits(weights, cfg, last, head_out, c) >= 0 for c in range(n)], dim=1)
+
+
+def predict_scores(weights, cfg, item_seq, item_feature, all_item_tags, target_tags, logs=None):
+    """HSTU.predict. model/IDNet/hstu.py:874-1016.
 
     item_feature [N,D] (re-normalised here, hstu.py:974-975), all_item_tags [C,N],
-    target_tags [B,eval_pred_len,C].  Returns scores [B,H,N] with -inf masks.
+    target_tags [B,eval_pred_len,C].  Returns scores [B,H,N] with -inf masks; `logs` (optional dict) receives the
+    reference's wandb counters (num_samples, head_cat_*_num_correct).
     """
     S, C = cfg["num_segment_head"], cfg["num_prior_head"]
     u = user_head_embeddings(weights, cfg, item_seq)                       # [B,H,D]
+    names = cfg.get("int_to_category") or {c: str(c) for c in range(C)}
+    pred = None
+    if cfg["loss"] == "prior" and cfg.get("prior_switch") in ("in", "in_out"):
+        pred = predict_switch(weights, cfg, item_seq)
+        if logs is not None:
+            for c in range(pred.shape[1]):
+                label = target_tags[:, :, c].sum(dim=-1) > 0
+                logs[f"head_cat_{names[c]}_num_correct"] = float((label == pred[:, c]).sum())
+    if logs is not None:
+        logs["num_samples"] = cfg["eval_pred_len"] * item_seq.shape[0]
     it = l2n(item_feature.float())
     scores = u @ it.T                                                      # [B,H,N]
     if cfg["loss"] == "prior":
@@ -409,4 +479,13 @@ def predict_scores(weights, cfg, item_seq, item_feature, all_item_tags, target_t
             scores[:, S:] = scores[:, S:].masked_fill(~tagm[None], float("-inf"))
         else:
             scores = scores.masked_fill(~tagm.repeat(S, 1)[None], float("-inf"))
+        if pred is not None and cfg.get("use_prior_switch_test"):          # hstu.py:1002-1015: heads switched off
+            if cfg.get("master_switch"):
+                off = torch.cat([~pred[:, :1], pred[:, :1].expand(-1, C - 1)], dim=1)          # [B,C]
+            else:
+                off = ~pred
+            if additive:
+                scores[:, S:] = scores[:, S:].masked_fill(off[:, :, None], float("-inf"))
+            else:
+                scores = scores.masked_fill(off.repeat(1, S)[:, :, None], float("-inf"))
     return scores

@@ -131,7 +131,7 @@ def run_train_case(name, cfg, N, B, n_neg, seed, grads=("item_embedding.weight",
             d["grad/" + k] = named[k].grad.numpy()
     # every head parameter's gradient too (small)
     for k, p_ in named.items():
-        if ("medusa" in k or "segment_emb" in k or "position_embedding" in k) and p_.grad is not None:
+        if ("medusa" in k or "segment_emb" in k or "position_embedding" in k or "aux_cat_head" in k) and p_.grad is not None:
             d["grad/" + k] = p_.grad.numpy()
     d["cfg/json"] = np.asarray(cfg_json(cfg, N, C))
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
@@ -189,6 +189,8 @@ def run_predict_case(name, cfg, N, B, seed):
         model.given_prior_len = 2 if given else E
         scores, logs, _, _ = model.predict(item_seq, None, feat, item_tags.t().contiguous(), target_tags)
         d[f"out/scores_given{int(given)}"] = scores.numpy()
+        for k_, v_ in logs.items():
+            d[f"out/log_given{int(given)}/{k_}"] = np.asarray(float(v_))
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
     print(f"{name}: scores {tuple(scores.shape)} -inf frac {float(torch.isinf(scores).float().mean()):.3f}")
 
@@ -292,9 +294,37 @@ def run_schedule_and_adam():
     print("schedule_adam ok")
 
 
+def switch_cases():
+    """Prior-switch fixtures (reference hstu.py:512-544, 757-805, 935-956, 1002-1015), added after the first batch:
+    `python tests/gen_golden.py switch` writes only these."""
+    run_train_case("hstu_switch_in", base_cfg(pred_len=4, eval_pred_len=4, num_segment_head=1, num_prior_head=3,
+                                              head_interaction="multiplicative", medusa_num_layers=1, loss="prior",
+                                              prior_switch="in", prior_switch_loss_weight=0.5),
+                   N=401, B=5, n_neg=6, seed=41)
+    run_train_case("hstu_switch_inout_asym", base_cfg(pred_len=4, eval_pred_len=4, num_segment_head=2, num_prior_head=3,
+                                                      head_interaction="additive", medusa_num_layers=1, loss="prior",
+                                                      prior_switch="in_out", prior_switch_loss_weight=0.25,
+                                                      asym_switch_loss=True, master_switch=True, detach_aux_in=True),
+                   N=401, B=5, n_neg=6, seed=42)
+    run_train_case("hstu_switch_last", base_cfg(pred_len=2, eval_pred_len=2, num_segment_head=1, num_prior_head=2,
+                                                head_interaction="multiplicative", medusa_num_layers=1, loss="prior",
+                                                prior_switch="in_out", prior_switch_loss_weight=1.0, switch_last_only=True),
+                   N=301, B=4, n_neg=5, seed=43)
+    run_predict_case("predict_switch", base_cfg(pred_len=4, eval_pred_len=4, num_segment_head=1, num_prior_head=3,
+                                                medusa_num_layers=1, loss="prior", prior_switch="in_out",
+                                                prior_switch_loss_weight=0.5, use_prior_switch_test=True), N=257, B=8, seed=44)
+    run_predict_case("predict_switch_master", base_cfg(pred_len=4, eval_pred_len=4, num_segment_head=2, num_prior_head=3,
+                                                       head_interaction="additive", medusa_num_layers=1, loss="prior",
+                                                       prior_switch="in", prior_switch_loss_weight=0.5,
+                                                       use_prior_switch_test=True, master_switch=True), N=257, B=8, seed=45)
+
+
 def main():
     _setup()
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "switch":
+        switch_cases()
+        return
     # F1: plain next-item NCE, identity heads
     run_train_case("hstu_nce_tiny", base_cfg(), N=501, B=4, n_neg=8, seed=11)
     # F1b: multi-step NCE with one ResBlock head per segment

@@ -16,7 +16,7 @@ from oracle import metrics_oracle as MO
 from oracle import optim_oracle as OO
 
 TRAIN_CASES = ["hstu_nce_tiny", "hstu_nce_multistep", "hstu_prior_hier", "hstu_prior_mult",
-               "hstu_prior_additive", "hstu_prior_proj"]
+               "hstu_prior_additive", "hstu_prior_proj", "hstu_switch_in", "hstu_switch_inout_asym", "hstu_switch_last"]
 
 
 def cfg_of(g):
@@ -77,7 +77,7 @@ def test_attention_unit():
         np.testing.assert_allclose(out.numpy(), g[f"{tag}/out"], rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize("name", ["predict_mult", "predict_additive"])
+@pytest.mark.parametrize("name", ["predict_mult", "predict_additive", "predict_switch", "predict_switch_master"])
 def test_predict_scores(name):
     g = load_golden(name)
     cfg = cfg_of(g)
@@ -89,11 +89,15 @@ def test_predict_scores(name):
     tt = torch.from_numpy(g["in/target_tags"])
     for given in (0, 1):
         c = dict(cfg, prior_given_at_test=bool(given), given_prior_len=2 if given else cfg["eval_pred_len"])
-        s = HO.predict_scores(w, c, seq, feat, tags, tt).numpy()
+        logs = {}
+        s = HO.predict_scores(w, c, seq, feat, tags, tt, logs=logs).numpy()
         ref = g[f"out/scores_given{given}"]
         assert np.array_equal(np.isinf(s), np.isinf(ref))
         fin = np.isfinite(ref)
         np.testing.assert_allclose(s[fin], ref[fin], rtol=1e-4, atol=2e-6)
+        for k in g:                                              # the reference's wandb counters (newer fixtures only)
+            if k.startswith(f"out/log_given{given}/"):
+                assert float(g[k]) == logs[k.split("/", 2)[2]], k
 
 
 COLLECT = ["collector_combine", "collector_smallcat", "collector_additive", "collector_k200",
