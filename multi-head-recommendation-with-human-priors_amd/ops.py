@@ -258,11 +258,14 @@ def token_compact(mask, q_all, p_all, o_all, tok_cap=None):
     return q_idx, p_idx, o_idx, n_tok
 
 
+STREAM_DIMS = (16, 32, 64, 128, 256)      # feature dims of the register-stationary streaming kernels
+
+
 class NceSaved:
     """Tensors the forward keeps for the backward (all preallocated at token capacity)."""
     __slots__ = ("qn", "pn", "supp", "q_inv", "p_inv", "s_pos", "lse", "loss", "n_valid", "rank", "negs",
                  "n_tok_dev", "tok_cap", "cap", "thres", "dim", "n_neg", "groups", "q_idx", "p_idx", "bucket_idx", "n_buckets",
-                 "bucket_sum", "bucket_cnt", "u")
+                 "bucket_sum", "bucket_cnt", "u", "wide")
 
 
 def nce_fwd(q_rows, q_idx, p_rows, p_idx, negs, n_tok_dev, tok_cap, logit_scale, thres=0.99, want_logs=False,
@@ -292,6 +295,7 @@ def nce_fwd(q_rows, q_idx, p_rows, p_idx, negs, n_tok_dev, tok_cap, logit_scale,
             bucket_idx = torch.nn.functional.pad(bucket_idx, (0, cap - tok_cap)).contiguous()
     sv = NceSaved()
     sv.q_idx, sv.p_idx = q_idx, p_idx
+    sv.wide = D not in STREAM_DIMS            # feature dims beyond the register-stationary kernels: wide.py (library GEMMs)
     sv.bucket_idx, sv.n_buckets, sv.bucket_sum, sv.bucket_cnt = bucket_idx, int(n_buckets), None, None
     if bucket_idx is not None:       # per-(group, bucket) loss sums and token counts come out of the finalize kernel
         _chk(bucket_idx, "bucket_idx", torch.int32)
@@ -303,17 +307,26 @@ def nce_fwd(q_rows, q_idx, p_rows, p_idx, negs, n_tok_dev, tok_cap, logit_scale,
     n_valid = torch.zeros(G, cap, dtype=torch.int32, device=dev) if want_logs else None
     rank = torch.zeros(G, cap, dtype=torch.int32, device=dev) if want_logs else None
     sv.s_pos = torch.empty(G, cap, dtype=torch.float32, device=dev)
-    if for_backward:
+    if for_backward or sv.wide:
         sv.qn = torch.empty(G, cap, D, dtype=torch.bfloat16, device=dev)
         sv.pn = torch.empty(G, cap, D, dtype=torch.bfloat16, device=dev)
-        sv.supp = torch.empty(G, (n_neg + 31) // 32, cap, dtype=torch.int32, device=dev)
         sv.q_inv = torch.empty(G, cap, dtype=torch.float32, device=dev)
         sv.p_inv = torch.empty(G, cap, dtype=torch.float32, device=dev)
-        sv.u = torch.empty(G, cap, D, dtype=torch.float32, device=dev)      # unnormalised token-side gradient (fused forward)
+        sv.supp = sv.u = None
+        if not sv.wide:
+            sv.supp = torch.empty(G, (n_neg + 31) // 32, cap, dtype=torch.int32, device=dev)
+            sv.u = torch.empty(G, cap, D, dtype=torch.float32, device=dev)  # unnormalised token-side gradient (fused forward)
     else:
         sv.qn = sv.pn = sv.supp = sv.q_inv = sv.p_inv = sv.u = None
     sv.negs = negs
     sv.n_tok_dev, sv.tok_cap, sv.cap, sv.thres, sv.dim, sv.n_neg, sv.groups = n_tok_dev, tok_cap, cap, float(thres), D, n_neg, G
+    if sv.wide:
+        from . import wide
+        wide.nce_fwd_wide(sv, q_rows, p_rows, negs, logit_scale, want_logs, bucket_idx, loss, n_valid, rank)
+        sv.loss = loss[:, :tok_cap]
+        sv.n_valid = None if n_valid is None else n_valid[:, :tok_cap]
+        sv.rank = None if rank is None else rank[:, :tok_cap]
+        return sv
     ssum = torch.zeros(G, cap, dtype=torch.float32, device=dev)
     st = _stream()
     _timed_call("mhr_nce_fwd", q_rows.data_ptr(), q_idx.data_ptr(), p_rows.data_ptr(), p_idx.data_ptr(), _dt(q_rows),
@@ -349,6 +362,11 @@ def nce_bwd(sv, w, logit_scale, q_idx, p_idx, dq_rows, dp_rows, d_negs=None, d_l
     _chk(w, "w", torch.float32)
     _chk(dq_rows, "dq_rows", torch.float32)
     _chk(dp_rows, "dp_rows", torch.float32)
+    if sv.wide:
+        from . import wide
+        w_tok = torch.gather(w, 1, sv.bucket_idx.long().clamp(0, sv.n_buckets - 1)) if bucketed else w
+        wide.nce_bwd_wide(sv, w_tok, logit_scale, dq_rows, dp_rows, d_negs, d_logit_scale)
+        return d_negs, d_logit_scale
     lw = torch.empty(G, cap, dtype=torch.float32, device=dev)     # lse log2e - log2 w: written by bwd_tokens, read by bwd_negs
     st = _stream()
     _timed_call("mhr_nce_bwd_tokens", sv.qn.data_ptr(), sv.pn.data_ptr(), sv.u.data_ptr(), D,
@@ -447,6 +465,9 @@ def catalog_topk(users, H, items, tag_bits, row_bits, hist_ptr, hist_items, k, c
     n_rows, D = users.shape
     N = items.shape[0] if n_items is None else int(n_items)
     dev = users.device
+    if D not in STREAM_DIMS:
+        from . import wide
+        return wide.catalog_topk_wide(users, H, items, N, tag_bits, row_bits, hist_ptr, hist_items, k)
     ninf = torch.full((n_rows,), float("-inf"), dtype=torch.float32, device=dev)
     if N <= cap:
         cand = catalog_emit(users, H, items, tag_bits, row_bits, ninf, hist_ptr, hist_items, N, n_items=N)

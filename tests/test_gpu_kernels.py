@@ -284,7 +284,8 @@ def _nce_oracle(q, p, negs_n, ls, thres, w=None):
 
 
 @pytest.mark.parametrize("D,n_tok,n_neg,dtype", [(16, 37, 30, torch.float32), (64, 200, 96, torch.bfloat16),
-                                                 (256, 300, 512, torch.bfloat16), (256, 129, 8192, torch.bfloat16)])
+                                                 (256, 300, 512, torch.bfloat16), (256, 129, 8192, torch.bfloat16),
+                                                 (512, 150, 96, torch.float32)])     # 512: the generic-width (library GEMM) path
 def test_nce_fwd_bwd(ops, D, n_tok, n_neg, dtype):
     g = torch.Generator().manual_seed(8 + D)
     n_src = 2 * n_tok
@@ -493,7 +494,8 @@ def _check_topk(ov, oi, scores, k):
     return ov, oi
 
 
-@pytest.mark.parametrize("B,H,C,N,D,k", [(3, 4, 4, 300, 16, 20), (5, 4, 4, 3000, 64, 200), (2, 6, 3, 700, 256, 50)])
+@pytest.mark.parametrize("B,H,C,N,D,k", [(3, 4, 4, 300, 16, 20), (5, 4, 4, 3000, 64, 200), (2, 6, 3, 700, 256, 50),
+                                         (3, 4, 4, 900, 512, 40)])                   # 512: the generic-width path
 def test_catalog_topk_small(ops, B, H, C, N, D, k):
     users, items, tag_bits, row_bits, hp, hi, scores = _catalog_case(B, H, C, N, D, 40 + N, disabled_row=1)
     ov, oi = ops.catalog_topk(dev(users), H, dev(items), dev(tag_bits), dev(row_bits), dev(hp), dev(hi), k, cap=4096)

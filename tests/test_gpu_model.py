@@ -210,3 +210,49 @@ def test_training_reduces_loss(rec):
     losses = [float(tr.train_step_fn(fixed)["loss"]) for _ in range(60)]
     assert losses[-1] < 0.7 * losses[1], losses[::10]
     assert all(np.isfinite(losses))
+
+
+def test_wide_model_trains_and_decodes(rec):
+    """cfg2-like width (D = 512 > 256: generic-width loss and decode, head_dim 64, prior heads with a shared pool):
+    the whole train step and the fused decode run, the loss falls, and the decode equals the oracle decode of the
+    model's own bf16 head / item embeddings (indices exact up to numerical ties)."""
+    import mhr_amd.synth as synth
+    from oracle import decode_oracle as DO
+    from REC.config.configurator import Config, apply_run_fixups
+    from REC.trainer import Trainer
+    from REC.utils import get_model
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(5)
+    cfgd = synth.base_config(MAX_ITEM_LIST_LENGTH=32, pred_len=1, eval_pred_len=1, n_layers=2, n_heads=8, item_embedding_size=512,
+                             hstu_embedding_size=512, loss='prior', num_prior_head=2, num_segment_head=1, medusa_num_layers=1,
+                             neg_sample_by_cat=False, num_negatives=256, device=dev, total_iters=40, eval_interval=0,
+                             checkpoint_dir=None, save_model_note="t", scheduler_args={'type': 'cosine', 'warmup': 0.1},
+                             optim_args={'learning_rate': 2e-3, 'weight_decay': 0.0}, topk=[5, 20])
+    cfg = apply_run_fixups(Config(config_dict=cfgd))
+    data = synth.SyntheticData(cfg, 700, dev)
+    cfg["int_to_category"] = data.int_to_category
+    model = get_model("HSTU")(cfg, data).to(dev)
+    tr = Trainer(cfg)
+    tr.setup_model(model)
+    fixed = data.train_batch(16)
+    losses = [float(tr.train_step_fn(fixed)["loss"]) for _ in range(40)]
+    assert all(np.isfinite(losses)) and losses[-1] < 0.8 * losses[1], losses[::8]
+    model.eval()
+    eb = data.eval_batch(8)
+    item_seq, target_tags = eb[1].to(dev), eb[6].to(dev)
+    feat = model.compute_item_all()
+    tags = data.item_tags.long().t().contiguous()
+    k = 20
+    fused = model.predict_topk(item_seq, feat, tags, target_tags, None, k=k, suppress_history=False)
+    users = model._user_heads(item_seq).to(torch.bfloat16).float().cpu()
+    items = feat.to(torch.bfloat16).float().cpu()
+    dense = (users @ items.T).numpy()
+    scores, _, _, _ = model.predict(item_seq, None, feat, tags, target_tags)
+    dense[~np.isfinite(scores.cpu().numpy())] = -np.inf
+    dense[:, :, 0] = -np.inf
+    rv, ri = DO.per_head_topk(dense, k)
+    fi, fv = fused.indices.cpu().numpy(), fused.values.cpu().numpy()
+    finm = np.isfinite(rv)
+    np.testing.assert_allclose(fv[finm], rv[finm], rtol=1e-4, atol=1e-6)
+    for b, h, j in np.argwhere((fi != ri) & finm):
+        assert abs(dense[b, h, fi[b, h, j]] - rv[b, h, j]) < 2e-6
