@@ -262,6 +262,12 @@ def main():
                         out["roofline"]["traffic"] = rec["hbm_bytes_per_launch"]
                         out["roofline"]["traffic_source"] = os.path.relpath(files[-1], ROOT)
             out["kernel_ms_per_step"] = per_step
+            if "mhr_embedding_gather_fwd" in prof and args.mode == "train":
+                # item ids + negative-pool ids: table rows read and written as fp32, plus the position-added encoder input
+                n_pools = C if (cfg["loss"] == "prior" and cfg.get("neg_sample_by_cat")) else 1
+                n_ids = B * (L + P) + data.n_neg(B) * B * n_pools
+                gbytes = (n_ids * 2 + B * L) * D * 4.0
+                out["embedding_gather_GBps"] = round(gbytes / (prof["mhr_embedding_gather_fwd"][2] / args.steps * 1e-3) / 1e9, 1)
             if "mhr_adam_rows" in prof:
                 ms = prof["mhr_adam_rows"][1]
                 out["adam_rows_GBps"] = round(N * D * 24.0 / (ms * 1e-3) / 1e9, 1)

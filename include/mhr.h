@@ -45,13 +45,14 @@ int mhr_abi_version(void);
 /* out[r,:] = table[ids[r],:]  (nn.Embedding forward, model/IDNet/hstu.py:413,637,670,752,883).
  * Optional fused position add (hstu.py:640-643): when x_out != NULL, ids is viewed as
  * [n_ids/window_len, window_len] and x_out[b,l,:] = table[ids[b,l],:] + pos_table[l,:] for
- * l < seq_len (x_out is [n_ids/window_len, seq_len, dim], dtype x_dtype).
+ * l < seq_len (x_out is [n_x_ids/window_len, seq_len, dim], dtype x_dtype), for the first n_x_ids ids only
+ * (n_x_ids <= 0: all of them) - so the item windows and the negative-pool ids of a step are ONE launch.
  * `out` may be NULL when only x_out is wanted.  dim % 4 == 0.  ids outside [0,n_rows) are clamped. */
 int mhr_embedding_gather_fwd(const float* table, int64_t n_rows, int dim,
                              const int64_t* ids, int64_t n_ids,
                              void* out, int out_dtype,
                              const float* pos_table, int seq_len, int window_len,
-                             void* x_out, int x_dtype, void* stream);
+                             void* x_out, int x_dtype, int64_t n_x_ids, void* stream);
 
 /* Dense embedding backward (ATen embedding_dense_backward): grad_table[ids[r],:] += grad_rows[r,:]
  * with float atomics.  grad_table [n_rows, dim] f32 must be zeroed by the caller. */

@@ -141,15 +141,13 @@ class EmbeddingGatherFn(Function):
         B = n_item_ids // window
         # items part with the fused position add
         items = ids_all[:n_item_ids].view(B, window)
+        # ONE launch: item windows (rows + position-added x) and negative-pool ids (rows only), written in place
         if pos_table is not None:
-            r_items, x = ops.embedding_gather(table, items, torch.float32, pos_table, L, torch.float32)
+            _, x = ops.embedding_gather(table, ids_all, torch.float32, pos_table, L, torch.float32, out=rows, window=window,
+                                        n_x_ids=n_item_ids)
         else:                                  # projection tower in between: the position add happens after it
-            r_items, _ = ops.embedding_gather(table, items, torch.float32)
+            ops.embedding_gather(table, ids_all, torch.float32, out=rows)
             x = torch.zeros(1, device=table.device)
-        rows[:n_item_ids] = r_items.view(-1, D)
-        if ids_all.numel() > n_item_ids:
-            r_neg, _ = ops.embedding_gather(table, ids_all[n_item_ids:].contiguous(), torch.float32)
-            rows[n_item_ids:] = r_neg
         ctx.save_for_backward(ids_all)
         ctx.meta = (n_item_ids, L, window, holder, table.shape[0], D)
         return rows, x

@@ -14,7 +14,7 @@ template <typename OT, typename XT>
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ table, int64_t n_rows, int dim,
                                                           const int64_t* __restrict__ ids, int64_t n_ids,
                                                           OT* __restrict__ out, const float* __restrict__ pos,
-                                                          int seq_len, int window_len, XT* __restrict__ x_out) {
+                                                          int seq_len, int window_len, XT* __restrict__ x_out, int64_t n_x_ids) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
         int64_t r = r0 + u;
         if (r >= n_ids) continue;
         if (out) Vec4IO<OT>::store(out + r * dim + c, v[u]);
-        if (x_out) {
+        if (x_out && r < n_x_ids) {
           int64_t b = r / window_len;
           int l = (int)(r - b * window_len);
           if (l < seq_len) {
@@ -53,23 +53,25 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
 
 extern "C" int mhr_embedding_gather_fwd(const float* table, int64_t n_rows, int dim, const int64_t* ids, int64_t n_ids,
                                         void* out, int out_dtype, const float* pos_table, int seq_len, int window_len,
-                                        void* x_out, int x_dtype, void* stream) {
+                                        void* x_out, int x_dtype, int64_t n_x_ids, void* stream) {
   MHR_REQUIRE(table && ids, "embedding_gather_fwd: null table/ids");
   MHR_REQUIRE(out || x_out, "embedding_gather_fwd: no output requested");
   MHR_REQUIRE(dim > 0 && dim % 4 == 0, "embedding_gather_fwd: dim=%d must be a positive multiple of 4", dim);
   MHR_REQUIRE(n_rows > 0 && n_ids >= 0, "embedding_gather_fwd: bad sizes");
   if (x_out) {
-    MHR_REQUIRE(pos_table && window_len > 0 && seq_len > 0 && seq_len <= window_len && n_ids % window_len == 0,
-                "embedding_gather_fwd: x_out needs pos_table and n_ids %% window_len == 0 (n_ids=%lld window=%d seq=%d)",
-                (long long)n_ids, window_len, seq_len);
+    const int64_t nx = (n_x_ids <= 0 || n_x_ids > n_ids) ? n_ids : n_x_ids;
+    MHR_REQUIRE(pos_table && window_len > 0 && seq_len > 0 && seq_len <= window_len && nx % window_len == 0,
+                "embedding_gather_fwd: x_out needs pos_table and n_x_ids %% window_len == 0 (n_x_ids=%lld window=%d seq=%d)",
+                (long long)nx, window_len, seq_len);
   }
   if (n_ids == 0) return MHR_OK;
   hipStream_t s = (hipStream_t)stream;
   int grid = mhr_grid_for(n_ids, 16);
   if (window_len <= 0) window_len = 1;
+  if (n_x_ids <= 0 || n_x_ids > n_ids) n_x_ids = n_ids;
 #define LAUNCH(OT, XT)                                                                                     \
   hipLaunchKernelGGL((gather_rows_kernel<OT, XT>), dim3(grid), dim3(256), 0, s, table, n_rows, dim, ids,   \
-                     n_ids, (OT*)out, pos_table, seq_len, window_len, (XT*)x_out)
+                     n_ids, (OT*)out, pos_table, seq_len, window_len, (XT*)x_out, n_x_ids)
   bool ob = out && out_dtype == MHR_BF16, xb = x_out && x_dtype == MHR_BF16;
   if (ob && xb) LAUNCH(bf16_t, bf16_t);
   else if (ob) LAUNCH(bf16_t, float);

@@ -66,21 +66,32 @@ def _chk(t, name, dtype=None):
 # embedding
 # ------------------------------------------------------------------------------------------------
 def embedding_gather(table, ids, out_dtype=torch.bfloat16, pos_table=None, seq_len=0, x_dtype=torch.float32,
-                     want_rows=True):
-    """rows = table[ids] (-> [*ids.shape, D]); with pos_table also x = table[ids[:, :seq_len]] + pos[:seq_len]."""
+                     want_rows=True, out=None, window=None, n_x_ids=0):
+    """rows = table[ids] (-> [*ids.shape, D]); with pos_table also x = table[ids[:, :seq_len]] + pos[:seq_len].
+    `out`: optional preallocated contiguous [ids.numel(), D] destination (e.g. a slice of a larger row matrix)."""
     _chk(table, "table", torch.float32)
     _chk(ids, "ids", torch.int64)
     D = table.shape[1]
     n = ids.numel()
-    out = torch.empty(*ids.shape, D, dtype=out_dtype, device=table.device) if want_rows else None
+    if out is not None:
+        _chk(out, "out")
+        assert out.numel() == n * D
+    elif want_rows:
+        out = torch.empty(*ids.shape, D, dtype=out_dtype, device=table.device)
     x = None
-    window = ids.shape[-1] if pos_table is not None else 0
+    # `window` / `n_x_ids`: flat ids whose first n_x_ids entries are [n_x_ids / window, window] item windows (they get
+    # the position-added x), followed by ids that only need their rows (the negative pools): one launch for both
+    if window is None:
+        window = ids.shape[-1] if pos_table is not None else 0
     if pos_table is not None:
         _chk(pos_table, "pos_table", torch.float32)
-        x = torch.empty(*ids.shape[:-1], seq_len, D, dtype=x_dtype, device=table.device)
+        if n_x_ids:
+            x = torch.empty(n_x_ids // window, seq_len, D, dtype=x_dtype, device=table.device)
+        else:
+            x = torch.empty(*ids.shape[:-1], seq_len, D, dtype=x_dtype, device=table.device)
     _timed_call("mhr_embedding_gather_fwd", table.data_ptr(), table.shape[0], D, ids.data_ptr(), n,
              _ptr(out), _dt(out) if out is not None else F32, _ptr(pos_table), seq_len, window,
-             _ptr(x), _dt(x) if x is not None else F32, _stream())
+             _ptr(x), _dt(x) if x is not None else F32, int(n_x_ids), _stream())
     return out, x
 
 
