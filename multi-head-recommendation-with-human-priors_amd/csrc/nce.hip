@@ -413,53 +413,75 @@ __global__ __launch_bounds__(256, 1) void nce_fwd_u_kernel(const IT* __restrict_
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // published by the first ring barrier
   dma_all(std::integral_constant<int, 0>{}, 0);
   dma_all(std::integral_constant<int, 1>{}, min(1, t_last));
+  // scalars first used inside the loop: touch them here, or hipcc places the `s_waitcnt lgkmcnt(0)` that covers their
+  // kernel-argument load INSIDE the loop body, where it drains the LDS read pipeline once per tile
+  asm volatile("" ::"s"(thres), "s"(c1), "s"(tok_cap), "s"(n_neg));
   // S / f accumulators ping-pong by tile parity: tile t's epilogue runs one iteration later, straight from the other set
   f32x16 sf[2][2] = {{sg::zero16(), sg::zero16()}, {sg::zero16(), sg::zero16()}};
   uint32_t alive_prev = 0;               // live-row bits of the previous tile, pre-shifted by 4*half
+  uint32_t my_word = 0, other_word = 0;  // suppression bits of the tile before the previous one (store pending)
   // the loop exists twice (with / without the rank + n_valid counting of the logged group): a per-element runtime test
   // would put a branch into every MFMA gap
+  STAMP_DECL
+  STAMP(-1)
   auto run = [&](auto logs_c) {
     constexpr bool WITH_LOGS = decltype(logs_c)::value;
     sg::ring_loop<4>(n_tiles + 1, [&](auto slot_c, int i) {
       constexpr int cur = decltype(slot_c)::value, nxt = (cur + 2) % 4, prv = (cur + 3) % 4, par = cur & 1;
+      STAMP(2)
       sg::wait_vmcnt<P::PW>();
+      STAMP(0)
       sg::ring_barrier();
+      STAMP(1)
       const int tn = min(i + 2, t_last);
       sf[par][0] = sg::zero16();
       sf[par][1] = sg::zero16();
       const f32x16& s_prev = sf[par ^ 1][0];
-      const f32x16& f_prev = sf[par ^ 1][1];
-      uint32_t sbits = 0;
+      const f32x16& f_cur = sf[par][1];
+      uint32_t sbits = 0;                  // false negatives of THIS tile (bit (g&3)+8(g>>2) = accumulator row g of my half)
       sg::tile_step<NKS, ND, cur * T::BYTES, prv * T::BYTES, P::PW, 2>(
           ra, ta, frag, sf[par], u, [](auto) {},
-          [&](int g) { return gate_alive(s_prev[g], c1, c1, alive_prev, (g & 3) + 8 * (g >> 2)); },
-          [&](auto k_c) { dma_k(k_c, std::integral_constant<int, nxt>{}, tn); },
-          [&](int g, float e) {
-            const int pos = (g & 3) + 8 * (g >> 2);
-            const int sm = f_prev[g] > thres ? -1 : 0;          // false negative: cos(positive, negative) > thres
-            const float ek = __builtin_bit_cast(float, __builtin_bit_cast(int, e) & ~sm);
-            sum += ek;
-            sbits = ((uint32_t)sm & (1u << pos)) | sbits;       // v_and_or_b32
+          [&](int g) {                     // gated logit of the previous tile: alive_prev already excludes its false negatives
+            const float ek = gate_alive(s_prev[g], c1, c1, alive_prev, (g & 3) + 8 * (g >> 2));
+            asm volatile("v_add_f32 %0, %0, %1" : "+v"(sum) : "v"(ek));      // volatile: keep the accumulation in this gap
             if constexpr (WITH_LOGS) {
-              const int km = (((int)(alive_prev << (31 - pos))) >> 31) & ~sm;      // -1: a kept, live logit
+              const int pos = (g & 3) + 8 * (g >> 2);
+              const int km = ((int)(alive_prev << (31 - pos))) >> 31;       // -1: a kept, live logit
               nv -= km;
               rk -= s_prev[g] > spos ? km : 0;
             }
             return ek;
-          });
-      // suppression word of the tile whose epilogue just ran (bit j = negative 32(t-1)+j suppressed for my token)
-      if (i > 0) {
-        uint32_t word = sbits << (4 * half);
-        word |= __shfl_xor(word, 32, 64);
-        if (in_cap && half == 0) supp_out[(int64_t)(i - 1) * tok_cap + tok] = live ? word : 0xFFFFFFFFu;
-      }
+          },
+          [&](auto k_c) {                  // gaps of the second product: next tile's DMA + this tile's suppression tests
+            constexpr int k = decltype(k_c)::value;
+            if constexpr (k < P::PW) dma_k(k_c, std::integral_constant<int, nxt>{}, tn);
+            uint32_t& sb = sbits;         // (named here: an asm operand alone does not capture it in a generic lambda)
+            // the 16 tests are spread over gaps 2 .. 2 ND - 1: the first two gaps still wait for the f accumulator chain
+            constexpr int G = 2 * ND - 2;
+            constexpr int g_lo = G > 0 ? (k >= 2 ? (k - 2) * 16 / G : 0) : 0;
+            constexpr int g_hi = G > 0 ? (k >= 2 ? (k - 1) * 16 / G : 0) : (k == 2 * ND - 1 ? 16 : 0);
+#pragma unroll
+            for (int g = g_lo; g < g_hi; ++g) {
+              const int sm = f_cur[g] > thres ? -1 : 0;                      // false negative: cos(positive, negative) > thres
+              asm volatile("v_and_or_b32 %0, %1, %2, %0" : "+v"(sb) : "v"(sm), "s"(1u << ((g & 3) + 8 * (g >> 2))));
+            }
+          },
+          sg::EpiIdentity{}, [&] { STAMP(3) });
+      STAMP(4)
+      // suppression word of this tile (bit j = negative 32 i + j suppressed for my token): the two lane halves hold
+      // disjoint bits; the cross-half exchange is issued here and consumed (stored) at the top of the next iteration
+      if (i > 0 && in_cap && half == 0) supp_out[(int64_t)(i - 1) * tok_cap + tok] = live ? (my_word | other_word) : 0xFFFFFFFFu;
+      my_word = sbits << (4 * half);
+      other_word = __shfl_xor(my_word, 32, 64);
       const int rem = n_neg - i * 32;
       const uint32_t tail = rem >= 32 ? 0xFFFFFFFFu : (rem > 0 ? ~(0xFFFFFFFFu << rem) : 0u);
-      alive_prev = (live && i < n_tiles) ? (tail >> (4 * half)) : 0u;
+      alive_prev = (live && i < n_tiles) ? ((tail >> (4 * half)) & ~sbits) : 0u;
     });
   };
   if (do_logs) run(std::true_type{});
   else run(std::false_type{});
+  STAMP(2)
+  STAMP_FLUSH
   sg::wait_vmcnt<0>();
 
   sum += __shfl_xor(sum, 32, 64);
@@ -743,7 +765,9 @@ __global__ __launch_bounds__(256, 1) void nce_bwd_n_kernel(const bf16_t* qn, con
           const f32x4 lf = __builtin_bit_cast(f32x4, l4[g >> 2]);
           return gate_dead(s_prev[g], c1, lf[g & 3], s4[g >> 2][g & 3], r);
         },
-        [&](auto k_c) { dma_k(k_c, std::integral_constant<int, nxt>{}, tn); });
+        [&](auto k_c) {
+          if constexpr (decltype(k_c)::value < P::PW + 1) dma_k(k_c, std::integral_constant<int, nxt>{}, tn);
+        });
     s_prev = acc;
   });
   sg::wait_vmcnt<0>();

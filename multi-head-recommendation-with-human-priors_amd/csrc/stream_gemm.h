@@ -468,8 +468,9 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
 }
 
 // epi(e) -> float : element e (accumulator register index) of the gated previous tile, already masked.
-// dma(k)          : k = 0..NDMA-1, the next tile's LDS-DMA instructions, one per gap of the second product (those
-//                   gaps carry only two transposed reads, the S gaps are full of epilogue).
+// dma(k)          : called once in every gap k = 0..2*ND-1 of the second product (and for k up to NDMA-1 afterwards if
+//                   there are fewer gaps): those gaps carry only two transposed reads, so the caller places the next
+//                   tile's LDS-DMA instructions there (k < its DMA count) and any VALU work that does not fit the S gaps.
 // Values read from LDS by the caller's own inline-asm reads (issued BEFORE bwd_tile) must be passed through this after
 // the wait that covers them: an asm output looks "ready" to hipcc at the read itself, so ordinary code or non-volatile
 // asm consuming it could otherwise be scheduled above the wait.  `ready(n)` in bwd_tile is the place: n = LDS reads
@@ -488,15 +489,18 @@ __device__ __forceinline__ void wait_lgkm_values(V&... v) {
 struct EpiIdentity {
   __device__ __forceinline__ float operator()(int, float g) const { return g; }
 };
+struct NoMid {
+  __device__ __forceinline__ void operator()() const {}
+};
 
 // RF = 1: one stationary fragment set (the backward kernels).  RF = 2: two sets sharing every row-fragment read (the
 // fused forward: s = q.n and f = p.n); the per-element epilogue is then split over the two MFMA gaps of a k-step:
 // epi(e) after the first MFMA, epi2(e, value) after the second.
 template <int NKS, int ND, int OFF_CUR, int OFF_PRV, int NDMA, int RF, typename Ready, typename Epi, typename DmaFn,
-          typename Epi2 = EpiIdentity>
+          typename Epi2 = EpiIdentity, typename Mid = NoMid>
 __device__ __forceinline__ void tile_step(const RowAddr<NKS>& ra, const TrAddr<NKS>& ta, const bf16x8 (&frag)[RF][NKS],
                                           f32x16 (&accs)[RF], f32x16 (&out)[ND], Ready ready, Epi epi, DmaFn dma,
-                                          Epi2 epi2 = Epi2{}) {
+                                          Epi2 epi2 = Epi2{}, Mid mid = Mid{}) {
   using T = Tile<NKS>;
   constexpr int PA = NKS < 4 ? NKS : 4;
   constexpr int PT = ND < 2 ? ND : 2;
@@ -551,6 +555,7 @@ __device__ __forceinline__ void tile_step(const RowAddr<NKS>& ra, const TrAddr<N
     __builtin_amdgcn_sched_barrier(0);
   };
   static_for<NKS>(s_step);
+  mid();                                   // (phase-timing hook of the stamped builds; nothing in the product)
   const u32x4 g0v = {pk[0], pk[1], pk[2], pk[3]}, g1v = {pk[4], pk[5], pk[6], pk[7]};
   const bf16x8 g0 = __builtin_bit_cast(bf16x8, g0v), g1 = __builtin_bit_cast(bf16x8, g1v);
   auto t_step = [&](auto dc_c) {
@@ -561,14 +566,14 @@ __device__ __forceinline__ void tile_step(const RowAddr<NKS>& ra, const TrAddr<N
     wait_lgkm<4 * ahead>(q[0], q[1], q[2], q[3]);
     const u32x4 b0 = {q[0].x, q[0].y, q[1].x, q[1].y}, b1 = {q[2].x, q[2].y, q[3].x, q[3].y};
     out[dc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g0, __builtin_bit_cast(bf16x8, b0), out[dc], 0, 0, 0);
-    if constexpr (2 * dc < NDMA) dma(std::integral_constant<int, 2 * dc>{});
+    dma(std::integral_constant<int, 2 * dc>{});
     __builtin_amdgcn_sched_barrier(0);
     out[dc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g1, __builtin_bit_cast(bf16x8, b1), out[dc], 0, 0, 0);
-    if constexpr (2 * dc + 1 < NDMA) dma(std::integral_constant<int, 2 * dc + 1>{});
+    dma(std::integral_constant<int, 2 * dc + 1>{});
     __builtin_amdgcn_sched_barrier(0);
   };
   static_for<ND>(t_step);
-  // DMA pieces that did not fit a gap (narrow feature dims have few gaps)
+  // callbacks beyond the 2*ND gaps (narrow feature dims have few gaps)
   auto rest = [&](auto k_c) {
     constexpr int k = decltype(k_c)::value;
     if constexpr (k >= 2 * ND) dma(k_c);

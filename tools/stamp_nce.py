@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 VARIANT = os.environ.get("VARIANT", "")          # e.g. VARIANT="EXP_NOEPI" adds -DEXP_NOEPI and builds into tools/_stamp_EXP_NOEPI
 OUT = os.path.join(ROOT, "tools", "_stamp" + ("_" + VARIANT.replace(" ", "_") if VARIANT else ""))
 LIB = os.path.join(OUT, "libmhr_hip.so")
-NAMES = ["vmcnt wait", "barrier", "DMA issue", "S MFMAs + epilogue", "G.N (tr) MFMAs", "loop overhead"]
+NAMES = ["vmcnt wait", "barrier", "loop top / tail", "s,f MFMAs + epilogue", "E.N (tr) MFMAs + DMA issue", "-"]
 
 if sys.argv[1] == "build":
     os.makedirs(OUT, exist_ok=True)
@@ -28,7 +28,7 @@ else:
     dll = ctypes.CDLL(LIB)
     buf = (ctypes.c_ulonglong * 16)()
     assert dll.mhr_debug_read_stamps(buf) == 0
-    n_tiles = int(os.environ.get("TILES", 129))
+    n_tiles = int(os.environ.get("TILES", 257))
     tot = sum(buf[:6])
     for k, nm in enumerate(NAMES):
         print(f"{nm:24s} {buf[k] / n_tiles:9.0f} cycles/tile  {100.0 * buf[k] / max(1, tot):5.1f} %")
