@@ -75,8 +75,8 @@ class SplitKLinearFn(Function):
             dw = torch.bmm(dys.transpose(1, 2), xs)               # [S, N, K]
         else:
             dw = torch.bmm(xs.transpose(1, 2), dys)               # [S, K, N]
-        dw = dw.float().sum(0) if S > 1 else dw[0].float()
-        db = dy.float().sum(0) if ctx.has_bias else None
+        dw = torch.sum(dw, 0, dtype=torch.float32) if S > 1 else dw[0].float()      # cast fused into the reduction
+        db = torch.sum(dy, 0, dtype=torch.float32) if ctx.has_bias else None
         return dx, dw, db, None, None
 
 
