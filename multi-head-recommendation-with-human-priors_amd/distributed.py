@@ -45,11 +45,22 @@ def exchange_sparse_rows(ids_all, d_rows, n_private):
     shared_ids, shared_rows = ids_all[n_private:], d_rows[n_private:].contiguous()
     if shared_rows.numel():
         dist.all_reduce(shared_rows, op=dist.ReduceOp.SUM)
-    g_ids = [torch.empty_like(priv_ids) for _ in range(W)]
-    g_rows = [torch.empty_like(priv_rows) for _ in range(W)]
-    dist.all_gather(g_ids, priv_ids)
-    dist.all_gather(g_rows, priv_rows)
-    return torch.cat(g_ids + [shared_ids]), torch.cat(g_rows + [shared_rows])
+    n_sh = shared_ids.numel()
+    ids_out = torch.empty(W * n_private + n_sh, dtype=ids_all.dtype, device=ids_all.device)
+    rows_out = torch.empty(W * n_private + n_sh, d_rows.shape[1], dtype=d_rows.dtype, device=d_rows.device)
+    ids_out[W * n_private:] = shared_ids
+    rows_out[W * n_private:] = shared_rows
+    if dist.get_backend() == "nccl":          # gather straight into the output (no per-rank list + concatenation)
+        dist.all_gather_into_tensor(ids_out[:W * n_private], priv_ids)
+        dist.all_gather_into_tensor(rows_out[:W * n_private], priv_rows)
+    else:
+        g_ids = [torch.empty_like(priv_ids) for _ in range(W)]
+        g_rows = [torch.empty_like(priv_rows) for _ in range(W)]
+        dist.all_gather(g_ids, priv_ids)
+        dist.all_gather(g_rows, priv_rows)
+        ids_out[:W * n_private] = torch.cat(g_ids)
+        rows_out[:W * n_private] = torch.cat(g_rows)
+    return ids_out, rows_out
 
 
 def allreduce_metric_sums(values):
