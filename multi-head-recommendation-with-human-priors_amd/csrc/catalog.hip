@@ -205,6 +205,8 @@ __global__ __launch_bounds__(256, 2) void catalog_emit_sliced_kernel(
     };
     sg::LaneAddr<NKS> la;
     la.init(lane);
+    sg::RowAddr<NKS> ra;
+    ra.init(la, tiles);
     const int n_loc = t1 - t0, t_last = t1 - 1;
     dma_tile(std::integral_constant<int, 0>{}, t0);
     dma_tile(std::integral_constant<int, 1>{}, min(t0 + 1, t_last));
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(256, 2) void catalog_emit_sliced_kernel(
       f32x16 acc[RF];
 #pragma unroll
       for (int f = 0; f < RF; ++f) acc[f] = sg::zero16();
-      sg::mma_tile<NKS, RF>(tiles + cur * T::BYTES, la, frag, acc);
+      sg::mma_tile_asm<NKS, RF, cur * T::BYTES>(ra, frag, acc);
       const uint32_t* tw = reinterpret_cast<const uint32_t*>(words + cur * 1024 + wv * 256);
 #pragma unroll
       for (int f = 0; f < RF; ++f) {

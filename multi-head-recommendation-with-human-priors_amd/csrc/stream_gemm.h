@@ -471,6 +471,32 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
 // dma(k)          : called once in every gap k = 0..2*ND-1 of the second product (and for k up to NDMA-1 afterwards if
 //                   there are fewer gaps): those gaps carry only two transposed reads, so the caller places the next
 //                   tile's LDS-DMA instructions there (k < its DMA count) and any VALU work that does not fit the S gaps.
+// acc[f] (+)= tile . frag[f]^T like mma_tile, with the row-fragment reads as inline asm (PA k-steps ahead, counted
+// lgkmcnt waits) and one sched_barrier per k-step: hipcc's own schedule of the builtin form leaves the MFMAs waiting on
+// `s_waitcnt lgkmcnt(0)` after short read batches.  OFF: compile-time byte offset of the tile in the ring whose LDS
+// addresses are in `ra`.
+template <int NKS, int RF, int OFF>
+__device__ __forceinline__ void mma_tile_asm(const RowAddr<NKS>& ra, const bf16x8 (&frag)[RF][NKS], f32x16 (&acc)[RF]) {
+  constexpr int PA = NKS < 4 ? NKS : 4;
+  u32x4 a[PA + 1];
+  auto issue_a = [&](auto ks_c) {
+    constexpr int ks = decltype(ks_c)::value;
+    a[ks % (PA + 1)] = ds_read_b128_asm<OFF + 256 * (ks >> 3)>(ra.a[ks & 7]);
+  };
+  static_for<PA>(issue_a);
+  auto step = [&](auto ks_c) {
+    constexpr int ks = decltype(ks_c)::value;
+    if constexpr (ks + PA < NKS) issue_a(std::integral_constant<int, ks + PA>{});
+    constexpr int a_after = (ks + PA < NKS ? ks + PA : NKS - 1) - ks;
+    wait_lgkm1<a_after>(a[ks % (PA + 1)]);
+    const bf16x8 av = __builtin_bit_cast(bf16x8, a[ks % (PA + 1)]);
+#pragma unroll
+    for (int f = 0; f < RF; ++f) acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, frag[f][ks], acc[f], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  static_for<NKS>(step);
+}
+
 // Values read from LDS by the caller's own inline-asm reads (issued BEFORE bwd_tile) must be passed through this after
 // the wait that covers them: an asm output looks "ready" to hipcc at the read itself, so ordinary code or non-volatile
 // asm consuming it could otherwise be scheduled above the wait.  `ready(n)` in bwd_tile is the place: n = LDS reads

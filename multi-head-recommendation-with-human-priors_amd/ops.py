@@ -26,13 +26,13 @@ def _timed_call(name, *args):
         lib.call(name, *args)
 
 
-def profile_summary():
-    """name -> (launches, mean ms, total ms); call after torch.cuda.synchronize()."""
+def profile_summary(with_max=False):
+    """name -> (launches, mean ms, total ms[, max ms]); call after torch.cuda.synchronize()."""
     out = {}
     for name, evs in (PROFILE or {}).items():
         if evs:
             ms = [a.elapsed_time(b) for a, b in evs]
-            out[name] = (len(ms), sum(ms) / len(ms), sum(ms))
+            out[name] = (len(ms), sum(ms) / len(ms), sum(ms)) + ((max(ms),) if with_max else ())
     return out
 
 
