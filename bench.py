@@ -179,7 +179,12 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
-    prof_max = {k: v[3] for k, v in ops.profile_summary(with_max=True).items()} if ops.PROFILE is not None else {}
+    prof_max = {}
+    if ops.PROFILE is not None:           # median of each step's longest launch (robust against one slow outlier)
+        for k_ in list(ops.PROFILE):
+            raw = sorted(ops.profile_raw(k_), reverse=True)[:args.steps]
+            if raw:
+                prof_max[k_] = raw[len(raw) // 2]
     prof = ops.profile_summary() if ops.PROFILE is not None else {}
     ops.PROFILE = None
 

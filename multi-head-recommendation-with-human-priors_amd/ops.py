@@ -36,6 +36,11 @@ def profile_summary(with_max=False):
     return out
 
 
+def profile_raw(name):
+    """Every measured duration (ms) of one entry point, in launch order."""
+    return [a.elapsed_time(b) for a, b in (PROFILE or {}).get(name, [])]
+
+
 def _dt(t):
     if t.dtype == torch.float32:
         return F32
@@ -464,7 +469,7 @@ def topk_select_sliced(cand, H, hist_ptr, hist_items, k):
     return out_val, out_idx, kth, count, status
 
 
-def catalog_topk(users, H, items, tag_bits, row_bits, hist_ptr, hist_items, k, cap=4096, target=1024, stats=None, n_items=None):
+def catalog_topk(users, H, items, tag_bits, row_bits, hist_ptr, hist_items, k, cap=4096, target=None, stats=None, n_items=None):
     """Exact per-row top-k over the whole catalog (value desc, index asc), rows = (user, head) pairs.
 
     users [B*H, D] bf16 normalised, items [>= N, D] bf16 normalised (rows beyond n_items = N are padding: give the
@@ -484,6 +489,11 @@ def catalog_topk(users, H, items, tag_bits, row_bits, hist_ptr, hist_items, k, c
         cand = catalog_emit(users, H, items, tag_bits, row_bits, ninf, hist_ptr, hist_items, N, n_items=N)
         ov, oi, _, _ = topk_select(cand, N, k)
         return ov, oi
+    if target is None:
+        # candidates aimed at per row.  The threshold is the (target/s2)-th largest of a 1/s2 sample: its rank estimate
+        # scatters by about 1/sqrt(target/s2), so 2.5 k leaves > 5 sigma before a row would come up short (and such a
+        # row is only re-run, never wrong); every candidate above what is needed costs a divergent slow-path visit.
+        target = max(512, int(2.5 * k))
     s1 = max(1, -(-N // 2048))
     s2 = max(1, -(-N // 32768))
     t1 = 8
