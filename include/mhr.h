@@ -146,6 +146,57 @@ int mhr_hstu_attn_bwd(const void* q_pre, const void* k_pre, const void* v_pre, i
                       int B, int L, int n_heads, int head_dim, int apply_silu, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * LLM decoder blocks of the HLLM twin: the user decoder `user_llm(inputs_embeds=...)`
+ * (model/HLLM/hllm.py:501-502, 781-783) and the item tower (hllm.py:399-464) are Llama-style stacks
+ * (model/HLLM/modeling_llama.py:729-795, baichuan/modeling_baichuan.py:110-338).  The dense projections stay library
+ * GEMMs; everything between them is here.
+ * ---------------------------------------------------------------------------------------- */
+
+/* RMSNorm (modeling_llama.py:266-280), optionally fused with the residual add in front of it (779/783, 785/768):
+ *   x_out = x (+ res);  y = bf16(weight * x_out * rsqrt(mean(x_out^2) + eps));  rstd [rows] saved for the backward.
+ * x, x_out f32 [rows, dim]; res, y bf16; weight f32 [dim].  res == NULL: plain norm of x (x_out ignored).  dim <= 4096. */
+int mhr_rmsnorm_fwd(const float* x, const void* res_bf16, const float* weight, float* x_out, void* y_bf16, float* rstd,
+                    int64_t rows, int dim, float eps, void* stream);
+/* dx = rstd * (dy*w - x_hat * mean(dy*w*x_hat)) (+ d_xout, the residual path's gradient, may be NULL) as f32 and, when
+ * dres_bf16 != NULL, the same values as bf16 (the gradient of the fused residual branch).  The weight gradient
+ * sum_rows dy * x_hat is returned as dw_part [mhr_rmsnorm_bwd_parts(rows), dim] f32 partials (deterministic; the caller
+ * sums dim 0). */
+int mhr_rmsnorm_bwd_parts(int64_t rows);
+int mhr_rmsnorm_bwd(const void* dy_bf16, const float* x_out, const float* weight, const float* rstd, const float* d_xout,
+                    float* dx, void* dres_bf16, float* dw_part, int64_t rows, int dim, void* stream);
+
+/* SwiGLU gate of the MLP (modeling_llama.py:484; xformers swiglu in modeling_baichuan.py:197-206) on the output of one
+ * [gate | up] GEMM:  act[r, c] = silu(gate_up[r, c]) * gate_up[r, ffn + c].  All bf16; ffn % 8 == 0. */
+int mhr_swiglu_fwd(const void* gate_up_bf16, void* act_bf16, int64_t rows, int ffn, void* stream);
+int mhr_swiglu_bwd(const void* gate_up_bf16, const void* d_act_bf16, void* d_gate_up_bf16, int64_t rows, int ffn, void* stream);
+
+/* Rotary position embedding, in place, rotate_half convention (modeling_llama.py:426-441), on `n_heads` consecutive
+ * heads of width head_dim at the start of each row of x (bf16, row stride in elements): q and k of a packed qkv row
+ * in one call.  positions [n_tokens] int32 (NULL: token t sits at t % seq_len); cos/sin tables [max_pos, head_dim/2]
+ * f32.  inverse != 0 applies the transposed rotation (the backward). */
+int mhr_rope_inplace(void* x_bf16, int64_t row_stride, const int32_t* positions, const float* cos_table,
+                     const float* sin_table, int64_t n_tokens, int seq_len, int n_heads, int head_dim, int max_pos,
+                     int inverse, void* stream);
+
+/* Causal softmax attention with grouped KV heads (modeling_llama.py:648-682; flash path 683-705 ->
+ * flash_self_attn.py:61-130).  q/k/v are column blocks of one token matrix with a common row stride (elements): query
+ * head h at q + h*head_dim, KV head g at k / v + g*head_dim, g = h / (n_heads / n_kv_heads).  Sequence b is the row range
+ * [cu_seqlens[b], cu_seqlens[b+1]) (packed `cu_input_lens` batches) or, with cu_seqlens == NULL, [b*max_len, (b+1)*max_len);
+ * every sequence must be <= max_len rows.  key_valid [n_tokens] uint8 (NULL: all valid) masks padding keys.
+ *   out [n_tokens, n_heads*head_dim] bf16,  lse [n_tokens, n_heads] f32 (natural log, scaled scores; 0 for rows with no
+ *   admissible key, whose output is 0).  K and V of one sequence stay in LDS: max_len * head_dim <= ~40k.
+ * Backward: dq into a matrix with row stride dq_stride (query head h at column h*head_dim); dk / dv hold ONE SLAB PER
+ * QUERY HEAD ([n_tokens, n_heads*head_dim], row stride dkv_stride) - the caller sums each group of n_heads/n_kv_heads
+ * slabs into its KV head.  No atomics, bitwise reproducible. */
+int mhr_softmax_attn_fwd(const void* q, const void* k, const void* v, int64_t row_stride, const int32_t* cu_seqlens,
+                         const uint8_t* key_valid, void* out, float* lse, int n_seqs, int max_len, int n_heads,
+                         int n_kv_heads, int head_dim, float scale, void* stream);
+int mhr_softmax_attn_bwd(const void* q, const void* k, const void* v, int64_t row_stride, const int32_t* cu_seqlens,
+                         const uint8_t* key_valid, const void* out, const void* d_out, const float* lse, void* dq,
+                         int64_t dq_stride, void* dk, void* dv, int64_t dkv_stride, int n_seqs, int max_len, int n_heads,
+                         int n_kv_heads, int head_dim, float scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Token compaction (replaces the boolean-mask indexing of model/IDNet/hstu.py:688-690, 814-829 and its host-side
  * `mask.sum() == 0` branch).  mask [n_groups, n_slots] uint8 (0/1) marks the live (group, slot) pairs; q_all
  * [n_groups, n_slots], p_all / o_all [n_slots] int32 are static tables (query row, target row, prediction offset

@@ -91,7 +91,10 @@ class Trainer(object):
             except StopIteration:
                 iterator = iter(train_data)
                 data = next(iterator)
-            data = tuple(d.to(self.device, non_blocking=True) for d in data)
+            if isinstance(data, dict):                                         # HLLM batches are dicts (hllm.py:482-493)
+                data = {k: (v.to(self.device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in data.items()}
+            else:
+                data = tuple(d.to(self.device, non_blocking=True) for d in data)
             out = self.train_step_fn(data)
             running = out
             if verbose and self.train_step % self.update_interval == 0:

@@ -17,14 +17,11 @@
 // atomic is needed and the result is bitwise reproducible; every inner-loop operand comes from LDS.
 #include "mhr_common.h"
 #include "stream_gemm.h"
+#include "attn_tiles.h"
 
 namespace {
 
-using sg::crow;
-using sg::zero16;
-using sg::zero8;
-
-constexpr float LOG2E_F = 1.4426950408889634f;
+using namespace attn;
 
 #ifdef MHR_STAMP   // in-kernel phase timing, only in the builds tools/stamp_nce.py makes
 __device__ unsigned long long g_attn_stamps[16];
@@ -40,63 +37,6 @@ __device__ unsigned long long g_attn_stamps[16];
 #define ASTAMP(k)
 #endif
 
-// sigmoid with one v_exp and one v_rcp (the division form costs a Newton step per element; every score tile applies it
-// to 16 values per lane, which is where these kernels spend their VALU time)
-__device__ __forceinline__ float fast_sigmoid(float x) {
-  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-x * LOG2E_F));
-}
-
-__device__ __forceinline__ bf16x8 silu8(bf16x8 x) {
-  bf16x8 y;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) y[i] = (bf16_t)silu_f((float)x[i]);
-  return y;
-}
-
-// 8 consecutive elements of row `row` at column `koff` of a [rows, stride] bf16 matrix (zeros outside).
-__device__ __forceinline__ bf16x8 load_frag(const bf16_t* base, int64_t stride, int row, int n_rows, int koff, int n_cols) {
-  if (row < n_rows && koff < n_cols) return *reinterpret_cast<const bf16x8*>(base + (int64_t)row * stride + koff);
-  return zero8();
-}
-
-__device__ __forceinline__ void pack_acc(const f32x16& x, bf16x8& f0, bf16x8& f1) {
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    f0[j] = (bf16_t)x[j];
-    f1[j] = (bf16_t)x[8 + j];
-  }
-}
-
-// Stage a [L, hd] row-major global block as ceil(L/32) swizzled 32-row tile images (stream_gemm.h Tile<NKS>, feature
-// dim padded to 16*NKS with zeros, rows >= L zero).  One image serves BOTH access shapes the kernels need: row
-// fragments (ds_read_b128: operand rows on the lanes, features on the vector) and transposed fragments
-// (ds_read_b64_tr_b16: operand summed over the ROW index) - so no transposed copy is ever built.
-template <int NKS>
-__device__ __forceinline__ void stage_tiles(unsigned char* dst, const bf16_t* src, int64_t stride, int L, int Lp, int hd,
-                                            bool do_silu, bf16_t* act, int64_t act_stride) {
-  using T = sg::Tile<NKS>;
-  for (int c = threadIdx.x; c < Lp * T::CH; c += blockDim.x) {
-    const int m = c / T::CH, j = c % T::CH;
-    bf16x8 val = zero8();
-    if (m < L && j * 8 < hd) {
-      val = *reinterpret_cast<const bf16x8*>(src + (int64_t)m * stride + j * 8);
-      if (do_silu) val = silu8(val);
-      if (act) *reinterpret_cast<bf16x8*>(act + (int64_t)m * act_stride + j * 8) = val;
-    }
-    *reinterpret_cast<bf16x8*>(dst + (m >> 5) * T::BYTES + T::off(m & 31, j)) = val;
-  }
-}
-
-__device__ __forceinline__ void build_valid_mask(uint32_t* vmask, const uint8_t* kv, int L, int nb) {
-  if ((int)threadIdx.x < nb) {
-    uint32_t bits = 0;
-    for (int i = 0; i < 32; ++i) {
-      int m = threadIdx.x * 32 + i;
-      if (m < L && kv[m]) bits |= 1u << i;
-    }
-    vmask[threadIdx.x] = bits;
-  }
-}
 
 // ------------------------------------------------------------------------------------------
 // forward
@@ -393,25 +333,8 @@ __global__ __launch_bounds__(256) void hstu_attn_bwd_kernel(
   ASTAMP(5)
 }
 
-struct AttnShape {
-  int nks, nd;
-};
-inline bool attn_shape(int hd, AttnShape& s) {
-  if (hd <= 0 || hd % 8 != 0 || hd > 128) return false;
-  if (hd <= 16) s = {1, 1};
-  else if (hd <= 32) s = {2, 1};
-  else if (hd <= 64) s = {4, 2};
-  else s = {8, 4};
-  return true;
-}
-
 }  // namespace
 
-#define ATTN_DISPATCH(shape, MACRO)                  \
-  if (shape.nks == 1) { MACRO(1, 1); }               \
-  else if (shape.nks == 2) { MACRO(2, 1); }          \
-  else if (shape.nks == 4) { MACRO(4, 2); }          \
-  else { MACRO(8, 4); }
 
 extern "C" int mhr_hstu_attn_fwd(const void* q, const void* k, const void* v, int64_t row_stride, const uint8_t* key_valid,
                                  void* out, void* act_q, void* act_k, void* act_v, int64_t act_stride, int B, int L,

@@ -471,3 +471,147 @@ extern "C" int mhr_l2norm_rows(const void* x, int x_dtype, void* y, int y_dtype,
   MHR_CHECK_LAUNCH("l2norm_rows");
   return MHR_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// RMSNorm of the LLM decoder blocks (HLLM user / item towers), optionally fused with the residual add that precedes it.
+// Reference: LlamaRMSNorm model/HLLM/modeling_llama.py:266-280 (statistics in fp32, `weight * x_hat`), used at
+// modeling_llama.py:768, 783, 1108 around `residual + hidden_states` (779, 785); Baichuan's RMSNorm
+// (baichuan/modeling_baichuan.py:110-133) is the same arithmetic.
+//   fwd: x_out = x (+ res);  y = bf16(w * x_out * rsqrt(mean(x_out^2) + eps))
+//   bwd: g = dy * w;  dx = rstd * (g - x_hat * mean(g * x_hat)) (+ d_xout);  dw partial = sum_rows dy * x_hat
+// The weight gradient is reduced deterministically: every wave keeps a private partial over the rows it visits, the four
+// waves of a workgroup are summed through LDS, and one [grid, dim] block of partials goes to the caller's fp32 sum.
+// ------------------------------------------------------------------------------------------
+static inline int nc_for_rms(int dim) { return dim <= 2048 ? nc_for(dim) : 16; }
+#define DISPATCH_NC_RMS(dim, MACRO) \
+  switch (nc_for_rms(dim)) {        \
+    case 1: MACRO(1); break;        \
+    case 2: MACRO(2); break;        \
+    case 4: MACRO(4); break;        \
+    case 8: MACRO(8); break;        \
+    default: MACRO(16); break;      \
+  }
+
+template <int NC>
+__global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restrict__ x, const bf16_t* __restrict__ res,
+                                                          const float* __restrict__ w, float* __restrict__ x_out,
+                                                          bf16_t* __restrict__ y, float* __restrict__ rstd_o, int64_t rows,
+                                                          int dim, float eps) {
+  RowRegs<NC> wv;
+  load_row<float, NC>(w, dim, threadIdx.x & 63, wv);
+  WAVE_ROW_LOOP(rows) {
+    RowRegs<NC> r;
+    load_row<float, NC>(x + row * dim, dim, lane, r);
+    if (res) {
+      RowRegs<NC> b;
+      load_row<bf16_t, NC>(res + row * dim, dim, lane, b);
+#pragma unroll
+      for (int i = 0; i < NC; ++i)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r.v[i][k] += b.v[i][k];
+      store_row<float, NC>(x_out + row * dim, dim, lane, r);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; ++i)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) s += r.v[i][k] * r.v[i][k];       // columns >= dim hold zeros
+    const float rstd = rsqrtf(wave_sum(s) / (float)dim + eps);
+#pragma unroll
+    for (int i = 0; i < NC; ++i)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) r.v[i][k] = wv.v[i][k] * (r.v[i][k] * rstd);
+    store_row<bf16_t, NC>(y + row * dim, dim, lane, r);
+    if (lane == 0) rstd_o[row] = rstd;
+  }
+}
+
+template <int NC>
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restrict__ dy, const float* __restrict__ x_out,
+                                                          const float* __restrict__ w, const float* __restrict__ rstd_i,
+                                                          const float* __restrict__ d_xout, float* __restrict__ dx,
+                                                          bf16_t* __restrict__ dres, float* __restrict__ dw_part, int64_t rows,
+                                                          int dim) {
+  extern __shared__ float red[];                   // [3][dim] partials of waves 1..3
+  RowRegs<NC> wv, acc;
+  load_row<float, NC>(w, dim, threadIdx.x & 63, wv);
+#pragma unroll
+  for (int i = 0; i < NC; ++i) acc.v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  WAVE_ROW_LOOP(rows) {
+    RowRegs<NC> g, xv;
+    load_row<bf16_t, NC>(dy + row * dim, dim, lane, g);
+    load_row<float, NC>(x_out + row * dim, dim, lane, xv);
+    const float rstd = rstd_i[row];
+    float s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; ++i)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float xh = xv.v[i][k] * rstd;
+        acc.v[i][k] += g.v[i][k] * xh;
+        g.v[i][k] *= wv.v[i][k];
+        xv.v[i][k] = xh;
+        s2 += g.v[i][k] * xh;
+      }
+    s2 = wave_sum(s2) / (float)dim;
+    RowRegs<NC> o;
+    if (d_xout) load_row<float, NC>(d_xout + row * dim, dim, lane, o);
+#pragma unroll
+    for (int i = 0; i < NC; ++i)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float d = rstd * (g.v[i][k] - xv.v[i][k] * s2);
+        o.v[i][k] = d_xout ? o.v[i][k] + d : d;
+      }
+    store_row<float, NC>(dx + row * dim, dim, lane, o);
+    if (dres) store_row<bf16_t, NC>(dres + row * dim, dim, lane, o);
+  }
+  const int wv_id = threadIdx.x >> 6, ln = threadIdx.x & 63;
+  if (wv_id > 0) store_row<float, NC>(red + (wv_id - 1) * dim, dim, ln, acc);
+  __syncthreads();
+  if (wv_id == 0) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      RowRegs<NC> t;
+      load_row<float, NC>(red + j * dim, dim, ln, t);
+#pragma unroll
+      for (int i = 0; i < NC; ++i) acc.v[i] += t.v[i];
+    }
+    store_row<float, NC>(dw_part + (int64_t)blockIdx.x * dim, dim, ln, acc);
+  }
+}
+
+extern "C" int mhr_rmsnorm_fwd(const float* x, const void* res_bf16, const float* weight, float* x_out, void* y_bf16,
+                               float* rstd, int64_t rows, int dim, float eps, void* stream) {
+  MHR_REQUIRE(x && weight && y_bf16 && rstd, "rmsnorm_fwd: null pointer");
+  MHR_REQUIRE(!res_bf16 || x_out, "rmsnorm_fwd: x_out is required with a residual branch");
+  MHR_REQUIRE(dim > 0 && dim % 4 == 0 && dim <= 4096, "rmsnorm_fwd: dim=%d unsupported (multiple of 4, <= 4096)", dim);
+  if (rows <= 0) return MHR_OK;
+  const int grid = mhr_grid_for(rows, 4);
+#define L(NC)                                                                                                          \
+  hipLaunchKernelGGL((rmsnorm_fwd_kernel<NC>), dim3(grid), dim3(256), 0, (hipStream_t)stream, x, (const bf16_t*)res_bf16, \
+                     weight, x_out, (bf16_t*)y_bf16, rstd, rows, dim, eps)
+  DISPATCH_NC_RMS(dim, L);
+#undef L
+  MHR_CHECK_LAUNCH("rmsnorm_fwd");
+  return MHR_OK;
+}
+
+extern "C" int mhr_rmsnorm_bwd_parts(int64_t rows) { return mhr_grid_for(rows, 16, 1024); }
+
+extern "C" int mhr_rmsnorm_bwd(const void* dy_bf16, const float* x_out, const float* weight, const float* rstd,
+                               const float* d_xout, float* dx, void* dres_bf16, float* dw_part, int64_t rows, int dim,
+                               void* stream) {
+  MHR_REQUIRE(dy_bf16 && x_out && weight && rstd && dx && dw_part, "rmsnorm_bwd: null pointer");
+  MHR_REQUIRE(dim > 0 && dim % 4 == 0 && dim <= 4096, "rmsnorm_bwd: dim=%d unsupported (multiple of 4, <= 4096)", dim);
+  MHR_REQUIRE(rows > 0, "rmsnorm_bwd: no rows");
+  const int grid = mhr_rmsnorm_bwd_parts(rows);               // dw_part is [grid, dim]
+  const size_t lds = (size_t)3 * dim * sizeof(float);
+#define L(NC)                                                                                                            \
+  hipLaunchKernelGGL((rmsnorm_bwd_kernel<NC>), dim3(grid), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)dy_bf16,  \
+                     x_out, weight, rstd, d_xout, dx, (bf16_t*)dres_bf16, dw_part, rows, dim)
+  DISPATCH_NC_RMS(dim, L);
+#undef L
+  MHR_CHECK_LAUNCH("rmsnorm_bwd");
+  return MHR_OK;
+}

@@ -248,6 +248,127 @@ def hstu_attn_bwd(h, act, key_valid, d_out, dh, B, L, n_heads, head_dim, apply_s
 
 
 # ------------------------------------------------------------------------------------------------
+# LLM decoder blocks (HLLM twin): RMSNorm, SwiGLU, RoPE, causal softmax attention
+# ------------------------------------------------------------------------------------------------
+def rmsnorm_fwd(x, weight, res=None, eps=1e-6):
+    """x f32 [rows, D] (+ res bf16) -> (x_out f32 (x itself without res), y bf16, rstd f32 [rows])."""
+    _chk(x, "x", torch.float32)
+    _chk(weight, "weight", torch.float32)
+    D = x.shape[-1]
+    rows = x.numel() // D
+    y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    x_out = x
+    if res is not None:
+        _chk(res, "res", torch.bfloat16)
+        x_out = torch.empty_like(x)
+    _timed_call("mhr_rmsnorm_fwd", x.data_ptr(), _ptr(res), weight.data_ptr(), x_out.data_ptr(), y.data_ptr(), rstd.data_ptr(),
+                rows, D, float(eps), _stream())
+    return x_out, y, rstd
+
+
+def rmsnorm_bwd(dy, x_out, weight, rstd, d_xout=None, want_dres=False):
+    """-> (dx f32, dres bf16 or None, dw f32 [D])."""
+    _chk(dy, "dy", torch.bfloat16)
+    _chk(x_out, "x_out", torch.float32)
+    D = x_out.shape[-1]
+    rows = x_out.numel() // D
+    dx = torch.empty_like(x_out)
+    dres = torch.empty(x_out.shape, dtype=torch.bfloat16, device=x_out.device) if want_dres else None
+    parts = lib.load().mhr_rmsnorm_bwd_parts(rows)
+    dw_part = torch.empty(parts, D, dtype=torch.float32, device=x_out.device)
+    if d_xout is not None:
+        _chk(d_xout, "d_xout", torch.float32)
+    _timed_call("mhr_rmsnorm_bwd", dy.data_ptr(), x_out.data_ptr(), weight.data_ptr(), rstd.data_ptr(), _ptr(d_xout),
+                dx.data_ptr(), _ptr(dres), dw_part.data_ptr(), rows, D, _stream())
+    return dx, dres, dw_part.sum(0)
+
+
+def swiglu_fwd(gate_up):
+    _chk(gate_up, "gate_up", torch.bfloat16)
+    F2 = gate_up.shape[-1]
+    rows = gate_up.numel() // F2
+    act = torch.empty(*gate_up.shape[:-1], F2 // 2, dtype=torch.bfloat16, device=gate_up.device)
+    _timed_call("mhr_swiglu_fwd", gate_up.data_ptr(), act.data_ptr(), rows, F2 // 2, _stream())
+    return act
+
+
+def swiglu_bwd(gate_up, d_act):
+    _chk(gate_up, "gate_up", torch.bfloat16)
+    _chk(d_act, "d_act", torch.bfloat16)
+    F2 = gate_up.shape[-1]
+    rows = gate_up.numel() // F2
+    d = torch.empty_like(gate_up)
+    _timed_call("mhr_swiglu_bwd", gate_up.data_ptr(), d_act.data_ptr(), d.data_ptr(), rows, F2 // 2, _stream())
+    return d
+
+
+def rope_inplace(x, n_heads, head_dim, cos, sin, positions=None, seq_len=0, inverse=False):
+    """Rotate the first n_heads heads of every row of x [T, stride] bf16 in place."""
+    _chk(x, "x", torch.bfloat16)
+    _chk(cos, "cos", torch.float32)
+    _chk(sin, "sin", torch.float32)
+    if positions is not None:
+        _chk(positions, "positions", torch.int32)
+    assert cos.shape == sin.shape and cos.shape[1] == head_dim // 2 and n_heads * head_dim <= x.shape[-1]
+    T = x.numel() // x.shape[-1]
+    _timed_call("mhr_rope_inplace", x.data_ptr(), x.shape[-1], _ptr(positions), cos.data_ptr(), sin.data_ptr(), T, int(seq_len),
+                n_heads, head_dim, cos.shape[0], 1 if inverse else 0, _stream())
+    return x
+
+
+def softmax_attn_fwd(qkv, n_seqs, max_len, n_heads, n_kv_heads, head_dim, scale, cu_seqlens=None, key_valid=None):
+    """qkv [T, (n_heads + 2 n_kv_heads) * head_dim] bf16 (q | k | v column blocks) -> (out [T, n_heads*head_dim] bf16, lse)."""
+    _chk(qkv, "qkv", torch.bfloat16)
+    T, stride = qkv.shape
+    assert stride == (n_heads + 2 * n_kv_heads) * head_dim
+    if cu_seqlens is not None:
+        _chk(cu_seqlens, "cu_seqlens", torch.int32)
+        assert cu_seqlens.numel() == n_seqs + 1
+    else:
+        assert T == n_seqs * max_len
+    if key_valid is not None:
+        _chk(key_valid, "key_valid", torch.uint8)
+        assert key_valid.numel() == T
+    out = torch.empty(T, n_heads * head_dim, dtype=torch.bfloat16, device=qkv.device)
+    lse = torch.empty(T, n_heads, dtype=torch.float32, device=qkv.device)
+    e = qkv.element_size()
+    q, k = qkv.data_ptr(), qkv.data_ptr() + n_heads * head_dim * e
+    v = k + n_kv_heads * head_dim * e
+    _timed_call("mhr_softmax_attn_fwd", q, k, v, stride, _ptr(cu_seqlens), _ptr(key_valid), out.data_ptr(), lse.data_ptr(),
+                n_seqs, max_len, n_heads, n_kv_heads, head_dim, float(scale), _stream())
+    return out, lse
+
+
+def softmax_attn_bwd(qkv, out, d_out, lse, n_seqs, max_len, n_heads, n_kv_heads, head_dim, scale, cu_seqlens=None,
+                     key_valid=None):
+    """-> dqkv [T, (n_heads + 2 n_kv_heads) * head_dim] bf16 (KV-head gradients summed over their query-head group in fp32)."""
+    _chk(qkv, "qkv", torch.bfloat16)
+    _chk(out, "out", torch.bfloat16)
+    _chk(d_out, "d_out", torch.bfloat16)
+    T, stride = qkv.shape
+    dqkv = torch.empty_like(qkv)
+    e = qkv.element_size()
+    q, k = qkv.data_ptr(), qkv.data_ptr() + n_heads * head_dim * e
+    v = k + n_kv_heads * head_dim * e
+    group = n_heads // n_kv_heads
+    if group == 1:
+        dk_ptr = dqkv.data_ptr() + n_heads * head_dim * e
+        dv_ptr = dk_ptr + n_kv_heads * head_dim * e
+        dkv_stride, slabs = stride, None
+    else:
+        slabs = torch.empty(2, T, n_heads * head_dim, dtype=torch.bfloat16, device=qkv.device)
+        dk_ptr, dv_ptr, dkv_stride = slabs[0].data_ptr(), slabs[1].data_ptr(), n_heads * head_dim
+    _timed_call("mhr_softmax_attn_bwd", q, k, v, stride, _ptr(cu_seqlens), _ptr(key_valid), out.data_ptr(), d_out.data_ptr(),
+                lse.data_ptr(), dqkv.data_ptr(), stride, dk_ptr, dv_ptr, dkv_stride, n_seqs, max_len, n_heads, n_kv_heads,
+                head_dim, float(scale), _stream())
+    if slabs is not None:
+        red = torch.sum(slabs.view(2, T, n_kv_heads, group, head_dim), dim=3, dtype=torch.float32)      # [2, T, n_kv, hd]
+        dqkv[:, n_heads * head_dim:].view(T, 2, n_kv_heads * head_dim).copy_(red.view(2, T, -1).transpose(0, 1))
+    return dqkv
+
+
+# ------------------------------------------------------------------------------------------------
 # sampled softmax
 # ------------------------------------------------------------------------------------------------
 def token_compact(mask, q_all, p_all, o_all, tok_cap=None):

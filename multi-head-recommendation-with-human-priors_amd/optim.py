@@ -1,5 +1,5 @@
-"""Fused AdamW for the HSTU model: one kernel over the flat dense-parameter buffer, one over the item table whose
-gradient arrives as a sparse row set (reference: DeepSpeed FusedAdam / torch AdamW over every parameter,
+"""Fused AdamW for the HSTU / HLLM models: one kernel over the flat dense-parameter buffer, one over the item table (HSTU;
+the HLLM twin has no trainable table) whose gradient arrives as a sparse row set (reference: DeepSpeed FusedAdam / torch AdamW over every parameter,
 `code/REC/trainer/trainer.py:292-299`; update semantics identical: every table row is updated every step)."""
 import torch
 
@@ -12,10 +12,11 @@ class FusedAdamW:
         self.model = model
         self.lr, self.weight_decay, self.betas, self.eps = lr, weight_decay, betas, eps
         self.step_count = 0
-        self.table = model.item_embedding.weight
-        dev = self.table.device
-        self.t_m = torch.zeros_like(self.table)
-        self.t_v = torch.zeros_like(self.table)
+        emb = getattr(model, "item_embedding", None)
+        self.table = emb.weight if emb is not None else None
+        dev = next(model.parameters()).device
+        self.t_m = torch.zeros_like(self.table) if self.table is not None else None
+        self.t_v = torch.zeros_like(self.table) if self.table is not None else None
         self.dense = [p for n, p in model.named_parameters() if p.requires_grad and p is not self.table]
         seen, uniq = set(), []
         for p in self.dense:
@@ -40,7 +41,8 @@ class FusedAdamW:
 
     def zero_grad(self):
         self.flat_g.zero_()
-        self.table.grad = None
+        if self.table is not None:
+            self.table.grad = None
         self.model.sparse_grad = None
 
     def step(self):
@@ -50,6 +52,8 @@ class FusedAdamW:
         D.allreduce_mean_(self.flat_g)
         ops.adam_flat(self.flat_w, self.flat_g, self.flat_m, self.flat_v, self.step_count, lr, 1.0, self.betas, self.eps,
                       self.weight_decay)
+        if self.table is None:
+            return
         sg = self.model.finish_sparse_grad() if hasattr(self.model, "finish_sparse_grad") else self.model.sparse_grad
         if sg is not None:
             ops.adam_rows(self.table, self.t_m, self.t_v, sg.rows, sg.row_slot, self.step_count, lr, 1.0 / W, self.betas,
@@ -61,9 +65,12 @@ class FusedAdamW:
                           self.weight_decay)
 
     def state_dict(self):
-        return {"step": self.step_count, "flat_m": self.flat_m, "flat_v": self.flat_v, "t_m": self.t_m, "t_v": self.t_v}
+        sd = {"step": self.step_count, "flat_m": self.flat_m, "flat_v": self.flat_v}
+        if self.table is not None:
+            sd.update(t_m=self.t_m, t_v=self.t_v)
+        return sd
 
     def load_state_dict(self, sd):
         self.step_count = int(sd["step"])
-        for k in ("flat_m", "flat_v", "t_m", "t_v"):
+        for k in ("flat_m", "flat_v") + (("t_m", "t_v") if self.table is not None else ()):
             getattr(self, k).copy_(sd[k])

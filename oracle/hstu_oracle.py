@@ -344,12 +344,6 @@ def train_forward(weights, cfg, batch, extra_negs=None):
 
     e, x = embed_inputs(weights, cfg, items)
     out = hstu_encoder(x, weights, cfg, mask[:, :L])
-    heads = decode_heads(weights, cfg, out).permute(0, 2, 1, 3)          # [B,H,L,D]
-    tgt, valid, tg = future_targets(e, mask, tags, L, P)
-    p_grid = torch.arange(P)[None, :, None].expand(B, P, L)
-
-    res = OrderedDict()
-    res["loss"] = torch.zeros(())
 
     def negs_for(pool):
         n = gather_negatives(weights, neg_items[:, pool])
@@ -357,9 +351,33 @@ def train_forward(weights, cfg, batch, extra_negs=None):
             n = torch.cat([n, extra_negs[pool]], 0)
         return n
 
+    return multihead_loss(weights, cfg, e, out, mask, tags, negs_for, neg_items.shape[1])
+
+
+def multihead_loss(weights, cfg, e, out, mask, tags, negs_for, n_pools):
+    """Everything of the training forward after the sequence encoder: decoding heads, future windows, sampled softmax per
+    head / prior category, per-offset weighting, prior switch.  model/IDNet/hstu.py:648-872 and, line for line the same
+    code, model/HLLM/hllm.py:506-763.  e [B,L+P,D] item embeddings (targets), out [B,L,D] encoder output, mask [B,L+P]
+    bool, tags [B,L+P,C]; negs_for(pool) -> [M,D] L2-normalised negatives of pool `pool` (-1 = the shared pool)."""
+    L, P = cfg["MAX_ITEM_LIST_LENGTH"], cfg["pred_len"]
+    S, C = cfg["num_segment_head"], cfg["num_prior_head"]
+    B = e.shape[0]
+    hi = cfg["head_interaction"]
+    loss_kind = cfg["loss"]
+    by_cat = bool(cfg.get("neg_sample_by_cat")) and loss_kind == "prior"
+    thres = cfg.get("nce_thres") or 0.99
+    lam = horizon_discount(cfg)
+    names = cfg.get("int_to_category") or {c: str(c) for c in range(C)}
+    heads = decode_heads(weights, cfg, out).permute(0, 2, 1, 3)          # [B,H,L,D]
+    tgt, valid, tg = future_targets(e, mask, tags, L, P)
+    p_grid = torch.arange(P)[None, :, None].expand(B, P, L)
+
+    res = OrderedDict()
+    res["loss"] = torch.zeros(())
+
     shared = None
     if (not by_cat) or (loss_kind == "prior" and hi == "additive"):
-        shared = negs_for(-1 if neg_items.shape[1] > 1 else 0)
+        shared = negs_for(-1 if n_pools > 1 else 0)
 
     if loss_kind == "nce" or (loss_kind == "prior" and hi == "additive"):
         seg_len = seg_len_of(cfg)
@@ -425,26 +443,28 @@ def compute_item_all(weights):
     return l2n(item_tower(weights, weights["item_embedding.weight"]))
 
 
-def user_head_embeddings(weights, cfg, item_seq):
-    """Encoder on [B,L] (front zero-padded), last position, H heads, fp32 L2-norm.
-    model/IDNet/hstu.py:879-931, 965-966.  Returns [B,H,D]."""
+def last_hidden(weights, cfg, item_seq):
+    """Encoder on [B,L] (front zero-padded) -> output at the last position [B,D].  model/IDNet/hstu.py:879-913."""
     _, x = embed_inputs(weights, cfg, item_seq)
-    out = hstu_encoder(x, weights, cfg, item_seq != 0)
-    last = out[:, -1]
+    return hstu_encoder(x, weights, cfg, item_seq != 0)[:, -1]
+
+
+def user_head_embeddings(weights, cfg, item_seq, last=None):
+    """Last position, H heads, fp32 L2-norm.  model/IDNet/hstu.py:915-931, 965-966.  Returns [B,H,D]."""
+    last = last_hidden(weights, cfg, item_seq) if last is None else last
     return l2n(decode_heads(weights, cfg, last).float())
 
 
-def predict_switch(weights, cfg, item_seq):
+def predict_switch(weights, cfg, item_seq, last=None):
     """Prior-switch decisions at the last position: pred [B, n] bool (n = 1 with master_switch, else C).
     model/IDNet/hstu.py:935-956."""
-    _, x = embed_inputs(weights, cfg, item_seq)
-    last = hstu_encoder(x, weights, cfg, item_seq != 0)[:, -1]             # [B,D]
+    last = last_hidden(weights, cfg, item_seq) if last is None else last      # [B,D]
     head_out = decode_heads(weights, cfg, last)                            # [B,H,D] (not normalised)
     n = 1 if cfg.get("master_switch") else cfg["num_prior_head"]
     return torch.stack([switch_logits(weights, cfg, last, head_out, c) >= 0 for c in range(n)], dim=1)
 
 
-def predict_scores(weights, cfg, item_seq, item_feature, all_item_tags, target_tags, logs=None):
+def predict_scores(weights, cfg, item_seq, item_feature, all_item_tags, target_tags, logs=None, last=None):
     """HSTU.predict. model/IDNet/hstu.py:874-1016.
 
     item_feature [N,D] (re-normalised here, hstu.py:974-975), all_item_tags [C,N],
@@ -452,11 +472,13 @@ def predict_scores(weights, cfg, item_seq, item_feature, all_item_tags, target_t
     reference's wandb counters (num_samples, head_cat_*_num_correct).
     """
     S, C = cfg["num_segment_head"], cfg["num_prior_head"]
-    u = user_head_embeddings(weights, cfg, item_seq)                       # [B,H,D]
+    if last is None:            # `last` given: the caller ran its own sequence encoder (HLLM twin, hllm.py:781-783)
+        last = last_hidden(weights, cfg, item_seq)
+    u = user_head_embeddings(weights, cfg, item_seq, last)                 # [B,H,D]
     names = cfg.get("int_to_category") or {c: str(c) for c in range(C)}
     pred = None
     if cfg["loss"] == "prior" and cfg.get("prior_switch") in ("in", "in_out"):
-        pred = predict_switch(weights, cfg, item_seq)
+        pred = predict_switch(weights, cfg, item_seq, last)
         if logs is not None:
             for c in range(pred.shape[1]):
                 label = target_tags[:, :, c].sum(dim=-1) > 0

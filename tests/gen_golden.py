@@ -319,11 +319,66 @@ def switch_cases():
                                                        use_prior_switch_test=True, master_switch=True), N=257, B=8, seed=45)
 
 
+def run_llama_cases():
+    """Decoder blocks of the HLLM twin: the reference's own REC/model/HLLM/modeling_llama.py (eager attention path) on
+    tiny random-init configs -> last hidden state and parameter / input gradients.  Two shapes: grouped KV heads with
+    front-padded sequences (the user decoder's call, hllm.py:501-502) and head_dim 64 without padding."""
+    import numpy as np
+    import torch
+    from REC.model.HLLM.modeling_llama import LlamaConfig, LlamaForCausalLM
+    cases = {
+        "llama_decoder_gqa": dict(hidden_size=64, intermediate_size=96, num_hidden_layers=2, num_attention_heads=4,
+                                  num_key_value_heads=2, B=3, L=12, pad=[5, 1, 0], seed=11, rope_theta=10000.0, eps=1e-5),
+        "llama_decoder_hd64": dict(hidden_size=128, intermediate_size=160, num_hidden_layers=1, num_attention_heads=2,
+                                   num_key_value_heads=2, B=2, L=40, pad=[0, 7], seed=12, rope_theta=500000.0, eps=1e-6),
+    }
+    for name, c in cases.items():
+        torch.manual_seed(c["seed"])
+        cfg = LlamaConfig(hidden_size=c["hidden_size"], intermediate_size=c["intermediate_size"],
+                          num_hidden_layers=c["num_hidden_layers"], num_attention_heads=c["num_attention_heads"],
+                          num_key_value_heads=c["num_key_value_heads"], vocab_size=32, max_position_embeddings=64,
+                          rms_norm_eps=c["eps"], rope_theta=c["rope_theta"], pretraining_tp=1)
+        cfg.use_ft_flash_attn, cfg.use_cache, cfg.output_hidden_states, cfg.return_dict = False, False, True, True
+        model = LlamaForCausalLM(cfg)
+        with torch.no_grad():                              # norm weights away from 1 so that their maths is visible
+            for n_, p_ in model.named_parameters():
+                if "norm" in n_:
+                    p_.add_(0.2 * torch.randn_like(p_))
+        B, L, D = c["B"], c["L"], c["hidden_size"]
+        x = torch.randn(B, L, D, requires_grad=True)
+        mask = torch.ones(B, L, dtype=torch.bool)
+        for b, pad in enumerate(c["pad"]):
+            mask[b, :pad] = False
+        hidden = model(inputs_embeds=x, attention_mask=mask).hidden_states[-1]
+        probe = torch.randn(B, L, D)
+        loss = (hidden * probe * mask[..., None]).sum()            # padded rows are not read by any caller
+        loss.backward()
+        out = {"w/" + k: v.detach().numpy() for k, v in model.state_dict().items() if not k.startswith("lm_head")}
+        out.update(x=x.detach().numpy(), mask=mask.numpy(), probe=probe.numpy(), hidden=hidden.detach().numpy(),
+                   loss=np.float64(loss.item()), dx=x.grad.numpy())
+        for k, p_ in model.named_parameters():
+            keep = ("layers.0.self_attn.q_proj", "layers.0.self_attn.k_proj", "layers.0.self_attn.v_proj",
+                    "layers.0.mlp.up_proj", "norm")
+            if p_.grad is not None and any(t in k for t in keep):
+                out["g/" + k] = p_.grad.numpy()
+        import json
+        out["lcfg"] = np.array(json.dumps(dict(hidden_size=D, intermediate_size=c["intermediate_size"],
+                                                num_hidden_layers=c["num_hidden_layers"],
+                                                num_attention_heads=c["num_attention_heads"],
+                                                num_key_value_heads=c["num_key_value_heads"], rms_norm_eps=c["eps"],
+                                                rope_theta=c["rope_theta"])))
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+        print("wrote", name, "loss", loss.item())
+
+
 def main():
     _setup()
     os.makedirs(OUT, exist_ok=True)
     if len(sys.argv) > 1 and sys.argv[1] == "switch":
         switch_cases()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "llama":
+        run_llama_cases()
         return
     # F1: plain next-item NCE, identity heads
     run_train_case("hstu_nce_tiny", base_cfg(), N=501, B=4, n_neg=8, seed=11)
@@ -362,6 +417,8 @@ def main():
     run_collector_case("collector_average", N=300, B=5, S=1, C=4, hi="multiplicative", K=20, E=4, seed=36,
                        split_mode="average")
     run_schedule_and_adam()
+    switch_cases()
+    run_llama_cases()
 
 
 if __name__ == "__main__":

@@ -1,0 +1,396 @@
+"""LLM decoder blocks of the HLLM twin on a real MI355X: the RMSNorm / SwiGLU / RoPE / causal softmax attention kernels
+(through the C ABI) and the native Llama decoder built on them, against the CPU oracle (oracle/hllm_oracle.py, pinned
+to the reference's modeling_llama.py by tests/golden/llama_decoder_*.npz) on the SAME bf16-rounded operands.
+
+Tolerances: tensors the kernel stores in bf16: 2^-7 of the row scale (one or two bf16 roundings); gradients that pass a
+bf16-rounded probability tile through a second MFMA: 2e-2 of the max-abs; whole-decoder outputs (bf16 GEMMs, fp32
+residual stream, vs the fp32 oracle): 3e-2 of the max-abs.
+"""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import hllm_oracle as LO
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import mhr_amd  # noqa: F401
+    from mhr_amd import ops as _ops
+    return _ops
+
+
+def bf(t):
+    return t.to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("rows,D,with_res", [(7, 64, False), (300, 256, True), (33, 2048, True), (5, 4096, False)])
+def test_rmsnorm_fwd_bwd(ops, rows, D, with_res):
+    g = torch.Generator().manual_seed(rows + D)
+    x = torch.randn(rows, D, generator=g)
+    res = bf(torch.randn(rows, D, generator=g)) if with_res else None
+    w = 1.0 + 0.3 * torch.randn(D, generator=g)
+    dy = bf(torch.randn(rows, D, generator=g))
+    d_xout = torch.randn(rows, D, generator=g) if with_res else None
+    eps = 1e-5
+    # oracle on the same operands
+    xs = (x + res.float()) if with_res else x
+    xs = xs.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    y_ref = LO.rms_norm(xs, wr, eps)
+    (y_ref * dy.float()).sum().backward()
+    x_out, y, rstd = ops.rmsnorm_fwd(x.cuda(), w.cuda(), None if res is None else res.cuda(), eps)
+    dx, dres, dw = ops.rmsnorm_bwd(dy.cuda(), x_out, w.cuda(), rstd, None if d_xout is None else d_xout.cuda(), want_dres=with_res)
+    torch.cuda.synchronize()
+    assert torch.equal(x_out.cpu(), xs.detach())                                        # fp32 add: bit-exact
+    assert float((y.float().cpu() - y_ref.detach()).abs().max()) <= 2 ** -7 * float(y_ref.abs().max())
+    want_dx = xs.grad + (d_xout if d_xout is not None else 0)
+    assert float((dx.cpu() - want_dx).abs().max()) <= 1e-4 * float(want_dx.abs().max())
+    assert float((dw.cpu() - wr.grad).abs().max()) <= 1e-4 * float(wr.grad.abs().max())
+    if with_res:
+        assert torch.equal(dres.cpu(), bf(dx.cpu()))
+
+
+def test_swiglu_fwd_bwd(ops):
+    g = torch.Generator().manual_seed(3)
+    rows, Fh = 37, 352
+    gu = bf(torch.randn(rows, 2 * Fh, generator=g) * 2)
+    da = bf(torch.randn(rows, Fh, generator=g))
+    gr = gu.float().requires_grad_(True)
+    a_ref = torch.nn.functional.silu(gr[:, :Fh]) * gr[:, Fh:]
+    (a_ref * da.float()).sum().backward()
+    a = ops.swiglu_fwd(gu.cuda())
+    d = ops.swiglu_bwd(gu.cuda(), da.cuda())
+    torch.cuda.synchronize()
+    assert float((a.float().cpu() - a_ref.detach()).abs().max()) <= 2 ** -8 * float(a_ref.abs().max())
+    assert float((d.float().cpu() - gr.grad).abs().max()) <= 2 ** -7 * float(gr.grad.abs().max())
+
+
+def test_rope_matches_oracle_and_inverts(ops):
+    g = torch.Generator().manual_seed(4)
+    B, L, nh, nkv, hd = 3, 11, 4, 2, 32
+    stride = (nh + 2 * nkv) * hd
+    qkv = bf(torch.randn(B * L, stride, generator=g))
+    pos = torch.randint(0, 40, (B, L), generator=g)
+    cos, sin = LO.rope_tables(hd, 64, 10000.0)
+    q = qkv[:, :nh * hd].float().view(B, L, nh, hd).transpose(1, 2)
+    k = qkv[:, nh * hd:(nh + nkv) * hd].float().view(B, L, nkv, hd).transpose(1, 2)
+    q_ref = LO.apply_rope(q, cos, sin, pos).transpose(1, 2).reshape(B * L, -1)
+    k_ref = LO.apply_rope(k, cos, sin, pos).transpose(1, 2).reshape(B * L, -1)
+    x = qkv.cuda().clone()
+    ops.rope_inplace(x, nh + nkv, hd, cos.cuda().contiguous(), sin.cuda().contiguous(), pos.reshape(-1).int().cuda())
+    torch.cuda.synchronize()
+    got = x.float().cpu()
+    assert torch.equal(got[:, (nh + nkv) * hd:], qkv[:, (nh + nkv) * hd:].float())          # v untouched
+    assert float((got[:, :nh * hd] - q_ref).abs().max()) <= 2 ** -8 * float(q_ref.abs().max())
+    assert float((got[:, nh * hd:(nh + nkv) * hd] - k_ref).abs().max()) <= 2 ** -8 * float(k_ref.abs().max())
+    ops.rope_inplace(x, nh + nkv, hd, cos.cuda().contiguous(), sin.cuda().contiguous(), pos.reshape(-1).int().cuda(), inverse=True)
+    torch.cuda.synchronize()
+    assert float((x.float().cpu() - qkv.float()).abs().max()) <= 2 ** -6 * float(qkv.float().abs().max())
+    # default positions: token t of a [B, L] batch sits at t % L
+    y = qkv.cuda().clone()
+    ops.rope_inplace(y, nh, hd, cos.cuda().contiguous(), sin.cuda().contiguous(), None, seq_len=L)
+    q_def = LO.apply_rope(q, cos, sin, torch.arange(L)[None].expand(B, L)).transpose(1, 2).reshape(B * L, -1)
+    torch.cuda.synchronize()
+    assert float((y.float().cpu()[:, :nh * hd] - q_def).abs().max()) <= 2 ** -8 * float(q_def.abs().max())
+
+
+def _attn_ref(qkv, B, L, nh, nkv, hd, allowed):
+    q = qkv[:, :nh * hd].view(B, L, nh, hd).transpose(1, 2)
+    k = qkv[:, nh * hd:(nh + nkv) * hd].view(B, L, nkv, hd).transpose(1, 2).repeat_interleave(nh // nkv, dim=1)
+    v = qkv[:, (nh + nkv) * hd:].view(B, L, nkv, hd).transpose(1, 2).repeat_interleave(nh // nkv, dim=1)
+    return LO.attention(q, k, v, allowed).transpose(1, 2).reshape(B * L, nh * hd)
+
+
+@pytest.mark.parametrize("B,L,nh,nkv,hd,pads", [(3, 12, 4, 2, 16, [5, 1, 0]), (2, 50, 8, 2, 64, [13, 0]), (2, 200, 4, 4, 32, [0, 77]),
+                                                 (1, 70, 2, 1, 128, [3]), (2, 33, 2, 2, 64, [32, 0])])
+def test_softmax_attention_fwd_bwd(ops, B, L, nh, nkv, hd, pads):
+    g = torch.Generator().manual_seed(B * 1000 + L)
+    stride = (nh + 2 * nkv) * hd
+    qkv = bf(torch.randn(B * L, stride, generator=g))
+    valid = torch.ones(B, L, dtype=torch.bool)
+    for b, p in enumerate(pads):
+        valid[b, :p] = False
+    d_out = bf(torch.randn(B * L, nh * hd, generator=g)) * valid.reshape(-1, 1)           # padded rows receive no gradient
+    allowed = torch.tril(torch.ones(L, L, dtype=torch.bool))[None, None] & valid[:, None, None, :]
+    qr = qkv.float().requires_grad_(True)
+    o_ref = _attn_ref(qr, B, L, nh, nkv, hd, allowed)
+    (o_ref * d_out.float()).sum().backward()
+    scale = 1.0 / math.sqrt(hd)
+    out, lse = ops.softmax_attn_fwd(qkv.cuda(), B, L, nh, nkv, hd, scale, key_valid=valid.reshape(-1).to(torch.uint8).cuda())
+    dqkv = ops.softmax_attn_bwd(qkv.cuda(), out, d_out.cuda(), lse, B, L, nh, nkv, hd, scale,
+                                key_valid=valid.reshape(-1).to(torch.uint8).cuda())
+    torch.cuda.synchronize()
+    rows = valid.reshape(-1)
+    got = out.float().cpu()
+    assert float((got[rows] - o_ref.detach()[rows]).abs().max()) <= 2 ** -6 * float(o_ref.detach()[rows].abs().max())
+    assert float(got[~rows].abs().max() if (~rows).any() else 0.0) == 0.0                  # rows with no admissible key
+    dg = dqkv.float().cpu()
+    assert float((dg - qr.grad).abs().max()) <= 2e-2 * float(qr.grad.abs().max())
+
+
+def test_softmax_attention_packed_sequences(ops):
+    """`cu_input_lens` batches of the item tower: one packed row of concatenated sequences (flash_self_attn.py:61-130)."""
+    g = torch.Generator().manual_seed(9)
+    lens = [5, 40, 1, 33, 17]
+    nh, nkv, hd = 4, 2, 32
+    T = sum(lens)
+    qkv = bf(torch.randn(T, (nh + 2 * nkv) * hd, generator=g))
+    d_out = bf(torch.randn(T, nh * hd, generator=g))
+    seg = torch.repeat_interleave(torch.arange(len(lens)), torch.tensor(lens))[None]
+    allowed = torch.tril(torch.ones(T, T, dtype=torch.bool))[None, None] & (seg[:, None, :, None] == seg[:, None, None, :])
+    qr = qkv.float().requires_grad_(True)
+    o_ref = _attn_ref(qr, 1, T, nh, nkv, hd, allowed)
+    (o_ref * d_out.float()).sum().backward()
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32).cuda()
+    scale = 1.0 / math.sqrt(hd)
+    out, lse = ops.softmax_attn_fwd(qkv.cuda(), len(lens), max(lens), nh, nkv, hd, scale, cu_seqlens=cu)
+    dqkv = ops.softmax_attn_bwd(qkv.cuda(), out, d_out.cuda(), lse, len(lens), max(lens), nh, nkv, hd, scale, cu_seqlens=cu)
+    torch.cuda.synchronize()
+    assert float((out.float().cpu() - o_ref.detach()).abs().max()) <= 2 ** -6 * float(o_ref.abs().max())
+    assert float((dqkv.float().cpu() - qr.grad).abs().max()) <= 2e-2 * float(qr.grad.abs().max())
+
+
+@pytest.mark.parametrize("name", ["llama_decoder_gqa", "llama_decoder_hd64"])
+def test_llama_decoder_matches_reference_fixture(ops, name):
+    """The native decoder (REC/model/HLLM/modeling_llama.py) loaded with the reference model's weights reproduces the
+    reference's last hidden state and gradients on the fixture's inputs (valid positions; bf16-mixed vs fp32)."""
+    from REC.model.HLLM.modeling_llama import LlamaConfig, LlamaForCausalLM
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    lcfg = json.loads(str(z["lcfg"]))
+    model = LlamaForCausalLM(LlamaConfig(vocab_size=32, max_position_embeddings=64, **lcfg))
+    missing = model.load_state_dict({k[2:]: torch.tensor(z[k]) for k in z.files if k.startswith("w/")}, strict=False)
+    assert set(missing.missing_keys) <= {"lm_head.weight"} and not missing.unexpected_keys
+    model = model.cuda().train()
+    x = torch.tensor(z["x"]).cuda().requires_grad_(True)
+    mask = torch.tensor(z["mask"]).cuda()
+    hidden = model(inputs_embeds=x, attention_mask=mask).hidden_states[-1]
+    m = mask[..., None]
+    ref = torch.tensor(z["hidden"]).cuda()
+    assert float(((hidden.float() - ref) * m).abs().max()) <= 3e-2 * float(ref.abs().max())
+    loss = (hidden.float() * torch.tensor(z["probe"]).cuda() * m).sum()
+    loss.backward()
+    assert abs(float(loss) - float(z["loss"])) <= 3e-2 * max(1.0, abs(float(z["loss"])))
+    dx_ref = torch.tensor(z["dx"]).cuda()
+    assert float((x.grad - dx_ref).abs().max()) <= 5e-2 * float(dx_ref.abs().max())
+    grads = dict(model.named_parameters())
+    for k in z.files:
+        if k.startswith("g/"):
+            gref = torch.tensor(z[k]).cuda()
+            got = grads[k[2:]].grad
+            assert got is not None, k
+            assert float((got - gref).abs().max()) <= 5e-2 * float(gref.abs().max()), k
+
+
+# ------------------------------------------------------------------------------------------------
+# HLLM twin: user decoder + shared multi-head loss / decode, frozen item tower
+# ------------------------------------------------------------------------------------------------
+CODE = os.path.join(os.path.dirname(GOLD), "..", "multi-head-recommendation-with-human-priors_amd", "code")
+
+
+class _FakeData:
+    def __init__(self, n, C):
+        self.item_num = n
+        self.category_to_int = {f"cat{c}": c for c in range(C)}
+        self.category_counts = {f"cat{c}": 10 + 7 * c for c in range(C)}
+
+
+def _hllm_cfg(**kw):
+    C = kw.get("num_prior_head", 3)
+    c = dict(model="HLLM", MAX_ITEM_LIST_LENGTH=12, pred_len=2, eval_pred_len=2, medusa_lambda=0.99, num_segment_head=1,
+             num_prior_head=C, head_interaction="multiplicative", medusa_num_layers=1, category_by="item", loss="prior",
+             neg_sample_by_cat=True, pos_sample_mix_ratio=0, fix_temp=False, nce_thres=None, weighted_prior_loss=True,
+             prior_switch=None, split_mode="combine", freeze_item_llm=True, dummy_llm=False, item_emb_token_n=1,
+             user_llm_config=dict(hidden_size=64, intermediate_size=96, num_hidden_layers=2, num_attention_heads=4,
+                                  num_key_value_heads=2, vocab_size=32, rms_norm_eps=1e-5, rope_theta=10000.0),
+             int_to_category={i: f"cat{i}" for i in range(C)})
+    c.update(kw)
+    return c
+
+
+def _hllm_batch(g, N, B, L, P, C, n_neg, item_tags):
+    ids = torch.randint(1, N, (B, L + P), generator=g)
+    mask = torch.ones(B, L + P, dtype=torch.int64)
+    for b in range(B):
+        mask[b, :int(torch.randint(0, L // 2, (1,), generator=g))] = 0           # front context padding
+        if b % 3 == 1:
+            mask[b, L + P - 1:] = 0                                               # short prediction window
+    it = dict(attention_mask=mask, pos_item_ids=ids, pos_tag_categories=item_tags[ids],
+              neg_item_ids=torch.randint(1, N, (B, n_neg), generator=g))
+    for c in range(C):
+        it[f"neg_item_ids_cat{c}"] = torch.randint(1, N, (B, n_neg), generator=g)
+    return it
+
+
+def _build_hllm(cfgd, N):
+    import sys
+    if os.path.abspath(CODE) not in sys.path:
+        sys.path.insert(0, os.path.abspath(CODE))
+    import REC  # noqa: F401
+    from REC.config.configurator import Config
+    from REC.utils import get_model
+    torch.manual_seed(5)
+    model = get_model("HLLM")(Config(config_dict=cfgd), _FakeData(N, cfgd["num_prior_head"])).cuda()
+    with torch.no_grad():                      # heads start at zero in the reference (ResBlock zero_init): make them visible
+        for n_, p_ in model.named_parameters():
+            if n_.startswith("medusa") or "norm" in n_:
+                p_.add_(0.05 * torch.randn_like(p_))
+    return model
+
+
+def _oracle_weights(model):
+    from oracle import hstu_oracle as HO
+    w = {k: v.detach().float().cpu().clone().requires_grad_(v.is_floating_point()) for k, v in model.state_dict().items()}
+    return HO.tie_repeated_resblocks(w)
+
+
+@pytest.mark.parametrize("variant", ["prior_bycat", "nce_shared", "additive_switch", "dummy"])
+def test_hllm_train_step_matches_oracle(ops, variant):
+    kw = dict(prior_bycat={}, nce_shared=dict(loss="nce", num_prior_head=1, pred_len=4, eval_pred_len=4, num_segment_head=2,
+                                               neg_sample_by_cat=False),
+              additive_switch=dict(head_interaction="additive", num_segment_head=2, prior_switch="in", prior_switch_loss_weight=0.5),
+              dummy=dict(dummy_llm=True))[variant]
+    cfgd = _hllm_cfg(**kw)
+    N, B, n_neg = 301, 5, 24
+    L, P, C = cfgd["MAX_ITEM_LIST_LENGTH"], cfgd["pred_len"], cfgd["num_prior_head"]
+    g = torch.Generator().manual_seed(17)
+    item_tags = (torch.rand(N, C, generator=g) < 0.5).long()
+    item_tags[torch.arange(N), torch.randint(0, C, (N,), generator=g)] = 1
+    table = torch.randn(N, 64, generator=g)
+    batch = _hllm_batch(g, N, B, L, P, C, n_neg, item_tags)
+    model = _build_hllm(cfgd, N).train()
+    model.set_all_item_embeds(table.cuda())
+    out = model({k: v.cuda() for k, v in batch.items()})
+    out["loss"].backward()
+    w = _oracle_weights(model)
+    ocfg = dict(cfgd)
+    ocfg.update(category_counts=_FakeData(N, C).category_counts, category_to_int=_FakeData(N, C).category_to_int)
+    ref = LO.train_forward(w, ocfg, batch, table)
+    ref["loss"].backward()
+    assert abs(float(out["loss"]) - float(ref["loss"])) <= 2e-2 * abs(float(ref["loss"])) + 2e-3
+    for k, v in ref.items():
+        if k.endswith("_loss") and k in out:
+            assert abs(float(out[k]) - float(v)) <= 2e-2 * abs(float(v)) + 2e-3, k
+    named = dict(model.named_parameters())
+    checked = 0
+    for k, p in named.items():
+        if not p.requires_grad or w[k].grad is None:
+            continue
+        if any(t in k for t in ("layers.0.self_attn.q_proj", "layers.1.mlp.down_proj", "layers.0.input_layernorm", "model.norm",
+                                "medusa", "logit_scale", "aux_cat_head.0", "embed_layer")):
+            gref = w[k].grad
+            assert p.grad is not None, k
+            assert float((p.grad.cpu() - gref).abs().max()) <= 6e-2 * float(gref.abs().max()) + 1e-5, k
+            checked += 1
+    assert checked >= 3
+
+
+def test_hllm_predict_and_fused_decode(ops):
+    from oracle import decode_oracle as DO
+    cfgd = _hllm_cfg()
+    N, B, K = 301, 6, 20
+    L, C = cfgd["MAX_ITEM_LIST_LENGTH"], cfgd["num_prior_head"]
+    g = torch.Generator().manual_seed(23)
+    item_tags = (torch.rand(N, C, generator=g) < 0.5).long()
+    item_tags[torch.arange(N), torch.randint(0, C, (N,), generator=g)] = 1
+    table = torch.randn(N, 64, generator=g)
+    seq = torch.randint(1, N, (B, L), generator=g)
+    for b in range(B):
+        seq[b, :int(torch.randint(0, L - 1, (1,), generator=g))] = 0
+    tt = item_tags[torch.randint(1, N, (B, cfgd["eval_pred_len"]), generator=g)]
+    model = _build_hllm(cfgd, N).eval()
+    model.set_all_item_embeds(table.cuda())
+    feat = model.compute_item_all()
+    tags_cn = item_tags.t().contiguous()
+    scores, logs, _, _ = model((seq.cuda(), None, feat, tags_cn.cuda(), tt.cuda()), mode='predict')
+    w = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    ocfg = dict(cfgd)
+    ref = LO.predict_scores(w, ocfg, seq, table, tags_cn, tt)
+    s, r = scores.cpu().numpy(), ref.detach().numpy()
+    assert np.array_equal(np.isinf(s), np.isinf(r))
+    fin = np.isfinite(r)
+    assert np.abs(s[fin] - r[fin]).max() < 2e-2                                          # cosines, bf16 decoder
+    fused = model.predict_topk(seq.cuda(), feat, tags_cn.cuda(), tt.cuda(), None, k=K, suppress_history=False)
+    users = model._heads_at_last(model._last_hidden(seq.cuda(), feat)).to(torch.bfloat16).float().cpu()
+    items = (table / table.norm(dim=-1, keepdim=True)).to(torch.bfloat16).float()
+    dense = (users @ items.T).numpy()
+    dense[~np.isfinite(s)] = -np.inf
+    dense[:, :, 0] = -np.inf
+    rv, ri = DO.per_head_topk(dense, K)
+    fi, fv = fused.indices.cpu().numpy(), fused.values.cpu().numpy()
+    finm = np.isfinite(rv)
+    assert np.array_equal(np.isfinite(fv), finm)
+    for b, h, j in np.argwhere((fi != ri) & finm):                                         # only numerical ties may differ
+        assert abs(dense[b, h, fi[b, h, j]] - rv[b, h, j]) < 2e-6
+    np.testing.assert_allclose(fv[finm], rv[finm], rtol=1e-4, atol=1e-6)
+
+
+def test_hllm_item_tower_packed_tokens_and_training(ops):
+    """Trainable item tower: `forward_item_emb` on a packed `cu_input_lens` batch equals the oracle decoder restricted to
+    each item's own tokens, and a train step through both towers produces gradients in both."""
+    cfgd = _hllm_cfg(freeze_item_llm=False, loss="nce", num_prior_head=1, neg_sample_by_cat=False, medusa_num_layers=0,
+                     MAX_ITEM_LIST_LENGTH=6, pred_len=1, eval_pred_len=1,
+                     item_llm_config=dict(hidden_size=64, intermediate_size=96, num_hidden_layers=1, num_attention_heads=2,
+                                          num_key_value_heads=2, vocab_size=50, rms_norm_eps=1e-5))
+    model = _build_hllm(cfgd, 10).train()
+    g = torch.Generator().manual_seed(31)
+    B, S, n_neg = 3, 7, 4
+
+    def packed(n_items):
+        lens = torch.randint(2, 9, (n_items,), generator=g)
+        ids = torch.randint(0, 50, (int(lens.sum()),), generator=g)
+        pos = torch.cat([torch.arange(int(l)) for l in lens])
+        return ids, pos, lens.int()
+
+    pid, ppos, plen = packed(B * S)
+    nid, npos, nlen = packed(B * n_neg)
+    emb = model.forward_item_emb(pid.cuda(), ppos.cuda(), plen.cuda(), 1, model.item_emb_tokens, model.item_llm)
+    w = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    x = w["item_llm.model.embed_tokens.weight"][pid].clone()
+    last = torch.cumsum(plen, 0).long() - 1
+    x[last] = w["item_emb_tokens"].view(1, -1)
+    seg = torch.repeat_interleave(torch.arange(plen.numel()), plen.long())
+    hid = LO.llama_decoder(w, cfgd["item_llm_config"], x[None], None, ppos[None], seg[None], prefix="item_llm.model.")[0]
+    ref = hid[last]
+    assert float((emb.float().cpu() - ref).abs().max()) <= 3e-2 * float(ref.abs().max())
+    mask = torch.ones(B, S, dtype=torch.int64)
+    mask[0, :2] = 0
+    it = dict(attention_mask=mask.cuda(), pos_input_ids=pid.cuda(), pos_position_ids=ppos.cuda(), pos_cu_input_lens=plen.cuda(),
+              neg_input_ids=nid.cuda(), neg_position_ids=npos.cuda(), neg_cu_input_lens=nlen.cuda())
+    out = model(it)
+    assert torch.isfinite(out["loss"])
+    out["loss"].backward()
+    gi = model.item_llm.model.layers[0].self_attn.q_proj.weight.grad
+    gu = model.user_llm.model.layers[0].self_attn.q_proj.weight.grad
+    assert gi is not None and float(gi.abs().max()) > 0 and gu is not None and float(gu.abs().max()) > 0
+    assert model.item_emb_tokens.grad is not None and float(model.item_emb_tokens.grad.abs().max()) > 0
+
+
+def test_hllm_trainer_steps_reduce_loss(ops):
+    import sys
+    from mhr_amd import synth
+    cfgd = synth.base_config(**_hllm_cfg(optim_args={'learning_rate': 1e-3, 'weight_decay': 0.0}, total_iters=8, topk=[5],
+                                         scheduler_args=None, save_model_note="t"))
+    N, B, n_neg = 301, 8, 24
+    L, P, C = cfgd["MAX_ITEM_LIST_LENGTH"], cfgd["pred_len"], cfgd["num_prior_head"]
+    g = torch.Generator().manual_seed(41)
+    item_tags = (torch.rand(N, C, generator=g) < 0.5).long()
+    item_tags[torch.arange(N), torch.randint(0, C, (N,), generator=g)] = 1
+    model = _build_hllm(cfgd, N).train()
+    model.set_all_item_embeds(torch.randn(N, 64, generator=g).cuda())
+    from REC.config.configurator import Config
+    from REC.trainer import Trainer
+    tr = Trainer(Config(config_dict=cfgd))
+    tr.setup_model(model)
+    batch = {k: v.cuda() for k, v in _hllm_batch(g, N, B, L, P, C, n_neg, item_tags).items()}
+    losses = [float(tr.train_step_fn(batch)["loss"].detach()) for _ in range(8)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]

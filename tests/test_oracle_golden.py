@@ -159,3 +159,31 @@ def test_schedule_and_adam():
     for t in range(g["grads"].shape[0]):
         OO.adamw_step(w, torch.from_numpy(g["grads"][t]), m, v, t + 1, lr=1e-2, weight_decay=0.01)
         np.testing.assert_allclose(w.numpy(), g["ws"][t], rtol=2e-6, atol=1e-7)
+
+
+# ------------------------------------------------------------------------------------------------
+# HLLM twin: the Llama decoder restatement against the reference's own modeling_llama.py (eager path)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["llama_decoder_gqa", "llama_decoder_hd64"])
+def test_llama_decoder_oracle_matches_reference(name):
+    import json
+    from oracle import hllm_oracle as LO
+    g = load_golden(name)
+    lcfg = json.loads(str(g["lcfg"]))
+    w = {k[2:]: torch.tensor(v).requires_grad_(True) for k, v in g.items() if k.startswith("w/")}
+    x = torch.tensor(g["x"]).requires_grad_(True)
+    mask = torch.tensor(g["mask"])
+    hidden = LO.llama_decoder(w, lcfg, x, mask)
+    m = mask[..., None]
+    ref = torch.tensor(g["hidden"])
+    assert float(((hidden - ref) * m).abs().max()) <= 1e-5 * float(ref.abs().max())       # valid positions (see LO.attention)
+    loss = (hidden * torch.tensor(g["probe"]) * m).sum()
+    loss.backward()
+    assert abs(float(loss) - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
+    assert float((x.grad - torch.tensor(g["dx"])).abs().max()) <= 1e-5 * float(np.abs(g["dx"]).max())
+    n = 0
+    for k, v in g.items():
+        if k.startswith("g/"):
+            assert float((w[k[2:]].grad - torch.tensor(v)).abs().max()) <= 1e-5 * float(np.abs(v).max()), k
+            n += 1
+    assert n >= 7
