@@ -10,9 +10,9 @@ embeddings come from the frozen tower's cache `all_item_embeds` (hllm.py:485-488
 embedding-gather kernel, or from the item tower itself (`forward_item_emb`, hllm.py:399-464) on packed
 `cu_input_lens` token batches.
 
-Scope notes: text-only Llama-architecture towers (`model_type: llama`, e.g. TinyLlama-1.1B, the reference's
-default pair) and the reference's `dummy_llm` debug tower; the Baichuan / Qwen2 / Mistral / Bert / vision variants of
-`create_llm` (hllm.py:317-376) raise NotImplementedError naming the architecture.  Pretrained weights are read from
+Scope notes: text-only Llama-architecture towers (`model_type` llama / mistral / qwen2 - e.g. TinyLlama-1.1B,
+Qwen2.5-1.5B, the user towers of the reference's scripts) and the reference's `dummy_llm` debug tower; the Baichuan /
+Bert / vision variants of `create_llm` (hllm.py:325-376) raise NotImplementedError naming the architecture.  Pretrained weights are read from
 `<dir>/model.safetensors` when present; there is no network here, so synthetic runs pass `user_llm_config` /
 `item_llm_config` dicts instead of directories.  There is no CPU path.
 """
@@ -106,9 +106,9 @@ class HLLM(MultiHeadDecoding, BaseModel):
         if self.dummy_llm:
             self.logger.info('Using a dummy LLM for debugging...')
             return DummyLLM(lcfg.vocab_size, lcfg.hidden_size)
-        if lcfg.model_type != "llama":
+        if lcfg.model_type not in ("llama", "qwen2", "mistral"):     # same decoder maths (qwen2: + q/k/v biases)
             raise NotImplementedError(f"create_llm: architecture '{lcfg.model_type}' is not built on the MI355X path yet "
-                                      "(llama-architecture towers only)")
+                                      "(llama / qwen2 / mistral text decoders only)")
         if init and cfg_dict is None:
             return LlamaForCausalLM.from_pretrained(pretrain_dir, config=lcfg)
         return LlamaForCausalLM(lcfg)

@@ -31,7 +31,7 @@ class LlamaConfig:
 
     def __init__(self, hidden_size=2048, intermediate_size=5632, num_hidden_layers=22, num_attention_heads=32,
                  num_key_value_heads=None, vocab_size=32000, max_position_embeddings=2048, rms_norm_eps=1e-5,
-                 rope_theta=10000.0, hidden_act="silu", pad_token_id=None, **unused):
+                 rope_theta=10000.0, hidden_act="silu", pad_token_id=None, attention_bias=None, **unused):
         self.hidden_size, self.intermediate_size = hidden_size, intermediate_size
         self.num_hidden_layers, self.num_attention_heads = num_hidden_layers, num_attention_heads
         self.num_key_value_heads = num_key_value_heads or num_attention_heads
@@ -39,6 +39,8 @@ class LlamaConfig:
         self.rms_norm_eps, self.rope_theta, self.hidden_act = rms_norm_eps, rope_theta, hidden_act
         self.pad_token_id = pad_token_id
         self.model_type = unused.get("model_type", "llama")
+        # Qwen2 (the reference's Pixel8M user tower, modeling_qwen2.py) is this decoder with biases on q / k / v
+        self.attention_bias = (self.model_type == "qwen2") if attention_bias is None else bool(attention_bias)
         if hidden_act != "silu":
             raise NotImplementedError("only hidden_act='silu' (SwiGLU) is implemented in the fused kernels")
         if unused.get("rope_scaling"):
@@ -66,9 +68,9 @@ class LlamaAttention(nn.Module):
         if D % nh:
             raise ValueError(f"hidden_size must be divisible by num_heads (got {D} and {nh})")
         hd = D // nh
-        self.q_proj = nn.Linear(D, nh * hd, bias=False)
-        self.k_proj = nn.Linear(D, nkv * hd, bias=False)
-        self.v_proj = nn.Linear(D, nkv * hd, bias=False)
+        self.q_proj = nn.Linear(D, nh * hd, bias=config.attention_bias)
+        self.k_proj = nn.Linear(D, nkv * hd, bias=config.attention_bias)
+        self.v_proj = nn.Linear(D, nkv * hd, bias=config.attention_bias)
         self.o_proj = nn.Linear(nh * hd, D, bias=False)
 
 
@@ -102,6 +104,8 @@ class LlamaModel(nn.Module):
         for m in self.modules():                       # reference `_init_weights`: N(0, initializer_range = 0.02)
             if isinstance(m, (nn.Linear, nn.Embedding)):
                 nn.init.normal_(m.weight, mean=0.0, std=0.02)
+                if getattr(m, "bias", None) is not None:
+                    nn.init.zeros_(m.bias)
 
     def get_input_embeddings(self):
         return self.embed_tokens
@@ -124,12 +128,14 @@ class LlamaModel(nn.Module):
         """[q;k;v] and [gate;up] as single GEMM operands.  In training they are re-concatenated from the fp32 masters every
         step (autograd splits the gradient back); under no_grad in eval mode the bf16 copies are built once."""
         a, m = layer.self_attn, layer.mlp
+        b_qkv = torch.cat([a.q_proj.bias, a.k_proj.bias, a.v_proj.bias]) if a.q_proj.bias is not None else None
         if self.training or torch.is_grad_enabled():
-            return torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], 0), torch.cat([m.gate_proj.weight, m.up_proj.weight], 0), None
+            return (torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], 0), b_qkv,
+                    torch.cat([m.gate_proj.weight, m.up_proj.weight], 0), None)
         hit = self._w_cache.get(i)
         if hit is None:
             bf = torch.bfloat16
-            hit = self._w_cache[i] = (torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], 0).to(bf),
+            hit = self._w_cache[i] = (torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], 0).to(bf), b_qkv,
                                       torch.cat([m.gate_proj.weight, m.up_proj.weight], 0).to(bf),
                                       (a.o_proj.weight.to(bf), m.down_proj.weight.to(bf)))
         return hit
@@ -174,13 +180,13 @@ class LlamaModel(nn.Module):
 
         branch = None
         for i, layer in enumerate(self.layers):
-            w_qkv, w_gu, cached = self._fused_weights(i, layer)
+            w_qkv, b_qkv, w_gu, cached = self._fused_weights(i, layer)
             pre = cached is not None
             if branch is None:
                 h = RMSNormFn.apply(x, layer.input_layernorm.weight, layer.input_layernorm.variance_epsilon)
             else:
                 x, h = AddRMSNormFn.apply(x, branch, layer.input_layernorm.weight, layer.input_layernorm.variance_epsilon)
-            qkv = SplitKLinearFn.apply(h, w_qkv, None, True, w_qkv if pre else None)
+            qkv = SplitKLinearFn.apply(h, w_qkv, b_qkv, True, w_qkv if pre else None)
             a = RopeAttentionFn.apply(qkv, cos, sin, positions, key_valid, cu, n_seqs, max_len, nh, nkv, hd, scale)
             o = SplitKLinearFn.apply(a, layer.self_attn.o_proj.weight, None, True, cached[0] if pre else None)
             x, h = AddRMSNormFn.apply(x, o, layer.post_attention_layernorm.weight, layer.post_attention_layernorm.variance_epsilon)

@@ -257,6 +257,6 @@ class NceLossFn(Function):
         w = d_out.contiguous().float()
         if sv.bucket_idx is not None:
             w = w / sv.bucket_cnt.clamp_min(1.0)                      # d(mean)/d(loss_t) = 1 / count of the bucket
-        d_negs, d_ls = ops.nce_bwd(sv, w, logit_scale.detach().view(1), q_idx, p_idx, dq, dp)
+        d_negs, d_ls = ops.nce_bwd(sv, w, logit_scale.detach().view(1), q_idx, p_idx, dq, dp, want_negs=ctx.needs_input_grad[2])
         ctx.sv = None
         return dq, dp, d_negs, d_ls.view(logit_scale.shape), None, None, None, None, None, None, None, None, None, None

@@ -479,17 +479,18 @@ def nce_fwd(q_rows, q_idx, p_rows, p_idx, negs, n_tok_dev, tok_cap, logit_scale,
     return sv
 
 
-def nce_bwd(sv, w, logit_scale, q_idx, p_idx, dq_rows, dp_rows, d_negs=None, d_logit_scale=None):
+def nce_bwd(sv, w, logit_scale, q_idx, p_idx, dq_rows, dp_rows, d_negs=None, d_logit_scale=None, want_negs=True):
     """w [G, tok_cap] f32 = dLoss/dloss[g, t] - or [G, n_buckets] when the forward was given bucket_idx (every token
     of a bucket then has the same weight).  Accumulates into dq_rows [Rq, D] / dp_rows [Rp, D] (f32, the
     forward's shared row spaces); returns (d_negs [G, n_neg, D] f32, d_logit_scale [1]).  q_idx / p_idx are the
-    forward's index lists (the padded copies saved by nce_fwd are what the kernels read)."""
+    forward's index lists (the padded copies saved by nce_fwd are what the kernels read).  want_negs=False skips the
+    negative-side product (frozen negatives, e.g. the HLLM twin's cached item tower) and returns d_negs = None."""
     dev = sv.negs.device
     D, cap, G = sv.dim, sv.cap, sv.groups
     if w.dim() == 1:
         w = w[None]
     bucketed = sv.bucket_idx is not None and w.shape == (G, sv.n_buckets) and sv.n_buckets != sv.tok_cap
-    if d_negs is None:
+    if d_negs is None and want_negs:
         d_negs = torch.zeros(G, sv.n_neg, D, dtype=torch.float32, device=dev)
     if d_logit_scale is None:
         d_logit_scale = torch.zeros(1, dtype=torch.float32, device=dev)
@@ -511,8 +512,9 @@ def nce_bwd(sv, w, logit_scale, q_idx, p_idx, dq_rows, dp_rows, d_negs=None, d_l
                 sv.p_inv.data_ptr(), sv.s_pos.data_ptr(), sv.q_idx.data_ptr(), sv.p_idx.data_ptr(), dq_rows.data_ptr(),
                 dp_rows.data_ptr(), d_logit_scale.data_ptr(), lw.data_ptr(), sv.bucket_idx.data_ptr() if bucketed else 0,
                 sv.n_buckets if bucketed else 0, st)
-    _timed_call("mhr_nce_bwd_negs", sv.qn.data_ptr(), sv.negs.data_ptr(), sv.supp.data_ptr(), sv.n_neg, D, G,
-                sv.n_tok_dev.data_ptr(), cap, logit_scale.data_ptr(), lw.data_ptr(), d_negs.data_ptr(), st)
+    if want_negs:
+        _timed_call("mhr_nce_bwd_negs", sv.qn.data_ptr(), sv.negs.data_ptr(), sv.supp.data_ptr(), sv.n_neg, D, G,
+                    sv.n_tok_dev.data_ptr(), cap, logit_scale.data_ptr(), lw.data_ptr(), d_negs.data_ptr(), st)
     return d_negs, d_logit_scale
 
 

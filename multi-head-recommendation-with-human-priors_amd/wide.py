@@ -18,6 +18,12 @@ import torch
 CHUNK = 8192          # tokens per logit block: 8192 x 8192 fp32 = 256 MB
 
 
+def _mm(a, b):
+    """bf16 x bf16 -> fp32 library GEMM: exact fp32 products of the bf16 operands, fp32 accumulation, fp32 result (MFMA
+    rate; an fp32-operand GEMM would run at a fraction of it)."""
+    return torch.mm(a, b, out_dtype=torch.float32)
+
+
 def _scale(logit_scale):
     return torch.exp(logit_scale.detach().float().clamp(0, math.log(100.0))).reshape(())
 
@@ -39,11 +45,11 @@ def nce_fwd_wide(sv, q_rows, p_rows, negs, logit_scale, want_logs, bucket_idx, l
         sv.qn[g], sv.pn[g], sv.q_inv[g], sv.p_inv[g] = qn, pn, qi, pi
         s_pos = (qn.float() * pn.float()).sum(-1)
         sv.s_pos[g] = s_pos
-        ngf = negs[g, :sv.n_neg].float()
+        ngt = negs[g, :sv.n_neg].t()
         for c0 in range(0, cap, CHUNK):
             sl = slice(c0, min(cap, c0 + CHUNK))
-            s = qn[sl].float() @ ngf.t()                          # bf16-rounded operands, fp32 products and accumulation
-            keep = ~((pn[sl].float() @ ngf.t()) > thres)          # false-negative suppression
+            s = _mm(qn[sl], ngt)                                  # bf16-rounded operands, fp32 products and accumulation
+            keep = ~(_mm(pn[sl], ngt) > thres)                    # false-negative suppression
             tot = (torch.exp(scale * (s - 1.0)) * keep).sum(-1) + torch.exp(scale * (s_pos[sl] - 1.0))
             lse = scale + torch.log(tot)
             sv.lse[g, sl] = lse
@@ -64,17 +70,19 @@ def nce_bwd_wide(sv, w_tok, logit_scale, dq_rows, dp_rows, d_negs, d_logit_scale
     live = torch.arange(cap, device=dq_rows.device)[None, :] < sv.n_tok_dev[:, None]
     dls = torch.zeros((), dtype=torch.float32, device=dq_rows.device)
     for g in range(G):
-        ngf = sv.negs[g, :sv.n_neg].float()
+        ng = sv.negs[g, :sv.n_neg]
+        ngt = ng.t()
         for c0 in range(0, cap, CHUNK):
             sl = slice(c0, min(cap, c0 + CHUNK))
             qn, pn = sv.qn[g, sl], sv.pn[g, sl]
             w = torch.where(live[g, sl], w_tok[g, sl], torch.zeros_like(w_tok[g, sl]))
-            s = qn.float() @ ngf.t()
-            keep = ~((pn.float() @ ngf.t()) > thres)
+            s = _mm(qn, ngt)
+            keep = ~(_mm(pn, ngt) > thres)
             gmat = (w[:, None] * torch.exp(scale * s - sv.lse[g, sl, None]) * keep)
-            gmat = torch.where(live[g, sl, None], gmat, torch.zeros_like(gmat))
-            dq_raw = gmat @ ngf                                                                  # sum_j g_ij n_j
-            d_negs[g] += scale * (gmat.t() @ qn.float())
+            gmat = torch.where(live[g, sl, None], gmat, torch.zeros_like(gmat)).to(torch.bfloat16)   # like the fused kernels'
+            dq_raw = _mm(gmat, ng)                                                               # sum_j g_ij n_j     # bf16 tile
+            if d_negs is not None:
+                d_negs[g, :sv.n_neg] += scale * _mm(gmat.t(), qn)
             sp = sv.s_pos[g, sl]
             coef = torch.where(live[g, sl], w * (torch.exp(scale * sp - sv.lse[g, sl]) - 1.0), torch.zeros_like(w))
             qf, pf = qn.float(), pn.float()
@@ -105,7 +113,7 @@ def catalog_topk_wide(users, H, items, n_items, tag_bits, row_bits, hist_ptr, hi
         hist_mask = (hu, hist_items.long())
     for i0 in range(0, n_items, chunk):
         i1 = min(n_items, i0 + chunk)
-        sc = users.float() @ items[i0:i1].float().t()                                             # [n_rows, chunk], fp32 accumulation
+        sc = _mm(users, items[i0:i1].t())                                                         # [n_rows, chunk], fp32 accumulation
         if tag_bits is not None:
             ok = (tag_bits[i0:i1].int()[None, :] & rb[:, None]) != 0
         else:

@@ -64,9 +64,13 @@ def decoder_layer(x, w, pfx, lcfg, allowed, cos, sin, position_ids):
     nh, nkv = lcfg["num_attention_heads"], lcfg["num_key_value_heads"]
     hd = D // nh
     h = rms_norm(x, w[pfx + "input_layernorm.weight"], lcfg["rms_norm_eps"])
-    q = (h @ w[pfx + "self_attn.q_proj.weight"].T).view(B, L, nh, hd).transpose(1, 2)
-    k = (h @ w[pfx + "self_attn.k_proj.weight"].T).view(B, L, nkv, hd).transpose(1, 2)
-    v = (h @ w[pfx + "self_attn.v_proj.weight"].T).view(B, L, nkv, hd).transpose(1, 2)
+    def proj(name):                # Qwen2 towers carry q/k/v biases (modeling_qwen2.py), Llama / Mistral do not
+        y = h @ w[pfx + f"self_attn.{name}_proj.weight"].T
+        return y + w[pfx + f"self_attn.{name}_proj.bias"] if pfx + f"self_attn.{name}_proj.bias" in w else y
+
+    q = proj("q").view(B, L, nh, hd).transpose(1, 2)
+    k = proj("k").view(B, L, nkv, hd).transpose(1, 2)
+    v = proj("v").view(B, L, nkv, hd).transpose(1, 2)
     q, k = apply_rope(q, cos, sin, position_ids), apply_rope(k, cos, sin, position_ids)
     k = k.repeat_interleave(nh // nkv, dim=1)                   # repeat_kv, modeling_llama.py:489-500
     v = v.repeat_interleave(nh // nkv, dim=1)

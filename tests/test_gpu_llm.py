@@ -242,7 +242,7 @@ def _build_hllm(cfgd, N):
     model = get_model("HLLM")(Config(config_dict=cfgd), _FakeData(N, cfgd["num_prior_head"])).cuda()
     with torch.no_grad():                      # heads start at zero in the reference (ResBlock zero_init): make them visible
         for n_, p_ in model.named_parameters():
-            if n_.startswith("medusa") or "norm" in n_:
+            if n_.startswith("medusa") or "norm" in n_ or n_.endswith("_proj.bias"):
                 p_.add_(0.05 * torch.randn_like(p_))
     return model
 
@@ -253,12 +253,16 @@ def _oracle_weights(model):
     return HO.tie_repeated_resblocks(w)
 
 
-@pytest.mark.parametrize("variant", ["prior_bycat", "nce_shared", "additive_switch", "dummy"])
+@pytest.mark.parametrize("variant", ["prior_bycat", "nce_shared", "additive_switch", "dummy", "qwen2_hier"])
 def test_hllm_train_step_matches_oracle(ops, variant):
     kw = dict(prior_bycat={}, nce_shared=dict(loss="nce", num_prior_head=1, pred_len=4, eval_pred_len=4, num_segment_head=2,
                                                neg_sample_by_cat=False),
               additive_switch=dict(head_interaction="additive", num_segment_head=2, prior_switch="in", prior_switch_loss_weight=0.5),
-              dummy=dict(dummy_llm=True))[variant]
+              dummy=dict(dummy_llm=True),
+              qwen2_hier=dict(head_interaction="hierarchical", num_segment_head=2, segment_embed=True, pred_len=4, eval_pred_len=4,
+                              user_llm_config=dict(hidden_size=64, intermediate_size=96, num_hidden_layers=1, num_attention_heads=2,
+                                                   num_key_value_heads=1, vocab_size=32, rms_norm_eps=1e-6, rope_theta=1e6,
+                                                   model_type="qwen2")))[variant]
     cfgd = _hllm_cfg(**kw)
     N, B, n_neg = 301, 5, 24
     L, P, C = cfgd["MAX_ITEM_LIST_LENGTH"], cfgd["pred_len"], cfgd["num_prior_head"]
@@ -286,7 +290,7 @@ def test_hllm_train_step_matches_oracle(ops, variant):
         if not p.requires_grad or w[k].grad is None:
             continue
         if any(t in k for t in ("layers.0.self_attn.q_proj", "layers.1.mlp.down_proj", "layers.0.input_layernorm", "model.norm",
-                                "medusa", "logit_scale", "aux_cat_head.0", "embed_layer")):
+                                "medusa", "logit_scale", "aux_cat_head.0", "embed_layer", "k_proj.bias", "segment_emb")):
             gref = w[k].grad
             assert p.grad is not None, k
             assert float((p.grad.cpu() - gref).abs().max()) <= 6e-2 * float(gref.abs().max()) + 1e-5, k
