@@ -322,6 +322,39 @@ int mhr_topk_select(const float* cand_val, const int32_t* cand_idx, const int32_
                     int n_rows, int k, float* out_val, int64_t* out_idx, float* kth_val, int32_t* status,
                     void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Wide-feature path (feature dim > 256: HSTU size-4, the HLLM twin): the logit contractions run as bf16 x bf16 -> f32
+ * library GEMMs over token / item chunks; these are the fused one-pass epilogues over one f32 chunk.
+ * ---------------------------------------------------------------------------------------- */
+
+/* Sampled-softmax epilogue (model/IDNet/hstu.py:600-629, 697) over rows [row_base, row_base + rows) of one group:
+ * neg_logits / fix_logits [rows, ld] f32 = cos(query, negative) / cos(target, negative); s_pos [rows] = cos(query, target);
+ * scale_dev[0] = exp(clamped logit_scale); negatives with fix > thres are suppressed.  Per row:
+ *   lse = scale + log(sum_kept exp(scale (s - 1)) + exp(scale (s_pos - 1))),  loss = lse - scale s_pos,
+ *   n_valid = #kept + 1, rank = #kept with s > s_pos   (n_valid / rank may be NULL).
+ * Rows at or beyond n_live_dev[0] (NULL: all live) get loss = 0, n_valid = rank = 0. */
+int mhr_nce_dense_fwd(const float* neg_logits, const float* fix_logits, int64_t ld, int n_neg, const float* s_pos,
+                      const float* scale_dev, float thres, const int32_t* n_live_dev, int64_t row_base, int64_t rows,
+                      float* lse, float* loss, int32_t* n_valid, int32_t* rank, void* stream);
+/* Gradient tile g[r, j] = w[r] exp(scale s[r, j] - lse[r]) keep[r, j] (0 on rows that are not live), bf16 [rows, ldg]:
+ * the operand of dQ = g . N and dN = g^T . Q. */
+int mhr_nce_dense_bwd(const float* neg_logits, const float* fix_logits, int64_t ld, int n_neg, const float* lse,
+                      const float* w, const float* scale_dev, float thres, const int32_t* n_live_dev, int64_t row_base,
+                      int64_t rows, void* g_bf16, int64_t ldg, void* stream);
+
+/* Catalog masks on a dense score chunk (model/IDNet/hstu.py:982-999, trainer.py:724): column j is item
+ * item_begin + j * item_stride; scores[r, j] = -inf unless (tag_bits[item] & row_bits[r]) != 0 and item != 0
+ * (tag_bits NULL: every item carries bit 31 only).  In place. */
+int mhr_catalog_mask_dense(float* scores, int64_t ld, int n_cols, int item_begin, int item_stride, const int32_t* tag_bits,
+                           const int32_t* row_bits, int n_rows, void* stream);
+/* Threshold emit from a dense score chunk into the list format of mhr_catalog_score_emit_sliced: the chunk's columns
+ * (items item_begin + j) are cut into ceil(n_cols / seg) segments; segment i of row r appends its admissible scores
+ * >= tau[r] to list list_base + i of [n_rows, n_lists, cap_s] (cand_cnt holds the unclamped count: > cap_s = overflow,
+ * flagged by mhr_topk_select_sliced).  Append order within a list is arbitrary. */
+int mhr_catalog_emit_dense(const float* scores, int64_t ld, int n_cols, int seg, int item_begin, const int32_t* tag_bits,
+                           const int32_t* row_bits, const float* tau, int n_rows, float* cand_val, int32_t* cand_idx,
+                           int32_t* cand_cnt, int n_lists, int list_base, int cap_s, void* stream);
+
 /* Cross-head merge (collector.py:249-275): per user, the H*k per-head candidates are ordered by value
  * descending (ties: head, then rank ascending), first occurrences kept, first k returned with their
  * source head.  vals/idx [B, H, k] -> out_idx [B,k] i64, out_val [B,k] f32, out_src [B,k] i32.

@@ -402,7 +402,7 @@ class NceSaved:
     """Tensors the forward keeps for the backward (all preallocated at token capacity)."""
     __slots__ = ("qn", "pn", "supp", "q_inv", "p_inv", "s_pos", "lse", "loss", "n_valid", "rank", "negs",
                  "n_tok_dev", "tok_cap", "cap", "thres", "dim", "n_neg", "groups", "q_idx", "p_idx", "bucket_idx", "n_buckets",
-                 "bucket_sum", "bucket_cnt", "u", "wide")
+                 "bucket_sum", "bucket_cnt", "u", "wide", "scale_dev", "cap_eff")
 
 
 def nce_fwd(q_rows, q_idx, p_rows, p_idx, negs, n_tok_dev, tok_cap, logit_scale, thres=0.99, want_logs=False,
@@ -592,6 +592,19 @@ def topk_select_sliced(cand, H, hist_ptr, hist_items, k):
     return out_val, out_idx, kth, count, status
 
 
+def sub_history(hist_ptr, hist_items, users_f):
+    """CSR history (ptr [B+1] int32, items sorted per user) restricted to the users `users_f` [F] (ascending)."""
+    if hist_ptr is None:
+        return None, None
+    dev = hist_ptr.device
+    lens = (hist_ptr[1:] - hist_ptr[:-1])[users_f].long()
+    sub_ptr = torch.zeros(users_f.numel() + 1, dtype=torch.int32, device=dev)
+    sub_ptr[1:] = torch.cumsum(lens, 0).int()
+    starts = hist_ptr[:-1][users_f].long()
+    off = torch.arange(int(lens.sum()), device=dev) - torch.repeat_interleave(sub_ptr[:-1].long(), lens)
+    return sub_ptr, hist_items[torch.repeat_interleave(starts, lens) + off].contiguous()
+
+
 def catalog_topk(users, H, items, tag_bits, row_bits, hist_ptr, hist_items, k, cap=4096, target=None, stats=None, n_items=None):
     """Exact per-row top-k over the whole catalog (value desc, index asc), rows = (user, head) pairs.
 
@@ -606,7 +619,7 @@ def catalog_topk(users, H, items, tag_bits, row_bits, hist_ptr, hist_items, k, c
     dev = users.device
     if D not in STREAM_DIMS:
         from . import wide
-        return wide.catalog_topk_wide(users, H, items, N, tag_bits, row_bits, hist_ptr, hist_items, k)
+        return wide.catalog_topk_wide(users, H, items, N, tag_bits, row_bits, hist_ptr, hist_items, k, target=target, stats=stats)
     ninf = torch.full((n_rows,), float("-inf"), dtype=torch.float32, device=dev)
     if N <= cap:
         cand = catalog_emit(users, H, items, tag_bits, row_bits, ninf, hist_ptr, hist_items, N, n_items=N)
@@ -641,14 +654,7 @@ def catalog_topk(users, H, items, tag_bits, row_bits, hist_ptr, hist_items, k, c
     if bool(flagged.any()):                               # one host sync per batch; results go to the host anyway
         users_f = torch.nonzero(flagged.view(-1, H).any(dim=1)).flatten()
         rows_f = (users_f[:, None] * H + torch.arange(H, device=dev)[None, :]).flatten()
-        sub_ptr, sub_items = None, None
-        if hist_ptr is not None:
-            lens = (hist_ptr[1:] - hist_ptr[:-1])[users_f].long()
-            sub_ptr = torch.zeros(users_f.numel() + 1, dtype=torch.int32, device=dev)
-            sub_ptr[1:] = torch.cumsum(lens, 0).int()
-            starts = hist_ptr[:-1][users_f].long()
-            off = torch.arange(int(lens.sum()), device=dev) - torch.repeat_interleave(sub_ptr[:-1].long(), lens)
-            sub_items = hist_items[torch.repeat_interleave(starts, lens) + off].contiguous()
+        sub_ptr, sub_items = sub_history(hist_ptr, hist_items, users_f)
         sub_users = users[rows_f].contiguous()
         sub_bits = row_bits[rows_f].contiguous()
         sub_tau = torch.full((rows_f.numel(),), float("-inf"), dtype=torch.float32, device=dev)

@@ -1,31 +1,41 @@
-"""Generic-width path of the sampled softmax and the catalog decode: feature dims the streaming kernels do not cover.
+"""Wide-feature path of the sampled softmax and the catalog decode: feature dims the streaming kernels do not cover.
 
 The row-stationary HIP kernels (csrc/nce.hip, csrc/catalog.hip) keep one operand of the logit GEMM in registers, which
-bounds the feature dim at 256 (cfg0 / cfg1).  cfg2 (HSTU size-4, D = 1024) and the HLLM twin (D = 2048) have
-GEMMs whose K is large enough for the library GEMM to be the right tool: here the same maths runs as
-token-chunked library GEMMs on the GPU (bf16-rounded operands, fp32 products and accumulation: the parity contract) with the epilogues as elementwise passes over one [chunk, n_neg] logit block at
-a time - never the reference's full [N_tok, n_neg] tensors.  Same interfaces and saved state as the fused path
-(ops.NceSaved), same parity tests; it is selected by ops.nce_fwd / ops.nce_bwd / ops.catalog_topk from the feature dim
-alone and is NOT a fallback for a missing library (ops still refuse to run without libmhr_hip.so).
+bounds the feature dim at 256 (cfg0 / cfg1).  cfg2 (HSTU size-4, D = 1024) and the HLLM twin (D = 1536 / 2048)
+have contractions deep enough for the library GEMM to be the right tool: the logits are produced by
+bf16 x bf16 -> fp32 hipBLASLt GEMMs over token / item chunks (exact fp32 products of the bf16-rounded operands, fp32
+accumulation: the parity contract of the fused kernels), and everything after the GEMM is ONE hand-written pass over
+the fp32 chunk (csrc/wide.hip: loss / lse / log counters; the bf16 softmax-gradient tile; catalog masks + threshold
+emit into the candidate lists of the shared exact select) - never the reference's [N_tok, n_neg] / [B, H, N] tensor chains.
+Same interfaces and saved state as the fused path (ops.NceSaved), same parity tests; selected by ops.nce_fwd /
+ops.nce_bwd / ops.catalog_topk from the feature dim alone and NOT a fallback for a missing library (everything here
+calls into libmhr_hip.so).  One host sync per training step: the live-token count bounds the chunk loop (the
+reference syncs per prior head, hstu.py:815-816); the streaming path has none.
 
-Reference: model/IDNet/hstu.py:600-619 (nce_loss), 697/833 (cross entropy), 965-1015 + trainer.py:724-726 +
+Reference: model/IDNet/hstu.py:600-629 (nce_loss, logs), 697/833 (cross entropy), 965-1015 + trainer.py:724-726 +
 collector.py:245 (scores, masks, per-head top-k).
 """
 import math
 
 import torch
 
-CHUNK = 8192          # tokens per logit block: 8192 x 8192 fp32 = 256 MB
+from . import lib
+
+CHUNK = 8192          # tokens per logit block: 8192 x 8192 fp32 = 256 MB (x2: negatives and false-negative logits)
+ITEM_CHUNK = 65536    # items per score block
+
+
+def _stream():
+    return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
 
 
 def _mm(a, b):
-    """bf16 x bf16 -> fp32 library GEMM: exact fp32 products of the bf16 operands, fp32 accumulation, fp32 result (MFMA
-    rate; an fp32-operand GEMM would run at a fraction of it)."""
+    """bf16 x bf16 -> fp32 library GEMM: exact fp32 products of the bf16 operands, fp32 accumulation, fp32 result."""
     return torch.mm(a, b, out_dtype=torch.float32)
 
 
 def _scale(logit_scale):
-    return torch.exp(logit_scale.detach().float().clamp(0, math.log(100.0))).reshape(())
+    return torch.exp(logit_scale.detach().float().clamp(0, math.log(100.0))).reshape(1).contiguous()
 
 
 def _norm_rows(rows, idx):
@@ -34,30 +44,41 @@ def _norm_rows(rows, idx):
     return (x * inv[:, None]).to(torch.bfloat16), inv
 
 
+def _live_cap(sv):
+    """Rows worth visiting: the largest live count over the groups, rounded up to 256 (one host sync)."""
+    n_max = int(sv.n_tok_dev.max())
+    return min(sv.cap, -(-max(n_max, 1) // 256) * 256)
+
+
 def nce_fwd_wide(sv, q_rows, p_rows, negs, logit_scale, want_logs, bucket_idx, loss, n_valid, rank):
     """Fills sv (qn, pn, q_inv, p_inv, s_pos, lse, bucket sums) and loss / n_valid / rank [G, cap] in place."""
     G, cap, thres = sv.groups, sv.cap, sv.thres
     scale = _scale(logit_scale)
-    live = torch.arange(cap, device=negs.device)[None, :] < sv.n_tok_dev[:, None]                 # [G, cap]
+    sv.scale_dev = scale
+    cap_eff = sv.cap_eff = _live_cap(sv)
+    loss.zero_()
+    sv.lse.zero_()
+    if want_logs:
+        n_valid.zero_()
+        rank.zero_()
+    st = _stream()
     for g in range(G):
-        qn, qi = _norm_rows(q_rows, sv.q_idx[g])
-        pn, pi = _norm_rows(p_rows, sv.p_idx[g])
-        sv.qn[g], sv.pn[g], sv.q_inv[g], sv.p_inv[g] = qn, pn, qi, pi
-        s_pos = (qn.float() * pn.float()).sum(-1)
-        sv.s_pos[g] = s_pos
+        qn, qi = _norm_rows(q_rows, sv.q_idx[g, :cap_eff])
+        pn, pi = _norm_rows(p_rows, sv.p_idx[g, :cap_eff])
+        sv.qn[g, :cap_eff], sv.pn[g, :cap_eff], sv.q_inv[g, :cap_eff], sv.p_inv[g, :cap_eff] = qn, pn, qi, pi
+        s_pos = (qn.float() * pn.float()).sum(-1).contiguous()
+        sv.s_pos[g, :cap_eff] = s_pos
         ngt = negs[g, :sv.n_neg].t()
-        for c0 in range(0, cap, CHUNK):
-            sl = slice(c0, min(cap, c0 + CHUNK))
-            s = _mm(qn[sl], ngt)                                  # bf16-rounded operands, fp32 products and accumulation
-            keep = ~(_mm(pn[sl], ngt) > thres)                    # false-negative suppression
-            tot = (torch.exp(scale * (s - 1.0)) * keep).sum(-1) + torch.exp(scale * (s_pos[sl] - 1.0))
-            lse = scale + torch.log(tot)
-            sv.lse[g, sl] = lse
-            loss[g, sl] = torch.where(live[g, sl], lse - scale * s_pos[sl], torch.zeros_like(lse))
-            if want_logs:
-                n_valid[g, sl] = torch.where(live[g, sl], keep.sum(-1).int() + 1, torch.zeros_like(n_valid[g, sl]))
-                rank[g, sl] = torch.where(live[g, sl], (keep & (s > s_pos[sl, None])).sum(-1).int(), torch.zeros_like(rank[g, sl]))
+        for c0 in range(0, cap_eff, CHUNK):
+            c1 = min(cap_eff, c0 + CHUNK)
+            s = _mm(qn[c0:c1], ngt)                               # cos(query, negative)
+            fx = _mm(pn[c0:c1], ngt)                              # cos(target, negative): false-negative test
+            lib.call("mhr_nce_dense_fwd", s.data_ptr(), fx.data_ptr(), s.shape[1], sv.n_neg, s_pos[c0:c1].data_ptr(),
+                     scale.data_ptr(), float(thres), sv.n_tok_dev[g:g + 1].data_ptr(), c0, c1 - c0, sv.lse[g, c0:c1].data_ptr(),
+                     loss[g, c0:c1].data_ptr(), n_valid[g, c0:c1].data_ptr() if want_logs else 0,
+                     rank[g, c0:c1].data_ptr() if want_logs else 0, st)
     if bucket_idx is not None:
+        live = torch.arange(cap, device=negs.device)[None, :] < sv.n_tok_dev[:, None]
         flat = (torch.arange(G, device=negs.device)[:, None] * sv.n_buckets + bucket_idx.long().clamp(0, sv.n_buckets - 1)).reshape(-1)
         sv.bucket_sum.view(-1).index_add_(0, flat, loss.reshape(-1))
         sv.bucket_cnt.view(-1).index_add_(0, flat, live.float().reshape(-1))
@@ -65,47 +86,59 @@ def nce_fwd_wide(sv, q_rows, p_rows, negs, logit_scale, want_logs, bucket_idx, l
 
 def nce_bwd_wide(sv, w_tok, logit_scale, dq_rows, dp_rows, d_negs, d_logit_scale):
     """w_tok [G, cap] per-token weights.  Accumulates dq_rows / dp_rows / d_negs / d_logit_scale in place."""
-    G, cap, thres = sv.groups, sv.cap, sv.thres
-    scale = _scale(logit_scale)
-    live = torch.arange(cap, device=dq_rows.device)[None, :] < sv.n_tok_dev[:, None]
-    dls = torch.zeros((), dtype=torch.float32, device=dq_rows.device)
+    G, thres = sv.groups, sv.thres
+    scale = sv.scale_dev
+    cap_eff = sv.cap_eff
+    dev = dq_rows.device
+    live = torch.arange(cap_eff, device=dev)[None, :] < sv.n_tok_dev[:, None]
+    dls = torch.zeros((), dtype=torch.float32, device=dev)
+    st = _stream()
+    w_tok = w_tok.contiguous()
     for g in range(G):
         ng = sv.negs[g, :sv.n_neg]
         ngt = ng.t()
-        for c0 in range(0, cap, CHUNK):
-            sl = slice(c0, min(cap, c0 + CHUNK))
-            qn, pn = sv.qn[g, sl], sv.pn[g, sl]
-            w = torch.where(live[g, sl], w_tok[g, sl], torch.zeros_like(w_tok[g, sl]))
+        for c0 in range(0, cap_eff, CHUNK):
+            c1 = min(cap_eff, c0 + CHUNK)
+            qn, pn = sv.qn[g, c0:c1], sv.pn[g, c0:c1]
             s = _mm(qn, ngt)
-            keep = ~(_mm(pn, ngt) > thres)
-            gmat = (w[:, None] * torch.exp(scale * s - sv.lse[g, sl, None]) * keep)
-            gmat = torch.where(live[g, sl, None], gmat, torch.zeros_like(gmat)).to(torch.bfloat16)   # like the fused kernels'
-            dq_raw = _mm(gmat, ng)                                                               # sum_j g_ij n_j     # bf16 tile
+            fx = _mm(pn, ngt)
+            gmat = torch.empty(c1 - c0, sv.n_neg, dtype=torch.bfloat16, device=dev)
+            lib.call("mhr_nce_dense_bwd", s.data_ptr(), fx.data_ptr(), s.shape[1], sv.n_neg, sv.lse[g, c0:c1].data_ptr(),
+                     w_tok[g, c0:c1].data_ptr(), scale.data_ptr(), float(thres), sv.n_tok_dev[g:g + 1].data_ptr(), c0, c1 - c0,
+                     gmat.data_ptr(), sv.n_neg, st)
+            del s, fx
+            dq_raw = _mm(gmat, ng)                                                               # sum_j g_ij n_j
             if d_negs is not None:
                 d_negs[g, :sv.n_neg] += scale * _mm(gmat.t(), qn)
-            sp = sv.s_pos[g, sl]
-            coef = torch.where(live[g, sl], w * (torch.exp(scale * sp - sv.lse[g, sl]) - 1.0), torch.zeros_like(w))
+            lv = live[g, c0:c1]
+            w = torch.where(lv, w_tok[g, c0:c1], torch.zeros_like(w_tok[g, c0:c1]))
+            sp = sv.s_pos[g, c0:c1]
+            coef = torch.where(lv, w * (torch.exp(scale * sp - sv.lse[g, c0:c1]) - 1.0), torch.zeros_like(w))
             qf, pf = qn.float(), pn.float()
             dls = dls + (qf * dq_raw).sum() + (coef * sp).sum()
             dqn = scale * (dq_raw + coef[:, None] * pf)
             dpn = scale * coef[:, None] * qf
-            dq = (dqn - qf * (qf * dqn).sum(-1, keepdim=True)) * sv.q_inv[g, sl, None]
-            dp = (dpn - pf * (pf * dpn).sum(-1, keepdim=True)) * sv.p_inv[g, sl, None]
-            keep_rows = live[g, sl, None]
-            qi = torch.where(live[g, sl], sv.q_idx[g, sl].long(), torch.zeros_like(sv.q_idx[g, sl].long()))
-            pi = torch.where(live[g, sl], sv.p_idx[g, sl].long(), torch.zeros_like(sv.p_idx[g, sl].long()))
-            dq_rows.index_add_(0, qi, torch.where(keep_rows, dq, torch.zeros_like(dq)))
-            dp_rows.index_add_(0, pi, torch.where(keep_rows, dp, torch.zeros_like(dp)))
-    d_logit_scale += dls * scale
+            dq = (dqn - qf * (qf * dqn).sum(-1, keepdim=True)) * sv.q_inv[g, c0:c1, None]
+            dp = (dpn - pf * (pf * dpn).sum(-1, keepdim=True)) * sv.p_inv[g, c0:c1, None]
+            zero = torch.zeros((), dtype=torch.int64, device=dev)
+            qi = torch.where(lv, sv.q_idx[g, c0:c1].long(), zero)
+            pi = torch.where(lv, sv.p_idx[g, c0:c1].long(), zero)
+            dq_rows.index_add_(0, qi, torch.where(lv[:, None], dq, torch.zeros_like(dq)))
+            dp_rows.index_add_(0, pi, torch.where(lv[:, None], dp, torch.zeros_like(dp)))
+    d_logit_scale += dls * scale.reshape(())
 
 
-def catalog_topk_wide(users, H, items, n_items, tag_bits, row_bits, hist_ptr, hist_items, k, chunk=65536):
-    """Exact per-row top-k (value desc, index asc) by item chunks: GEMM, masks, chunk top-k, running merge."""
+# ------------------------------------------------------------------------------------------------
+# catalog decode
+# ------------------------------------------------------------------------------------------------
+def _exact_rows(users, H, items, n_items, tag_bits, row_bits, hist_ptr, hist_items, k, chunk):
+    """Exact per-row top-k (value desc, index asc) with every score kept: GEMM by item chunks, masks, running merge.
+    Small catalogs and the rows the threshold pass could not certify."""
     n_rows = users.shape[0]
     dev = users.device
+    st = _stream()
     best_v = torch.full((n_rows, 0), float("-inf"), device=dev)
     best_i = torch.zeros((n_rows, 0), dtype=torch.int64, device=dev)
-    rb = row_bits.int()
     hist_mask = None
     if hist_ptr is not None and hist_items is not None and hist_items.numel() > 0:
         lens = (hist_ptr[1:] - hist_ptr[:-1]).long()
@@ -113,21 +146,15 @@ def catalog_topk_wide(users, H, items, n_items, tag_bits, row_bits, hist_ptr, hi
         hist_mask = (hu, hist_items.long())
     for i0 in range(0, n_items, chunk):
         i1 = min(n_items, i0 + chunk)
-        sc = _mm(users, items[i0:i1].t())                                                         # [n_rows, chunk], fp32 accumulation
-        if tag_bits is not None:
-            ok = (tag_bits[i0:i1].int()[None, :] & rb[:, None]) != 0
-        else:
-            ok = (rb != 0)[:, None].expand(-1, i1 - i0)
-        sc = sc.masked_fill(~ok, float("-inf"))
-        if i0 == 0:
-            sc[:, 0] = float("-inf")                                                              # pad id
+        sc = _mm(users, items[i0:i1].t())                                                         # [n_rows, chunk] fp32
+        lib.call("mhr_catalog_mask_dense", sc.data_ptr(), sc.shape[1], i1 - i0, i0, 1, 0 if tag_bits is None else tag_bits.data_ptr(),
+                 row_bits.data_ptr(), n_rows, st)
         if hist_mask is not None:
             hu, hi = hist_mask
             sel = (hi >= i0) & (hi < i1)
-            if bool(sel.any()):
-                rows = (hu[sel][:, None] * H + torch.arange(H, device=dev)[None, :]).reshape(-1)
-                cols = (hi[sel] - i0)[:, None].expand(-1, H).reshape(-1)
-                sc[rows, cols] = float("-inf")
+            rows = (hu[sel][:, None] * H + torch.arange(H, device=dev)[None, :]).reshape(-1)
+            cols = (hi[sel] - i0)[:, None].expand(-1, H).reshape(-1)
+            sc[rows, cols] = float("-inf")
         ids = torch.arange(i0, i1, device=dev)[None, :].expand(n_rows, -1)
         cv = torch.cat([best_v, sc], dim=1)
         ci = torch.cat([best_i, ids], dim=1)
@@ -146,3 +173,57 @@ def catalog_topk_wide(users, H, items, n_items, tag_bits, row_bits, hist_ptr, hi
             best_i[r, nsel:] = torch.tensor(free, dtype=torch.int64, device=dev)
             best_v[r, nsel:] = float("-inf")
     return best_v, best_i
+
+
+def catalog_topk_wide(users, H, items, n_items, tag_bits, row_bits, hist_ptr, hist_items, k, chunk=ITEM_CHUNK, target=None,
+                      stats=None):
+    """Exact per-row top-k over the catalog at any feature dim.  Thresholds from a strided sample of the catalog; the
+    full pass scores item chunks with the library GEMM and emits the few scores above the threshold (csrc/wide.hip) into
+    candidate lists; the exact select of the streaming path (topk_select_sliced) picks the top k with the history filter.
+    Rows it cannot certify (too few candidates, list overflow) are re-run keeping every score - sampling only affects speed."""
+    from . import ops
+    n_rows, D = users.shape
+    N = int(n_items)
+    dev = users.device
+    if N <= max(4 * k, 2048) or N <= chunk // 8:
+        return _exact_rows(users, H, items, N, tag_bits, row_bits, hist_ptr, hist_items, k, chunk)
+    st = _stream()
+    tagp = 0 if tag_bits is None else tag_bits.data_ptr()
+    if target is None:
+        target = max(512, int(2.5 * k))
+    # threshold: the score of rank ~target, estimated on every s-th item
+    s = max(1, N // 32768)
+    t = max(k // s + 1, target // s)
+    sample = items[0:N:s].contiguous()
+    sc = _mm(users, sample.t())
+    lib.call("mhr_catalog_mask_dense", sc.data_ptr(), sc.shape[1], sample.shape[0], 0, s, tagp, row_bits.data_ptr(), n_rows, st)
+    tau = torch.topk(sc, min(t, sc.shape[1]), dim=1).values[:, -1].contiguous()                  # -inf: too few admissible -> exact
+    del sc
+    n_chunks = -(-N // chunk)
+    per = 8
+    seg = -(-chunk // per)
+    n_lists = n_chunks * per
+    cap_s = max(32, 4 * -(-target // n_lists) + 16)
+    val = torch.empty(n_rows, n_lists, cap_s, dtype=torch.float32, device=dev)
+    idx = torch.empty(n_rows, n_lists, cap_s, dtype=torch.int32, device=dev)
+    cnt = torch.zeros(n_rows, n_lists, dtype=torch.int32, device=dev)
+    for ci, i0 in enumerate(range(0, N, chunk)):
+        i1 = min(N, i0 + chunk)
+        sc = _mm(users, items[i0:i1].t())
+        lib.call("mhr_catalog_emit_dense", sc.data_ptr(), sc.shape[1], i1 - i0, seg, i0, tagp, row_bits.data_ptr(), tau.data_ptr(),
+                 n_rows, val.data_ptr(), idx.data_ptr(), cnt.data_ptr(), n_lists, ci * per, cap_s, st)
+        del sc
+    ov, oi, _, got, stt = ops.topk_select_sliced((val, idx, cnt, n_lists), H, hist_ptr, hist_items, k)
+    flagged = (stt != 0) | ((got < k) & (row_bits != 0) & torch.isfinite(tau))
+    if stats is not None:
+        stats["mean_candidates"] = float(got.float().mean())
+        stats["flagged_rows"] = int(flagged.sum())
+    if bool(flagged.any()):                               # one host sync per batch; results go to the host anyway
+        users_f = torch.nonzero(flagged.view(-1, H).any(dim=1)).flatten()
+        rows_f = (users_f[:, None] * H + torch.arange(H, device=dev)[None, :]).flatten()
+        sub_ptr, sub_items = ops.sub_history(hist_ptr, hist_items, users_f)
+        fv, fi = _exact_rows(users[rows_f].contiguous(), H, items, N, tag_bits, row_bits[rows_f].contiguous(), sub_ptr, sub_items,
+                             k, chunk)
+        ov[rows_f] = fv
+        oi[rows_f] = fi
+    return ov, oi
