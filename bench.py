@@ -201,7 +201,7 @@ def main():
                        "global_batch": world * B, "seq_len": L, "parallelism": f"dp{world}"},
         }
         if last is not None and args.mode == "train":
-            out["loss"] = round(float(last["loss"]), 4)
+            out["loss"] = round(float(last["loss"].detach()), 4)
         # ---- roofline of the dominant kernel ----
         if prof:
             dom = max(prof.items(), key=lambda kv: kv[1][2])

@@ -193,10 +193,11 @@ def reduce_pending_rows(holder):
     from mhr_amd import distributed as dist_
     ids_all, d_rows, n_private = holder._pending_rows
     holder._pending_rows = None
-    ids, rows = dist_.exchange_sparse_rows(ids_all, d_rows, n_private)
+    ids, rows_priv, rows_shared = dist_.exchange_sparse_rows(ids_all, d_rows, n_private)
     sorted_ids, perm = torch.sort(ids)
-    out_rows = torch.zeros(ids.numel(), rows.shape[1], dtype=torch.float32, device=rows.device)
-    ops.sparse_rows_segment_sum(sorted_ids, perm, rows.contiguous(), None, None, 0, 0, out_rows, holder._row_slot)
+    out_rows = torch.zeros(ids.numel(), rows_shared.shape[1], dtype=torch.float32, device=rows_shared.device)
+    ops.sparse_rows_segment_sum(sorted_ids, perm, rows_priv.contiguous(), rows_shared.contiguous() if rows_shared.numel() else None,
+                                None, 0, 0, out_rows, holder._row_slot)
     holder.sparse_grad = SparseRowGrad(sorted_ids, out_rows, holder._row_slot, holder._row_slot.numel())
     return holder.sparse_grad
 

@@ -203,12 +203,15 @@ all_negs = all_gather_ids(my_negs).reshape(-1)                       # same on e
 ids_all = torch.cat([priv_ids, all_negs])
 rows = torch.randn(ids_all.numel(), Dm, generator=g)
 dense_local = torch.zeros(N, Dm).index_add_(0, ids_all, rows)
-ids, summed = D.exchange_sparse_rows(ids_all, rows.clone(), n_priv)
-dense_comb = torch.zeros(N, Dm).index_add_(0, ids, summed)
 ref = dense_local.clone(); dist.all_reduce(ref)                        # what DDP would produce (sum; /W applied later)
+ids, rp, rs = D.exchange_sparse_rows(ids_all, rows.clone(), n_priv, wire_dtype=torch.float32)
+dense_comb = torch.zeros(N, Dm).index_add_(0, ids, torch.cat([rp, rs]))
+ids_b, rp_b, rs_b = D.exchange_sparse_rows(ids_all, rows.clone(), n_priv)           # default wire dtype: bf16 private rows
+dense_bf = torch.zeros(N, Dm).index_add_(0, ids_b, torch.cat([rp_b.float(), rs_b]))
+ok_bf = rp_b.dtype == D.ROWS_WIRE_DTYPE and bool(torch.equal(ids_b, ids)) and bool(torch.allclose(dense_bf, ref, atol=3e-2, rtol=2 ** -7))
 flat = torch.full((7,), float(rank + 1)); D.allreduce_mean_(flat)
 vec = D.allreduce_metric_sums(torch.tensor([1.0 + rank, 10.0], dtype=torch.float64))
-ok = bool(torch.allclose(dense_comb, ref, atol=1e-5)) and bool(torch.allclose(flat, torch.full((7,), (1 + world) / 2 * 1.0))) \
+ok = ok_bf and bool(torch.allclose(dense_comb, ref, atol=1e-5)) and bool(torch.allclose(flat, torch.full((7,), (1 + world) / 2 * 1.0))) \
      and vec.tolist() == [sum(1.0 + r for r in range(world)), 10.0 * world] and all_negs.numel() == world * n_neg
 gathered = [None] * world
 dist.all_gather_object(gathered, all_negs.tolist())

@@ -109,7 +109,7 @@ def main():
            "decoder_gemm_TFLOPs": round(flops / (el / args.steps) / 1e12, 1),
            "kernel_ms_per_step": {k: round(v[2] / args.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][2])}}
     if last is not None:
-        out["loss"] = round(float(last["loss"]), 4)
+        out["loss"] = round(float(last["loss"].detach()), 4)
     print(json.dumps(out), flush=True)
 
 
