@@ -510,6 +510,279 @@ __global__ __launch_bounds__(256, 1) void nce_fwd_u_kernel(const IT* __restrict_
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// false-negative bits per (group, target row, negative): fixw[g][tile][row] bit j = cos(target row, negative 32 tile + j) > thres
+// ------------------------------------------------------------------------------------------
+// Same streaming skeleton as the catalog scorer (catalog.hip): 64 target rows per wave as two stationary fragment sets
+// (normalised and rounded exactly like the token kernels do: same helper, same bf16 values), the group's negative tiles
+// through a 3-slot LDS-DMA ring; the epilogue is 16 compares per fragment and one 128-byte store per (fragment, tile).
+template <int NKS, typename IT>
+__global__ __launch_bounds__(256, 2) void nce_fix_bits_kernel(const IT* __restrict__ p_rows, int n_rows, const bf16_t* negs,
+                                                              int n_neg, float thres, uint32_t* __restrict__ fixw,
+                                                              int n_rows_pad, int tiles_per_slice) {
+  using T = sg::Tile<NKS>;
+  constexpr int RF = 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int n_tiles = (n_neg + 31) >> 5;
+  negs += (int64_t)blockIdx.z * ((n_neg + 31) & ~31) * T::DIM;
+  fixw += (int64_t)blockIdx.z * n_tiles * n_rows_pad;
+  const int t0 = blockIdx.y * tiles_per_slice, t1 = min(n_tiles, t0 + tiles_per_slice);
+  if (t0 >= t1) return;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, half = lane >> 5;
+  bf16x8 frag[RF][NKS];
+  int row[RF];
+#pragma unroll
+  for (int f = 0; f < RF; ++f) {
+    row[f] = blockIdx.x * 256 + wave * 64 + f * 32 + r;
+    const bool live = row[f] < n_rows;
+    const IT* src = p_rows + (live ? (int64_t)row[f] * T::DIM : 0);
+    const float inv = row_inv_norm<NKS, IT>(src, live, half);
+    load_norm_frags<NKS, IT>(src, live, half, inv, frag[f]);
+  }
+  using P = sg::DmaPieces<NKS>;
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  P dp;
+  dp.init(wv, lane);
+  auto dma_tile = [&](auto slot_c, int tn) {
+    auto f = [&](auto k_c) {
+      dp.template piece<decltype(k_c)::value>(smem + decltype(slot_c)::value * T::BYTES,
+                                               reinterpret_cast<const char*>(negs) + (int64_t)tn * (32 * T::ROW_BYTES));
+    };
+    sg::static_for<P::PW>(f);
+  };
+  sg::LaneAddr<NKS> la;
+  la.init(lane);
+  sg::RowAddr<NKS> ra;
+  ra.init(la, smem);
+  const int t_last = t1 - 1;
+  dma_tile(std::integral_constant<int, 0>{}, t0);
+  dma_tile(std::integral_constant<int, 1>{}, min(t0 + 1, t_last));
+  sg::ring_loop<3>(t1 - t0, [&](auto slot_c, int i) {
+    constexpr int cur = decltype(slot_c)::value, nxt = (cur + 2) % 3;
+    const int t = t0 + i;
+    sg::wait_vmcnt<P::PW>();
+    sg::ring_barrier();
+    dma_tile(std::integral_constant<int, nxt>{}, min(t + 2, t_last));
+    f32x16 acc[RF];
+#pragma unroll
+    for (int f = 0; f < RF; ++f) acc[f] = sg::zero16();
+    sg::mma_tile_asm<NKS, RF, cur * T::BYTES>(ra, frag, acc);
+#pragma unroll
+    for (int f = 0; f < RF; ++f) {
+      uint32_t b = 0;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) b |= acc[f][g] > thres ? (1u << ((g & 3) + 8 * (g >> 2))) : 0u;
+      uint32_t w = b << (4 * half);
+      w |= __shfl_xor(w, 32, 64);
+      if (half == 0) fixw[(int64_t)t * n_rows_pad + row[f]] = w;       // rows >= n_rows are zero rows: w = 0, inside the padding
+    }
+  });
+  sg::wait_vmcnt<0>();
+}
+
+// ------------------------------------------------------------------------------------------
+// fused forward, false-negative test hoisted out (training path, default)
+// ------------------------------------------------------------------------------------------
+// cos(target, negative) > thres depends on the TARGET ROW, not on the token: at cfg1 every target row is the positive of up
+// to P = 8 (position, offset) tokens per category, so nce_fwd_u_kernel evaluates the same f = p.n product up to 8 times.
+// Here nce_fix_bits_kernel computes it once per (group, target row, negative) and leaves one bit per pair; this kernel
+// then carries ONE stationary fragment set (the query: 64 VGPRs fewer), 16 instead of 32 MFMAs in the S phase, no compare
+// chain - the tile's 32 suppression bits of a token arrive as one LDS-DMA word per lane, gathered by target row, riding the
+// same ring (one more piece per tile) - and the saved per-token suppression words for nce_bwd_n are that very word.
+template <int NKS, typename IT, bool LOGS>
+__global__ __launch_bounds__(256, 1) void nce_fwd_d_kernel(const IT* __restrict__ q_rows, const int32_t* q_idx,
+                                                           const IT* __restrict__ p_rows, const int32_t* p_idx,
+                                                           const bf16_t* negs, int n_neg,
+                                                           const int32_t* n_tok_dev, int tok_cap,
+                                                           const float* __restrict__ logit_scale_dev, float thres,
+                                                           float* sum_out, int32_t* n_valid, int32_t* rank,
+                                                           bf16_t* qn_out, bf16_t* pn_out,
+                                                           uint32_t* supp_out, float* q_inv,
+                                                           float* p_inv, float* s_pos_out, int log_group,
+                                                           float* __restrict__ u_out,
+                                                           const uint32_t* __restrict__ fixw, int n_rows_pad) {
+  using T = sg::Tile<NKS>;
+  constexpr int ND = (NKS + 1) / 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  {
+    const int64_t grp = blockIdx.z, to = grp * tok_cap;
+    q_idx += to; p_idx += to; n_tok_dev += grp; negs += grp * (int64_t)((n_neg + 31) & ~31) * T::DIM; sum_out += to;
+    if (n_valid) n_valid += to;
+    if (rank) rank += to;
+    qn_out += to * T::DIM; pn_out += to * T::DIM; u_out += to * T::DIM;
+    supp_out += grp * (int64_t)((n_neg + 31) >> 5) * tok_cap;
+    q_inv += to; p_inv += to; s_pos_out += to;
+    fixw += grp * (int64_t)((n_neg + 31) >> 5) * n_rows_pad;
+  }
+  const int n_tok = min(*n_tok_dev, tok_cap);
+  const int tok0 = blockIdx.x * 128;
+  if (tok0 >= n_tok) return;
+  const int n_tiles = (n_neg + 31) >> 5;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, half = lane >> 5;
+  const int tok = tok0 + wave * 32 + r;
+  const bool live = tok < n_tok;
+  const bool in_cap = tok < tok_cap;
+
+  bf16x8 frag[1][NKS];   // the normalised query (the positive only feeds s+ and the saved state here)
+  float qi = 0.f, pi = 0.f, spos = 0.f;
+  int p_row = 0;
+  {
+    bf16x8 pfrag[NKS];
+    p_row = live ? p_idx[tok] : 0;
+    const IT* qs = q_rows + (live ? (int64_t)q_idx[tok] * T::DIM : 0);
+    const IT* ps = p_rows + (int64_t)p_row * T::DIM;
+    qi = row_inv_norm<NKS, IT>(qs, live, half);
+    pi = row_inv_norm<NKS, IT>(ps, live, half);
+    load_norm_frags<NKS, IT>(qs, live, half, qi, frag[0]);
+    load_norm_frags<NKS, IT>(ps, live, half, pi, pfrag);
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) spos += (float)frag[0][ks][i] * (float)pfrag[ks][i];
+    spos += __shfl_xor(spos, 32, 64);
+    if (in_cap) {
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks)
+        *reinterpret_cast<bf16x8*>(pn_out + (int64_t)tok * T::DIM + ks * 16 + 8 * half) = pfrag[ks];
+    }
+  }
+  // saved state; lanes past n_tok inside the block write zero rows / all-ones suppression words (see nce_fwd_kernel)
+  if (in_cap) {
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      const int k0 = ks * 16 + 8 * half;
+      *reinterpret_cast<bf16x8*>(qn_out + (int64_t)tok * T::DIM + k0) = frag[0][ks];
+    }
+    if (live && half == 0) {
+      q_inv[tok] = qi;
+      p_inv[tok] = pi;
+      s_pos_out[tok] = spos;
+    }
+  }
+  const float scale = clamp_scale(logit_scale_dev);
+  const float c1 = scale * LOG2E;
+  const bool do_logs = LOGS && (log_group < 0 || (int)blockIdx.z == log_group);
+
+  f32x16 u[ND];
+#pragma unroll
+  for (int dc = 0; dc < ND; ++dc) u[dc] = sg::zero16();
+  float sum = 0.f;
+  int nv = 0, rk = 0;
+
+  using P = sg::DmaPieces<NKS>;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  P dp;
+  dp.init(wv, lane);
+  const int t_last = n_tiles - 1;
+  auto dma_k = [&](auto k_c, auto slot_c, int tn) {
+    dp.template piece<decltype(k_c)::value>(smem + decltype(slot_c)::value * T::BYTES,
+                                             reinterpret_cast<const char*>(negs) + (int64_t)tn * (32 * T::ROW_BYTES));
+  };
+  unsigned char* words = smem + 4 * T::BYTES;                  // 4 slots x [4 waves][64 lanes] suppression words of my token's target
+  const uint32_t* my_fix = fixw + p_row;                      // + tile * n_rows_pad
+  auto dma_w = [&](auto slot_c, int tn) {
+    sg::dma_words(my_fix + (int64_t)tn * n_rows_pad, words + decltype(slot_c)::value * 1024 + wv * 256);
+  };
+  auto dma_all = [&](auto slot_c, int tn) {
+    auto f = [&](auto k_c) { dma_k(k_c, slot_c, tn); };
+    sg::static_for<P::PW>(f);
+    dma_w(slot_c, tn);
+  };
+  const uint32_t word_addr = sg::lds_addr(words) + (uint32_t)(wv * 256 + lane * 4);
+  sg::LaneAddr<NKS> la;
+  la.init(lane);
+  sg::TrAddr<NKS> ta;
+  ta.init(la, smem);
+  sg::RowAddr<NKS> ra;
+  ra.init(la, smem);
+  // slot 3 is the "previous tile" of the first iteration (E = 0 there): make it finite
+  for (int o = threadIdx.x * 16; o < T::BYTES; o += 256 * 16) *reinterpret_cast<f32x4*>(smem + 3 * T::BYTES + o) = f32x4{0.f, 0.f, 0.f, 0.f};
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // published by the first ring barrier
+  dma_all(std::integral_constant<int, 0>{}, 0);
+  dma_all(std::integral_constant<int, 1>{}, min(1, t_last));
+  // scalars first used inside the loop: touch them here, or hipcc places the `s_waitcnt lgkmcnt(0)` that covers their
+  // kernel-argument load INSIDE the loop body, where it drains the LDS read pipeline once per tile
+  asm volatile("" ::"s"(n_rows_pad), "s"(c1), "s"(tok_cap), "s"(n_neg));
+  // S accumulators ping-pong by tile parity: tile t's epilogue runs one iteration later, straight from the other set
+  f32x16 sf[2][1] = {{sg::zero16()}, {sg::zero16()}};
+  uint32_t alive_prev = 0;               // live-row bits of the previous tile, pre-shifted by 4*half
+  // the loop exists twice (with / without the rank + n_valid counting of the logged group): a per-element runtime test
+  // would put a branch into every MFMA gap
+  STAMP_DECL
+  STAMP(-1)
+  auto run = [&](auto logs_c) {
+    constexpr bool WITH_LOGS = decltype(logs_c)::value;
+    sg::ring_loop<4>(n_tiles + 1, [&](auto slot_c, int i) {
+      constexpr int cur = decltype(slot_c)::value, nxt = (cur + 2) % 4, prv = (cur + 3) % 4, par = cur & 1;
+      STAMP(2)
+      sg::wait_vmcnt<P::PW + 1>();
+      STAMP(0)
+      sg::ring_barrier();
+      STAMP(1)
+      const int tn = min(i + 2, t_last);
+      sf[par][0] = sg::zero16();
+      const f32x16& s_prev = sf[par ^ 1][0];
+      // false negatives of THIS tile for my token: bit j = negative 32 i + j suppressed (precomputed per target row)
+      uint32_t word = sg::ds_read_b32_asm<cur * 1024>(word_addr);
+      sg::tile_step<NKS, ND, cur * T::BYTES, prv * T::BYTES, P::PW + 1, 1>(
+          ra, ta, frag, sf[par], u, [&](auto n_c) { sg::wait_lgkm_values<decltype(n_c)::value>(word); },
+          [&](int g) {                     // gated logit of the previous tile: alive_prev already excludes its false negatives
+            const float ek = gate_alive(s_prev[g], c1, c1, alive_prev, (g & 3) + 8 * (g >> 2));
+            asm volatile("v_add_f32 %0, %0, %1" : "+v"(sum) : "v"(ek));      // volatile: keep the accumulation in this gap
+            if constexpr (WITH_LOGS) {
+              const int pos = (g & 3) + 8 * (g >> 2);
+              const int km = ((int)(alive_prev << (31 - pos))) >> 31;       // -1: a kept, live logit
+              nv -= km;
+              rk -= s_prev[g] > spos ? km : 0;
+            }
+            return ek;
+          },
+          [&](auto k_c) {                  // gaps of the second product: next tile's DMA (tile pieces, then the words)
+            constexpr int k = decltype(k_c)::value;
+            if constexpr (k < P::PW) dma_k(k_c, std::integral_constant<int, nxt>{}, tn);
+            else if constexpr (k == P::PW) dma_w(std::integral_constant<int, nxt>{}, tn);
+          },
+          sg::EpiIdentity{}, [&] { STAMP(3) });
+      STAMP(4)
+      if (i < n_tiles && in_cap && half == 0) supp_out[(int64_t)i * tok_cap + tok] = live ? word : 0xFFFFFFFFu;
+      const uint32_t sbits = (word >> (4 * half)) & 0x0F0F0F0Fu;
+      const int rem = n_neg - i * 32;
+      const uint32_t tail = rem >= 32 ? 0xFFFFFFFFu : (rem > 0 ? ~(0xFFFFFFFFu << rem) : 0u);
+      alive_prev = (live && i < n_tiles) ? ((tail >> (4 * half)) & ~sbits) : 0u;
+    });
+  };
+  if (do_logs) run(std::true_type{});
+  else run(std::false_type{});
+  STAMP(2)
+  STAMP_FLUSH
+  sg::wait_vmcnt<0>();
+
+  sum += __shfl_xor(sum, 32, 64);
+  if (LOGS) {
+    nv += __shfl_xor(nv, 32, 64);
+    rk += __shfl_xor(rk, 32, 64);
+  }
+  if (live && half == 0) {
+    atomicAdd(sum_out + tok, sum);
+    if (do_logs) {
+      if (n_valid) atomicAdd(n_valid + tok, nv);
+      if (rank) atomicAdd(rank + tok, rk);
+    }
+  }
+  // U: rows (regs) = tokens wave*32 + crow(g, half), columns (lanes) = features dc*32 + r
+#pragma unroll
+  for (int g = 0; g < 16; ++g) {
+    const int tk = tok0 + wave * 32 + sg::crow(g, half);
+    if (tk < n_tok) {
+#pragma unroll
+      for (int dc = 0; dc < ND; ++dc) {
+        const int d = dc * 32 + r;
+        if (d < T::DIM) u_out[(int64_t)tk * T::DIM + d] = u[dc][g];
+      }
+    }
+  }
+}
+
 // lse / loss from the partial sums of all negative ranges
 constexpr int MAX_BUCKETS = 64;
 __global__ __launch_bounds__(256) void nce_finalize_kernel(const float* sum, const float* s_pos,
@@ -821,9 +1094,10 @@ extern "C" int mhr_nce_fwd(const void* q_rows, const int32_t* q_idx, const void*
                            const void* negs, int n_neg, int dim, int n_groups, const int32_t* n_tok_dev, int tok_cap,
                            const float* logit_scale_dev, float thres, float* sum_out, int32_t* n_valid, int32_t* rank,
                            void* qn_out, void* pn_out, uint32_t* supp_out, float* q_inv, float* p_inv, float* s_pos,
-                           int log_group, float* u_out, void* stream) {
+                           int log_group, float* u_out, int64_t n_p_rows, uint32_t* fix_words, void* stream) {
   MHR_REQUIRE(q_rows && q_idx && p_rows && p_idx && negs && n_tok_dev && logit_scale_dev && sum_out && s_pos,
               "nce_fwd: null pointer");
+  MHR_REQUIRE(!fix_words || (u_out && n_p_rows > 0 && n_p_rows < (1ll << 31) - 256), "nce_fwd: fix_words needs u_out and n_p_rows");
   MHR_REQUIRE(!u_out || (qn_out && pn_out && supp_out && q_inv && p_inv && tok_cap % 32 == 0),
               "nce_fwd: u_out (fused training path) needs every saved tensor and tok_cap %% 32 == 0");
   int nks;
@@ -852,6 +1126,35 @@ extern "C" int mhr_nce_fwd(const void* q_rows, const int32_t* q_idx, const void*
 #define UARGS(IT)                                                                                                        \
   (const IT*)q_rows, q_idx, (const IT*)p_rows, p_idx, (const bf16_t*)negs, n_neg, n_tok_dev, tok_cap, logit_scale_dev,   \
       thres, sum_out, n_valid, rank, (bf16_t*)qn_out, (bf16_t*)pn_out, supp_out, q_inv, p_inv, s_pos, log_group, u_out
+  if (u_out && fix_words) {
+    // false-negative bits once per (group, target row, negative), then the fused forward with one stationary operand
+    const int n_tiles = (n_neg + 31) / 32, n_rows_pad = (int)((n_p_rows + 255) / 256 * 256);
+    int slices = 1;                       // fill the 512 workgroup slots about twice over
+    while (slices < 8 && (n_rows_pad / 256) * n_groups * slices < 768 && n_tiles / (slices * 2) >= 16) slices *= 2;
+    const int tps_f = (n_tiles + slices - 1) / slices;
+#define LF_(NKS)                                                                                                         \
+  {                                                                                                                      \
+    const dim3 gf(n_rows_pad / 256, slices, n_groups);                                                                   \
+    const size_t ldsf = 3 * sg::Tile<NKS>::BYTES;                                                                        \
+    const size_t ldsd = 4 * sg::Tile<NKS>::BYTES + 4 * 1024;                                                             \
+    const dim3 gu((tok_cap + 127) / 128, 1, n_groups);                                                                   \
+    if (io_dtype == MHR_BF16) {                                                                                          \
+      hipLaunchKernelGGL((nce_fix_bits_kernel<NKS, bf16_t>), gf, dim3(256), ldsf, s, (const bf16_t*)p_rows, (int)n_p_rows, \
+                         (const bf16_t*)negs, n_neg, thres, fix_words, n_rows_pad, tps_f);                               \
+      if (logs) hipLaunchKernelGGL((nce_fwd_d_kernel<NKS, bf16_t, true>), gu, dim3(256), ldsd, s, UARGS(bf16_t), fix_words, n_rows_pad); \
+      else hipLaunchKernelGGL((nce_fwd_d_kernel<NKS, bf16_t, false>), gu, dim3(256), ldsd, s, UARGS(bf16_t), fix_words, n_rows_pad);     \
+    } else {                                                                                                             \
+      hipLaunchKernelGGL((nce_fix_bits_kernel<NKS, float>), gf, dim3(256), ldsf, s, (const float*)p_rows, (int)n_p_rows, \
+                         (const bf16_t*)negs, n_neg, thres, fix_words, n_rows_pad, tps_f);                               \
+      if (logs) hipLaunchKernelGGL((nce_fwd_d_kernel<NKS, float, true>), gu, dim3(256), ldsd, s, UARGS(float), fix_words, n_rows_pad); \
+      else hipLaunchKernelGGL((nce_fwd_d_kernel<NKS, float, false>), gu, dim3(256), ldsd, s, UARGS(float), fix_words, n_rows_pad);     \
+    }                                                                                                                    \
+  }
+    NKS_SWITCH(nks, LF_);
+#undef LF_
+    MHR_CHECK_LAUNCH("nce_fwd (fused, hoisted false-negative test)");
+    return MHR_OK;
+  }
   if (u_out) {
     NKS_SWITCH(nks, LU_);
     MHR_CHECK_LAUNCH("nce_fwd (fused)");

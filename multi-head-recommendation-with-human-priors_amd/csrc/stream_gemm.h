@@ -443,6 +443,13 @@ __device__ __forceinline__ u32x4 ds_read_b128_asm(uint32_t addr) {
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(IMM));
   return v;
 }
+template <int IMM>
+__device__ __forceinline__ uint32_t ds_read_b32_asm(uint32_t addr) {
+  static_assert(IMM >= 0 && IMM < 65536, "LDS offset field is 16 bits");
+  uint32_t v;
+  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(IMM));
+  return v;
+}
 template <int N>
 __device__ __forceinline__ void wait_lgkm1(u32x4& a) {
   static_assert(N >= 0 && N <= 15, "lgkmcnt is 4 bits");

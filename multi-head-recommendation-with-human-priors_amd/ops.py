@@ -4,6 +4,8 @@ PyTorch is plumbing here: device memory (`Tensor.data_ptr()`), the current HIP s
 `torch.distributed`.  Every function enqueues hand-written gfx950 kernels from libmhr_hip.so on the
 current stream; none of them synchronises, and none has a CPU or eager fallback.
 """
+import os
+
 import torch
 
 from . import lib
@@ -398,6 +400,9 @@ def token_compact(mask, q_all, p_all, o_all, tok_cap=None):
 STREAM_DIMS = (16, 32, 64, 128, 256)      # feature dims of the register-stationary streaming kernels
 
 
+HOIST_FALSE_NEGATIVE_TEST = os.environ.get("MHR_NCE_HOIST", "1") != "0"
+
+
 class NceSaved:
     """Tensors the forward keeps for the backward (all preallocated at token capacity)."""
     __slots__ = ("qn", "pn", "supp", "q_inv", "p_inv", "s_pos", "lse", "loss", "n_valid", "rank", "negs",
@@ -466,10 +471,16 @@ def nce_fwd(q_rows, q_idx, p_rows, p_idx, negs, n_tok_dev, tok_cap, logit_scale,
         return sv
     ssum = torch.zeros(G, cap, dtype=torch.float32, device=dev)
     st = _stream()
+    # training path: the false-negative test runs once per (group, target row, negative) into a bit table (see mhr.h)
+    n_p_rows = p_rows.shape[0]
+    fix_words = None
+    if sv.u is not None and HOIST_FALSE_NEGATIVE_TEST:
+        fix_words = torch.empty(G, (n_neg + 31) // 32, (n_p_rows + 255) // 256 * 256, dtype=torch.int32, device=dev)
     _timed_call("mhr_nce_fwd", q_rows.data_ptr(), q_idx.data_ptr(), p_rows.data_ptr(), p_idx.data_ptr(), _dt(q_rows),
                 negs.data_ptr(), n_neg, D, G, n_tok_dev.data_ptr(), cap, logit_scale.data_ptr(), float(thres),
                 ssum.data_ptr(), _ptr(n_valid), _ptr(rank), _ptr(sv.qn), _ptr(sv.pn),
-                _ptr(sv.supp), _ptr(sv.q_inv), _ptr(sv.p_inv), _ptr(sv.s_pos), int(log_group), _ptr(sv.u), st)
+                _ptr(sv.supp), _ptr(sv.q_inv), _ptr(sv.p_inv), _ptr(sv.s_pos), int(log_group), _ptr(sv.u), n_p_rows,
+                _ptr(fix_words), st)
     lib.call("mhr_nce_finalize", ssum.data_ptr(), sv.s_pos.data_ptr(), G, n_tok_dev.data_ptr(), cap,
              logit_scale.data_ptr(), loss.data_ptr(), sv.lse.data_ptr(), _ptr(n_valid), _ptr(bucket_idx), int(n_buckets),
              _ptr(sv.bucket_sum), _ptr(sv.bucket_cnt), st)
