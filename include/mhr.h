@@ -230,13 +230,18 @@ int mhr_token_compact(const uint8_t* mask, const int32_t* q_all, const int32_t* 
  * p_rows.  The false-negative test cos(p, neg) > thres depends on the TARGET ROW only, and a row is the positive of many
  * tokens (every (position, offset) pair that points at it): with fix_words the test runs once per (group, row, negative)
  * into this bit table (a second launch, in front) and the fused forward carries the query operand only.  Same results.
+ * fix_row_list [n_groups, round_up(n_p_rows, 256)] int32 + fix_n_rows [n_groups] int32 (device) + fix_slot_of_row
+ * [n_groups, n_p_rows] int32 scratch (optional, together): the rows of p_rows that tokens of each group can point at
+ * (any superset); only those are tested, column j of the bit table = list entry j, and the inverse map is written to
+ * fix_slot_of_row.  Rows outside the list must not be referenced by live tokens of that group.
  * ---------------------------------------------------------------------------------------- */
 int mhr_nce_fwd(const void* q_rows, const int32_t* q_idx, const void* p_rows, const int32_t* p_idx, int io_dtype,
                 const void* negs, int n_neg, int dim, int n_groups, const int32_t* n_tok_dev, int tok_cap,
                 const float* logit_scale_dev, float thres,
                 float* sum_out, int32_t* n_valid, int32_t* rank,
                 void* qn_out, void* pn_out, uint32_t* supp_out, float* q_inv, float* p_inv, float* s_pos,
-                int log_group, float* u_out, int64_t n_p_rows, uint32_t* fix_words, void* stream);
+                int log_group, float* u_out, int64_t n_p_rows, uint32_t* fix_words, const int32_t* fix_row_list,
+                const int32_t* fix_n_rows, int32_t* fix_slot_of_row, void* stream);
 /* log_group: the one group whose n_valid / rank are wanted (-1 = every group); the other groups skip the counting.
  * u_out (may be NULL; needs every saved tensor and tok_cap % 32 == 0): the TRAINING path.  [n_groups, tok_cap, dim] f32,
  *   u_out[g, t, :] = sum_j keep_tj exp(scale (s_tj - 1)) negs[g, j, :]

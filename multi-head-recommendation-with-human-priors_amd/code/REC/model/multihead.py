@@ -231,7 +231,7 @@ class MultiHeadDecoding:
             self._tok_cache[key] = (q_all, p_all, o_all)
         return self._tok_cache[key]
 
-    def _grouped_loss(self, head_rows, e_rows, negs_g, valid_g, head_for_p, log_group):
+    def _grouped_loss(self, head_rows, e_rows, negs_g, valid_g, head_for_p, log_group, p_row_mask=None):
         """Sampled-softmax loss of G (token mask, negative pool) groups in ONE fused launch per kernel.
         valid_g [G,B,P,L] bool, negs_g [G,n_neg,D] bf16, head_for_p [G,P].  Returns (mean loss per (group, offset)
         [G,P] fp32, logs of `log_group` or None).  No host sync: tokens are compacted by scatter at fixed capacity
@@ -249,7 +249,7 @@ class MultiHeadDecoding:
         logs = {} if want_logs else None
         mean_p = NceLossFn.apply(head_rows, e_rows, negs_g, self.logit_scale, q_idx, p_idx, n_tok, cap,
                                  float(self.nce_thres), want_logs, logs, o_idx, P,
-                                 log_group if want_logs else -1)                                     # [G, P]
+                                 log_group if want_logs else -1, p_row_mask)                         # [G, P]
         live = (torch.arange(cap, device=dev)[None, :] < n_tok[:, None]).float() if want_logs else None
         out_logs = None
         if want_logs:
@@ -296,8 +296,10 @@ class MultiHeadDecoding:
 
         # one group per (token mask, head assignment, negative pool): the nce branch and every prior category
         groups = []                       # (valid [B,P,L], head_for_p [P], pool slot, weight, kind, index)
+        row_masks = []                    # per group: the target rows (b, j) its tokens can point at (a superset is enough)
         if self.loss == 'nce' or (self.loss == 'prior' and additive):
             groups.append((base_valid, torch.arange(P) // self.seg_len, pool_slot[pools[0]], 1.0, 'nce', 0))
+            row_masks.append(mask)
         tag_win = None
         if self.loss == 'prior':
             seg_len = P if additive else self.seg_len
@@ -310,13 +312,15 @@ class MultiHeadDecoding:
                 head_for_p = torch.full((P,), S + c) if additive else seg_for_p * C + c
                 pool = pool_slot[c] if self.neg_sample_by_cat else pool_slot[pools[0]]
                 groups.append((valid, head_for_p, pool, float(self.prior_loss_weight[c]), 'prior', c))
+                row_masks.append(mask if self.pos_sample_mix_ratio > 0.0 else mask & pos_tags[..., c].bool())
         valid_g = torch.stack([g[0] for g in groups])
         head_for_p_g = torch.stack([g[1] for g in groups])
         slots = [g[2] for g in groups]
         negs_g = negs_pools if slots == list(range(len(pools))) else negs_pools[torch.tensor(slots, device=dev)]
         # reference: top-k logs come from the nce branch, then are overwritten by prior category 0 (hstu.py:723, 863)
         log_group = max(i for i, g in enumerate(groups) if g[4] == 'nce' or g[5] == 0)
-        mean_gp, logs = self._grouped_loss(head_rows, e_rows, negs_g.contiguous(), valid_g, head_for_p_g, log_group)
+        p_row_mask = torch.stack(row_masks).reshape(len(groups), -1)
+        mean_gp, logs = self._grouped_loss(head_rows, e_rows, negs_g.contiguous(), valid_g, head_for_p_g, log_group, p_row_mask)
         per_gp = mean_gp * self.horizon_discount.float()[None, :] * torch.tensor([g[3] for g in groups], device=dev)[:, None]
 
         model_out = defaultdict(float)

@@ -519,7 +519,9 @@ __global__ __launch_bounds__(256, 1) void nce_fwd_u_kernel(const IT* __restrict_
 template <int NKS, typename IT>
 __global__ __launch_bounds__(256, 2) void nce_fix_bits_kernel(const IT* __restrict__ p_rows, int n_rows, const bf16_t* negs,
                                                               int n_neg, float thres, uint32_t* __restrict__ fixw,
-                                                              int n_rows_pad, int tiles_per_slice) {
+                                                              int n_rows_pad, int tiles_per_slice,
+                                                              const int32_t* __restrict__ row_list, const int32_t* __restrict__ n_list,
+                                                              int32_t* __restrict__ slot_of_row) {
   using T = sg::Tile<NKS>;
   constexpr int RF = 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -528,14 +530,27 @@ __global__ __launch_bounds__(256, 2) void nce_fix_bits_kernel(const IT* __restri
   fixw += (int64_t)blockIdx.z * n_tiles * n_rows_pad;
   const int t0 = blockIdx.y * tiles_per_slice, t1 = min(n_tiles, t0 + tiles_per_slice);
   if (t0 >= t1) return;
+  // with a row list only the rows some token of this group points at are tested (slot j of the list = column j of the
+  // bit table; the inverse map is written here for the token kernel)
+  const int n_live = row_list ? min(n_list[blockIdx.z], n_rows_pad) : n_rows;
+  if ((int)blockIdx.x * 256 >= n_live) return;
+  if (row_list) {
+    row_list += (int64_t)blockIdx.z * n_rows_pad;
+    slot_of_row += (int64_t)blockIdx.z * n_rows;
+  }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, half = lane >> 5;
   bf16x8 frag[RF][NKS];
   int row[RF];
 #pragma unroll
   for (int f = 0; f < RF; ++f) {
     row[f] = blockIdx.x * 256 + wave * 64 + f * 32 + r;
-    const bool live = row[f] < n_rows;
-    const IT* src = p_rows + (live ? (int64_t)row[f] * T::DIM : 0);
+    const bool live = row[f] < n_live;
+    int src_row = row[f];
+    if (row_list) {
+      src_row = live ? row_list[row[f]] : 0;
+      if (live && half == 0 && blockIdx.y == 0) slot_of_row[src_row] = row[f];
+    }
+    const IT* src = p_rows + (live ? (int64_t)src_row * T::DIM : 0);
     const float inv = row_inv_norm<NKS, IT>(src, live, half);
     load_norm_frags<NKS, IT>(src, live, half, inv, frag[f]);
   }
@@ -600,7 +615,8 @@ __global__ __launch_bounds__(256, 1) void nce_fwd_d_kernel(const IT* __restrict_
                                                            uint32_t* supp_out, float* q_inv,
                                                            float* p_inv, float* s_pos_out, int log_group,
                                                            float* __restrict__ u_out,
-                                                           const uint32_t* __restrict__ fixw, int n_rows_pad) {
+                                                           const uint32_t* __restrict__ fixw, int n_rows_pad,
+                                                           const int32_t* __restrict__ slot_of_row, int n_p_rows) {
   using T = sg::Tile<NKS>;
   constexpr int ND = (NKS + 1) / 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -613,6 +629,7 @@ __global__ __launch_bounds__(256, 1) void nce_fwd_d_kernel(const IT* __restrict_
     supp_out += grp * (int64_t)((n_neg + 31) >> 5) * tok_cap;
     q_inv += to; p_inv += to; s_pos_out += to;
     fixw += grp * (int64_t)((n_neg + 31) >> 5) * n_rows_pad;
+    if (slot_of_row) slot_of_row += grp * (int64_t)n_p_rows;
   }
   const int n_tok = min(*n_tok_dev, tok_cap);
   const int tok0 = blockIdx.x * 128;
@@ -679,7 +696,7 @@ __global__ __launch_bounds__(256, 1) void nce_fwd_d_kernel(const IT* __restrict_
                                              reinterpret_cast<const char*>(negs) + (int64_t)tn * (32 * T::ROW_BYTES));
   };
   unsigned char* words = smem + 4 * T::BYTES;                  // 4 slots x [4 waves][64 lanes] suppression words of my token's target
-  const uint32_t* my_fix = fixw + p_row;                      // + tile * n_rows_pad
+  const uint32_t* my_fix = fixw + (slot_of_row && live ? slot_of_row[p_row] : (slot_of_row ? 0 : p_row));   // + tile * n_rows_pad
   auto dma_w = [&](auto slot_c, int tn) {
     sg::dma_words(my_fix + (int64_t)tn * n_rows_pad, words + decltype(slot_c)::value * 1024 + wv * 256);
   };
@@ -1094,10 +1111,14 @@ extern "C" int mhr_nce_fwd(const void* q_rows, const int32_t* q_idx, const void*
                            const void* negs, int n_neg, int dim, int n_groups, const int32_t* n_tok_dev, int tok_cap,
                            const float* logit_scale_dev, float thres, float* sum_out, int32_t* n_valid, int32_t* rank,
                            void* qn_out, void* pn_out, uint32_t* supp_out, float* q_inv, float* p_inv, float* s_pos,
-                           int log_group, float* u_out, int64_t n_p_rows, uint32_t* fix_words, void* stream) {
+                           int log_group, float* u_out, int64_t n_p_rows, uint32_t* fix_words, const int32_t* fix_row_list,
+                           const int32_t* fix_n_rows, int32_t* fix_slot_of_row, void* stream) {
   MHR_REQUIRE(q_rows && q_idx && p_rows && p_idx && negs && n_tok_dev && logit_scale_dev && sum_out && s_pos,
               "nce_fwd: null pointer");
   MHR_REQUIRE(!fix_words || (u_out && n_p_rows > 0 && n_p_rows < (1ll << 31) - 256), "nce_fwd: fix_words needs u_out and n_p_rows");
+  MHR_REQUIRE((fix_row_list != nullptr) == (fix_n_rows != nullptr) && (fix_row_list != nullptr) == (fix_slot_of_row != nullptr) &&
+                  (!fix_row_list || fix_words),
+              "nce_fwd: fix_row_list, fix_n_rows and fix_slot_of_row go together (and need fix_words)");
   MHR_REQUIRE(!u_out || (qn_out && pn_out && supp_out && q_inv && p_inv && tok_cap % 32 == 0),
               "nce_fwd: u_out (fused training path) needs every saved tensor and tok_cap %% 32 == 0");
   int nks;
@@ -1140,14 +1161,16 @@ extern "C" int mhr_nce_fwd(const void* q_rows, const int32_t* q_idx, const void*
     const dim3 gu((tok_cap + 127) / 128, 1, n_groups);                                                                   \
     if (io_dtype == MHR_BF16) {                                                                                          \
       hipLaunchKernelGGL((nce_fix_bits_kernel<NKS, bf16_t>), gf, dim3(256), ldsf, s, (const bf16_t*)p_rows, (int)n_p_rows, \
-                         (const bf16_t*)negs, n_neg, thres, fix_words, n_rows_pad, tps_f);                               \
-      if (logs) hipLaunchKernelGGL((nce_fwd_d_kernel<NKS, bf16_t, true>), gu, dim3(256), ldsd, s, UARGS(bf16_t), fix_words, n_rows_pad); \
-      else hipLaunchKernelGGL((nce_fwd_d_kernel<NKS, bf16_t, false>), gu, dim3(256), ldsd, s, UARGS(bf16_t), fix_words, n_rows_pad);     \
+                         (const bf16_t*)negs, n_neg, thres, fix_words, n_rows_pad, tps_f, fix_row_list, fix_n_rows,     \
+                         fix_slot_of_row);                                                                               \
+      if (logs) hipLaunchKernelGGL((nce_fwd_d_kernel<NKS, bf16_t, true>), gu, dim3(256), ldsd, s, UARGS(bf16_t), fix_words, n_rows_pad, fix_slot_of_row, (int)n_p_rows); \
+      else hipLaunchKernelGGL((nce_fwd_d_kernel<NKS, bf16_t, false>), gu, dim3(256), ldsd, s, UARGS(bf16_t), fix_words, n_rows_pad, fix_slot_of_row, (int)n_p_rows);     \
     } else {                                                                                                             \
       hipLaunchKernelGGL((nce_fix_bits_kernel<NKS, float>), gf, dim3(256), ldsf, s, (const float*)p_rows, (int)n_p_rows, \
-                         (const bf16_t*)negs, n_neg, thres, fix_words, n_rows_pad, tps_f);                               \
-      if (logs) hipLaunchKernelGGL((nce_fwd_d_kernel<NKS, float, true>), gu, dim3(256), ldsd, s, UARGS(float), fix_words, n_rows_pad); \
-      else hipLaunchKernelGGL((nce_fwd_d_kernel<NKS, float, false>), gu, dim3(256), ldsd, s, UARGS(float), fix_words, n_rows_pad);     \
+                         (const bf16_t*)negs, n_neg, thres, fix_words, n_rows_pad, tps_f, fix_row_list, fix_n_rows,     \
+                         fix_slot_of_row);                                                                               \
+      if (logs) hipLaunchKernelGGL((nce_fwd_d_kernel<NKS, float, true>), gu, dim3(256), ldsd, s, UARGS(float), fix_words, n_rows_pad, fix_slot_of_row, (int)n_p_rows); \
+      else hipLaunchKernelGGL((nce_fwd_d_kernel<NKS, float, false>), gu, dim3(256), ldsd, s, UARGS(float), fix_words, n_rows_pad, fix_slot_of_row, (int)n_p_rows);     \
     }                                                                                                                    \
   }
     NKS_SWITCH(nks, LF_);

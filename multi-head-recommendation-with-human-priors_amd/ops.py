@@ -410,11 +410,16 @@ class NceSaved:
                  "bucket_sum", "bucket_cnt", "u", "wide", "scale_dev", "cap_eff")
 
 
+_ROW_IOTA = {}
+
+
 def nce_fwd(q_rows, q_idx, p_rows, p_idx, negs, n_tok_dev, tok_cap, logit_scale, thres=0.99, want_logs=False,
-            for_backward=True, bucket_idx=None, n_buckets=0, log_group=-1):
+            for_backward=True, bucket_idx=None, n_buckets=0, log_group=-1, p_row_mask=None):
     """Grouped sampled softmax.  q_rows/p_rows [*, D] (bf16 or f32, same dtype, shared by all groups);
     q_idx/p_idx [G, tok_cap] int32; negs [G, n_neg, D] bf16 normalised; n_tok_dev [G] int32.
-    (1-D q_idx / 2-D negs are accepted as a single group.)  Saved tensors carry the leading group axis."""
+    (1-D q_idx / 2-D negs are accepted as a single group.)  Saved tensors carry the leading group axis.
+    p_row_mask [G, p_rows.shape[0]] bool/uint8 (optional): per group, a superset of the rows of p_rows that live tokens
+    point at - the hoisted false-negative test then visits only those rows."""
     if q_idx.dim() == 1:
         q_idx, p_idx, negs, n_tok_dev = q_idx[None], p_idx[None], negs[None], n_tok_dev.view(1)
     _chk(negs, "negs", torch.bfloat16)
@@ -474,13 +479,24 @@ def nce_fwd(q_rows, q_idx, p_rows, p_idx, negs, n_tok_dev, tok_cap, logit_scale,
     # training path: the false-negative test runs once per (group, target row, negative) into a bit table (see mhr.h)
     n_p_rows = p_rows.shape[0]
     fix_words = None
+    row_list = n_list = slot_of_row = None
     if sv.u is not None and HOIST_FALSE_NEGATIVE_TEST:
-        fix_words = torch.empty(G, (n_neg + 31) // 32, (n_p_rows + 255) // 256 * 256, dtype=torch.int32, device=dev)
+        rp_pad = (n_p_rows + 255) // 256 * 256
+        fix_words = torch.empty(G, (n_neg + 31) // 32, rp_pad, dtype=torch.int32, device=dev)
+        if p_row_mask is not None:
+            assert p_row_mask.shape == (G, n_p_rows)
+            key = (G, n_p_rows, str(dev))
+            if key not in _ROW_IOTA:
+                ar = torch.arange(n_p_rows, dtype=torch.int32, device=dev)
+                _ROW_IOTA[key] = (ar[None].expand(G, -1).contiguous(), ar)
+            iota_g, iota = _ROW_IOTA[key]
+            row_list, _, _, n_list = token_compact(p_row_mask.contiguous(), iota_g, iota, iota, tok_cap=rp_pad)
+            slot_of_row = torch.zeros(G, n_p_rows, dtype=torch.int32, device=dev)     # zero: any lookup stays in bounds
     _timed_call("mhr_nce_fwd", q_rows.data_ptr(), q_idx.data_ptr(), p_rows.data_ptr(), p_idx.data_ptr(), _dt(q_rows),
                 negs.data_ptr(), n_neg, D, G, n_tok_dev.data_ptr(), cap, logit_scale.data_ptr(), float(thres),
                 ssum.data_ptr(), _ptr(n_valid), _ptr(rank), _ptr(sv.qn), _ptr(sv.pn),
                 _ptr(sv.supp), _ptr(sv.q_inv), _ptr(sv.p_inv), _ptr(sv.s_pos), int(log_group), _ptr(sv.u), n_p_rows,
-                _ptr(fix_words), st)
+                _ptr(fix_words), _ptr(row_list), _ptr(n_list), _ptr(slot_of_row), st)
     lib.call("mhr_nce_finalize", ssum.data_ptr(), sv.s_pos.data_ptr(), G, n_tok_dev.data_ptr(), cap,
              logit_scale.data_ptr(), loss.data_ptr(), sv.lse.data_ptr(), _ptr(n_valid), _ptr(bucket_idx), int(n_buckets),
              _ptr(sv.bucket_sum), _ptr(sv.bucket_cnt), st)
