@@ -192,8 +192,8 @@ class MultiHeadDecoding:
             return self.aux_cat_head[c](aux_in).squeeze(-1).float()
 
     def _switch_loss(self, out, head_out, tag_win, c):
-        """(loss, accuracy) of the category-c switch (reference hstu.py:757-805).  tag_win [B,P,L,C] future tags."""
-        target = tag_win[..., c].any(dim=1).float()                            # [B,L]
+        """(loss, accuracy) of the category-c switch (reference hstu.py:757-805).  tag_win [B,L,P,C] future tags."""
+        target = tag_win[..., c].any(dim=2).float()                            # [B,L]
         logits = self._switch_logits(out, head_out, c)                         # [B,L]
         if self.switch_last_only:
             target, logits = target[:, -1:], logits[:, -1:]
@@ -219,26 +219,28 @@ class MultiHeadDecoding:
         e.view(-1,D) [B*P*L], prediction offset [B*P*L].  head_for_p: [G, P] long (head used by group g at offset p)."""
         key = (B, str(device), tuple(head_for_p.reshape(-1).tolist()))
         if key not in self._tok_cache:
+            # slot order (b, l, p), offset fastest: the tokens that share a head row (b, head, l) are neighbours in the
+            # compacted lists, which lets the row-wise backward kernel combine their gradient rows before its atomics
             L, P, H = self.max_seq_length, self.pred_len, self.medusa_num_heads
             b = torch.arange(B, device=device)[None, :, None, None]
-            p = torch.arange(P, device=device)[None, None, :, None]
-            l = torch.arange(L, device=device)[None, None, None, :]
-            hp = head_for_p.to(device)[:, None, :, None]                                        # [G,1,P,1]
+            l = torch.arange(L, device=device)[None, None, :, None]
+            p = torch.arange(P, device=device)[None, None, None, :]
+            hp = head_for_p.to(device)[:, None, None, :]                                        # [G,1,1,P]
             G = hp.shape[0]
-            q_all = ((b * H + hp) * L + l).expand(G, B, P, L).reshape(G, -1).int().contiguous()
-            p_all = (b * (L + P) + l + 1 + p).expand(1, B, P, L).reshape(-1).int().contiguous()
-            o_all = p.expand(1, B, P, L).reshape(-1).int().contiguous()
+            q_all = ((b * H + hp) * L + l).expand(G, B, L, P).reshape(G, -1).int().contiguous()
+            p_all = (b * (L + P) + l + 1 + p).expand(1, B, L, P).reshape(-1).int().contiguous()
+            o_all = p.expand(1, B, L, P).reshape(-1).int().contiguous()
             self._tok_cache[key] = (q_all, p_all, o_all)
         return self._tok_cache[key]
 
     def _grouped_loss(self, head_rows, e_rows, negs_g, valid_g, head_for_p, log_group, p_row_mask=None):
         """Sampled-softmax loss of G (token mask, negative pool) groups in ONE fused launch per kernel.
-        valid_g [G,B,P,L] bool, negs_g [G,n_neg,D] bf16, head_for_p [G,P].  Returns (mean loss per (group, offset)
+        valid_g [G,B,L,P] bool (offset fastest), negs_g [G,n_neg,D] bf16, head_for_p [G,P].  Returns (mean loss per (group, offset)
         [G,P] fp32, logs of `log_group` or None).  No host sync: tokens are compacted by scatter at fixed capacity
         and the live counts stay on the device (reference: boolean-mask compaction + `mask.sum() == 0` host branch,
         hstu.py:688-690, 814-829)."""
         from REC.model.hstu_functional import NceLossFn
-        G, B, P, L = valid_g.shape
+        G, B, L, P = valid_g.shape
         dev = valid_g.device
         n_slots = B * P * L
         q_all, p_all, o_all = self._token_tables(B, dev, head_for_p)
@@ -291,11 +293,11 @@ class MultiHeadDecoding:
         head_embs = self._heads(out).permute(0, 2, 1, 3).contiguous()     # [B,H,L,D]
         head_rows = head_embs.view(-1, D)
 
-        idx = torch.arange(L, device=dev)[None, :] + 1 + torch.arange(P, device=dev)[:, None]      # [P,L]
-        base_valid = mask[:, None, :L] & mask[:, idx]                                              # [B,P,L]
+        idx = torch.arange(L, device=dev)[:, None] + 1 + torch.arange(P, device=dev)[None, :]      # [L,P]: target of (l, p)
+        base_valid = mask[:, :L, None] & mask[:, idx]                                              # [B,L,P]
 
         # one group per (token mask, head assignment, negative pool): the nce branch and every prior category
-        groups = []                       # (valid [B,P,L], head_for_p [P], pool slot, weight, kind, index)
+        groups = []                       # (valid [B,L,P], head_for_p [P], pool slot, weight, kind, index)
         row_masks = []                    # per group: the target rows (b, j) its tokens can point at (a superset is enough)
         if self.loss == 'nce' or (self.loss == 'prior' and additive):
             groups.append((base_valid, torch.arange(P) // self.seg_len, pool_slot[pools[0]], 1.0, 'nce', 0))
@@ -304,7 +306,7 @@ class MultiHeadDecoding:
         if self.loss == 'prior':
             seg_len = P if additive else self.seg_len
             seg_for_p = torch.arange(P) // seg_len
-            tag_win = pos_tags[:, idx].bool()                                                      # [B,P,L,C]
+            tag_win = pos_tags[:, idx].bool()                                                      # [B,L,P,C]
             for c in range(C):
                 valid = base_valid & tag_win[..., c]
                 if self.pos_sample_mix_ratio > 0.0:

@@ -876,7 +876,7 @@ __global__ __launch_bounds__(256) void nce_bwd_rows_kernel(const bf16_t* qn, con
                                                            float* __restrict__ dp_rows, float* __restrict__ d_logit_scale,
                                                            float* __restrict__ lw_out, const int32_t* __restrict__ w_bucket,
                                                            int n_buckets) {
-  constexpr int TB = 4;            // tokens in flight per wave
+  constexpr int TB = 8;            // consecutive tokens per wave pass (loads in flight; runs sharing a head row are combined)
   constexpr int NC = 4;            // 64-column chunks (dim <= 256)
   {
     const int64_t grp = blockIdx.z, to = grp * tok_cap;
@@ -914,6 +914,21 @@ __global__ __launch_bounds__(256) void nce_bwd_rows_kernel(const bf16_t* qn, con
         uv[b][c] = ok ? u[(int64_t)tk * dim + d] : 0.f;
       }
     }
+    // With the token lists ordered prediction-offset-fastest (multihead.py) consecutive tokens of a group share their
+    // head row (the offsets p of one position): their dQ rows are summed in registers and leave as ONE 256-float atomic
+    // set per run instead of one per token (the float-atomic rate bounds this kernel).
+    float accq[NC] = {0.f, 0.f, 0.f, 0.f};
+    int run_row = -1;
+    auto flush = [&]() {
+      if (run_row >= 0) {
+        float* qdst = dq_rows + (int64_t)run_row * dim;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          const int d = c * 64 + lane;
+          if (d < dim) atomicAdd(qdst + d, accq[c]);
+        }
+      }
+    };
 #pragma unroll
     for (int b = 0; b < TB; ++b) {
       const int tk = t0 + b;
@@ -935,18 +950,23 @@ __global__ __launch_bounds__(256) void nce_bwd_rows_kernel(const bf16_t* qn, con
       dot_q = wave_sum(dot_q);
       dot_p = wave_sum(dot_p);
       dls += wave_sum(dot_raw) + coef * sp[b];      // sum_j g_ij s_ij = qn_i . dQn_i, plus the positive term
-      // several tokens share a head row (offsets p of one segment) or a target row (l + 1 + p = const): float atomics
-      float* qdst = dq_rows + (int64_t)qi[b] * dim;
+      if (qi[b] != run_row) {                        // wave-uniform
+        flush();
+        run_row = qi[b];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) accq[c] = 0.f;
+      }
+#pragma unroll
+      for (int c = 0; c < NC; ++c) accq[c] += (dqn[c] - qv[b][c] * dot_q) * iq[b];
+      // target rows (l + 1 + p = const) are shared too, but not by neighbours in the list: float atomics per token
       float* pdst = dp_rows + (int64_t)pi[b] * dim;
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
         const int d = c * 64 + lane;
-        if (d < dim) {
-          atomicAdd(qdst + d, (dqn[c] - qv[b][c] * dot_q) * iq[b]);
-          atomicAdd(pdst + d, (dpn[c] - pv[b][c] * dot_p) * ip[b]);
-        }
+        if (d < dim) atomicAdd(pdst + d, (dpn[c] - pv[b][c] * dot_p) * ip[b]);
       }
     }
+    flush();
   }
   if (lane == 0 && d_logit_scale && dls != 0.f) atomicAdd(d_logit_scale, dls * scale);   // d/d(param), scale = exp(param)
 }
@@ -1226,7 +1246,7 @@ extern "C" int mhr_nce_bwd_tokens(const void* qn, const void* pn, const float* u
   MHR_REQUIRE(q_idx && p_idx && dq_rows && dp_rows, "nce_bwd_tokens: null index/output pointer");
   MHR_REQUIRE(dim > 0 && dim <= 256, "nce_bwd_tokens: dim=%d unsupported (<= 256)", dim);
   MHR_REQUIRE(tok_cap > 0 && n_groups >= 1 && n_groups <= 65535, "nce_bwd_tokens: bad sizes");
-  int blocks = (tok_cap + 15) / 16;                 // 4 waves x 4 tokens per pass
+  int blocks = (tok_cap + 31) / 32;                 // 4 waves x 8 tokens per pass
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(nce_bwd_rows_kernel, dim3(blocks, 1, n_groups), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qn,
                      (const bf16_t*)pn, u, dim, n_tok_dev, tok_cap, logit_scale_dev, lse, w, q_inv, p_inv, s_pos, q_idx, p_idx,
