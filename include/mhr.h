@@ -83,9 +83,11 @@ int mhr_adam_rows(float* w, float* m, float* v, int64_t n_rows, int dim,
                   const float* grad_rows, int32_t* row_slot, float grad_scale,
                   float lr, float beta1, float beta2, float eps, float weight_decay, int step, void* stream);
 
-/* Dense AdamW over a flat parameter buffer (all non-table parameters live in one flat buffer). */
+/* Dense AdamW over a flat parameter buffer (all non-table parameters live in one flat buffer).  w_bf16 (optional, [n]):
+ * bf16 copy of the updated weights, written in the same pass - the operand of the next step's bf16 GEMMs, so no
+ * per-step cast kernels (the reference's autocast re-casts every weight every step). */
 int mhr_adam_flat(float* w, const float* g, float* m, float* v, int64_t n, float grad_scale,
-                  float lr, float beta1, float beta2, float eps, float weight_decay, int step, void* stream);
+                  float lr, float beta1, float beta2, float eps, float weight_decay, int step, void* w_bf16, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Normalisation / gating (HSTU layer, model/IDNet/hstu.py:213-219, 241, 277-285).

@@ -57,11 +57,34 @@ class SplitKLinearFn(Function):
 
     @staticmethod
     def forward(ctx, x, w, b, w_is_nk, w_bf16):
+        if w_bf16 is None:
+            sh = getattr(w, "_mhr_bf16", None)       # shadow kept by the fused optimizer, valid while nobody edited w
+            w_bf16 = sh if (sh is not None and w._version == w._mhr_ver) else None
         wb = w.to(torch.bfloat16) if w_bf16 is None else w_bf16
-        y = torch.nn.functional.linear(x, wb, None if b is None else b.to(torch.bfloat16)) if w_is_nk else x @ wb
+        bb = None
+        if b is not None:
+            sh = getattr(b, "_mhr_bf16", None)
+            bb = sh if (sh is not None and b._version == b._mhr_ver) else b.to(torch.bfloat16)
+        y = torch.nn.functional.linear(x, wb, bb) if w_is_nk else x @ wb
         ctx.save_for_backward(x, wb)
         ctx.w_is_nk, ctx.has_bias = w_is_nk, b is not None
+        # parameters whose .grad is a view of the optimizer's flat gradient buffer receive their gradient in place
+        ctx.w_leaf = w if getattr(w, "_mhr_direct_grad", False) and w.grad is not None else None
+        ctx.b_leaf = b if (b is not None and getattr(b, "_mhr_direct_grad", False) and b.grad is not None) else None
         return y
+
+    @staticmethod
+    def _into(leaf, parts, dim0_sum):
+        """Write (first use in this step) or add the fp32 reduction of `parts` over dim 0 into leaf.grad."""
+        from mhr_amd import optim
+        if getattr(leaf, "_mhr_epoch", -1) != optim.GRAD_EPOCH:
+            leaf._mhr_epoch = optim.GRAD_EPOCH
+            if dim0_sum:
+                torch.sum(parts, 0, dtype=torch.float32, out=leaf.grad)
+            else:
+                leaf.grad.copy_(parts)
+        else:
+            leaf.grad.add_(torch.sum(parts, 0, dtype=torch.float32) if dim0_sum else parts)
 
     @staticmethod
     def backward(ctx, dy):
@@ -75,8 +98,17 @@ class SplitKLinearFn(Function):
             dw = torch.bmm(dys.transpose(1, 2), xs)               # [S, N, K]
         else:
             dw = torch.bmm(xs.transpose(1, 2), dys)               # [S, K, N]
-        dw = torch.sum(dw, 0, dtype=torch.float32) if S > 1 else dw[0].float()      # cast fused into the reduction
-        db = torch.sum(dy, 0, dtype=torch.float32) if ctx.has_bias else None
+        if ctx.w_leaf is not None:                                # reduction of the split-K partials straight into p.grad
+            SplitKLinearFn._into(ctx.w_leaf, dw if S > 1 else dw[0], S > 1)
+            dw = None
+        else:
+            dw = torch.sum(dw, 0, dtype=torch.float32) if S > 1 else dw[0].float()      # cast fused into the reduction
+        db = None
+        if ctx.has_bias:
+            if ctx.b_leaf is not None:
+                SplitKLinearFn._into(ctx.b_leaf, dy, True)
+            else:
+                db = torch.sum(dy, 0, dtype=torch.float32)
         return dx, dw, db, None, None
 
 

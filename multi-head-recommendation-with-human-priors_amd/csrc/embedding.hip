@@ -286,7 +286,7 @@ extern "C" int mhr_adam_rows(float* w, float* m, float* v, int64_t n_rows, int d
 
 __global__ __launch_bounds__(256) void adam_flat_kernel(float* __restrict__ w, const float* __restrict__ g,
                                                         float* __restrict__ m, float* __restrict__ v, int64_t n,
-                                                        AdamConst a) {
+                                                        AdamConst a, bf16_t* __restrict__ w16) {
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t nt = (int64_t)gridDim.x * blockDim.x;
   const int64_t n4 = n / 4;
@@ -297,6 +297,7 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(float* __restrict__ w, c
     reinterpret_cast<f32x4*>(w)[i] = wv;
     reinterpret_cast<f32x4*>(m)[i] = mv;
     reinterpret_cast<f32x4*>(v)[i] = vv;
+    if (w16) Vec4IO<bf16_t>::store(w16 + i * 4, wv);        // bf16 shadow of the updated weights (the GEMM operand)
   }
   for (int64_t i = n4 * 4 + tid; i < n; i += nt) {  // tail
     float gk = g[i] * a.grad_scale;
@@ -306,19 +307,21 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(float* __restrict__ w, c
     w[i] = wk - a.step_size * (mk / (sqrtf(vk) * a.inv_sqrt_bc2 + a.eps));
     m[i] = mk;
     v[i] = vk;
+    if (w16) w16[i] = (bf16_t)w[i];
   }
 }
 
 extern "C" int mhr_adam_flat(float* w, const float* g, float* m, float* v, int64_t n, float grad_scale, float lr,
-                             float beta1, float beta2, float eps, float weight_decay, int step, void* stream) {
+                             float beta1, float beta2, float eps, float weight_decay, int step, void* w_bf16, void* stream) {
   MHR_REQUIRE(w && g && m && v, "adam_flat: null pointer");
+  MHR_REQUIRE(!w_bf16 || (uintptr_t)w_bf16 % 8 == 0, "adam_flat: the bf16 shadow must be 8-byte aligned");
   MHR_REQUIRE(n >= 0 && step >= 1, "adam_flat: bad sizes");
   MHR_REQUIRE(((uintptr_t)w % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)m % 16 == 0) && ((uintptr_t)v % 16 == 0),
               "adam_flat: buffers must be 16-byte aligned");
   if (n == 0) return MHR_OK;
   AdamConst a = make_adam(lr, beta1, beta2, eps, weight_decay, step, grad_scale);
   int grid = mhr_grid_for(n / 4 + 1, 256, 2048);
-  hipLaunchKernelGGL(adam_flat_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, g, m, v, n, a);
+  hipLaunchKernelGGL(adam_flat_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, g, m, v, n, a, (bf16_t*)w_bf16);
   MHR_CHECK_LAUNCH("adam_flat");
   return MHR_OK;
 }

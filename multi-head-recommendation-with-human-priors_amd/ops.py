@@ -126,9 +126,9 @@ def adam_rows(w, m, v, grad_rows, row_slot, step, lr, grad_scale=1.0, betas=(0.9
              _ptr(row_slot), grad_scale, lr, betas[0], betas[1], eps, weight_decay, step, _stream())
 
 
-def adam_flat(w, g, m, v, step, lr, grad_scale=1.0, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+def adam_flat(w, g, m, v, step, lr, grad_scale=1.0, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, w_bf16=None):
     lib.call("mhr_adam_flat", w.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), w.numel(), grad_scale, lr,
-             betas[0], betas[1], eps, weight_decay, step, _stream())
+             betas[0], betas[1], eps, weight_decay, step, _ptr(w_bf16), _stream())
 
 
 # ------------------------------------------------------------------------------------------------

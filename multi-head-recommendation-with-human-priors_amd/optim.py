@@ -1,10 +1,15 @@
 """Fused AdamW for the HSTU / HLLM models: one kernel over the flat dense-parameter buffer, one over the item table (HSTU;
 the HLLM twin has no trainable table) whose gradient arrives as a sparse row set (reference: DeepSpeed FusedAdam / torch AdamW over every parameter,
 `code/REC/trainer/trainer.py:292-299`; update semantics identical: every table row is updated every step)."""
+import os
+
 import torch
 
 from . import distributed as D
 from . import ops
+
+
+GRAD_EPOCH = 0        # bumped by zero_grad(): lets a backward kernel know its first write into p.grad of this step
 
 
 class FusedAdamW:
@@ -30,16 +35,25 @@ class FusedAdamW:
         self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_m = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_v = torch.zeros(total, dtype=torch.float32, device=dev)
+        # bf16 shadow of the flat weights, rewritten by the Adam kernel: the GEMM operand of the next step (SplitKLinearFn
+        # takes `p._mhr_bf16` while `p._version` still equals `p._mhr_ver`, i.e. nobody edited the parameter in between)
+        self.flat_w16 = torch.zeros(total, dtype=torch.bfloat16, device=dev)
         off = 0
         for p, sz in zip(self.dense, sizes):
             n = p.numel()
             self.flat_w[off:off + n].copy_(p.data.reshape(-1))
             p.data = self.flat_w[off:off + n].view(p.shape)
             p.grad = self.flat_g[off:off + n].view(p.shape)
+            if os.environ.get("MHR_OPT_SHADOW", "1") != "0":
+                p._mhr_bf16 = self.flat_w16[off:off + n].view(p.shape)
+                p._mhr_ver = -1                                          # shadow not valid before the first step
+            p._mhr_direct_grad = os.environ.get("MHR_OPT_DIRECT", "1") != "0"   # backward kernels may write p.grad in place
             off += sz
         self.param_groups = [{"lr": lr}]                                 # scheduler-facing view
 
     def zero_grad(self):
+        global GRAD_EPOCH
+        GRAD_EPOCH += 1                                                  # first gradient write of a step overwrites
         self.flat_g.zero_()
         if self.table is not None:
             self.table.grad = None
@@ -51,7 +65,10 @@ class FusedAdamW:
         W = D.world_size()
         D.allreduce_mean_(self.flat_g)
         ops.adam_flat(self.flat_w, self.flat_g, self.flat_m, self.flat_v, self.step_count, lr, 1.0, self.betas, self.eps,
-                      self.weight_decay)
+                      self.weight_decay, w_bf16=self.flat_w16)
+        for p in self.dense:
+            if hasattr(p, "_mhr_bf16"):
+                p._mhr_ver = p._version
         if self.table is None:
             return
         sg = self.model.finish_sparse_grad() if hasattr(self.model, "finish_sparse_grad") else self.model.sparse_grad
