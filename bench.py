@@ -227,8 +227,10 @@ def main():
                     n_tok = float(valid.sum())
                     n_groups = 1
                 n_neg = world * B * data.n_neg(B)
-                # fused forward: neg logits + false-negative logits + the token-side gradient product = 3 x 2 N_tok N_neg D;
-                # negative-side backward: dN only (its logit recompute is not counted)
+                # fused forward: neg logits + false-negative logits + the token-side gradient product = 3 x 2 N_tok N_neg D
+                # ALGORITHMIC flop (what the reference's formulation computes per token; the false-negative
+                # product is executed once per target row instead of once per token); negative-side backward: dN only (its
+                # logit recompute is not counted)
                 mult = 6.0 if name == "mhr_nce_fwd" else 2.0
                 flops = mult * n_tok * n_neg * D
                 ach = flops / (mean_ms * 1e-3) / 1e12
@@ -261,15 +263,17 @@ def main():
             # HBM bytes per launch of that kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE run on this same
             # command and condensed by tools/summarize_profiles.py; counters cannot be read from inside the process)
             if "roofline" in out and args.config == "cfg1" and not args.batch:
-                kname = {"mhr_nce_bwd_tokens": "nce_bwd_rows_kernel", "mhr_nce_bwd_negs": "nce_bwd_n_kernel", "mhr_nce_fwd": "nce_fwd_u_kernel",
-                         "mhr_catalog_score_emit": "catalog_emit_kernel", "mhr_catalog_score_emit_sliced": "catalog_emit_sliced_kernel",
-                         "mhr_adam_rows": "adam_rows_kernel"}.get(name)
+                # one C-ABI call may be several launches (mhr_nce_fwd = false-negative bit table + fused forward): their sum
+                knames = {"mhr_nce_bwd_tokens": ["nce_bwd_rows_kernel"], "mhr_nce_bwd_negs": ["nce_bwd_n_kernel"],
+                          "mhr_nce_fwd": ["nce_fwd_d_kernel", "nce_fix_bits_kernel"],
+                          "mhr_catalog_score_emit": ["catalog_emit_kernel"], "mhr_catalog_score_emit_sliced": ["catalog_emit_sliced_kernel"],
+                          "mhr_adam_rows": ["adam_rows_kernel"]}.get(name)
                 import glob
                 files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_hbm_traffic{'_eval' if args.mode == 'eval' else ''}.json")))
-                if kname and files:
-                    rec = json.load(open(files[-1]))["kernels"].get(kname)
-                    if rec:
-                        out["roofline"]["traffic"] = rec["hbm_bytes_per_launch"]
+                if knames and files:
+                    recs = [json.load(open(files[-1]))["kernels"].get(k) for k in knames]
+                    if recs[0]:
+                        out["roofline"]["traffic"] = sum(r["hbm_bytes_per_launch"] for r in recs if r)
                         out["roofline"]["traffic_source"] = os.path.relpath(files[-1], ROOT)
             out["kernel_ms_per_step"] = per_step
             if "mhr_embedding_gather_fwd" in prof and args.mode == "train":
