@@ -446,6 +446,18 @@ def test_nce_grouped_launch_equals_per_group(ops):
     assert float((dq.cpu() - dq_ref).abs().max()) < 2e-2 * float(dq_ref.abs().max())
     assert float((dp.cpu() - dp_ref).abs().max()) < 2e-2 * float(dp_ref.abs().max())
     assert abs(float(dls.cpu()) - dls_ref) < 2e-2 * abs(dls_ref) + 1e-4
+    # the hoisted false-negative test restricted to the target rows each group can reference (a superset: the referenced
+    # rows plus a few others; the empty group references none): identical losses, counters and saved suppression words
+    mask = torch.zeros(G, n_src, dtype=torch.bool)
+    for gi in range(G):
+        mask[gi, pi[gi, :n_toks[gi]].long()] = True
+        mask[gi, torch.randint(0, n_src, (7,), generator=g)] = True
+    mask[1] = False
+    sv2 = ops.nce_fwd(dev(q_rows), dev(qi), dev(p_rows), dev(pi), dev(negs), ntd, cap, ls, 0.99, want_logs=True, p_row_mask=dev(mask))
+    torch.cuda.synchronize()
+    assert torch.equal(sv2.loss, sv.loss) and torch.equal(sv2.n_valid, sv.n_valid) and torch.equal(sv2.rank, sv.rank)
+    for gi in (0, 2):
+        assert torch.equal(sv2.supp[gi, :, :n_toks[gi]], sv.supp[gi, :, :n_toks[gi]])
 
 
 # ------------------------------------------------------------------------------------------------
