@@ -142,7 +142,8 @@ class LlamaModel(nn.Module):
 
     def forward(self, input_ids=None, attention_mask=None, cu_input_lens=None, position_ids=None, inputs_embeds=None,
                 max_input_len=None, **unused):
-        from REC.model.hstu_functional import SplitKLinearFn
+        from mhr_amd.optim import fused_views
+        from REC.model.hstu_functional import FusedParamLinearFn, SplitKLinearFn
         from REC.model.llm_functional import AddRMSNormFn, RMSNormFn, RopeAttentionFn, SwigluFn
         if (input_ids is None) == (inputs_embeds is None):
             raise ValueError("You have to specify exactly one of input_ids / inputs_embeds")
@@ -180,17 +181,33 @@ class LlamaModel(nn.Module):
 
         branch = None
         for i, layer in enumerate(self.layers):
-            w_qkv, b_qkv, w_gu, cached = self._fused_weights(i, layer)
+            fv_qkv = fv_gu = None
+            if torch.is_grad_enabled() and layer.self_attn.q_proj.bias is None:
+                # parameters laid out back to back by the fused optimizer: bf16 shadow view in, flat gradient view out
+                a_, m_ = layer.self_attn, layer.mlp
+                fv_qkv = fused_views([a_.q_proj.weight, a_.k_proj.weight, a_.v_proj.weight])
+                fv_gu = fused_views([m_.gate_proj.weight, m_.up_proj.weight])
+            if fv_qkv is not None and fv_gu is not None:
+                w_qkv = b_qkv = w_gu = cached = None
+            else:
+                fv_qkv = fv_gu = None
+                w_qkv, b_qkv, w_gu, cached = self._fused_weights(i, layer)
             pre = cached is not None
             if branch is None:
                 h = RMSNormFn.apply(x, layer.input_layernorm.weight, layer.input_layernorm.variance_epsilon)
             else:
                 x, h = AddRMSNormFn.apply(x, branch, layer.input_layernorm.weight, layer.input_layernorm.variance_epsilon)
-            qkv = SplitKLinearFn.apply(h, w_qkv, b_qkv, True, w_qkv if pre else None)
+            if fv_qkv is not None:
+                qkv = FusedParamLinearFn.apply(h, fv_qkv[0], fv_qkv[1], layer.self_attn.q_proj.weight)
+            else:
+                qkv = SplitKLinearFn.apply(h, w_qkv, b_qkv, True, w_qkv if pre else None)
             a = RopeAttentionFn.apply(qkv, cos, sin, positions, key_valid, cu, n_seqs, max_len, nh, nkv, hd, scale)
             o = SplitKLinearFn.apply(a, layer.self_attn.o_proj.weight, None, True, cached[0] if pre else None)
             x, h = AddRMSNormFn.apply(x, o, layer.post_attention_layernorm.weight, layer.post_attention_layernorm.variance_epsilon)
-            gu = SplitKLinearFn.apply(h, w_gu, None, True, w_gu if pre else None)
+            if fv_gu is not None:
+                gu = FusedParamLinearFn.apply(h, fv_gu[0], fv_gu[1], layer.mlp.gate_proj.weight)
+            else:
+                gu = SplitKLinearFn.apply(h, w_gu, None, True, w_gu if pre else None)
             act = SwigluFn.apply(gu)
             branch = SplitKLinearFn.apply(act, layer.mlp.down_proj.weight, None, True, cached[1] if pre else None)
         if branch is None:

@@ -92,7 +92,11 @@ class SplitKLinearFn(Function):
         dy = dy.contiguous()
         dx = dy @ wb if ctx.w_is_nk else dy @ wb.t()
         R = x.shape[0]
-        S = next((s for s in (16, 8, 4, 2) if R % s == 0 and R // s >= 256), 1)
+        # split the token axis only as far as the output needs it: a [1024, 256] gradient is 4 macro-tiles on a 256-CU part,
+        # a [11264, 2048] one (LLM decoder) already has 352 and splitting it would only add partials to write and sum
+        tiles = -(-wb.shape[0] // 256) * -(-wb.shape[1] // 256)
+        s_max = max(1, 256 // tiles)
+        S = next((s for s in (16, 8, 4, 2) if s <= s_max and R % s == 0 and R // s >= 256), 1)
         xs, dys = x.view(S, R // S, -1), dy.view(S, R // S, -1)
         if ctx.w_is_nk:
             dw = torch.bmm(dys.transpose(1, 2), xs)               # [S, N, K]
@@ -110,6 +114,33 @@ class SplitKLinearFn(Function):
             else:
                 db = torch.sum(dy, 0, dtype=torch.float32)
         return dx, dw, db, None, None
+
+
+class FusedParamLinearFn(Function):
+    """y = x @ [W0; W1; ...]^T for parameters the fused optimizer laid out back to back (mhr_amd.optim.fused_views): the
+    operand is the bf16 shadow view of the flat weight buffer and the weight gradient goes straight into the flat gradient
+    view - no concatenation, no cast, no autograd accumulation (a 1.1 B-parameter decoder otherwise moves ~24 GB per step
+    for those three).  `leaf` is the first parameter of the group (carries the per-step first-write marker)."""
+
+    @staticmethod
+    def forward(ctx, x, w16, gview, leaf):
+        ctx.save_for_backward(x, w16)
+        ctx.gview, ctx.leaf = gview, leaf
+        return torch.nn.functional.linear(x, w16)
+
+    @staticmethod
+    def backward(ctx, dy):
+        from mhr_amd import optim
+        x, w16 = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = dy @ w16
+        dw = torch.mm(dy.t(), x, out_dtype=torch.float32)              # fp32 straight out of the MFMA accumulators
+        if getattr(ctx.leaf, "_mhr_epoch_f", -1) != optim.GRAD_EPOCH:
+            ctx.leaf._mhr_epoch_f = optim.GRAD_EPOCH
+            ctx.gview.copy_(dw)
+        else:
+            ctx.gview.add_(dw)
+        return dx, None, None, None
 
 
 class HSTUCoreFn(Function):

@@ -12,6 +12,26 @@ from . import ops
 GRAD_EPOCH = 0        # bumped by zero_grad(): lets a backward kernel know its first write into p.grad of this step
 
 
+def fused_views(params):
+    """[p0, p1, ...] 2-D parameters with the same trailing dim that FusedAdamW laid out back to back (consecutive in
+    `named_parameters()`, e.g. q_proj / k_proj / v_proj or gate_proj / up_proj of a decoder layer): returns
+    (bf16 shadow view [sum rows, K], fp32 gradient view [sum rows, K]) of the flat buffers - ONE GEMM operand and ONE
+    gradient destination without concatenating or casting anything - or None when they are not adjacent, not laid out,
+    or a shadow is stale (somebody edited the parameter since the last optimizer step)."""
+    k = params[0].shape[-1]
+    rows = 0
+    for i, p in enumerate(params):
+        sh = getattr(p, "_mhr_bf16", None)
+        if sh is None or p.grad is None or p.dim() != 2 or p.shape[-1] != k or p._version != p._mhr_ver or not getattr(p, "_mhr_direct_grad", False):
+            return None
+        if i and (p.data_ptr() != params[i - 1].data_ptr() + params[i - 1].numel() * 4
+                  or sh.data_ptr() != params[i - 1]._mhr_bf16.data_ptr() + params[i - 1].numel() * 2
+                  or p.grad.data_ptr() != params[i - 1].grad.data_ptr() + params[i - 1].numel() * 4):
+            return None
+        rows += p.shape[0]
+    return (torch.as_strided(params[0]._mhr_bf16, (rows, k), (k, 1)), torch.as_strided(params[0].grad, (rows, k), (k, 1)))
+
+
 class FusedAdamW:
     def __init__(self, model, lr=1e-3, weight_decay=0.0, betas=(0.9, 0.999), eps=1e-8):
         self.model = model

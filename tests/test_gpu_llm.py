@@ -398,3 +398,23 @@ def test_hllm_trainer_steps_reduce_loss(ops):
     batch = {k: v.cuda() for k, v in _hllm_batch(g, N, B, L, P, C, n_neg, item_tags).items()}
     losses = [float(tr.train_step_fn(batch)["loss"].detach()) for _ in range(8)]
     assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+    # after an optimizer step the decoder runs on the flat buffers' fused views (bf16 shadow operand, gradient written in
+    # place): same loss and gradients as the concatenate-and-cast path taken when the shadows are declared stale
+    from mhr_amd.optim import fused_views
+    lay = model.user_llm.model.layers[0]
+    assert fused_views([lay.self_attn.q_proj.weight, lay.self_attn.k_proj.weight, lay.self_attn.v_proj.weight]) is not None
+    tr.optimizer.zero_grad()
+    out_f = model(batch)
+    out_f["loss"].backward()
+    g_fused = tr.optimizer.flat_g.clone()
+    tr.optimizer.zero_grad()
+    vers = {p_: p_._mhr_ver for p_ in tr.optimizer.dense}
+    for p_ in tr.optimizer.dense:
+        p_._mhr_ver = -2
+    out_c = model(batch)
+    out_c["loss"].backward()
+    g_cat = tr.optimizer.flat_g.clone()
+    for p_, v_ in vers.items():
+        p_._mhr_ver = v_
+    assert abs(float(out_f["loss"]) - float(out_c["loss"])) <= 1e-5 * abs(float(out_c["loss"])) + 1e-6
+    assert float((g_fused - g_cat).abs().max()) <= 2e-2 * float(g_cat.abs().max())
