@@ -11,6 +11,10 @@ from torch.autograd import Function
 from mhr_amd import ops
 
 
+import os
+_SPLITK_MAX = int(os.environ.get("MHR_SPLITK_MAX", "16"))
+
+
 class LayerNormFn(Function):
     """Affine-free LayerNorm, fp32 in -> bf16 out (reference model/IDNet/hstu.py:213-214, 241)."""
 
@@ -95,8 +99,8 @@ class SplitKLinearFn(Function):
         # split the token axis only as far as the output needs it: a [1024, 256] gradient is 4 macro-tiles on a 256-CU part,
         # a [11264, 2048] one (LLM decoder) already has 352 and splitting it would only add partials to write and sum
         tiles = -(-wb.shape[0] // 256) * -(-wb.shape[1] // 256)
-        s_max = max(1, 256 // tiles)
-        S = next((s for s in (16, 8, 4, 2) if s <= s_max and R % s == 0 and R // s >= 256), 1)
+        s_max = min(max(1, 256 // tiles), _SPLITK_MAX)
+        S = next((s for s in (64, 32, 16, 8, 4, 2) if s <= s_max and R % s == 0 and R // s >= 256), 1)
         xs, dys = x.view(S, R // S, -1), dy.view(S, R // S, -1)
         if ctx.w_is_nk:
             dw = torch.bmm(dys.transpose(1, 2), xs)               # [S, N, K]
