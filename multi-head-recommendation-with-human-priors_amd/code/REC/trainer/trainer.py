@@ -139,12 +139,37 @@ class Trainer(object):
 
     # ------------------------------------------------------------------------------------------
     @torch.no_grad()
-    def compute_item_feature(self, item_tags):
-        """item_tags [N, C] (the data layer's multi-hot) -> cached item table + [C, N] tags (reference trainer.py:731-824)."""
+    def compute_item_feature(self, item_tags=None, item_loader=None):
+        """Cached item table + [C, N] tags for the evaluation (reference trainer.py:731-824).
+        ID models (and HLLM with a frozen, already cached item tower): `compute_item_all()` and the data layer's multi-hot
+        item_tags [N, C].  Text models: `item_loader` yields the reference's packed item-text batches (dicts with
+        pos_input_ids / pos_position_ids / pos_cu_input_lens / pos_tag_categories / pos_original_tag_categories,
+        batchset.py:57-268) in item-id order; every batch goes through the item tower once (`mode='compute_item'`,
+        trainer.py:770) and the embeddings / tags are concatenated."""
         self.model.eval()
-        self.item_feature = self.model.module.compute_item_all()
-        self.eval_collector.set_all_tags(item_tags.long())
+        if item_loader is not None:
+            feats, tags, orig = [], [], []
+            for items in item_loader:
+                items = {k: (v.to(self.device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in items.items()}
+                f, t, o = self.model(items, mode="compute_item")
+                feats.append(f)
+                tags.append(t)
+                orig.append(o)
+            self.item_feature = torch.cat(feats)
+            item_tags, orig_tags = torch.cat(tags), torch.cat(orig)
+        else:
+            self.item_feature = self.model.module.compute_item_all()
+            orig_tags = item_tags
+        self.eval_collector.set_all_tags(orig_tags.long())
         self.all_item_tags = item_tags.long().transpose(0, 1).contiguous()
+
+    @torch.no_grad()
+    def cache_item_tower(self, item_loader):
+        """freeze_item_llm: run the item tower over the catalog once and hand the table to the model
+        (reference trainer.py:466-470 -> hllm.py:889-891)."""
+        self.compute_item_feature(item_loader=item_loader)
+        self.model.module.set_all_item_embeds(self.item_feature)
+        return self.item_feature
 
     @torch.no_grad()
     def _full_sort_batch_eval(self, batched_data, stats=None):
