@@ -156,8 +156,13 @@ class HLLM(MultiHeadDecoding, BaseModel):
             self._item_table = self.all_item_embeds.float().contiguous()
         return self._item_table
 
+    def train(self, mode=True):
+        self._item_cache = None
+        return super().train(mode)
+
     @torch.no_grad()
     def compute_item_all(self):
+        self._item_cache = None
         return self.all_item_embeds
 
     @torch.no_grad()

@@ -146,6 +146,7 @@ class HSTU(MultiHeadDecoding, BaseModel):
 
     def train(self, mode=True):
         self._bf16_cache = {}
+        self._item_cache = None            # keyed on the feature tensor's address: a new table may reuse a freed one's
         return super().train(mode)
 
     def load_state_dict(self, *args, **kwargs):
@@ -228,6 +229,7 @@ class HSTU(MultiHeadDecoding, BaseModel):
     def compute_item_all(self):
         """L2-normalised (projected) item table, fp32 [N, D] (reference hstu.py:1018-1021)."""
         from mhr_amd import ops
+        self._item_cache = None
         w = self.item_id_proj_tower(self.item_embedding.weight)
         return ops.l2norm_rows(w.contiguous(), torch.float32)
 

@@ -1,0 +1,158 @@
+"""Host data path: the vectorised train / eval batchers against a line-by-line Python restatement of the
+reference's per-sample code (trainset.py:155-177, evalset.py:80-150, collate_fn.py:59-90) for everything deterministic,
+and against the sampling contract (pool membership, blacklist, no repeats, uniformity) for the random parts.  CPU only."""
+import math
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+
+CODE = os.path.join(ROOT, "multi-head-recommendation-with-human-priors_amd", "code")
+if CODE not in sys.path:
+    sys.path.insert(0, CODE)
+
+
+def _data(seed=0, n_users=40, N=120, C=3):
+    g = np.random.default_rng(seed)
+    tags = g.random((N, C)) < 0.45
+    tags[np.arange(N), g.integers(0, C, N)] = True
+    tags[0] = False
+    user_seq = [[]] + [g.integers(1, N, int(g.integers(10, 45))).tolist() for _ in range(n_users)]
+    train_len = [0] + [len(s) - 8 for s in user_seq[1:]]            # train prefix | 4 validation items | 4 test items
+    return user_seq, train_len, tags
+
+
+def _cfg(**kw):
+    from REC.config.configurator import Config
+    c = dict(MAX_ITEM_LIST_LENGTH=8, pred_len=3, eval_pred_len=4, loss='prior', neg_sample_by_cat=True, category_by='item',
+             neg_sample_mix_ratio=0, pad_random_sample=True, num_negatives=64, train_batch_size=16, eval_batch_size=7,
+             eval_num_cats=3, outlier_user_metrics='category')
+    c.update(kw)
+    return Config(config_dict=c)
+
+
+def test_train_batch_matches_reference_sample_construction():
+    from REC.data import SeqStore, SeqTrainBatcher
+    user_seq, train_len, tags = _data()
+    cfg = _cfg()
+    st = SeqStore(user_seq, train_len, tags)
+    tb = SeqTrainBatcher(cfg, st, seed=3)
+    L, P, C = 8, 3, 3
+    W = L + P
+    # sample locations: dataload.py:163-195
+    want = []
+    for uid in range(1, len(user_seq)):
+        n = train_len[uid]
+        if n <= 1:
+            continue
+        want += [(uid, n - 1)] if n <= L else [(uid, e) for e in range((n - 1) % L, n, L)]
+    assert tb.loc.tolist() == [list(x) for x in want]
+    idx = torch.arange(tb.loc.shape[0])
+    items, neg, mask, tg = tb.batch(idx)
+    assert items.shape == (len(want), W) and neg.shape == (len(want), C + 1, tb.n_neg) and tg.shape == (len(want), W, C)
+    assert tb.n_neg == math.ceil(64 / 16)
+    pools = [set(np.nonzero(tags[:, c])[0].tolist()) for c in range(C)] + [set(range(1, tags.shape[0]))]
+    for r, (uid, end) in enumerate(want):                       # trainset.py:155-177 restated
+        start = max(0, end - L)
+        cpad = L - end + start
+        n_pred = min(train_len[uid] - end, P)
+        seq = user_seq[uid][start:end + n_pred]
+        m = [0] * cpad + [1] * len(seq) + [0] * (P - n_pred)
+        assert mask[r].tolist() == m
+        row = items[r].tolist()
+        assert row[cpad:cpad + len(seq)] == seq
+        pads = row[:cpad] + row[cpad + len(seq):]
+        assert all(1 <= x < tags.shape[0] and x not in set(seq) for x in pads) and len(set(pads)) == len(pads)
+        window = set(row)
+        for c in range(C + 1):
+            draw = neg[r, c].tolist()
+            assert len(set(draw)) == len(draw) and set(draw) <= pools[c] and not (set(draw) & window)
+        assert torch.equal(tg[r], torch.from_numpy(tags)[items[r]].long())
+    # without random pads: zeros; nce loss: one global pool, no tags
+    tb2 = SeqTrainBatcher(_cfg(pad_random_sample=False, loss='nce'), st, seed=3)
+    it2, ng2, mk2, tg2 = tb2.batch(idx)
+    assert torch.equal(mk2, mask) and bool((it2[mk2 == 0] == 0).all()) and torch.equal(it2[mk2 == 1], items[mask == 1])
+    assert ng2.shape[1] == 1 and tg2.shape == (len(want), 0)
+
+
+def test_negative_sampling_is_uniform_without_replacement():
+    from REC.data.batcher import _draw_without_replacement
+    g = torch.Generator().manual_seed(1)
+    pool = torch.arange(10, 50)                                   # 40 items
+    black = torch.tensor([[10, 11, 12, 99]]).repeat(4000, 1)      # 3 of them blacklisted
+    out = _draw_without_replacement(pool, 5, black, g)
+    assert bool(((out >= 13) & (out < 50)).all())
+    assert all(len(set(r)) == 5 for r in out[:200].tolist())
+    freq = torch.bincount(out.reshape(-1), minlength=50)[13:50].float()
+    p = 5 / 37
+    sigma = math.sqrt(4000 * p * (1 - p))
+    assert float((freq - 4000 * p).abs().max()) < 5 * sigma       # every admissible item equally likely
+    # exhausting a pool: all remaining items, each once
+    out2 = _draw_without_replacement(pool, 37, black[:3], g)
+    assert all(sorted(r) == list(range(13, 50)) for r in out2.tolist())
+    with pytest.raises(ValueError):
+        _draw_without_replacement(pool[:6], 5, black[:1], g)
+
+
+def test_eval_batch_matches_reference_collate():
+    from REC.data import SeqEvalBatcher, SeqStore
+    user_seq, train_len, tags = _data(seed=5)
+    st = SeqStore(user_seq, train_len, tags)
+    L, E = 8, 4
+    for phase in ("valid", "test"):
+        eb = SeqEvalBatcher(_cfg(), st, phase=phase)
+        seen = []
+        for uid, item_seq, target, (hu, hi), pos_u, _, tt, outlier in eb:
+            for r, u in enumerate(uid.tolist()):                 # evalset.py:80-150 restated
+                seq = user_seq[u]
+                last = train_len[u] if phase == "valid" else len(seq) - E
+                hist, tgt = seq[:last], seq[last:last + E]
+                pad = [0] * max(0, L - len(hist)) + hist[-L:]
+                assert item_seq[r].tolist() == pad and target[r].tolist() == tgt
+                assert hi[hu == r].tolist() == hist
+                assert tt[r].tolist() == [[int(x) for x in tags[i]] for i in tgt]
+
+                def fixed(i):
+                    t = tags[i]
+                    return [False] * len(t) if t.all() else t.tolist()
+                cover = [any(col) for col in zip(*[fixed(i) for i in hist])]
+                unc = any(tc and not cover[k] for i in tgt for k, tc in enumerate(fixed(i)))
+                assert bool(outlier[r]) == unc
+                seen.append(u)
+            assert torch.equal(pos_u, torch.arange(uid.numel())[:, None].repeat(1, E))
+        assert seen == list(range(1, len(user_seq)))
+
+
+def test_sharding_matches_the_reference_samplers():
+    from REC.data import SeqEvalBatcher, SeqStore, SeqTrainBatcher
+    user_seq, train_len, tags = _data(seed=7, n_users=33)
+    st = SeqStore(user_seq, train_len, tags)
+    cfg = _cfg(train_batch_size=5)
+    ranks = [SeqTrainBatcher(cfg, st, rank=r, world=2, seed=11) for r in range(2)]
+    n = ranks[0].loc.shape[0]
+    got = []
+    for tb in ranks:
+        assert tb.n_neg == math.ceil(64 / 2 / 5)
+        rows = sum(b[0].shape[0] for b in tb)
+        assert rows == math.ceil(n / 2)
+        got.append(rows)
+    # same epoch -> the two ranks' index sets partition one shared permutation
+    for tb in ranks:
+        tb.epoch = 0
+    perm = torch.randperm(n, generator=torch.Generator().manual_seed(11))
+    total = math.ceil(n / 2) * 2
+    perm = torch.cat([perm, perm[:total - n]])
+    for r, tb in enumerate(ranks):
+        # the first real item of each window identifies the sample
+        first_real = torch.tensor([user_seq[int(u)][max(0, int(e) - 8)] for u, e in tb.loc[perm[r::2]].tolist()])
+        tb.epoch = 0
+        rows = torch.cat([b[0][torch.arange(b[0].shape[0]), (b[2] == 1).float().argmax(1)] for b in tb])
+        assert torch.equal(rows, first_real)
+    ev = [SeqEvalBatcher(cfg, st, rank=r, world=2) for r in range(2)]
+    u0 = torch.cat([b[0] for b in ev[0]]).tolist()
+    u1 = torch.cat([b[0] for b in ev[1]]).tolist()
+    assert u0 == list(range(1, 34, 2)) and u1 == list(range(2, 34, 2)) and ev[0].num_total_examples == 33
