@@ -195,7 +195,7 @@ def main():
             "value": round(value, 2), "unit": "seq/s" if args.mode == "train" else "users/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1000 * elapsed / args.steps, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"{args.config}: HSTU Pixel8M-shaped {args.mode} step, L={L} P={P} D={D} {cfg['n_layers']} layers x "
+            "config": {"workload": f"{args.config}: HSTU {'Pixel8M' if args.config != 'cfg2' else 'MerRec'}-shaped {args.mode} step, L={L} P={P} D={D} {cfg['n_layers']} layers x "
                                    f"{cfg['n_heads']} heads, {C} prior heads, N={N} items, {cfg['num_negatives']} negatives/pool, "
                                    f"B={B}/GPU, loss={cfg['loss']}, bf16-mixed, fused AdamW over all parameters",
                        "global_batch": world * B, "seq_len": L, "parallelism": f"dp{world}"},

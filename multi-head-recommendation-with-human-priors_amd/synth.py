@@ -24,11 +24,14 @@ class SyntheticData:
         self.P = config['pred_len']
         self.E = config['eval_pred_len']
         self.C = C = config['num_prior_head'] if config['loss'] == 'prior' else 1
-        self.by_cat = bool(config['neg_sample_by_cat']) and config['loss'] == 'prior'
+        self.by_event = (config['category_by'] or 'item') == 'event'     # categories = interaction event types (MerRec)
+        self.by_cat = bool(config['neg_sample_by_cat']) and config['loss'] == 'prior' and not self.by_event
         self.world = world
         g = np.random.default_rng(seed)                       # item-level structure is the same on every rank
         tags = g.random((N, C)) < 0.375
         tags[np.arange(N), g.integers(0, C, N)] = True
+        if (config['category_by'] or 'item') == 'event':      # every item admissible in every head (batchset.py:36-38)
+            tags[:] = True
         tags[0] = False
         self.item_tags = torch.from_numpy(tags).to(device)                              # [N,C] bool
         self.category_to_int = {f"cat{c}": c for c in range(C)}
@@ -71,7 +74,10 @@ class SyntheticData:
             neg = torch.stack(pools, dim=1)
         else:
             neg = self._uniform_items((B, 1, n_neg))
-        if self.config['loss'] == 'prior':
+        if self.config['loss'] == 'prior' and self.by_event:   # one event type per interaction (trainset.py:137-143)
+            ev = torch.randint(0, C, (B, W), generator=self.gen, device=dev)
+            tags = torch.nn.functional.one_hot(ev, C).long() * mask[..., None]
+        elif self.config['loss'] == 'prior':
             tags = self.item_tags[items].long()
         else:
             tags = torch.zeros(B, 0, dtype=torch.long, device=dev)
@@ -89,7 +95,10 @@ class SyntheticData:
         keep = item_seq != 0
         hu = torch.cat([torch.nonzero(keep)[:, 0], torch.arange(B, device=dev).repeat_interleave(hist_extra)])
         hi = torch.cat([item_seq[keep], older.reshape(-1)])
-        target_tags = self.item_tags[target].long()
+        if self.by_event:
+            target_tags = torch.nn.functional.one_hot(torch.randint(0, self.C, (B, E), generator=self.gen, device=dev), self.C).long()
+        else:
+            target_tags = self.item_tags[target].long()
         positive_u = torch.arange(B, device=dev)[:, None].repeat(1, E)
         users = torch.arange(B, device=dev)
         outlier = torch.zeros(B, dtype=torch.bool, device=dev)
@@ -126,4 +135,13 @@ CONFIGS = {
                                                    num_prior_head=4, num_segment_head=1, head_interaction='multiplicative',
                                                    eval_num_cats=4, neg_sample_by_cat=True,
                                                    optim_args={'learning_rate': 1e-4, 'weight_decay': 0.0})),
+    # BASELINE.json configs[2]: HSTU MerRec-shaped, seqlen 512, size-4 (D = 1024, 16 layers x 16 heads), 8 event-type prior
+    # heads on one shared negative pool, prior given at test (the catalog size 2^20 is an assumption)
+    "cfg2": dict(item_num=1 << 20, cfg=base_config(MAX_ITEM_LIST_LENGTH=512, pred_len=1, eval_pred_len=1, n_layers=16, n_heads=16,
+                                                    item_embedding_size=1024, hstu_embedding_size=1024, train_batch_size=64,
+                                                    eval_batch_size=64, num_negatives=4096, loss='prior', medusa_num_layers=1,
+                                                    num_prior_head=8, num_segment_head=1, head_interaction='multiplicative',
+                                                    eval_num_cats=8, neg_sample_by_cat=False, category_by='event',
+                                                    prior_given_at_test=True, dataset='merrec-synthetic',
+                                                    optim_args={'learning_rate': 1e-4, 'weight_decay': 0.0})),
 }
