@@ -233,7 +233,7 @@ class MultiHeadDecoding:
             self._tok_cache[key] = (q_all, p_all, o_all)
         return self._tok_cache[key]
 
-    def _grouped_loss(self, head_rows, e_rows, negs_g, valid_g, head_for_p, log_group, p_row_mask=None):
+    def _grouped_loss(self, head_rows, e_rows, negs_g, valid_g, head_for_p, log_group, p_row_mask=None, q_all=None):
         """Sampled-softmax loss of G (token mask, negative pool) groups in ONE fused launch per kernel.
         valid_g [G,B,L,P] bool (offset fastest), negs_g [G,n_neg,D] bf16, head_for_p [G,P].  Returns (mean loss per (group, offset)
         [G,P] fp32, logs of `log_group` or None).  No host sync: tokens are compacted by scatter at fixed capacity
@@ -243,7 +243,8 @@ class MultiHeadDecoding:
         G, B, L, P = valid_g.shape
         dev = valid_g.device
         n_slots = B * P * L
-        q_all, p_all, o_all = self._token_tables(B, dev, head_for_p)
+        q_static, p_all, o_all = self._token_tables(B, dev, head_for_p)
+        q_all = q_static if q_all is None else q_all          # (a model may pick the query row per token itself: ComiRec)
         from mhr_amd import ops
         q_idx, p_idx, o_idx, n_tok = ops.token_compact(valid_g.reshape(G, n_slots), q_all, p_all, o_all)
         cap = q_idx.shape[1]
@@ -431,15 +432,18 @@ class MultiHeadDecoding:
         return self._item_cache[1], self._item_cache[2]
 
     @torch.no_grad()
-    def _decode_topk(self, last, all_item_feature, all_item_tags, target_tags, history, k, suppress_history, stats, n_ids):
+    def _decode_topk(self, last, all_item_feature, all_item_tags, target_tags, history, k, suppress_history, stats, n_ids,
+                     heads_n=None):
         """Heads at the last position -> catalog scoring with tag / pad / history / switch masks -> exact per-head top-k.
         Replaces reference hstu.py:915-1015 + trainer.py:724-726 + collector.py:245 without the [B,H,N] tensor."""
         from mhr_amd import ops
-        B = last.shape[0]
+        B = (last if heads_n is None else heads_n).shape[0]
         H = self.medusa_num_heads
-        dev = last.device
+        dev = (last if heads_n is None else heads_n).device
         switched_off, logs = None, {'num_samples': self.eval_pred_len * B}
-        if self.prior_switch is not None:
+        if heads_n is not None:                          # the model brings its own L2-normalised [B,H,D] read-outs
+            pass
+        elif self.prior_switch is not None:
             heads_n, pred = self._heads_at_last(last, want_switch=True)
             self._switch_logs(pred, target_tags, logs)
             if self.use_prior_switch_test:
@@ -461,11 +465,13 @@ class MultiHeadDecoding:
         return FusedTopK(vals.view(B, H, k), idx.view(B, H, k), logs)
 
     @torch.no_grad()
-    def _dense_scores(self, last, all_item_feature, all_item_tags, target_tags, save_for_eval):
+    def _dense_scores(self, last, all_item_feature, all_item_tags, target_tags, save_for_eval, heads_n=None):
         """Reference contract of `predict`: dense scores [B,H,N] fp32 with -inf masks (hstu.py:915-1016 / hllm.py:785-883)."""
         S, C = self.num_segment_head, self.num_prior_head
         pred = None
-        if self.prior_switch is not None:
+        if heads_n is not None:
+            heads = heads_n
+        elif self.prior_switch is not None:
             heads, pred = self._heads_at_last(last, want_switch=True)                              # [B,H,D] fp32, [B,n] bool
         else:
             heads = self._heads_at_last(last)
@@ -491,11 +497,11 @@ class MultiHeadDecoding:
                     scores[:, S:].masked_fill_(off.unsqueeze(-1), float('-inf'))
                 else:
                     scores.masked_fill_(off.repeat(1, S).unsqueeze(-1), float('-inf'))
-        wandb_logs = {'num_samples': self.eval_pred_len * last.shape[0]}
+        wandb_logs = {'num_samples': self.eval_pred_len * heads.shape[0]}
         if pred is not None:
             self._switch_logs(pred, target_tags, wandb_logs)
         saved_user = saved_head = None
         if save_for_eval:
-            saved_user = last.float().cpu().numpy()
+            saved_user = None if last is None else last.float().cpu().numpy()
             saved_head = heads.float().cpu().numpy()
         return scores, wandb_logs, saved_user, saved_head

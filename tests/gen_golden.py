@@ -371,6 +371,48 @@ def run_llama_cases():
         print("wrote", name, "loss", loss.item())
 
 
+def run_comirec_cases():
+    """ComiRec baseline (REC/model/IDNet/comirec.py) on the reference itself: one training step with gradients and one
+    predict call."""
+    import numpy as np
+    import torch
+    from REC.model.IDNet.comirec import ComiRec
+    N, B, L, P, n_neg = 301, 5, 12, 3, 9
+    cfg = base_cfg(pred_len=P, eval_pred_len=P, interest_num=3, interest_hidden=8, loss="nce", n_layers=2, n_heads=2)
+    torch.manual_seed(41)
+    model = ComiRec(cfg, FakeData(N, 1))
+    model._verbose = False
+    model.eval()                                            # dropout off (attention_net holds one)
+    with torch.no_grad():                                   # trunc-normal(0.02) leaves the interests almost tied: spread them
+        for n_, p_ in model.named_parameters():
+            if n_.startswith("attention_net"):
+                p_.mul_(20.0)
+    g = torch.Generator().manual_seed(42)
+    items, neg, mask, tags = make_batch(g, N, B, L, P, 1, n_neg, 1, None)
+    out = model((items, neg, mask, tags))
+    out["loss"].backward()
+    save = np_state(model)
+    save.update({"in/items": items.numpy(), "in/neg_items": neg.numpy(), "in/mask": mask.numpy(), "cfg/json": np.array(cfg_json(cfg, N, 1))})
+    for k, v in out.items():
+        save["out/" + k] = np.float64(float(v))
+    grads = dict(model.named_parameters())
+    for k in ("attention_net.0.weight", "attention_net.3.weight", "_hstu._attention_layers.0._uvqk", "logit_scale"):
+        save["grad/" + k] = grads[k].grad.numpy()
+    ge = grads["item_embedding.weight"].grad
+    save["grad/item_embedding.weight"] = ge.numpy()
+    seq = torch.randint(1, N, (4, L), generator=g)
+    seq[0, :5] = 0
+    seq[2, :1] = 0
+    with torch.no_grad():
+        feat = model.compute_item_all()
+        import contextlib, io
+        with contextlib.redirect_stdout(io.StringIO()):
+            scores, _, _, _ = model.predict(seq, None, feat, None, None)
+    save.update({"in/item_seq": seq.numpy(), "out/item_feature": feat.numpy(), "out/scores": scores.numpy()})
+    np.savez_compressed(os.path.join(OUT, "comirec_nce.npz"), **save)
+    print("wrote comirec_nce loss", float(out["loss"]))
+
+
 def main():
     _setup()
     os.makedirs(OUT, exist_ok=True)
@@ -379,6 +421,9 @@ def main():
         return
     if len(sys.argv) > 1 and sys.argv[1] == "llama":
         run_llama_cases()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "comirec":
+        run_comirec_cases()
         return
     # F1: plain next-item NCE, identity heads
     run_train_case("hstu_nce_tiny", base_cfg(), N=501, B=4, n_neg=8, seed=11)
@@ -419,6 +464,7 @@ def main():
     run_schedule_and_adam()
     switch_cases()
     run_llama_cases()
+    run_comirec_cases()
 
 
 if __name__ == "__main__":

@@ -361,3 +361,50 @@ def test_fit_and_evaluate_on_the_device_batchers(rec):
     after = tr.evaluate(valid, item_tags=store.item_tags)
     key = [k for k in after if k.startswith("pred_")][-1]
     assert after[key]["recall@20"] > before[key]["recall@20"] + 0.1, (before[key], after[key])
+
+
+def test_comirec_vs_reference_golden(rec):
+    """ComiRec baseline on the shared kernels against the reference's own comirec.py outputs."""
+    from REC.config.configurator import Config
+    from REC.utils import get_model
+    from oracle import decode_oracle as DO
+    g = load_golden("comirec_nce")
+    c = json.loads(str(g["cfg/json"]))
+    c["int_to_category"] = {int(k): v for k, v in c["int_to_category"].items()}
+    model = get_model("ComiRec")(Config(config_dict=c), FakeData(c))
+    sd = {k[2:]: torch.from_numpy(np.array(v)) for k, v in g.items() if k.startswith("w/")}
+    model.load_state_dict(sd, strict=True)
+    model = model.cuda().train()
+    batch = tuple(torch.from_numpy(g["in/" + k]).cuda() for k in ("items", "neg_items", "mask")) + (None,)
+    out = model(batch)
+    assert abs(float(out["loss"]) - float(g["out/loss"])) <= 2e-2 * abs(float(g["out/loss"])) + 2e-3
+    for k, v in g.items():
+        if k.startswith("out/nce_top") or k == "out/nce_samples":
+            assert abs(float(out[k[4:]]) - float(v)) <= 0.15 * max(1.0, abs(float(v))), k
+    out["loss"].backward()
+    dense = model.finish_sparse_grad().to_dense().cpu().numpy()
+    ref = g["grad/item_embedding.weight"]
+    assert np.abs(dense - ref).max() < 6e-2 * np.abs(ref).max()
+    named = dict(model.named_parameters())
+    for k, v in g.items():
+        if k.startswith("grad/") and k != "grad/item_embedding.weight":
+            got = named[k[5:]].grad
+            assert got is not None, k
+            assert float((got.cpu() - torch.from_numpy(v)).abs().max()) < 6e-2 * float(np.abs(v).max()) + 1e-5, k
+    model.eval()
+    seq = torch.from_numpy(g["in/item_seq"]).cuda()
+    feat = model.compute_item_all()
+    np.testing.assert_allclose(feat.cpu().numpy(), g["out/item_feature"], rtol=1e-5, atol=1e-6)
+    scores, _, _, _ = model.predict(seq, None, feat, None, None)
+    assert np.abs(scores.cpu().numpy() - g["out/scores"]).max() < 2e-2                      # cosines, bf16 encoder
+    k = 20
+    fused = model.predict_topk(seq, feat, None, None, None, k=k, suppress_history=False)
+    users = model._interest_heads(seq).to(torch.bfloat16).float().cpu()
+    items = torch.from_numpy(g["out/item_feature"]).to(torch.bfloat16).float()
+    dense_s = (users @ items.T).numpy()
+    dense_s[:, :, 0] = -np.inf
+    rv, ri = DO.per_head_topk(dense_s, k)
+    fi, fv = fused.indices.cpu().numpy(), fused.values.cpu().numpy()
+    for b, h, j in np.argwhere(fi != ri):                                                     # only numerical ties may differ
+        assert abs(dense_s[b, h, fi[b, h, j]] - rv[b, h, j]) < 2e-6
+    np.testing.assert_allclose(fv, rv, rtol=1e-4, atol=1e-6)

@@ -187,3 +187,28 @@ def test_llama_decoder_oracle_matches_reference(name):
             assert float((w[k[2:]].grad - torch.tensor(v)).abs().max()) <= 1e-5 * float(np.abs(v).max()), k
             n += 1
     assert n >= 7
+
+
+# ------------------------------------------------------------------------------------------------
+# ComiRec baseline: multi-interest read-out on the HSTU encoder
+# ------------------------------------------------------------------------------------------------
+def test_comirec_oracle_matches_reference():
+    from oracle import comirec_oracle as CO
+    g = load_golden("comirec_nce")
+    cfg = cfg_of(g)
+    w = weights_of(g, requires_grad=True)
+    batch = tuple(torch.from_numpy(g["in/" + k]) for k in ("items", "neg_items", "mask")) + (None,)
+    out = CO.train_forward(w, cfg, batch)
+    for k, v in g.items():
+        if k.startswith("out/") and k not in ("out/item_feature", "out/scores"):
+            assert abs(float(out[k[4:]]) - float(v)) <= 2e-5 * max(1.0, abs(float(v))), k
+    out["loss"].backward()
+    for k, v in g.items():
+        if k.startswith("grad/"):
+            got = w[k[5:]].grad
+            assert float((got - torch.from_numpy(v)).abs().max()) <= 2e-5 * float(np.abs(v).max()) + 1e-7, k
+    with torch.no_grad():
+        feat = HO.compute_item_all(w)
+        np.testing.assert_allclose(feat.numpy(), g["out/item_feature"], rtol=1e-5, atol=1e-6)
+        scores = CO.predict_scores(w, cfg, torch.from_numpy(g["in/item_seq"]), feat)
+    np.testing.assert_allclose(scores.numpy(), g["out/scores"], rtol=2e-5, atol=2e-6)
