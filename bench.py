@@ -273,7 +273,8 @@ def main():
                 if knames and files:
                     recs = [json.load(open(files[-1]))["kernels"].get(k) for k in knames]
                     if recs[0]:
-                        out["roofline"]["traffic"] = sum(r["hbm_bytes_per_launch"] for r in recs if r)
+                        key_ = "hbm_bytes_max_launch" if (args.mode == "eval" and "hbm_bytes_max_launch" in recs[0]) else "hbm_bytes_per_launch"
+                        out["roofline"]["traffic"] = sum(r[key_] for r in recs if r)
                         out["roofline"]["traffic_source"] = os.path.relpath(files[-1], ROOT)
             out["kernel_ms_per_step"] = per_step
             if "mhr_embedding_gather_fwd" in prof and args.mode == "train":

@@ -55,10 +55,10 @@ def kernel_stats(rnd, leg, top=40):
     print("wrote", out)
 
 
-def traffic(rnd):
+def traffic(rnd, mode=""):
     acc = {}
     for leg, counter, scale in (("fetch", "FETCH_SIZE", 2.0 * 1024), ("write", "WRITE_SIZE", 1024.0)):
-        f = newest(os.path.join(ROOT, "gpurun_out", f"pmc_{rnd}_{leg}", "*", "*_counter_collection.csv"))
+        f = newest(os.path.join(ROOT, "gpurun_out", f"pmc_{rnd}_{mode}{leg}", "*", "*_counter_collection.csv"))
         if f is None:
             continue
         for r in csv.DictReader(open(f)):
@@ -74,10 +74,12 @@ def traffic(rnd):
         fb = sum(e["fetch"]) / max(1, len(e["fetch"]))
         wb = sum(e["write"]) / max(1, len(e["write"]))
         out[k] = {"launches_sampled": len(e["fetch"]), "hbm_read_bytes_per_launch": round(fb), "hbm_write_bytes_per_launch": round(wb),
-                  "hbm_bytes_per_launch": round(fb + wb)}
+                  "hbm_bytes_per_launch": round(fb + wb),
+                  # the largest launch of the kernel (eval: the full-catalog pass next to the two small sample passes)
+                  "hbm_bytes_max_launch": round(max(e["fetch"], default=0) + max(e["write"], default=0))}
     if out:
-        p = os.path.join(ROOT, "profiles", f"{rnd}_hbm_traffic.json")
-        json.dump({"how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `python bench.py --no-cpu-baseline "
+        p = os.path.join(ROOT, "profiles", f"{rnd}_hbm_traffic{'_eval' if mode else ''}.json")
+        json.dump({"how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `python bench.py " + ("--mode eval " if mode else "") + "--no-cpu-baseline "
                           "--steps 4 --warmup 2`; FETCH_SIZE KB x 2 (gfx950 tallies 128-B requests at 64 B), WRITE_SIZE KB x 1; "
                           "mean over all launches of the kernel", "kernels": out}, open(p, "w"), indent=1)
         print("wrote", p)
@@ -185,4 +187,5 @@ if __name__ == "__main__":
     for leg in ("train", "eval", "hllm_train"):
         kernel_stats(rnd, leg)
     traffic(rnd)
+    traffic(rnd, "eval_")
     readme(rnd)
