@@ -89,6 +89,11 @@ int mhr_adam_rows(float* w, float* m, float* v, int64_t n_rows, int dim,
 int mhr_adam_flat(float* w, const float* g, float* m, float* v, int64_t n, float grad_scale,
                   float lr, float beta1, float beta2, float eps, float weight_decay, int step, void* w_bf16, void* stream);
 
+/* out[c] += sum_r x[r, c]: x bf16 [rows, cols] (cols % 8 == 0), out fp32 [cols].  The reduction of split-K weight-gradient
+ * partials and of bias gradients straight into the flat gradient buffer (autograd's accumulate semantics: the caller
+ * zeroes the buffer once per step).  Many-row inputs are reduced by several workgroups meeting through float atomics. */
+int mhr_sum_rows_into(const void* x_bf16, int64_t rows, int64_t cols, float* out, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Normalisation / gating (HSTU layer, model/IDNet/hstu.py:213-219, 241, 277-285).
  * ---------------------------------------------------------------------------------------- */

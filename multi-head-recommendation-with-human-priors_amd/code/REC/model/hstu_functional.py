@@ -13,6 +13,7 @@ from mhr_amd import ops
 
 import os
 _SPLITK_MAX = int(os.environ.get("MHR_SPLITK_MAX", "16"))
+_SUM_KERNEL = os.environ.get("MHR_SUM_KERNEL", "1") != "0"
 
 
 class LayerNormFn(Function):
@@ -78,17 +79,14 @@ class SplitKLinearFn(Function):
         return y
 
     @staticmethod
-    def _into(leaf, parts, dim0_sum):
-        """Write (first use in this step) or add the fp32 reduction of `parts` over dim 0 into leaf.grad."""
-        from mhr_amd import optim
-        if getattr(leaf, "_mhr_epoch", -1) != optim.GRAD_EPOCH:
-            leaf._mhr_epoch = optim.GRAD_EPOCH
-            if dim0_sum:
-                torch.sum(parts, 0, dtype=torch.float32, out=leaf.grad)
-            else:
-                leaf.grad.copy_(parts)
+    def _into(leaf, parts):
+        """leaf.grad (a view of the optimizer's flat fp32 gradient buffer, zeroed once per step) += sum of `parts` over
+        dim 0: one kernel for the split-K reduction / the bias column sum, no autograd accumulate pass."""
+        g = leaf.grad
+        if _SUM_KERNEL and parts.dtype == torch.bfloat16 and parts.is_contiguous() and g.is_contiguous() and g.numel() % 8 == 0:
+            ops.sum_rows_into(parts, g)
         else:
-            leaf.grad.add_(torch.sum(parts, 0, dtype=torch.float32) if dim0_sum else parts)
+            g.add_(torch.sum(parts, 0, dtype=torch.float32).view_as(g))
 
     @staticmethod
     def backward(ctx, dy):
@@ -107,14 +105,14 @@ class SplitKLinearFn(Function):
         else:
             dw = torch.bmm(xs.transpose(1, 2), dys)               # [S, K, N]
         if ctx.w_leaf is not None:                                # reduction of the split-K partials straight into p.grad
-            SplitKLinearFn._into(ctx.w_leaf, dw if S > 1 else dw[0], S > 1)
+            SplitKLinearFn._into(ctx.w_leaf, dw)
             dw = None
         else:
             dw = torch.sum(dw, 0, dtype=torch.float32) if S > 1 else dw[0].float()      # cast fused into the reduction
         db = None
         if ctx.has_bias:
             if ctx.b_leaf is not None:
-                SplitKLinearFn._into(ctx.b_leaf, dy, True)
+                SplitKLinearFn._into(ctx.b_leaf, dy)
             else:
                 db = torch.sum(dy, 0, dtype=torch.float32)
         return dx, dw, db, None, None

@@ -125,3 +125,67 @@ extern "C" int mhr_rope_inplace(void* x_bf16, int64_t row_stride, const int32_t*
   MHR_CHECK_LAUNCH("rope_inplace");
   return MHR_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// out[c] += sum_r x[r, c]   (x bf16 [rows, cols], out fp32 [cols])
+// ------------------------------------------------------------------------------------------
+// The reduction of split-K weight-gradient partials ([S, N*K] bf16) and the bias gradient (column sums of dy) straight into
+// the optimizer's flat fp32 gradient buffer: torch's generic dim-0 reduce takes 13 us for 8 MB, 26 times per step at cfg1.
+// Block = 32 column threads (8 columns each) x 8 row lanes; row ranges are split over blockIdx.y when there are many rows
+// (then the partial sums meet in out[] through float atomics; with one row range the update is a plain read-modify-write).
+namespace {
+__global__ __launch_bounds__(256) void sum_rows_into_kernel(const bf16_t* __restrict__ x, int64_t rows, int64_t cols,
+                                                            float* __restrict__ out, int64_t rows_per_block) {
+  __shared__ float red[8][32][8];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int64_t c0 = ((int64_t)blockIdx.x * 32 + tx) * 8;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (c0 < cols) {
+    for (int64_t r = r0 + ty; r < r1; r += 8) {
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + r * cols + c0);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += (float)v[e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[ty][tx][e] = acc[e];
+  __syncthreads();
+  if (ty == 0 && c0 < cols) {
+    float s[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      s[e] = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s[e] += red[j][tx][e];
+    }
+    if (gridDim.y > 1) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) atomicAdd(out + c0 + e, s[e]);
+    } else {                                               // 32 contiguous bytes per thread: two 16-byte read-modify-writes
+      f32x4* o = reinterpret_cast<f32x4*>(out + c0);
+      f32x4 a = o[0], b = o[1];
+      a += f32x4{s[0], s[1], s[2], s[3]};
+      b += f32x4{s[4], s[5], s[6], s[7]};
+      o[0] = a;
+      o[1] = b;
+    }
+  }
+}
+}  // namespace
+
+extern "C" int mhr_sum_rows_into(const void* x_bf16, int64_t rows, int64_t cols, float* out, void* stream) {
+  MHR_REQUIRE(x_bf16 && out, "sum_rows_into: null pointer");
+  MHR_REQUIRE(rows >= 0 && cols > 0 && cols % 8 == 0, "sum_rows_into: cols=%lld must be a positive multiple of 8", (long long)cols);
+  MHR_REQUIRE((uintptr_t)out % 16 == 0 && (uintptr_t)x_bf16 % 16 == 0, "sum_rows_into: buffers must be 16-byte aligned");
+  if (rows == 0) return MHR_OK;
+  const int64_t col_blocks = (cols / 8 + 31) / 32;
+  MHR_REQUIRE(col_blocks < (1ll << 31), "sum_rows_into: too many columns");
+  int64_t splits = 1;        // a few row ranges when there are few columns (many would only contend on the same atomics)
+  while (splits < 32 && col_blocks * splits < 512 && rows / (splits * 2) >= 64) splits *= 2;
+  const int64_t rpb = (rows + splits - 1) / splits;
+  hipLaunchKernelGGL(sum_rows_into_kernel, dim3((unsigned)col_blocks, (unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0,
+                     (hipStream_t)stream, (const bf16_t*)x_bf16, rows, cols, out, rpb);
+  MHR_CHECK_LAUNCH("sum_rows_into");
+  return MHR_OK;
+}

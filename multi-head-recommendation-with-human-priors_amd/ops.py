@@ -131,6 +131,16 @@ def adam_flat(w, g, m, v, step, lr, grad_scale=1.0, betas=(0.9, 0.999), eps=1e-8
              betas[0], betas[1], eps, weight_decay, step, _ptr(w_bf16), _stream())
 
 
+def sum_rows_into(x, out):
+    """out [cols] fp32 += column sums of x [rows, cols] bf16 (contiguous)."""
+    _chk(x, "x", torch.bfloat16)
+    _chk(out, "out", torch.float32)
+    cols = out.numel()
+    assert x.numel() % cols == 0
+    _timed_call("mhr_sum_rows_into", x.data_ptr(), x.numel() // cols, cols, out.data_ptr(), _stream())
+    return out
+
+
 # ------------------------------------------------------------------------------------------------
 # normalisation / gate
 # ------------------------------------------------------------------------------------------------

@@ -335,6 +335,21 @@ def test_nce_fwd_bwd(ops, D, n_tok, n_neg, dtype):
     assert abs(float(dls.cpu()) - float(lsr.grad)) < 2e-2 * abs(float(lsr.grad)) + 1e-4
 
 
+@pytest.mark.parametrize("rows,cols", [(16, 1024 * 256), (25600, 256), (3, 64), (1, 8), (4097, 1032)])
+def test_sum_rows_into(ops, rows, cols):
+    """Split-K partial / bias-gradient reduction into an fp32 accumulator: exact fp32 sums of the bf16 inputs up to the
+    summation order (1e-5 relative to the column scale), on top of what the accumulator already holds."""
+    g = torch.Generator().manual_seed(rows + cols)
+    x = bf(torch.randn(rows, cols, generator=g))
+    base = torch.randn(cols, generator=g)
+    out = dev(base.clone())
+    ops.sum_rows_into(dev(x), out)
+    torch.cuda.synchronize()
+    ref = base.double() + x.double().sum(0)
+    scale = float(x.float().abs().sum(0).max()) + 1.0
+    assert float((out.cpu().double() - ref).abs().max()) <= 1e-5 * scale
+
+
 @pytest.mark.parametrize("rows,D", [(7, 64), (300, 256), (33, 1024)])
 def test_add_layernorm_fwd_bwd(ops, rows, D):
     """Fused residual add + LayerNorm vs torch fp32 on the same bf16-rounded branch: x_out exact (fp32 add), xn and
