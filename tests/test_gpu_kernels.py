@@ -224,7 +224,8 @@ def _attn_oracle(h, valid, B, L, Hh, hd, d_out=None):
 
 
 @pytest.mark.parametrize("B,L,Hh,hd", [(3, 12, 2, 8), (2, 40, 4, 16), (2, 33, 2, 32), (2, 200, 8, 32), (1, 70, 2, 64),
-                                       (1, 50, 1, 128), (1, 300, 2, 64), (1, 512, 2, 64)])      # the last one: cfg2's sequence length / head dim
+                                       (1, 50, 1, 128), (1, 300, 2, 64), (1, 512, 2, 64), (2, 260, 3, 32), (1, 257, 1, 16),
+                                       (1, 290, 1, 24)])   # 512 x 64 = cfg2's shape
 def test_hstu_attention_fwd_bwd(ops, B, L, Hh, hd):
     h, valid, d_out = _attn_case(B, L, Hh, hd, 7 + L)
     D = Hh * hd
