@@ -408,3 +408,63 @@ def test_comirec_vs_reference_golden(rec):
     for b, h, j in np.argwhere(fi != ri):                                                     # only numerical ties may differ
         assert abs(dense_s[b, h, fi[b, h, j]] - rv[b, h, j]) < 2e-6
     np.testing.assert_allclose(fv, rv, rtol=1e-4, atol=1e-6)
+
+
+def test_event_category_heads_match_oracle(rec):
+    """The MerRec-style configuration (BASELINE config 2 in miniature): categories are the interaction's EVENT type
+    (`category_by = 'event'`: one-hot tag per position, every item admissible in every head, one shared negative pool) and
+    the prior is given at test time.  One training step (loss, per-head losses, gradients) and `predict` against the
+    fp32 oracle on the same weights and batch."""
+    import mhr_amd.synth as synth
+    from oracle import hstu_oracle as HO
+    from REC.config.configurator import Config, apply_run_fixups
+    from REC.utils import get_model
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(9)
+    cfgd = synth.base_config(MAX_ITEM_LIST_LENGTH=24, pred_len=2, eval_pred_len=2, n_layers=2, n_heads=2, item_embedding_size=64,
+                             hstu_embedding_size=64, loss='prior', num_prior_head=4, num_segment_head=1, medusa_num_layers=1,
+                             eval_num_cats=4, neg_sample_by_cat=False, category_by='event', prior_given_at_test=True,
+                             num_negatives=192, device=dev, hidden_dropout_prob=0.0, attn_dropout_prob=0.0,
+                             dataset='merrec-synthetic', topk=[5, 20])
+    cfg = apply_run_fixups(Config(config_dict=cfgd))
+    data = synth.SyntheticData(cfg, 600, dev)
+    cfg["int_to_category"] = data.int_to_category
+    model = get_model("HSTU")(cfg, data).to(dev).train()
+    with torch.no_grad():                                      # heads start at zero (ResBlock zero_init): make them visible
+        for n_, p_ in model.named_parameters():
+            if n_.startswith("medusa"):
+                p_.add_(0.05 * torch.randn_like(p_))
+    batch = data.train_batch(12)
+    items, neg, mask, tags = batch
+    assert neg.shape[1] == 1 and bool((tags.sum(-1) == mask).all())          # shared pool; one event type per real position
+    out = model(batch)
+    out["loss"].backward()
+    w = HO.tie_repeated_resblocks({k: v.detach().float().cpu().clone().requires_grad_(v.is_floating_point())
+                                   for k, v in model.state_dict().items()})
+    ocfg = dict(cfg.final_config_dict, category_counts=data.category_counts, category_to_int=data.category_to_int, item_num=600)
+    ref = HO.train_forward(w, ocfg, tuple(t.cpu() for t in batch))
+    ref["loss"].backward()
+    assert abs(float(out["loss"]) - float(ref["loss"])) <= 2e-2 * abs(float(ref["loss"])) + 2e-3
+    for k, v in ref.items():
+        if k.startswith("head_nce_"):
+            assert abs(float(out[k]) - float(v)) <= 2e-2 * abs(float(v)) + 2e-3, k
+    named = dict(model.named_parameters())
+    for k in ("_hstu._attention_layers.0._uvqk", "medusa_head.2.0.linear.weight", "logit_scale"):
+        gref = w[k].grad
+        assert float((named[k].grad.cpu() - gref).abs().max()) <= 6e-2 * float(gref.abs().max()) + 1e-5, k
+    dense = model.finish_sparse_grad().to_dense().cpu()
+    gref = w["item_embedding.weight"].grad
+    assert float((dense - gref).abs().max()) <= 6e-2 * float(gref.abs().max())
+    # predict with the prior given at test time: heads whose event type is absent from the targets are switched off
+    model.eval()
+    eb = data.eval_batch(6)
+    seq, tt = eb[1], eb[6]
+    feat = model.compute_item_all()
+    tags_cn = data.item_tags.long().t().contiguous()
+    scores, _, _, _ = model.predict(seq, None, feat, tags_cn, tt)
+    wd = {k: v.detach() for k, v in w.items()}
+    sref = HO.predict_scores(wd, ocfg, seq.cpu(), feat.cpu(), tags_cn.cpu(), tt.cpu())
+    s, r = scores.cpu().numpy(), sref.numpy()
+    assert np.array_equal(np.isinf(s), np.isinf(r)) and np.isinf(r).any()
+    fin = np.isfinite(r)
+    assert np.abs(s[fin] - r[fin]).max() < 2e-2
