@@ -145,7 +145,9 @@ int mhr_hstu_attn_fwd(const void* q, const void* k, const void* v, int64_t row_s
  * Backward: given d_out ([B*L, n_heads*head_dim] bf16) writes the gradients w.r.t. the PRE-activation
  * q,k,v (chain rule through the load-time SiLU included when apply_silu != 0) into column blocks with row
  * stride d_stride (bf16).  act_* are the activated operands saved by the forward (pass q,k,v themselves
- * when apply_silu == 0).  Two passes per (batch, head) workgroup, no atomics: bitwise reproducible. */
+ * when apply_silu == 0) - or all NULL with apply_silu != 0: silu(q), silu(k), silu(v) are then recomputed from the
+ * pre-activation inputs while they are staged (the forward need not store them: 3 B*L*D bf16 less to write and to read).
+ * Two passes per (batch, head) workgroup, no atomics: bitwise reproducible. */
 int mhr_hstu_attn_bwd(const void* q_pre, const void* k_pre, const void* v_pre, int64_t row_stride,
                       const void* act_q, const void* act_k, const void* act_v, int64_t act_stride,
                       const uint8_t* key_valid, const void* d_out,

@@ -156,20 +156,21 @@ class HSTUCoreFn(Function):
     @staticmethod
     def forward(ctx, h, key_valid, B, L, n_heads, head_dim, eps, dropout_p, seed):
         D = n_heads * head_dim
-        a, act = ops.hstu_attn_fwd(h, key_valid, B, L, n_heads, head_dim, apply_silu=True, save_act=True)
+        # the activated q / k / v are NOT saved: the backward recomputes silu() while it stages them (h is kept anyway)
+        a, _ = ops.hstu_attn_fwd(h, key_valid, B, L, n_heads, head_dim, apply_silu=True, save_act=False)
         o, mean, rstd = ops.ln_gate_fwd(h, a, D, torch.bfloat16, eps, dropout_p, seed)
-        ctx.save_for_backward(h, key_valid, a, act, mean, rstd)
+        ctx.save_for_backward(h, key_valid, a, mean, rstd)
         ctx.cfg = (B, L, n_heads, head_dim, dropout_p, seed)
         return o
 
     @staticmethod
     def backward(ctx, d_o):
-        h, key_valid, a, act, mean, rstd = ctx.saved_tensors
+        h, key_valid, a, mean, rstd = ctx.saved_tensors
         B, L, n_heads, head_dim, dropout_p, seed = ctx.cfg
         D = n_heads * head_dim
         dh = torch.empty_like(h)
         da = ops.ln_gate_bwd(d_o.contiguous(), h, a, mean, rstd, dh, D, dropout_p, seed)
-        ops.hstu_attn_bwd(h, act, key_valid, da, dh, B, L, n_heads, head_dim, apply_silu=True)
+        ops.hstu_attn_bwd(h, None, key_valid, da, dh, B, L, n_heads, head_dim, apply_silu=True)
         return dh, None, None, None, None, None, None, None, None
 
 

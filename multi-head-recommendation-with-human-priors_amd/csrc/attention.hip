@@ -155,9 +155,13 @@ __global__ __launch_bounds__(256, NKS <= 2 ? 3 : 1) void hstu_attn_bwd_kernel(
   const int b = blockIdx.x / n_heads, head = blockIdx.x % n_heads;
   const int64_t row0 = (int64_t)b * L;
   const int hoff = head * hd;
-  const bf16_t* aq = act_q + row0 * act_stride + hoff;
-  const bf16_t* ak = act_k + row0 * act_stride + hoff;
-  const bf16_t* av = act_v + row0 * act_stride + hoff;
+  // without saved activations (act_q == nullptr) silu(q), silu(k), silu(v) are recomputed from the pre-activation values
+  // while they are staged / loaded: 39 MB less to write in the forward and to read here per layer at cfg1
+  const bool redo = act_q == nullptr;
+  const int64_t a_stride = redo ? stride : act_stride;
+  const bf16_t* aq = redo ? q_pre + row0 * stride + hoff : act_q + row0 * act_stride + hoff;
+  const bf16_t* ak = redo ? k_pre + row0 * stride + hoff : act_k + row0 * act_stride + hoff;
+  const bf16_t* av = redo ? v_pre + row0 * stride + hoff : act_v + row0 * act_stride + hoff;
   const bf16_t* dop = d_out + row0 * do_stride + hoff;
   const bool chain = apply_silu != 0;
 
@@ -165,7 +169,7 @@ __global__ __launch_bounds__(256, NKS <= 2 ? 3 : 1) void hstu_attn_bwd_kernel(
   // K / V) fragments straight from global memory, one dependent L2 round trip per 8 MFMAs (386 MB of traffic per
   // launch against 65 MB of operands, 176 us per layer at cfg1).
   ASTAMP(0)
-  stage_tiles<NKS>(T0, aq, act_stride, L, Lp, hd, false, nullptr, 0);
+  stage_tiles<NKS>(T0, aq, a_stride, L, Lp, hd, redo, nullptr, 0);
   stage_tiles<NKS>(T1, dop, do_stride, L, Lp, hd, false, nullptr, 0);
   build_valid_mask(vmask, key_valid + row0, L, nb);
   __syncthreads();
@@ -184,8 +188,12 @@ __global__ __launch_bounds__(256, NKS <= 2 ? 3 : 1) void hstu_attn_bwd_kernel(
     bf16x8 kf[NKS], vf[NKS];
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
-      kf[ks] = load_frag(ak, act_stride, key, L, ks * 16 + 8 * half, hd);
-      vf[ks] = load_frag(av, act_stride, key, L, ks * 16 + 8 * half, hd);
+      kf[ks] = load_frag(ak, a_stride, key, L, ks * 16 + 8 * half, hd);
+      vf[ks] = load_frag(av, a_stride, key, L, ks * 16 + 8 * half, hd);
+      if (redo) {
+        kf[ks] = silu8(kf[ks]);
+        vf[ks] = silu8(vf[ks]);
+      }
     }
     f32x16 dvacc[ND], dkacc[ND];
 #pragma unroll
@@ -261,8 +269,8 @@ __global__ __launch_bounds__(256, NKS <= 2 ? 3 : 1) void hstu_attn_bwd_kernel(
   ASTAMP(2)
   __syncthreads();                      // everyone is done reading the Q / dO tiles
   ASTAMP(3)
-  stage_tiles<NKS>(T0, ak, act_stride, L, Lp, hd, false, nullptr, 0);
-  stage_tiles<NKS>(T1, av, act_stride, L, Lp, hd, false, nullptr, 0);
+  stage_tiles<NKS>(T0, ak, a_stride, L, Lp, hd, redo, nullptr, 0);
+  stage_tiles<NKS>(T1, av, a_stride, L, Lp, hd, redo, nullptr, 0);
   __syncthreads();
   ASTAMP(4)
   for (int it = 0; it * 4 < nb; ++it) {
@@ -272,7 +280,8 @@ __global__ __launch_bounds__(256, NKS <= 2 ? 3 : 1) void hstu_attn_bwd_kernel(
     bf16x8 qf[NKS], dof[NKS];
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
-      qf[ks] = load_frag(aq, act_stride, qcol, L, ks * 16 + 8 * half, hd);
+      qf[ks] = load_frag(aq, a_stride, qcol, L, ks * 16 + 8 * half, hd);
+      if (redo) qf[ks] = silu8(qf[ks]);
       dof[ks] = load_frag(dop, do_stride, qcol, L, ks * 16 + 8 * half, hd);
     }
     f32x16 dqacc[ND];
@@ -370,12 +379,16 @@ extern "C" int mhr_hstu_attn_bwd(const void* q_pre, const void* k_pre, const voi
                                  const void* act_q, const void* act_k, const void* act_v, int64_t act_stride,
                                  const uint8_t* key_valid, const void* d_out, void* dq, void* dk, void* dv, int64_t d_stride,
                                  int B, int L, int n_heads, int head_dim, int apply_silu, void* stream) {
-  MHR_REQUIRE(act_q && act_k && act_v && key_valid && d_out && dq && dk && dv, "hstu_attn_bwd: null pointer");
+  MHR_REQUIRE(key_valid && d_out && dq && dk && dv, "hstu_attn_bwd: null pointer");
+  MHR_REQUIRE((act_q != nullptr) == (act_k != nullptr) && (act_k != nullptr) == (act_v != nullptr),
+              "hstu_attn_bwd: act_q/act_k/act_v must be all set or all null");
+  MHR_REQUIRE(act_q || apply_silu, "hstu_attn_bwd: without saved activations the inputs are recomputed as silu(pre): apply_silu must be set");
   MHR_REQUIRE(!apply_silu || (q_pre && k_pre && v_pre), "hstu_attn_bwd: pre-activation inputs required with apply_silu");
   AttnShape sh;
   MHR_REQUIRE(attn_shape(head_dim, sh), "hstu_attn_bwd: head_dim=%d unsupported (multiple of 8, <= 128)", head_dim);
   MHR_REQUIRE(B > 0 && L > 0 && n_heads > 0, "hstu_attn_bwd: bad sizes");
-  MHR_REQUIRE(act_stride % 8 == 0 && ((int64_t)n_heads * head_dim) % 8 == 0, "hstu_attn_bwd: strides must be multiples of 8");
+  MHR_REQUIRE((!act_q || act_stride % 8 == 0) && row_stride % 8 == 0 && ((int64_t)n_heads * head_dim) % 8 == 0,
+              "hstu_attn_bwd: strides must be multiples of 8");
   const int Lp = (L + 31) & ~31, nb = Lp / 32;
   size_t lds = (size_t)2 * nb * (32 * sh.nks * 32) + (size_t)nb * 4 + 16;     // two tensors' tile images at a time
   MHR_REQUIRE(lds <= 160 * 1024 && nb <= 256, "hstu_attn_bwd: L=%d head_dim=%d needs %zu B of LDS (> 160 KiB)", L, head_dim, lds);

@@ -248,12 +248,15 @@ def hstu_attn_fwd(h, key_valid, B, L, n_heads, head_dim, apply_silu=True, save_a
 
 
 def hstu_attn_bwd(h, act, key_valid, d_out, dh, B, L, n_heads, head_dim, apply_silu=True):
-    """writes dv|dq|dk into dh[:, D:4D] (pre-activation gradients)."""
+    """writes dv|dq|dk into dh[:, D:4D] (pre-activation gradients).  act = None: the activated q / k / v are recomputed
+    from h inside the kernel (apply_silu only)."""
     D = n_heads * head_dim
     esz = 2
-    base, dbase, abase = h.data_ptr(), dh.data_ptr(), act.data_ptr()
+    base, dbase = h.data_ptr(), dh.data_ptr()
+    abase = act.data_ptr() if act is not None else 0
     _timed_call("mhr_hstu_attn_bwd", base + 2 * D * esz, base + 3 * D * esz, base + D * esz, h.stride(0),
-             abase, abase + D * esz, abase + 2 * D * esz, act.stride(0), key_valid.data_ptr(), d_out.data_ptr(),
+             abase, abase + D * esz if act is not None else 0, abase + 2 * D * esz if act is not None else 0,
+             act.stride(0) if act is not None else 0, key_valid.data_ptr(), d_out.data_ptr(),
              dbase + 2 * D * esz, dbase + 3 * D * esz, dbase + D * esz, dh.stride(0),
              B, L, n_heads, head_dim, 1 if apply_silu else 0, _stream())
     return dh

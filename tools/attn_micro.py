@@ -17,11 +17,11 @@ kv = (torch.arange(L, device="cuda")[None, :] >= (L - lens)[:, None]).to(torch.u
 d_out = (torch.randn(B * L, D, device="cuda", generator=g) * 0.1).bfloat16()
 dh = torch.zeros_like(h)
 for _ in range(3):
-    out, act = ops.hstu_attn_fwd(h, kv, B, L, H, hd)
+    out, act = ops.hstu_attn_fwd(h, kv, B, L, H, hd, save_act=not os.environ.get("NOACT"))
     ops.hstu_attn_bwd(h, act, kv, d_out, dh, B, L, H, hd)
 torch.cuda.synchronize()
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-ev[0].record(); out, act = ops.hstu_attn_fwd(h, kv, B, L, H, hd); ev[1].record()
+ev[0].record(); out, act = ops.hstu_attn_fwd(h, kv, B, L, H, hd, save_act=not os.environ.get("NOACT")); ev[1].record()
 ops.hstu_attn_bwd(h, act, kv, d_out, dh, B, L, H, hd); ev[2].record(); torch.cuda.synchronize()
 print(f"attn fwd {ev[0].elapsed_time(ev[1])*1e3:.1f} us  bwd {ev[1].elapsed_time(ev[2])*1e3:.1f} us  mean len {float(lens.float().mean()):.0f}")
 if os.environ.get("STAMP"):
