@@ -24,7 +24,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from REC.model.basemodel import BaseModel, all_gather_ids
+from REC.model.basemodel import BaseModel, all_gather_pool_ids
 from REC.model.multihead import FusedTopK, MultiHeadDecoding  # noqa: F401  (FusedTopK re-exported)
 from REC.utils.enum_type import InputType
 
@@ -112,6 +112,8 @@ class HSTU(MultiHeadDecoding, BaseModel):
         self.sparse_grad = None
         self._row_slot = None
         self._pending_rows = None
+        self._shared_pending = None
+        self._row_exchange = None
         self._bf16_cache = {}
         self._step_seed = 0
 
@@ -196,7 +198,7 @@ class HSTU(MultiHeadDecoding, BaseModel):
 
         # which negative pools the loss reads (reference hstu.py:669-670, 751-752); ids are shared across ranks
         pools = self._negative_pools(neg_items.shape[1])
-        pool_ids = [all_gather_ids(neg_items[:, p].contiguous()).reshape(-1) for p in pools]
+        pool_ids = all_gather_pool_ids(neg_items, pools)
         n_pool = pool_ids[0].numel()
         n_item_ids = B * (L + P)
         ids_all = torch.cat([items.reshape(-1)] + pool_ids).contiguous()
@@ -208,11 +210,20 @@ class HSTU(MultiHeadDecoding, BaseModel):
             rows_all = self.item_id_proj_tower(rows_all)
             x = rows_all[:n_item_ids].view(B, L + P, D)[:, :L] + self.position_embedding.weight[:L][None]
         e_rows = rows_all[:n_item_ids]                                   # targets, [B*(L+P), D] fp32
-        negs_pools = L2NormFn.apply(rows_all[n_item_ids:].contiguous()).view(len(pools), n_pool, D)
+        # data parallel: the negatives' gradient rows leave for their all-reduce from inside this backward (fused_pos:
+        # they are rows of the table itself), underneath the encoder backward
+        negs_pools = L2NormFn.apply(rows_all[n_item_ids:].contiguous(), self if fused_pos else None).view(len(pools), n_pool, D)
 
         key_valid = mask[:, :L].to(torch.uint8).contiguous()
         out = self._encode(x, key_valid)                                 # [B,L,D] fp32
         return self._multihead_loss(out, e_rows, negs_pools, pools, mask, pos_tags)
+
+    def begin_sparse_exchange(self):
+        """Data parallel: put the cross-rank exchange of the last backward's gradient rows on the wire (asynchronous;
+        `finish_sparse_grad` completes it).  Called by the fused optimizer before its flat Adam."""
+        if self._pending_rows is not None and self._row_exchange is None:
+            from REC.model.hstu_functional import begin_pending_rows
+            begin_pending_rows(self)
 
     def finish_sparse_grad(self):
         """The item table's gradient of the last backward as a SparseRowGrad (after the cross-rank exchange when

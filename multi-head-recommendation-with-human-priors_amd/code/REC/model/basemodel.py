@@ -27,10 +27,25 @@ def all_gather_ids(ids, group=None):
     fp32 embeddings (hstu.py:673, 755) - the negatives' gradient rows are then summed by the sparse embedding
     reduction - and moves D*4/8 times fewer bytes over xGMI with no backward collective."""
     if _world() > 1:
+        ids = ids.contiguous()
+        if dist.get_backend(group) == "nccl":              # straight into the stacked output
+            out = torch.empty((_world(),) + tuple(ids.shape), dtype=ids.dtype, device=ids.device)
+            dist.all_gather_into_tensor(out, ids, group=group)
+            return out
         out = [torch.empty_like(ids) for _ in range(_world())]
-        dist.all_gather(out, ids.contiguous(), group=group)
+        dist.all_gather(out, ids, group=group)
         return torch.stack(out, dim=0)
     return ids.unsqueeze(0)
+
+
+def all_gather_pool_ids(neg_items, pools, group=None):
+    """neg_items [B, n_pools, n_neg] int64, `pools` = the pool indices the loss reads: ONE id all-gather for all of
+    them (the reference gathers the embeddings of each pool separately inside its per-category loop,
+    hstu.py:669-673, 751-755).  Returns a list of [W*B*n_neg] id vectors, rank-major like all_gather_ids(pool)."""
+    sel = neg_items[:, list(pools)].contiguous()                                       # [B, G, n_neg]
+    g = all_gather_ids(sel, group=group)                                               # [W, B, G, n_neg]
+    g = g.permute(2, 0, 1, 3).reshape(len(pools), -1)
+    return [g[i] for i in range(len(pools))]
 
 
 def l2_norm(x, eps=1e-6):

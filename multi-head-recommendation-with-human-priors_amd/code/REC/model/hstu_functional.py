@@ -254,14 +254,22 @@ class EmbeddingGatherFn(Function):
         return None, d_pos, None, None, None, None, None
 
 
-def reduce_pending_rows(holder):
-    """Data-parallel tail of the embedding backward: exchange rows over RCCL, then the deterministic segment-sum."""
+def begin_pending_rows(holder):
+    """Data-parallel tail of the embedding backward, first half: the exchange goes on the wire (RCCL, asynchronous)."""
     from mhr_amd import distributed as dist_
     ids_all, d_rows, n_private = holder._pending_rows
-    holder._pending_rows = None
-    ids, rows_priv, rows_shared = dist_.exchange_sparse_rows(ids_all, d_rows, n_private)
-    sorted_ids, perm = torch.sort(ids)
-    out_rows = torch.zeros(ids.numel(), rows_shared.shape[1], dtype=torch.float32, device=rows_shared.device)
+    shared, holder._shared_pending = getattr(holder, "_shared_pending", None), None
+    holder._row_exchange = dist_.begin_row_exchange(ids_all, d_rows, n_private, shared_pending=shared)
+
+
+def reduce_pending_rows(holder):
+    """Second half: the ids are sorted while the rows are still travelling, then the deterministic segment-sum."""
+    if getattr(holder, "_row_exchange", None) is None:
+        begin_pending_rows(holder)
+    ex, holder._row_exchange, holder._pending_rows = holder._row_exchange, None, None
+    sorted_ids, perm = torch.sort(ex.wait_ids())
+    rows_priv, rows_shared = ex.wait_rows()
+    out_rows = torch.zeros(sorted_ids.numel(), rows_shared.shape[1], dtype=torch.float32, device=rows_shared.device)
     ops.sparse_rows_segment_sum(sorted_ids, perm, rows_priv.contiguous(), rows_shared.contiguous() if rows_shared.numel() else None,
                                 None, 0, 0, out_rows, holder._row_slot)
     holder.sparse_grad = SparseRowGrad(sorted_ids, out_rows, holder._row_slot, holder._row_slot.numel())
@@ -269,12 +277,17 @@ def reduce_pending_rows(holder):
 
 
 class L2NormFn(Function):
-    """y = x / ||x|| in fp32, emitted as bf16 for the MFMA operand (reference hstu.py:672, 754)."""
+    """y = x / ||x|| in fp32, emitted as bf16 for the MFMA operand (reference hstu.py:672, 754).
+
+    `holder` (data parallel, x = rows of the item table gathered for the shared negatives): the backward hands its
+    result to the cross-rank all-reduce right away - asynchronously, on RCCL's stream - and returns no gradient to
+    autograd; `reduce_pending_rows` picks the summed block up from `holder._shared_pending`."""
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, holder=None):
         y, norms = ops.l2norm_rows(x, torch.bfloat16, want_norms=True)
         ctx.save_for_backward(x, norms)
+        ctx.holder = holder
         return y
 
     @staticmethod
@@ -282,7 +295,12 @@ class L2NormFn(Function):
         x, norms = ctx.saved_tensors
         n = x / norms[:, None]
         dy = dy.float()
-        return (dy - n * (n * dy).sum(-1, keepdim=True)) / norms[:, None]
+        g = (dy - n * (n * dy).sum(-1, keepdim=True)) / norms[:, None]
+        from mhr_amd import distributed as dist_
+        if ctx.holder is not None and dist_.world_size() > 1 and dist_.OVERLAP:
+            ctx.holder._shared_pending = (g, dist_.allreduce_sum_begin(g))
+            return None, None
+        return g, None
 
 
 class NceLossFn(Function):

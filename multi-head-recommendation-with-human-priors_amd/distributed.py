@@ -8,7 +8,10 @@ One process per GPU; users (batch rows) are independent, so the only exchanges o
 The table update itself stays dense and local (Adam moments of untouched rows still decay - reference semantics,
 trainer.py:292-299), but only touched rows cross xGMI: at cfg1/W=8 about 60 MB per rank instead of the reference's
 465 MB dense table gradient.  xGMI is point-to-point (7 links per GPU), so few large collectives are preferred
-over many small ones: each of (2) and (3) is a single call.
+over many small ones: (1) is one call for all pools, (2) one call, (3) three (ids, shared block, private rows).
+Overlap: every collective is issued with async_op on RCCL's own stream; the shared-negative block leaves as soon as the
+loss backward has produced it (it crosses xGMI underneath the encoder backward), the dense bucket and the private rows
+leave at the end of the backward and travel underneath the id sort and the flat Adam (`optim.FusedAdamW.step`).
 """
 import os
 
@@ -18,6 +21,8 @@ import torch.distributed as dist
 # dtype of the rank-private gradient rows on the wire.  bf16 halves the step's largest collective (W x 26 624 rows x D at
 # cfg1); the per-id sum over ranks is still accumulated in fp32 by the segment-sum kernel.  The reference's DeepSpeed
 # bf16 runs reduce the whole gradient in bf16 (trainer.py:292-299, ds_config bf16); MHR_DP_WIRE=fp32 keeps fp32 rows.
+# MHR_DP_OVERLAP=0: the shared-negative block waits for the end of the backward like the other exchanges (A/B knob)
+OVERLAP = os.environ.get("MHR_DP_OVERLAP", "1") != "0"
 ROWS_WIRE_DTYPE = torch.float32 if os.environ.get("MHR_DP_WIRE", "bf16") == "fp32" else torch.bfloat16
 
 
@@ -37,37 +42,91 @@ def allreduce_mean_(flat):
     return flat
 
 
-def exchange_sparse_rows(ids_all, d_rows, n_private, wire_dtype=None):
-    """Combine the per-rank embedding-gradient rows of a step.
+def allreduce_sum_begin(t):
+    """Start an in-place SUM all-reduce of `t` on the collective stream and return its work handle (None when not data
+    parallel).  `handle.wait()` orders the CURRENT stream after the collective without blocking the host (RCCL), so
+    kernels launched in between overlap it.  Nobody may touch `t` until then."""
+    if world_size() == 1:
+        return None
+    return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)
+
+
+class RowExchange:
+    """In-flight exchange of a step's embedding-gradient rows (see `begin_row_exchange`)."""
+
+    def __init__(self, ids, rows_priv, rows_shared, w_ids=(), w_rows=(), finish=None):
+        self._ids, self._rows_priv, self._rows_shared = ids, rows_priv, rows_shared
+        self._w_ids, self._w_rows, self._finish = list(w_ids), list(w_rows), finish
+
+    def wait_ids(self):
+        """ids [W*n_private + n_shared] (private ids in rank order, then the shared ids)."""
+        for w in self._w_ids:
+            w.wait()
+        self._w_ids = []
+        if self._finish is not None:
+            self._finish[0]()
+        return self._ids
+
+    def wait_rows(self):
+        """(private rows [W*n_private, D] in the wire dtype, shared rows [n_shared, D] fp32 summed over ranks)."""
+        for w in self._w_rows:
+            w.wait()
+        self._w_rows = []
+        if self._finish is not None:
+            self._finish[1]()
+        return self._rows_priv, self._rows_shared
+
+
+def begin_row_exchange(ids_all, d_rows, n_private, wire_dtype=None, shared_pending=None):
+    """Start combining the per-rank embedding-gradient rows of a step; returns a RowExchange.
 
     ids_all [R] int64 / d_rows [R, D] fp32: the first `n_private` entries are rank-private (positives: every rank has
     its own users), the rest are the shared negatives (same ids, same order on every rank after the id all-gather).
-    Returns (ids [W*n_private + n_shared], private rows [W*n_private, D] in the wire dtype, shared rows [n_shared, D] fp32
-    summed over ranks); the caller sums duplicates in fp32 and scales by 1/W (DDP's gradient mean) inside the fused Adam.
+    `shared_pending` = (rows [n_shared, D] fp32, work): the shared block's all-reduce was already started earlier in
+    the backward (the negatives' gradient is complete before the encoder backward runs, so it travels underneath it);
+    d_rows[n_private:] is then ignored.  The collectives are issued asynchronously in the order ids, shared rows,
+    private rows: the caller sorts the ids while the rows are still on the wire.  The caller sums duplicates in fp32
+    and scales by 1/W (DDP's gradient mean) inside the fused Adam.
     """
     W = world_size()
     wire = ROWS_WIRE_DTYPE if wire_dtype is None else wire_dtype
     if W == 1:
-        return ids_all, d_rows[:n_private], d_rows[n_private:]
+        return RowExchange(ids_all, d_rows[:n_private], d_rows[n_private:])
     priv_ids, priv_rows = ids_all[:n_private].contiguous(), d_rows[:n_private].to(wire).contiguous()
-    shared_ids, shared_rows = ids_all[n_private:], d_rows[n_private:].contiguous()
-    if shared_rows.numel():
-        dist.all_reduce(shared_rows, op=dist.ReduceOp.SUM)
+    shared_ids = ids_all[n_private:]
     n_sh = shared_ids.numel()
     ids_out = torch.empty(W * n_private + n_sh, dtype=ids_all.dtype, device=ids_all.device)
     rows_priv = torch.empty(W * n_private, d_rows.shape[1], dtype=wire, device=d_rows.device)
     ids_out[W * n_private:] = shared_ids
+    w_ids, w_rows, finish = [], [], None
     if dist.get_backend() == "nccl":          # gather straight into the output (no per-rank list + concatenation)
-        dist.all_gather_into_tensor(ids_out[:W * n_private], priv_ids)
-        dist.all_gather_into_tensor(rows_priv, priv_rows)
+        w_ids.append(dist.all_gather_into_tensor(ids_out[:W * n_private], priv_ids, async_op=True))
     else:
         g_ids = [torch.empty_like(priv_ids) for _ in range(W)]
+        w_ids.append(dist.all_gather(g_ids, priv_ids, async_op=True))
+    if shared_pending is not None:
+        shared_rows, w_sh = shared_pending
+        if w_sh is not None:
+            w_rows.append(w_sh)
+    else:
+        shared_rows = d_rows[n_private:].contiguous()
+        if n_sh:
+            w_rows.append(dist.all_reduce(shared_rows, op=dist.ReduceOp.SUM, async_op=True))
+    if dist.get_backend() == "nccl":
+        w_rows.append(dist.all_gather_into_tensor(rows_priv, priv_rows, async_op=True))
+    else:
         g_rows = [torch.empty_like(priv_rows) for _ in range(W)]
-        dist.all_gather(g_ids, priv_ids)
-        dist.all_gather(g_rows, priv_rows)
-        ids_out[:W * n_private] = torch.cat(g_ids)
-        rows_priv.copy_(torch.cat(g_rows))
-    return ids_out, rows_priv, shared_rows
+        w_rows.append(dist.all_gather(g_rows, priv_rows, async_op=True))
+        finish = (lambda: ids_out[:W * n_private].copy_(torch.cat(g_ids)), lambda: rows_priv.copy_(torch.cat(g_rows)))
+    return RowExchange(ids_out, rows_priv, shared_rows, w_ids, w_rows, finish)
+
+
+def exchange_sparse_rows(ids_all, d_rows, n_private, wire_dtype=None, shared_pending=None):
+    """Blocking form of `begin_row_exchange`: returns (ids, private rows, shared rows)."""
+    ex = begin_row_exchange(ids_all, d_rows, n_private, wire_dtype, shared_pending)
+    ids = ex.wait_ids()
+    rows_priv, rows_shared = ex.wait_rows()
+    return ids, rows_priv, rows_shared
 
 
 def allreduce_metric_sums(values):

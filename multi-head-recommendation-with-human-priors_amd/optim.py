@@ -83,8 +83,14 @@ class FusedAdamW:
         self.step_count += 1
         lr = self.param_groups[0]["lr"]
         W = D.world_size()
-        D.allreduce_mean_(self.flat_g)
-        ops.adam_flat(self.flat_w, self.flat_g, self.flat_m, self.flat_v, self.step_count, lr, 1.0, self.betas, self.eps,
+        # data parallel: dense bucket and gradient rows go on the wire back to back (RCCL's stream); the flat Adam waits
+        # for the bucket only, so it - and the id sort of the row reduction - run underneath the row all-gather
+        dense_work = D.allreduce_sum_begin(self.flat_g)
+        if self.table is not None and hasattr(self.model, "begin_sparse_exchange"):
+            self.model.begin_sparse_exchange()
+        if dense_work is not None:
+            dense_work.wait()
+        ops.adam_flat(self.flat_w, self.flat_g, self.flat_m, self.flat_v, self.step_count, lr, 1.0 / W, self.betas, self.eps,
                       self.weight_decay, w_bf16=self.flat_w16)
         for p in self.dense:
             if hasattr(p, "_mhr_bf16"):

@@ -468,3 +468,117 @@ def test_event_category_heads_match_oracle(rec):
     assert np.array_equal(np.isinf(s), np.isinf(r)) and np.isinf(r).any()
     fin = np.isfinite(r)
     assert np.abs(s[fin] - r[fin]).max() < 2e-2
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# data parallel: two ranks (gloo, sharing the one card of the test box) run one train step each on their own
+# users; the exchanged gradient must equal the mean of the two ranks' single-process gradients, where a rank's
+# single-process gradient is computed here with the negatives of BOTH ranks in its pools (what the id all-gather gives it).
+# ----------------------------------------------------------------------------------------------------------------------
+DP_TRAIN_SCRIPT = r'''
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+root, code, out_dir, overlap = sys.argv[1:5]
+os.environ["MHR_DP_OVERLAP"] = overlap
+sys.path.insert(0, root); sys.path.insert(0, code)
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+import mhr_amd.synth as synth
+from REC.config.configurator import Config, apply_run_fixups
+from REC.trainer import Trainer
+from REC.utils import get_model
+cfgd = synth.base_config(**eval(open(os.path.join(out_dir, "cfg.txt")).read()), device=dev)
+cfg = apply_run_fixups(Config(config_dict=cfgd))
+data = synth.SyntheticData(cfg, 3000, dev, seed=11, rank=rank, world=world)
+cfg["int_to_category"] = data.int_to_category
+torch.manual_seed(5)
+model = get_model("HSTU")(cfg, data).to(dev)
+tr = Trainer(cfg); tr.setup_model(model); tr.train_step = 30
+opt = tr.optimizer
+batch = data.train_batch(8)
+out = model(batch)
+out["loss"].backward()
+w0 = model.item_embedding.weight.detach().clone()
+# the exchange exactly as FusedAdamW.step drives it
+from mhr_amd import distributed as D
+h = D.allreduce_sum_begin(opt.flat_g); model.begin_sparse_exchange(); h.wait()
+sg = model.finish_sparse_grad()
+slot = sg.row_slot.long()
+table_g = torch.zeros_like(w0)
+touched = slot >= 0
+table_g[touched] = sg.rows[slot[touched]]
+np.savez(os.path.join(out_dir, f"rank{rank}.npz"), loss=out["loss"].detach().float().cpu().numpy(),
+         flat_g=(opt.flat_g / world).cpu().numpy(), table_g=(table_g / world).cpu().numpy(),
+         **{f"b{i}": t.cpu().numpy() for i, t in enumerate(batch)})
+# and one real optimizer step on top (replicas must stay identical)
+opt.zero_grad()
+sg.row_slot.fill_(-1)
+for _ in range(3):
+    tr.train_step_fn(data.train_batch(8))
+torch.cuda.synchronize()
+np.savez(os.path.join(out_dir, f"after{rank}.npz"), table=model.item_embedding.weight.detach().cpu().numpy(),
+         flat=opt.flat_w.cpu().numpy())
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("overlap", ["1", "0"])
+def test_data_parallel_train_step_two_ranks_one_card(rec, tmp_path, overlap):
+    import subprocess
+    import mhr_amd.synth as synth
+    from REC.config.configurator import Config, apply_run_fixups
+    from REC.trainer import Trainer
+    from REC.utils import get_model
+    kw = dict(MAX_ITEM_LIST_LENGTH=16, pred_len=2, eval_pred_len=2, n_layers=2, n_heads=2, item_embedding_size=64,
+              hstu_embedding_size=64, num_negatives=256, total_iters=100, eval_interval=0, checkpoint_dir=None,
+              save_model_note="t", hidden_dropout_prob=0.0, attn_dropout_prob=0.0, loss='prior', num_prior_head=3,
+              medusa_num_layers=1, eval_num_cats=3)
+    (tmp_path / "cfg.txt").write_text(repr(kw))
+    script = tmp_path / "dp_train.py"
+    script.write_text(DP_TRAIN_SCRIPT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29630 + int(overlap)), WORLD_SIZE="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, CODE, str(tmp_path), overlap], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, (o[-2000:], e[-4000:])
+    r = [np.load(tmp_path / f"rank{i}.npz") for i in range(2)]
+    # both ranks hold the same combined gradient, bit for bit (same rows, same order, deterministic reduction)
+    assert np.array_equal(r[0]["flat_g"], r[1]["flat_g"]) and np.array_equal(r[0]["table_g"], r[1]["table_g"])
+    a = [np.load(tmp_path / f"after{i}.npz") for i in range(2)]
+    assert np.array_equal(a[0]["table"], a[1]["table"]) and np.array_equal(a[0]["flat"], a[1]["flat"])   # replicas stay replicas
+
+    # single-process gradients of each rank's users against the pools both ranks contributed
+    dev = torch.device("cuda", 0)
+    cfg = apply_run_fixups(Config(config_dict=synth.base_config(**kw, device=dev)))
+    data = synth.SyntheticData(cfg, 3000, dev, seed=11, rank=0, world=2)
+    cfg["int_to_category"] = data.int_to_category
+    torch.manual_seed(5)
+    model = get_model("HSTU")(cfg, data).to(dev)
+    tr = Trainer(cfg)
+    tr.setup_model(model)
+    opt = tr.optimizer
+    negs = [torch.from_numpy(r[i]["b1"]).to(dev) for i in range(2)]                     # [B, C+1, n_neg] per rank
+    flat_sum, table_sum, losses = 0, 0, []
+    for i in range(2):
+        b = [torch.from_numpy(r[i][f"b{j}"]).to(dev) for j in range(4)]
+        b[1] = torch.cat(negs, dim=2)
+        opt.flat_g.zero_()
+        out = model(tuple(b))
+        out["loss"].backward()
+        sg = model.finish_sparse_grad()
+        slot = sg.row_slot.long()
+        tg = torch.zeros_like(model.item_embedding.weight)
+        tg[slot >= 0] = sg.rows[slot[slot >= 0]]
+        sg.row_slot.fill_(-1)
+        flat_sum = flat_sum + opt.flat_g.clone()
+        table_sum = table_sum + tg
+        losses.append(float(out["loss"]))
+        assert abs(losses[-1] - float(r[i]["loss"])) <= 2e-3 * abs(losses[-1])           # same loss as the rank saw
+    want_flat, want_table = (flat_sum / 2).cpu().numpy(), (table_sum / 2).cpu().numpy()
+    for got, want in ((r[0]["flat_g"], want_flat), (r[0]["table_g"], want_table)):
+        assert np.abs(got - want).max() <= 2e-2 * np.abs(want).max()                    # bf16 rows on the wire, summation order
+    assert (np.abs(r[0]["table_g"]).sum(1) > 0).sum() == (np.abs(want_table).sum(1) > 0).sum()   # same touched rows
