@@ -173,8 +173,17 @@ def main():
     last = None
     for i in range(args.steps):
         last = step(args.warmup + i)
+    host_enqueue = time.perf_counter() - t0          # the host is done issuing; the GPU may still be working
     sync()
     elapsed = time.perf_counter() - t0
+    host_alone = []                                   # host cost of issuing ONE step into an idle queue (outside the timed region)
+    for i in range(5):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        step(args.warmup + args.steps + i)
+        host_alone.append(time.perf_counter() - t1)
+    sync()
+    host_alone = sorted(host_alone)[len(host_alone) // 2]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -200,6 +209,8 @@ def main():
                                    f"B={B}/GPU, loss={cfg['loss']}, bf16-mixed, fused AdamW over all parameters",
                        "global_batch": world * B, "seq_len": L, "parallelism": f"dp{world}"},
         }
+        out["host_enqueue_ms_per_step"] = round(1000 * host_enqueue / args.steps, 3)
+        out["host_issue_ms_idle_queue"] = round(1000 * host_alone, 3)
         if last is not None and args.mode == "train":
             out["loss"] = round(float(last["loss"].detach()), 4)
         # ---- roofline of the dominant kernel ----

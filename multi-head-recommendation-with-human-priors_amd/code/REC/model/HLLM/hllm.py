@@ -11,8 +11,8 @@ embedding-gather kernel, or from the item tower itself (`forward_item_emb`, hllm
 `cu_input_lens` token batches.
 
 Scope notes: text-only Llama-architecture towers (`model_type` llama / mistral / qwen2 - e.g. TinyLlama-1.1B,
-Qwen2.5-1.5B, the user towers of the reference's scripts) and the reference's `dummy_llm` debug tower; the Baichuan /
-Bert / vision variants of `create_llm` (hllm.py:325-376) raise NotImplementedError naming the architecture.  Pretrained weights are read from
+Qwen2.5-1.5B, the user towers of the reference's scripts), Baichuan2 (`model_type` baichuan: packed `W_pack` projection)
+and the reference's `dummy_llm` debug tower; the Bert / vision variants of `create_llm` (hllm.py:325-376) raise NotImplementedError naming the architecture.  Pretrained weights are read from
 `<dir>/model.safetensors` when present; there is no network here, so synthetic runs pass `user_llm_config` /
 `item_llm_config` dicts instead of directories.  There is no CPU path.
 """
@@ -103,15 +103,21 @@ class HLLM(MultiHeadDecoding, BaseModel):
                 return None
             raise ValueError("either a pretrain dir with config.json or an *_llm_config dict is required")
         lcfg = LlamaConfig(**cfg_dict) if cfg_dict is not None else LlamaConfig.from_pretrained(pretrain_dir)
+        if lcfg.model_type == "baichuan":                            # hllm.py:333-340
+            from REC.model.HLLM.baichuan.configuration_baichuan import BaichuanConfig
+            lcfg = BaichuanConfig(**cfg_dict) if cfg_dict is not None else BaichuanConfig.from_pretrained(pretrain_dir)
         if self.dummy_llm:
             self.logger.info('Using a dummy LLM for debugging...')
             return DummyLLM(lcfg.vocab_size, lcfg.hidden_size)
-        if lcfg.model_type not in ("llama", "qwen2", "mistral"):     # same decoder maths (qwen2: + q/k/v biases)
+        if lcfg.model_type not in ("llama", "qwen2", "mistral", "baichuan"):   # same decoder maths (qwen2: + q/k/v biases,
             raise NotImplementedError(f"create_llm: architecture '{lcfg.model_type}' is not built on the MI355X path yet "
-                                      "(llama / qwen2 / mistral text decoders only)")
+                                      "(llama / qwen2 / mistral / baichuan text decoders only)")          # baichuan: packed q|k|v)
+        cls = LlamaForCausalLM
+        if lcfg.model_type == "baichuan":
+            from REC.model.HLLM.baichuan.modeling_baichuan import BaichuanForCausalLM as cls
         if init and cfg_dict is None:
-            return LlamaForCausalLM.from_pretrained(pretrain_dir, config=lcfg)
-        return LlamaForCausalLM(lcfg)
+            return cls.from_pretrained(pretrain_dir, config=lcfg)
+        return cls(lcfg)
 
     # ------------------------------------------------------------------------------------------
     # item tower

@@ -92,11 +92,13 @@ class LlamaDecoderLayer(nn.Module):
 
 
 class LlamaModel(nn.Module):
+    layer_class = LlamaDecoderLayer
+
     def __init__(self, config):
         super().__init__()
         self.config = config
         self.embed_tokens = nn.Embedding(config.vocab_size, config.hidden_size, config.pad_token_id)
-        self.layers = nn.ModuleList([LlamaDecoderLayer(config) for _ in range(config.num_hidden_layers)])
+        self.layers = nn.ModuleList([self.layer_class(config) for _ in range(config.num_hidden_layers)])
         self.norm = LlamaRMSNorm(config.hidden_size, eps=config.rms_norm_eps)
         self.gradient_checkpointing = False
         self._rope = None
@@ -124,18 +126,29 @@ class LlamaModel(nn.Module):
             self._rope = (f.cos().contiguous(), f.sin().contiguous())
         return self._rope
 
+    @staticmethod
+    def _qkv_params(attn):
+        """([weights whose rows stack to the [q; k; v] projection], [their biases] or None).  Llama / Mistral / Qwen2 keep
+        three Linears; Baichuan keeps them packed in one (`W_pack`, baichuan/modeling_baichuan.py:224)."""
+        if hasattr(attn, "W_pack"):
+            return [attn.W_pack.weight], None
+        ws = [attn.q_proj.weight, attn.k_proj.weight, attn.v_proj.weight]
+        bs = [attn.q_proj.bias, attn.k_proj.bias, attn.v_proj.bias] if attn.q_proj.bias is not None else None
+        return ws, bs
+
     def _fused_weights(self, i, layer):
         """[q;k;v] and [gate;up] as single GEMM operands.  In training they are re-concatenated from the fp32 masters every
         step (autograd splits the gradient back); under no_grad in eval mode the bf16 copies are built once."""
         a, m = layer.self_attn, layer.mlp
-        b_qkv = torch.cat([a.q_proj.bias, a.k_proj.bias, a.v_proj.bias]) if a.q_proj.bias is not None else None
+        ws, bs = self._qkv_params(a)
+        b_qkv = torch.cat(bs) if bs is not None else None
+        w_qkv = ws[0] if len(ws) == 1 else torch.cat(ws, 0)
         if self.training or torch.is_grad_enabled():
-            return (torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], 0), b_qkv,
-                    torch.cat([m.gate_proj.weight, m.up_proj.weight], 0), None)
+            return (w_qkv, b_qkv, torch.cat([m.gate_proj.weight, m.up_proj.weight], 0), None)
         hit = self._w_cache.get(i)
         if hit is None:
             bf = torch.bfloat16
-            hit = self._w_cache[i] = (torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], 0).to(bf), b_qkv,
+            hit = self._w_cache[i] = (w_qkv.to(bf), b_qkv,
                                       torch.cat([m.gate_proj.weight, m.up_proj.weight], 0).to(bf),
                                       (a.o_proj.weight.to(bf), m.down_proj.weight.to(bf)))
         return hit
@@ -182,10 +195,11 @@ class LlamaModel(nn.Module):
         branch = None
         for i, layer in enumerate(self.layers):
             fv_qkv = fv_gu = None
-            if torch.is_grad_enabled() and layer.self_attn.q_proj.bias is None:
+            qkv_ws, qkv_bs = self._qkv_params(layer.self_attn)
+            if torch.is_grad_enabled() and qkv_bs is None:
                 # parameters laid out back to back by the fused optimizer: bf16 shadow view in, flat gradient view out
-                a_, m_ = layer.self_attn, layer.mlp
-                fv_qkv = fused_views([a_.q_proj.weight, a_.k_proj.weight, a_.v_proj.weight])
+                m_ = layer.mlp
+                fv_qkv = fused_views(qkv_ws)
                 fv_gu = fused_views([m_.gate_proj.weight, m_.up_proj.weight])
             if fv_qkv is not None and fv_gu is not None:
                 w_qkv = b_qkv = w_gu = cached = None
@@ -198,7 +212,7 @@ class LlamaModel(nn.Module):
             else:
                 x, h = AddRMSNormFn.apply(x, branch, layer.input_layernorm.weight, layer.input_layernorm.variance_epsilon)
             if fv_qkv is not None:
-                qkv = FusedParamLinearFn.apply(h, fv_qkv[0], fv_qkv[1], layer.self_attn.q_proj.weight)
+                qkv = FusedParamLinearFn.apply(h, fv_qkv[0], fv_qkv[1], qkv_ws[0])
             else:
                 qkv = SplitKLinearFn.apply(h, w_qkv, b_qkv, True, w_qkv if pre else None)
             a = RopeAttentionFn.apply(qkv, cos, sin, positions, key_valid, cu, n_seqs, max_len, nh, nkv, hd, scale)
@@ -219,10 +233,13 @@ class LlamaModel(nn.Module):
 
 
 class LlamaForCausalLM(nn.Module):
+    model_class = LlamaModel
+    config_class = LlamaConfig
+
     def __init__(self, config):
         super().__init__()
         self.config = config
-        self.model = LlamaModel(config)
+        self.model = self.model_class(config)
         self.vocab_size = config.vocab_size
         self.lm_head = nn.Linear(config.hidden_size, config.vocab_size, bias=False)
         nn.init.normal_(self.lm_head.weight, mean=0.0, std=0.02)
@@ -230,7 +247,7 @@ class LlamaForCausalLM(nn.Module):
     @classmethod
     def from_pretrained(cls, path, config=None):
         """Weights from `<path>/model.safetensors` (or `pytorch_model.bin`, loaded with weights_only=True)."""
-        config = config or LlamaConfig.from_pretrained(path)
+        config = config or cls.config_class.from_pretrained(path)
         model = cls(config)
         st = os.path.join(path, "model.safetensors")
         if os.path.exists(st):

@@ -103,6 +103,22 @@ def llama_decoder(w, lcfg, inputs_embeds, attention_mask=None, position_ids=None
     return rms_norm(x, w[prefix + "norm.weight"], lcfg["rms_norm_eps"])
 
 
+def baichuan_decoder(w, lcfg, inputs_embeds, attention_mask=None, position_ids=None, seg_ids=None, prefix="model."):
+    """BaichuanModel.forward (REC/model/HLLM/baichuan/modeling_baichuan.py:465-597) on `inputs_embeds`: the Llama block
+    structure (DecoderLayer 341-395 = RMSNorm -> attention -> residual -> RMSNorm -> SwiGLU MLP -> residual; RMSNorm
+    110-133; rotary embedding with base 10000 and rotate_half 136-180; softmax attention 301-334) with the q, k, v
+    projections stored as ONE `W_pack` Linear whose output is cut into thirds (224, 258-262) and as many KV heads as
+    query heads.  Restated by viewing W_pack's rows [0,D) / [D,2D) / [2D,3D) as q_proj / k_proj / v_proj."""
+    D = lcfg["hidden_size"]
+    view = dict(w)
+    for i in range(lcfg["num_hidden_layers"]):
+        pack = w[f"{prefix}layers.{i}.self_attn.W_pack.weight"]
+        for j, name in enumerate(("q_proj", "k_proj", "v_proj")):
+            view[f"{prefix}layers.{i}.self_attn.{name}.weight"] = pack[j * D:(j + 1) * D]
+    cfg = dict(lcfg, num_key_value_heads=lcfg["num_attention_heads"], rope_theta=10000.0)
+    return llama_decoder(view, cfg, inputs_embeds, attention_mask, position_ids, seg_ids, prefix)
+
+
 def dummy_llm(w, prefix, inputs_embeds):
     """REC/model/layers.py:94-111 DummyLLM: one Linear on the input embeddings."""
     return inputs_embeds @ w[prefix + "embed_layer.weight"].T + w[prefix + "embed_layer.bias"]
@@ -114,6 +130,8 @@ def dummy_llm(w, prefix, inputs_embeds):
 def user_encoder(w, cfg, embs, key_mask):
     if cfg.get("dummy_llm"):
         return dummy_llm(w, "user_llm.", embs)
+    if cfg["user_llm_config"].get("model_type") == "baichuan":
+        return baichuan_decoder(w, cfg["user_llm_config"], embs, key_mask, prefix="user_llm.model.")
     return llama_decoder(w, cfg["user_llm_config"], embs, key_mask, prefix="user_llm.model.")
 
 

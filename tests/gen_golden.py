@@ -371,6 +371,50 @@ def run_llama_cases():
         print("wrote", name, "loss", loss.item())
 
 
+def run_baichuan_cases():
+    """Baichuan2-style decoder (REC/model/HLLM/baichuan/modeling_baichuan.py: packed `W_pack` q|k|v projection, rotary base
+    10000, full multi-head attention, eager softmax path) on a tiny random-init config, called the way the user decoder
+    is (inputs_embeds + [B,L] attention mask): last hidden state, parameter and input gradients."""
+    import json
+    import numpy as np
+    import torch
+    from REC.model.HLLM.baichuan.configuration_baichuan import BaichuanConfig
+    from REC.model.HLLM.baichuan.modeling_baichuan import BaichuanForCausalLM
+    c = dict(hidden_size=64, intermediate_size=96, num_hidden_layers=2, num_attention_heads=4, B=3, L=12, pad=[5, 1, 0],
+             seed=21, eps=1e-6)
+    torch.manual_seed(c["seed"])
+    cfg = BaichuanConfig(vocab_size=32, hidden_size=c["hidden_size"], intermediate_size=c["intermediate_size"],
+                         num_hidden_layers=c["num_hidden_layers"], num_attention_heads=c["num_attention_heads"],
+                         max_position_embeddings=64, rms_norm_eps=c["eps"])
+    cfg.use_ft_flash_attn, cfg.use_cache, cfg.output_hidden_states, cfg.return_dict = False, False, True, True
+    model = BaichuanForCausalLM(cfg)
+    with torch.no_grad():
+        for n_, p_ in model.named_parameters():
+            if "norm" in n_:
+                p_.add_(0.2 * torch.randn_like(p_))
+    B, L, D = c["B"], c["L"], c["hidden_size"]
+    x = torch.randn(B, L, D, requires_grad=True)
+    mask = torch.ones(B, L, dtype=torch.bool)
+    for b, pad in enumerate(c["pad"]):
+        mask[b, :pad] = False
+    hidden = model(inputs_embeds=x, attention_mask=mask).hidden_states[-1]
+    probe = torch.randn(B, L, D)
+    loss = (hidden * probe * mask[..., None]).sum()
+    loss.backward()
+    out = {"w/" + k: v.detach().numpy() for k, v in model.state_dict().items() if not k.startswith("lm_head")}
+    out.update(x=x.detach().numpy(), mask=mask.numpy(), probe=probe.numpy(), hidden=hidden.detach().numpy(),
+               loss=np.float64(loss.item()), dx=x.grad.numpy())
+    for k, p_ in model.named_parameters():
+        keep = ("layers.0.self_attn.W_pack", "layers.1.self_attn.o_proj", "layers.0.mlp.up_proj", "layers.0.mlp.down_proj", "norm")
+        if p_.grad is not None and any(t in k for t in keep):
+            out["g/" + k] = p_.grad.numpy()
+    out["lcfg"] = np.array(json.dumps(dict(model_type="baichuan", hidden_size=D, intermediate_size=c["intermediate_size"],
+                                            num_hidden_layers=c["num_hidden_layers"],
+                                            num_attention_heads=c["num_attention_heads"], rms_norm_eps=c["eps"])))
+    np.savez_compressed(os.path.join(OUT, "baichuan_decoder.npz"), **out)
+    print("wrote baichuan_decoder loss", loss.item(), "keys", sorted(k for k in out if k.startswith("g/")))
+
+
 def run_comirec_cases():
     """ComiRec baseline (REC/model/IDNet/comirec.py) on the reference itself: one training step with gradients and one
     predict call."""
@@ -419,6 +463,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "switch":
         switch_cases()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "baichuan":
+        run_baichuan_cases()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "llama":
         run_llama_cases()
         return
@@ -464,6 +511,7 @@ def main():
     run_schedule_and_adam()
     switch_cases()
     run_llama_cases()
+    run_baichuan_cases()
     run_comirec_cases()
 
 

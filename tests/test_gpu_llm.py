@@ -164,14 +164,19 @@ def test_softmax_attention_packed_sequences(ops):
     assert float((dqkv.float().cpu() - qr.grad).abs().max()) <= 2e-2 * float(qr.grad.abs().max())
 
 
-@pytest.mark.parametrize("name", ["llama_decoder_gqa", "llama_decoder_hd64"])
+@pytest.mark.parametrize("name", ["llama_decoder_gqa", "llama_decoder_hd64", "baichuan_decoder"])
 def test_llama_decoder_matches_reference_fixture(ops, name):
-    """The native decoder (REC/model/HLLM/modeling_llama.py) loaded with the reference model's weights reproduces the
-    reference's last hidden state and gradients on the fixture's inputs (valid positions; bf16-mixed vs fp32)."""
+    """The native decoder (REC/model/HLLM/modeling_llama.py; baichuan/modeling_baichuan.py for the packed-projection
+    variant) loaded with the reference model's weights reproduces the reference's last hidden state and gradients on the
+    fixture's inputs (valid positions; bf16-mixed vs fp32)."""
     from REC.model.HLLM.modeling_llama import LlamaConfig, LlamaForCausalLM
     z = np.load(os.path.join(GOLD, name + ".npz"))
     lcfg = json.loads(str(z["lcfg"]))
-    model = LlamaForCausalLM(LlamaConfig(vocab_size=32, max_position_embeddings=64, **lcfg))
+    if lcfg.get("model_type") == "baichuan":
+        from REC.model.HLLM.baichuan.modeling_baichuan import BaichuanConfig, BaichuanForCausalLM
+        model = BaichuanForCausalLM(BaichuanConfig(vocab_size=32, max_position_embeddings=64, **lcfg))
+    else:
+        model = LlamaForCausalLM(LlamaConfig(vocab_size=32, max_position_embeddings=64, **lcfg))
     missing = model.load_state_dict({k[2:]: torch.tensor(z[k]) for k in z.files if k.startswith("w/")}, strict=False)
     assert set(missing.missing_keys) <= {"lm_head.weight"} and not missing.unexpected_keys
     model = model.cuda().train()
@@ -257,9 +262,11 @@ def _oracle_weights(model):
     return HO.tie_repeated_resblocks(w)
 
 
-@pytest.mark.parametrize("variant", ["prior_bycat", "nce_shared", "additive_switch", "dummy", "qwen2_hier"])
+@pytest.mark.parametrize("variant", ["prior_bycat", "nce_shared", "additive_switch", "dummy", "qwen2_hier", "baichuan"])
 def test_hllm_train_step_matches_oracle(ops, variant):
-    kw = dict(prior_bycat={}, nce_shared=dict(loss="nce", num_prior_head=1, pred_len=4, eval_pred_len=4, num_segment_head=2,
+    kw = dict(prior_bycat={},
+              baichuan=dict(user_llm_config=dict(model_type="baichuan", hidden_size=64, intermediate_size=96, num_hidden_layers=2,
+                                                 num_attention_heads=4, vocab_size=32, rms_norm_eps=1e-6)), nce_shared=dict(loss="nce", num_prior_head=1, pred_len=4, eval_pred_len=4, num_segment_head=2,
                                                neg_sample_by_cat=False),
               additive_switch=dict(head_interaction="additive", num_segment_head=2, prior_switch="in", prior_switch_loss_weight=0.5),
               dummy=dict(dummy_llm=True),
@@ -293,7 +300,7 @@ def test_hllm_train_step_matches_oracle(ops, variant):
     for k, p in named.items():
         if not p.requires_grad or w[k].grad is None:
             continue
-        if any(t in k for t in ("layers.0.self_attn.q_proj", "layers.1.mlp.down_proj", "layers.0.input_layernorm", "model.norm",
+        if any(t in k for t in ("layers.0.self_attn.q_proj", "layers.0.self_attn.W_pack", "layers.1.mlp.down_proj", "layers.0.input_layernorm", "model.norm",
                                 "medusa", "logit_scale", "aux_cat_head.0", "embed_layer", "k_proj.bias", "segment_emb")):
             gref = w[k].grad
             assert p.grad is not None, k
@@ -383,11 +390,14 @@ def test_hllm_item_tower_packed_tokens_and_training(ops):
     assert model.item_emb_tokens.grad is not None and float(model.item_emb_tokens.grad.abs().max()) > 0
 
 
-def test_hllm_trainer_steps_reduce_loss(ops):
+@pytest.mark.parametrize("arch", ["llama", "baichuan"])
+def test_hllm_trainer_steps_reduce_loss(ops, arch):
     import sys
     from mhr_amd import synth
+    extra = {} if arch == "llama" else dict(user_llm_config=dict(model_type="baichuan", hidden_size=64, intermediate_size=96,
+                                                                 num_hidden_layers=2, num_attention_heads=4, vocab_size=32))
     cfgd = synth.base_config(**_hllm_cfg(optim_args={'learning_rate': 1e-3, 'weight_decay': 0.0}, total_iters=8, topk=[5],
-                                         scheduler_args=None, save_model_note="t"))
+                                         scheduler_args=None, save_model_note="t", **extra))
     N, B, n_neg = 301, 8, 24
     L, P, C = cfgd["MAX_ITEM_LIST_LENGTH"], cfgd["pred_len"], cfgd["num_prior_head"]
     g = torch.Generator().manual_seed(41)
@@ -406,7 +416,9 @@ def test_hllm_trainer_steps_reduce_loss(ops):
     # place): same loss and gradients as the concatenate-and-cast path taken when the shadows are declared stale
     from mhr_amd.optim import fused_views
     lay = model.user_llm.model.layers[0]
-    assert fused_views([lay.self_attn.q_proj.weight, lay.self_attn.k_proj.weight, lay.self_attn.v_proj.weight]) is not None
+    qkv = [lay.self_attn.W_pack.weight] if arch == "baichuan" else [lay.self_attn.q_proj.weight, lay.self_attn.k_proj.weight,
+                                                                    lay.self_attn.v_proj.weight]
+    assert fused_views(qkv) is not None
     tr.optimizer.zero_grad()
     out_f = model(batch)
     out_f["loss"].backward()

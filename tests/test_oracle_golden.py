@@ -164,8 +164,10 @@ def test_schedule_and_adam():
 # ------------------------------------------------------------------------------------------------
 # HLLM twin: the Llama decoder restatement against the reference's own modeling_llama.py (eager path)
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("name", ["llama_decoder_gqa", "llama_decoder_hd64"])
+@pytest.mark.parametrize("name", ["llama_decoder_gqa", "llama_decoder_hd64", "baichuan_decoder"])
 def test_llama_decoder_oracle_matches_reference(name):
+    """baichuan_decoder: the same restatement behind the packed W_pack projection, against the reference's own
+    REC/model/HLLM/baichuan/modeling_baichuan.py."""
     import json
     from oracle import hllm_oracle as LO
     g = load_golden(name)
@@ -173,7 +175,7 @@ def test_llama_decoder_oracle_matches_reference(name):
     w = {k[2:]: torch.tensor(v).requires_grad_(True) for k, v in g.items() if k.startswith("w/")}
     x = torch.tensor(g["x"]).requires_grad_(True)
     mask = torch.tensor(g["mask"])
-    hidden = LO.llama_decoder(w, lcfg, x, mask)
+    hidden = (LO.baichuan_decoder if lcfg.get("model_type") == "baichuan" else LO.llama_decoder)(w, lcfg, x, mask)
     m = mask[..., None]
     ref = torch.tensor(g["hidden"])
     assert float(((hidden - ref) * m).abs().max()) <= 1e-5 * float(ref.abs().max())       # valid positions (see LO.attention)
