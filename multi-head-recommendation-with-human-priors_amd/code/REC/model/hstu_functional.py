@@ -238,12 +238,16 @@ class EmbeddingGatherFn(Function):
         if holder._row_slot is None or holder._row_slot.numel() != n_rows:
             holder._row_slot = torch.full((n_rows,), -1, dtype=torch.int32, device=dev)
         from mhr_amd import distributed as dist_
-        if dist_.world_size() > 1:
-            # data parallel: fold the input-side gradient into the rows and defer the reduction until the
-            # cross-rank exchange (HSTU.finish_sparse_grad, called by the optimizer)
+        if dist_.world_size() > 1 or getattr(holder, "accumulate_rows", False):
+            # data parallel / gradient accumulation: fold the input-side gradient into the rows and defer the reduction
+            # until the optimizer asks for it (HSTU.finish_sparse_grad: cross-rank exchange, then ONE segment-sum over the
+            # rows of every micro-batch since the last step)
             if d_x is not None:
                 d_rows[:n_item_ids].view(-1, window, D)[:, :L] += d_x
-            holder._pending_rows = (ids_all, d_rows, n_item_ids)
+            shared, holder._shared_pending = getattr(holder, "_shared_pending", None), None
+            if holder._pending_rows is None:
+                holder._pending_rows = []
+            holder._pending_rows.append((ids_all, d_rows, n_item_ids, shared))
             holder.sparse_grad = None
             return None, d_pos, None, None, None, None, None
         sorted_ids, perm = torch.sort(ids_all)
@@ -255,10 +259,29 @@ class EmbeddingGatherFn(Function):
 
 
 def begin_pending_rows(holder):
-    """Data-parallel tail of the embedding backward, first half: the exchange goes on the wire (RCCL, asynchronous)."""
+    """Data-parallel / accumulation tail of the embedding backward, first half: the exchange goes on the wire (RCCL,
+    asynchronous).  Several micro-batches (accumulate_grad > 1, reference trainer.py:521-533) are exchanged as one set:
+    their rank-private rows back to back, then their shared-negative blocks."""
     from mhr_amd import distributed as dist_
-    ids_all, d_rows, n_private = holder._pending_rows
-    shared, holder._shared_pending = getattr(holder, "_shared_pending", None), None
+    pend = holder._pending_rows
+    if len(pend) == 1:
+        ids_all, d_rows, n_private, shared = pend[0]
+    else:
+        shared_rows = []
+        for ids_i, rows_i, n_i, sp in pend:
+            if sp is None:
+                shared_rows.append(rows_i[n_i:])
+            else:
+                if sp[1] is not None:
+                    sp[1].wait()
+                shared_rows.append(sp[0])
+        any_reduced = any(p[3] is not None for p in pend)
+        if any_reduced and not all(p[3] is not None for p in pend):
+            raise RuntimeError("micro-batches of one step mix early-reduced and plain shared-negative blocks")
+        n_private = sum(p[2] for p in pend)
+        ids_all = torch.cat([p[0][:p[2]] for p in pend] + [p[0][p[2]:] for p in pend])
+        d_rows = torch.cat([p[1][:p[2]] for p in pend] + shared_rows)
+        shared = (d_rows[n_private:], None) if any_reduced else None
     holder._row_exchange = dist_.begin_row_exchange(ids_all, d_rows, n_private, shared_pending=shared)
 
 

@@ -57,6 +57,9 @@ class Trainer(object):
         from mhr_amd.optim import FusedAdamW
         self.model = model
         self.optimizer = FusedAdamW(model, lr=self.optim_args['learning_rate'], weight_decay=self.optim_args['weight_decay'])
+        self._micro_step = 0
+        if self.accumulate_grad > 1:                # the item-table gradient rows of all micro-batches are reduced at the step
+            model.accumulate_rows = True
 
     def _lr_at(self, step):
         base = self.optim_args['learning_rate']
@@ -70,14 +73,17 @@ class Trainer(object):
             raise ValueError('Training loss is nan')
 
     def train_step_fn(self, data):
-        """One optimisation step (forward, backward, exchange, fused Adam).  Returns the model_out dict (device tensors)."""
-        self.optimizer.param_groups[0]["lr"] = self._lr_at(self.train_step)
+        """One forward / backward; every `accumulate_grad`-th call also exchanges the gradients and runs the fused Adam
+        (reference trainer.py:511-536).  Returns the model_out dict (device tensors)."""
         model_out = self.model(data)
         loss = model_out["loss"]
         (loss / self.accumulate_grad).backward()
-        self.train_step += 1
-        self.optimizer.step()
-        self.optimizer.zero_grad()
+        self._micro_step += 1
+        if self._micro_step % self.accumulate_grad == 0:
+            self.optimizer.param_groups[0]["lr"] = self._lr_at(self.train_step)
+            self.train_step += 1
+            self.optimizer.step()
+            self.optimizer.zero_grad()
         return model_out
 
     def fit(self, train_data, valid_data=None, verbose=True, saved=True, show_progress=False, callback_fn=None):
@@ -85,7 +91,7 @@ class Trainer(object):
         iterator = iter(train_data)
         t0 = time.time()
         running = None
-        for it in range(self.train_step, self.total_iters):
+        for it in range(self.train_step * self.accumulate_grad, self.total_iters * self.accumulate_grad):
             try:
                 data = next(iterator)
             except StopIteration:
@@ -97,6 +103,8 @@ class Trainer(object):
                 data = tuple(d.to(self.device, non_blocking=True) for d in data)
             out = self.train_step_fn(data)
             running = out
+            if self._micro_step % self.accumulate_grad:
+                continue
             if verbose and self.train_step % self.update_interval == 0:
                 loss = out["loss"].item()                                   # the only host sync of the train loop
                 self._check_nan(out["loss"])

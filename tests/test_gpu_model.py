@@ -582,3 +582,57 @@ def test_data_parallel_train_step_two_ranks_one_card(rec, tmp_path, overlap):
     for got, want in ((r[0]["flat_g"], want_flat), (r[0]["table_g"], want_table)):
         assert np.abs(got - want).max() <= 2e-2 * np.abs(want).max()                    # bf16 rows on the wire, summation order
     assert (np.abs(r[0]["table_g"]).sum(1) > 0).sum() == (np.abs(want_table).sum(1) > 0).sum()   # same touched rows
+
+
+def test_gradient_accumulation_matches_separate_micro_batches(rec):
+    """accumulate_grad = 2 (reference trainer.py:521-533): the gradient the optimizer sees after two micro-batches is the
+    sum of the two halves' gradients - dense parameters in the flat buffer, item-table rows from ONE deferred reduction."""
+    import mhr_amd.synth as synth
+    from REC.config.configurator import Config, apply_run_fixups
+    from REC.trainer import Trainer
+    from REC.utils import get_model
+    dev = torch.device("cuda", 0)
+    kw = dict(MAX_ITEM_LIST_LENGTH=16, pred_len=2, eval_pred_len=2, n_layers=2, n_heads=2, item_embedding_size=64,
+              hstu_embedding_size=64, num_negatives=256, total_iters=100, eval_interval=0, checkpoint_dir=None, save_model_note="t",
+              hidden_dropout_prob=0.0, attn_dropout_prob=0.0, loss='prior', num_prior_head=3, medusa_num_layers=1, eval_num_cats=3,
+              device=dev)
+
+    def make(acc):
+        cfg = apply_run_fixups(Config(config_dict=synth.base_config(**kw, accumulate_grad=acc)))
+        data = synth.SyntheticData(cfg, 3000, dev, seed=11)
+        cfg["int_to_category"] = data.int_to_category
+        torch.manual_seed(5)
+        model = get_model("HSTU")(cfg, data).to(dev)
+        tr = Trainer(cfg)
+        tr.setup_model(model)
+        tr.train_step = 30
+        return model, tr, data
+
+    model, tr, data = make(2)
+    b1, b2 = data.train_batch(8), data.train_batch(8)
+    seen = {}
+    real_step = tr.optimizer.step
+
+    def spy():
+        seen["flat"] = tr.optimizer.flat_g.clone()
+        seen["table"] = model.finish_sparse_grad().to_dense()
+        real_step()
+    tr.optimizer.step = spy
+    w0 = model.item_embedding.weight.detach().clone()
+    tr.train_step_fn(b1)
+    assert not seen and torch.equal(model.item_embedding.weight, w0) and tr.train_step == 30      # no update after one micro-batch
+    tr.train_step_fn(b2)
+    assert seen and tr.train_step == 31 and not torch.equal(model.item_embedding.weight, w0)
+
+    model1, tr1, _ = make(1)
+    flat, table = 0, 0
+    for b in (b1, b2):
+        tr1.optimizer.zero_grad()
+        (model1(b)["loss"] / 2).backward()
+        sg = model1.finish_sparse_grad()
+        table = table + sg.to_dense()
+        sg.row_slot.fill_(-1)
+        flat = flat + tr1.optimizer.flat_g.clone()
+    assert float((seen["flat"] - flat).abs().max()) <= 1e-3 * float(flat.abs().max())
+    assert float((seen["table"] - table).abs().max()) <= 1e-3 * float(table.abs().max())
+    assert int((seen["table"].abs().sum(1) > 0).sum()) == int((table.abs().sum(1) > 0).sum())
