@@ -294,6 +294,48 @@ int mhr_nce_bwd_negs(const void* qn, const void* negs, const uint32_t* supp, int
                      const float* lw, float* d_negs, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Sampled softmax with QUERY-ROW SHARING (csrc/nce_shared.hip; same reference lines as mhr_nce_fwd, plus the window
+ * construction hstu.py:682-690, 808-829 that makes P tokens share one query).  The tokens (b, l, p), p = 0..P-1, of a
+ * prior category use the same query row and differ in their target only, so the negative-pool products are evaluated per
+ * DISTINCT ROW: the caller runs mhr_nce_fwd and mhr_nce_bwd_negs on the row list (no suppression: an all-zero bit table)
+ * and these entry points add what depends on the token.  Token lists must keep the tokens of a row adjacent.
+ *   tok2row [n_groups, tok_cap] int32: row of token t;  row arrays are [n_groups, row_cap(, dim)], token arrays
+ *   [n_groups, tok_cap(, dim)];  row_first [n_groups, row_cap] int32: first token of row r (entry n_row = n_tok).
+ * mhr_nce_fix_bits: the false-negative bit table of mhr_nce_fwd as a launch of its own (same arguments), plus
+ *   fix_any [n_groups, round_up(n_p_rows, 256)] int32 (caller zeroes): != 0 where a target row has any suppressed negative.
+ * mhr_nce_shared_fwd_tokens: per token: pn_out = bf16(target / |target|), p_inv, s_pos = qn_row . pn,
+ *   sum_tok = sum_row - sum over the token's suppressed negatives of exp(scale (s_j - 1)); with log counters:
+ *   n_valid_tok = n_valid_row - #suppressed, rank_tok = rank_row - #suppressed with s_j > s_pos (rank_row must have been
+ *   counted against this token's target: the caller gives the row kernel the target of the row's first token).
+ *   Then mhr_nce_finalize on the token arrays as usual.
+ * mhr_nce_shared_bwd_tokens: mhr_nce_bwd_tokens reading qn / u / q_inv of the token's ROW; takes the token's suppressed
+ *   negatives out of u (bf16-rounded, as the row kernel accumulated them) and subtracts their share from d_negs
+ *   ([n_groups, n_neg, dim] f32, may be NULL); writes lw_out per token.
+ * mhr_nce_row_lw: lw_row[r] = -log2 sum_{t in r} 2^(-lw_tok[t]) (the weight of a row in mhr_nce_bwd_negs); rows beyond
+ *   n_row are left untouched (the caller fills lw_row with +inf).
+ * ---------------------------------------------------------------------------------------- */
+int mhr_nce_fix_bits(const void* p_rows, int io_dtype, int64_t n_p_rows, const void* negs, int n_neg, int dim,
+                     int n_groups, float thres, uint32_t* fix_words, const int32_t* fix_row_list,
+                     const int32_t* fix_n_rows, int32_t* fix_slot_of_row, int32_t* fix_any, void* stream);
+int mhr_nce_shared_fwd_tokens(const void* p_rows, int io_dtype, int64_t n_p_rows, const int32_t* p_idx,
+                              const int32_t* tok2row, int n_groups, const int32_t* n_tok_dev, int tok_cap,
+                              int row_cap, const void* qn_row, const float* sum_row, const int32_t* n_valid_row,
+                              const int32_t* rank_row, const void* negs, int n_neg, int dim,
+                              const float* logit_scale_dev, const uint32_t* fix_words,
+                              const int32_t* fix_slot_of_row, const int32_t* fix_any, void* pn_out, float* p_inv,
+                              float* s_pos, float* sum_tok, int32_t* n_valid_tok, int32_t* rank_tok, void* stream);
+int mhr_nce_shared_bwd_tokens(const void* qn_row, const float* u_row, const float* q_inv_row, int row_cap,
+                              const int32_t* tok2row, const void* pn, int dim, int n_groups,
+                              const int32_t* n_tok_dev, int tok_cap, const float* logit_scale_dev,
+                              const float* lse, const float* w, const float* p_inv, const float* s_pos,
+                              const int32_t* q_idx, const int32_t* p_idx, float* dq_rows, float* dp_rows,
+                              float* d_logit_scale, float* lw_out, const int32_t* w_bucket, int n_buckets,
+                              const void* negs, int n_neg, const uint32_t* fix_words, int64_t n_p_rows,
+                              const int32_t* fix_slot_of_row, const int32_t* fix_any, float* d_negs, void* stream);
+int mhr_nce_row_lw(const float* lw_tok, const int32_t* row_first, const int32_t* n_row_dev, int n_groups,
+                   int tok_cap, int row_cap, float* lw_row, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Full-catalog multi-head scoring + top-k + cross-head merge
  * (model/IDNet/hstu.py:965-1015, trainer/trainer.py:724-726, evaluator/collector.py:241-282).
  * ---------------------------------------------------------------------------------------- */

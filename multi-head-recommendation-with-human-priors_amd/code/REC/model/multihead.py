@@ -252,7 +252,8 @@ class MultiHeadDecoding:
         logs = {} if want_logs else None
         mean_p = NceLossFn.apply(head_rows, e_rows, negs_g, self.logit_scale, q_idx, p_idx, n_tok, cap,
                                  float(self.nce_thres), want_logs, logs, o_idx, P,
-                                 log_group if want_logs else -1, p_row_mask)                         # [G, P]
+                                 log_group if want_logs else -1, p_row_mask,
+                                 P > 1 and q_all is q_static)     # the P offsets of a position share their query row   [G, P]
         live = (torch.arange(cap, device=dev)[None, :] < n_tok[:, None]).float() if want_logs else None
         out_logs = None
         if want_logs:

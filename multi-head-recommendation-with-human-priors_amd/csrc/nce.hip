@@ -521,13 +521,14 @@ __global__ __launch_bounds__(256, 2) void nce_fix_bits_kernel(const IT* __restri
                                                               int n_neg, float thres, uint32_t* __restrict__ fixw,
                                                               int n_rows_pad, int tiles_per_slice,
                                                               const int32_t* __restrict__ row_list, const int32_t* __restrict__ n_list,
-                                                              int32_t* __restrict__ slot_of_row) {
+                                                              int32_t* __restrict__ slot_of_row, int32_t* __restrict__ any_out) {
   using T = sg::Tile<NKS>;
   constexpr int RF = 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int n_tiles = (n_neg + 31) >> 5;
   negs += (int64_t)blockIdx.z * ((n_neg + 31) & ~31) * T::DIM;
   fixw += (int64_t)blockIdx.z * n_tiles * n_rows_pad;
+  if (any_out) any_out += (int64_t)blockIdx.z * n_rows_pad;
   const int t0 = blockIdx.y * tiles_per_slice, t1 = min(n_tiles, t0 + tiles_per_slice);
   if (t0 >= t1) return;
   // with a row list only the rows some token of this group points at are tested (slot j of the list = column j of the
@@ -590,6 +591,7 @@ __global__ __launch_bounds__(256, 2) void nce_fix_bits_kernel(const IT* __restri
       uint32_t w = b << (4 * half);
       w |= __shfl_xor(w, 32, 64);
       if (half == 0) fixw[(int64_t)t * n_rows_pad + row[f]] = w;       // rows >= n_rows are zero rows: w = 0, inside the padding
+      if (half == 0 && w != 0u && any_out) atomicOr(any_out + row[f], 1);   // rare: lets token kernels skip rows without hits
     }
   });
   sg::wait_vmcnt<0>();
@@ -1182,13 +1184,13 @@ extern "C" int mhr_nce_fwd(const void* q_rows, const int32_t* q_idx, const void*
     if (io_dtype == MHR_BF16) {                                                                                          \
       hipLaunchKernelGGL((nce_fix_bits_kernel<NKS, bf16_t>), gf, dim3(256), ldsf, s, (const bf16_t*)p_rows, (int)n_p_rows, \
                          (const bf16_t*)negs, n_neg, thres, fix_words, n_rows_pad, tps_f, fix_row_list, fix_n_rows,     \
-                         fix_slot_of_row);                                                                               \
+                         fix_slot_of_row, (int32_t*)nullptr);                                                            \
       if (logs) hipLaunchKernelGGL((nce_fwd_d_kernel<NKS, bf16_t, true>), gu, dim3(256), ldsd, s, UARGS(bf16_t), fix_words, n_rows_pad, fix_slot_of_row, (int)n_p_rows); \
       else hipLaunchKernelGGL((nce_fwd_d_kernel<NKS, bf16_t, false>), gu, dim3(256), ldsd, s, UARGS(bf16_t), fix_words, n_rows_pad, fix_slot_of_row, (int)n_p_rows);     \
     } else {                                                                                                             \
       hipLaunchKernelGGL((nce_fix_bits_kernel<NKS, float>), gf, dim3(256), ldsf, s, (const float*)p_rows, (int)n_p_rows, \
                          (const bf16_t*)negs, n_neg, thres, fix_words, n_rows_pad, tps_f, fix_row_list, fix_n_rows,     \
-                         fix_slot_of_row);                                                                               \
+                         fix_slot_of_row, (int32_t*)nullptr);                                                            \
       if (logs) hipLaunchKernelGGL((nce_fwd_d_kernel<NKS, float, true>), gu, dim3(256), ldsd, s, UARGS(float), fix_words, n_rows_pad, fix_slot_of_row, (int)n_p_rows); \
       else hipLaunchKernelGGL((nce_fwd_d_kernel<NKS, float, false>), gu, dim3(256), ldsd, s, UARGS(float), fix_words, n_rows_pad, fix_slot_of_row, (int)n_p_rows);     \
     }                                                                                                                    \
@@ -1220,6 +1222,39 @@ extern "C" int mhr_nce_fwd(const void* q_rows, const int32_t* q_idx, const void*
 #undef ARGS
 #undef UARGS
   MHR_CHECK_LAUNCH("nce_fwd");
+  return MHR_OK;
+}
+
+extern "C" int mhr_nce_fix_bits(const void* p_rows, int io_dtype, int64_t n_p_rows, const void* negs, int n_neg, int dim,
+                                int n_groups, float thres, uint32_t* fix_words, const int32_t* fix_row_list,
+                                const int32_t* fix_n_rows, int32_t* fix_slot_of_row, int32_t* fix_any, void* stream) {
+  MHR_REQUIRE(p_rows && negs && fix_words, "nce_fix_bits: null pointer");
+  MHR_REQUIRE((fix_row_list != nullptr) == (fix_n_rows != nullptr) && (fix_n_rows != nullptr) == (fix_slot_of_row != nullptr),
+              "nce_fix_bits: fix_row_list, fix_n_rows and fix_slot_of_row go together");
+  int nks;
+  MHR_REQUIRE(nks_for(dim, nks), "nce_fix_bits: dim=%d unsupported (16/32/64/128/256)", dim);
+  MHR_REQUIRE(n_neg > 0 && n_p_rows > 0 && n_groups >= 1 && n_groups <= 65535, "nce_fix_bits: bad sizes");
+  hipStream_t s = (hipStream_t)stream;
+  const int n_tiles = (n_neg + 31) / 32, n_rows_pad = (int)((n_p_rows + 255) / 256 * 256);
+  int slices = 1;                       // fill the 512 workgroup slots about twice over
+  while (slices < 8 && (n_rows_pad / 256) * n_groups * slices < 768 && n_tiles / (slices * 2) >= 16) slices *= 2;
+  const int tps_f = (n_tiles + slices - 1) / slices;
+#define LFB_(NKS)                                                                                                        \
+  {                                                                                                                      \
+    const dim3 gf(n_rows_pad / 256, slices, n_groups);                                                                   \
+    const size_t ldsf = 3 * sg::Tile<NKS>::BYTES;                                                                        \
+    if (io_dtype == MHR_BF16)                                                                                            \
+      hipLaunchKernelGGL((nce_fix_bits_kernel<NKS, bf16_t>), gf, dim3(256), ldsf, s, (const bf16_t*)p_rows, (int)n_p_rows, \
+                         (const bf16_t*)negs, n_neg, thres, fix_words, n_rows_pad, tps_f, fix_row_list, fix_n_rows,     \
+                         fix_slot_of_row, fix_any);                                                                      \
+    else                                                                                                                 \
+      hipLaunchKernelGGL((nce_fix_bits_kernel<NKS, float>), gf, dim3(256), ldsf, s, (const float*)p_rows, (int)n_p_rows, \
+                         (const bf16_t*)negs, n_neg, thres, fix_words, n_rows_pad, tps_f, fix_row_list, fix_n_rows,     \
+                         fix_slot_of_row, fix_any);                                                                      \
+  }
+  NKS_SWITCH(nks, LFB_);
+#undef LFB_
+  MHR_CHECK_LAUNCH("nce_fix_bits");
   return MHR_OK;
 }
 

@@ -1,0 +1,366 @@
+// Sampled softmax with QUERY-ROW SHARING (reference model/IDNet/hstu.py:600-619, 682-723, 808-870), gfx950.
+//
+// In the multi-head loss the tokens (b, l, p), p = 0..P-1, of one prior category all use the SAME query row - head c's
+// embedding at (b, l) - and differ in their target (position l + 1 + p) only.  The logits s_j = cos(q, n_j) against the
+// category's negative pool, the gated values E_j = exp(scale (s_j - 1)), the sum over them and the token-side gradient
+// U = sum_j E_j n_j therefore depend on the ROW, not on the token: the reference (and the per-token kernels in nce.hip)
+// evaluate them once per token, i.e. up to P times.  What does depend on the token:
+//   * the positive pair: s+ = cos(q, target_t)                              (one dot product per token)
+//   * the false-negative suppression: negative j is dropped for token t when cos(target_t, n_j) > thres; that is a
+//     property of the TARGET row (bit table of nce_fix_bits) and it fires for a few percent of the tokens at most (the
+//     sampled pool happens to contain the target or a near-duplicate).
+// So the two streaming MFMA kernels of nce.hip (mhr_nce_fwd fused forward, mhr_nce_bwd_negs) run here on the DISTINCT
+// ROWS with no suppression at all (cfg1: ~3.4x fewer rows than tokens), and the kernels of this file add the per-token
+// terms and take the suppressed pairs back out, pair by pair:
+//   sum_t = sum_row - sum_{j in J_t} E_j,   U_t = U_row - sum_{j in J_t} bf16(E_j) n_j,
+//   dN_j -= scale w_t exp(scale s_j - lse_t) qn_row   for j in J_t,
+//   n_valid_t = n_valid_row - |J_t|,   rank_t = rank_row - #{j in J_t : s_j > s+}
+// (bf16(E_j): the row kernel feeds the gated tile to the matrix pipe in bf16, the correction removes what went in).
+// Per-row weight of the negative-side backward: sum_t w_t exp(scale s - lse_t) = exp2(c1 s - lw_row),
+//   lw_row = -log2 sum_t 2^(-lw_t)  (mhr_nce_row_lw, evaluated max-shifted).
+//
+// Token lists are ordered prediction-offset-fastest (multihead.py), so the tokens of a row are neighbours: tok2row[t] is
+// the row of token t, row_first[r] .. row_first[r + 1] its tokens.
+#include "mhr_common.h"
+
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr int NC = 4;   // 64-column chunks (dim <= 256): lane owns columns c * 64 + lane
+
+__device__ __forceinline__ float clamp_scale(const float* logit_scale_dev) {
+  float ls = *logit_scale_dev;
+  ls = fminf(fmaxf(ls, 0.0f), 4.605170185988092f);   // [0, ln 100]  (hstu.py:602)
+  return __expf(ls);
+}
+
+template <typename IT>
+__device__ __forceinline__ float ld(const IT* p) { return (float)*p; }
+
+// Visits the suppressed negatives of one target row (wave-uniform control flow): f(j) for every set bit of the row's
+// column of the bit table.  fixw: [n_tiles, n_rows_pad] words of this group, bit b of word [tile, slot] = negative 32 tile + b.
+template <typename F>
+__device__ __forceinline__ void for_each_hit(const uint32_t* __restrict__ fixw, int n_tiles, int n_rows_pad, int slot, int n_neg,
+                                             int lane, F&& f) {
+  for (int w0 = 0; w0 < n_tiles; w0 += 64) {
+    const int tile = w0 + lane;
+    const uint32_t word = tile < n_tiles ? fixw[(int64_t)tile * n_rows_pad + slot] : 0u;
+    uint64_t m = __ballot(word != 0u);
+    while (m) {
+      const int l = __builtin_ctzll(m);
+      m &= m - 1;
+      uint32_t wv = (uint32_t)__builtin_amdgcn_readlane((int)word, l);
+      while (wv) {
+        const int b = __builtin_ctz(wv);
+        wv &= wv - 1;
+        const int j = (w0 + l) * 32 + b;
+        if (j < n_neg) f(j);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// forward, per token: normalised target, s+, the row's sum minus this token's suppressed negatives, log counters
+// ------------------------------------------------------------------------------------------
+template <typename IT>
+__global__ __launch_bounds__(256) void shared_tok_fwd_kernel(
+    const IT* __restrict__ p_rows, int n_p_rows, const int32_t* __restrict__ p_idx, const int32_t* __restrict__ tok2row,
+    const int32_t* __restrict__ n_tok_dev, int tok_cap, int row_cap, const bf16_t* __restrict__ qn_row,
+    const float* __restrict__ sum_row, const int32_t* __restrict__ n_valid_row, const int32_t* __restrict__ rank_row,
+    const bf16_t* __restrict__ negs, int n_neg, int dim, const float* __restrict__ logit_scale_dev,
+    const uint32_t* __restrict__ fixw, int n_rows_pad, const int32_t* __restrict__ slot_of_row,
+    const int32_t* __restrict__ fix_any, bf16_t* __restrict__ pn_out, float* __restrict__ p_inv, float* __restrict__ s_pos,
+    float* __restrict__ sum_tok, int32_t* __restrict__ n_valid_tok, int32_t* __restrict__ rank_tok) {
+  const int n_tiles = (n_neg + 31) >> 5;
+  {
+    const int64_t grp = blockIdx.z, to = grp * tok_cap, ro = grp * row_cap;
+    p_idx += to; tok2row += to; n_tok_dev += grp; pn_out += to * dim; p_inv += to; s_pos += to; sum_tok += to;
+    qn_row += ro * dim; sum_row += ro;
+    if (n_valid_row) { n_valid_row += ro; n_valid_tok += to; }
+    if (rank_row) { rank_row += ro; rank_tok += to; }
+    negs += grp * (int64_t)((n_neg + 31) & ~31) * dim;
+    fixw += grp * (int64_t)n_tiles * n_rows_pad;
+    fix_any += grp * (int64_t)n_rows_pad;
+    if (slot_of_row) slot_of_row += grp * (int64_t)n_p_rows;
+  }
+  const int n_tok = min(*n_tok_dev, tok_cap);
+  const int lane = threadIdx.x & 63;
+  const int wave_g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), n_waves = gridDim.x * (blockDim.x >> 6);
+  const float scale = clamp_scale(logit_scale_dev);
+  const float c1 = scale * LOG2E;
+  for (int tk = wave_g; tk < n_tok; tk += n_waves) {
+    const int r = tok2row[tk], pr = p_idx[tk];
+    const IT* ps = p_rows + (int64_t)pr * dim;
+    const bf16_t* qs = qn_row + (int64_t)r * dim;
+    float pv[NC], qv[NC];
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int d = c * 64 + lane;
+      pv[c] = d < dim ? ld<IT>(ps + d) : 0.f;
+      qv[c] = d < dim ? (float)qs[d] : 0.f;
+      ss += pv[c] * pv[c];
+    }
+    ss = wave_sum(ss);
+    const float inv = 1.0f / sqrtf(ss);
+    float sp = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int d = c * 64 + lane;
+      const bf16_t pb = (bf16_t)(pv[c] * inv);
+      if (d < dim) pn_out[(int64_t)tk * dim + d] = pb;
+      sp += qv[c] * (float)pb;
+    }
+    sp = wave_sum(sp);
+    float corr = 0.f;
+    int hits = 0, above = 0;
+    const int slot = slot_of_row ? slot_of_row[pr] : pr;
+    if (fix_any[slot] != 0) {                                     // wave-uniform; a few percent of the tokens
+      for_each_hit(fixw, n_tiles, n_rows_pad, slot, n_neg, lane, [&](int j) {
+        const bf16_t* ns = negs + (int64_t)j * dim;
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          const int d = c * 64 + lane;
+          s += d < dim ? qv[c] * (float)ns[d] : 0.f;
+        }
+        s = wave_sum(s);
+        corr += __builtin_amdgcn_exp2f(s * c1 - c1);
+        hits += 1;
+        above += s > sp ? 1 : 0;
+      });
+    }
+    if (lane == 0) {
+      p_inv[tk] = inv;
+      s_pos[tk] = sp;
+      sum_tok[tk] = fmaxf(sum_row[r] - corr, 0.f);
+      if (n_valid_row) n_valid_tok[tk] = n_valid_row[r] - hits;
+      if (rank_row) rank_tok[tk] = max(rank_row[r] - above, 0);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// backward, per token (the row-wise kernel of nce.hip reading the row's state): dq_rows, dp_rows, d(logit_scale), lw,
+// and the suppressed pairs taken back out of U (token side) and of d_negs (negative side)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void shared_tok_bwd_kernel(
+    const bf16_t* __restrict__ qn_row, const float* __restrict__ u_row, const float* __restrict__ q_inv_row, int row_cap,
+    const int32_t* __restrict__ tok2row, const bf16_t* __restrict__ pn, int dim, const int32_t* __restrict__ n_tok_dev,
+    int tok_cap, const float* __restrict__ logit_scale_dev, const float* __restrict__ lse, const float* __restrict__ w,
+    const float* __restrict__ p_inv, const float* __restrict__ s_pos, const int32_t* __restrict__ q_idx,
+    const int32_t* __restrict__ p_idx, float* __restrict__ dq_rows, float* __restrict__ dp_rows,
+    float* __restrict__ d_logit_scale, float* __restrict__ lw_out, const int32_t* __restrict__ w_bucket, int n_buckets,
+    const bf16_t* __restrict__ negs, int n_neg, const uint32_t* __restrict__ fixw, int n_rows_pad, int n_p_rows,
+    const int32_t* __restrict__ slot_of_row, const int32_t* __restrict__ fix_any, float* __restrict__ d_negs) {
+  const int n_tiles = (n_neg + 31) >> 5;
+  {
+    const int64_t grp = blockIdx.z, to = grp * tok_cap, ro = grp * row_cap;
+    qn_row += ro * dim; u_row += ro * dim; q_inv_row += ro;
+    tok2row += to; pn += to * dim; n_tok_dev += grp; lse += to; p_inv += to; s_pos += to; q_idx += to; p_idx += to;
+    lw_out += to;
+    if (w_bucket) { w_bucket += to; w += grp * n_buckets; } else { w += to; }
+    negs += grp * (int64_t)((n_neg + 31) & ~31) * dim;
+    fixw += grp * (int64_t)n_tiles * n_rows_pad;
+    fix_any += grp * (int64_t)n_rows_pad;
+    if (slot_of_row) slot_of_row += grp * (int64_t)n_p_rows;
+    if (d_negs) d_negs += grp * (int64_t)n_neg * dim;
+  }
+  const int n_tok = min(*n_tok_dev, tok_cap);
+  const int lane = threadIdx.x & 63;
+  const int wave_g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), n_waves = gridDim.x * (blockDim.x >> 6);
+  const float scale = clamp_scale(logit_scale_dev);
+  const float c1 = scale * LOG2E;
+  constexpr int TB = 8;      // consecutive tokens per wave pass: the tokens of a row are neighbours, their dq rows leave as one
+  float dls = 0.f;
+  for (int t0 = wave_g * TB; t0 < n_tok; t0 += n_waves * TB) {
+    float accq[NC] = {0.f, 0.f, 0.f, 0.f};
+    float qv[NC] = {0.f, 0.f, 0.f, 0.f}, uv[NC] = {0.f, 0.f, 0.f, 0.f};
+    int run_row = -1, cur_r = -1;
+    float iq = 0.f;
+    auto flush = [&]() {
+      if (run_row >= 0) {
+        float* qdst = dq_rows + (int64_t)run_row * dim;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          const int d = c * 64 + lane;
+          if (d < dim) atomicAdd(qdst + d, accq[c]);
+        }
+      }
+    };
+    for (int b = 0; b < TB; ++b) {
+      const int tk = t0 + b;
+      if (tk >= n_tok) break;
+      const int r = tok2row[tk];
+      if (r != cur_r) {                               // wave-uniform: the row's state is loaded once per run
+        cur_r = r;
+        iq = q_inv_row[r];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          const int d = c * 64 + lane;
+          qv[c] = d < dim ? (float)qn_row[(int64_t)r * dim + d] : 0.f;
+          uv[c] = d < dim ? u_row[(int64_t)r * dim + d] : 0.f;
+        }
+      }
+      const float wi = w_bucket ? w[w_bucket[tk]] : w[tk];
+      const float sp = s_pos[tk], ls = lse[tk], ip = p_inv[tk];
+      const int qi = q_idx[tk], pi = p_idx[tk];
+      float pv[NC];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const int d = c * 64 + lane;
+        pv[c] = d < dim ? (float)pn[(int64_t)tk * dim + d] : 0.f;
+      }
+      const float a = wi * __expf(scale - ls);                          // G_ij = a * E_ij
+      const float coef = wi * (__expf(scale * sp - ls) - 1.0f);         // w (p_pos - 1)
+      if (lane == 0) lw_out[tk] = ls * LOG2E - __log2f(wi);
+      // this token's suppressed negatives: out of U, and out of what the row-level negative-side kernel adds to d_negs
+      float uc[NC] = {0.f, 0.f, 0.f, 0.f};
+      const int slot = slot_of_row ? slot_of_row[pi] : pi;
+      if (fix_any[slot] != 0) {
+        for_each_hit(fixw, n_tiles, n_rows_pad, slot, n_neg, lane, [&](int j) {
+          const bf16_t* ns = negs + (int64_t)j * dim;
+          float nv[NC];
+          float s = 0.f;
+#pragma unroll
+          for (int c = 0; c < NC; ++c) {
+            const int d = c * 64 + lane;
+            nv[c] = d < dim ? (float)ns[d] : 0.f;
+            s += qv[c] * nv[c];
+          }
+          s = wave_sum(s);
+          const float eb = (float)(bf16_t)__builtin_amdgcn_exp2f(s * c1 - c1);       // what the row kernel put into U
+          const float gneg = -scale * wi * __expf(scale * s - ls);                   // what bwd_negs adds for this token
+#pragma unroll
+          for (int c = 0; c < NC; ++c) {
+            const int d = c * 64 + lane;
+            uc[c] += eb * nv[c];
+            if (d_negs && d < dim && wi != 0.f) atomicAdd(d_negs + (int64_t)j * dim + d, gneg * qv[c]);
+          }
+        });
+      }
+      float dqn[NC], dpn[NC];
+      float dot_q = 0.f, dot_p = 0.f, dot_raw = 0.f;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const float raw = a * (uv[c] - uc[c]);
+        dqn[c] = scale * (raw + coef * pv[c]);
+        dpn[c] = scale * coef * qv[c];
+        dot_raw += qv[c] * raw;
+        dot_q += qv[c] * dqn[c];
+        dot_p += pv[c] * dpn[c];
+      }
+      dot_q = wave_sum(dot_q);
+      dot_p = wave_sum(dot_p);
+      dls += wave_sum(dot_raw) + coef * sp;           // sum_j g_ij s_ij = qn_i . dQn_i, plus the positive term
+      if (qi != run_row) {                            // wave-uniform
+        flush();
+        run_row = qi;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) accq[c] = 0.f;
+      }
+#pragma unroll
+      for (int c = 0; c < NC; ++c) accq[c] += (dqn[c] - qv[c] * dot_q) * iq;
+      float* pdst = dp_rows + (int64_t)pi * dim;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const int d = c * 64 + lane;
+        if (d < dim) atomicAdd(pdst + d, (dpn[c] - pv[c] * dot_p) * ip);
+      }
+    }
+    flush();
+  }
+  if (lane == 0 && d_logit_scale && dls != 0.f) atomicAdd(d_logit_scale, dls * scale);   // d/d(param), scale = exp(param)
+}
+
+// lw_row[r] = -log2 sum_{t in row r} 2^(-lw_tok[t]), max-shifted; +inf when every token of the row has zero weight
+__global__ __launch_bounds__(256) void row_lw_kernel(const float* __restrict__ lw_tok, const int32_t* __restrict__ row_first,
+                                                     const int32_t* __restrict__ n_row_dev, int tok_cap, int row_cap,
+                                                     float* __restrict__ lw_row) {
+  const int64_t grp = blockIdx.y;
+  lw_tok += grp * tok_cap; row_first += grp * row_cap; lw_row += grp * row_cap;
+  const int n_row = min(n_row_dev[grp], row_cap - 1);
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_row) return;
+  const int t0 = row_first[r], t1 = min(row_first[r + 1], tok_cap);
+  float m = INFINITY;
+  for (int t = t0; t < t1; ++t) m = fminf(m, lw_tok[t]);
+  float out = INFINITY;
+  if (m < INFINITY) {
+    float acc = 0.f;
+    for (int t = t0; t < t1; ++t) acc += __builtin_amdgcn_exp2f(m - lw_tok[t]);
+    out = m - __log2f(acc);
+  }
+  lw_row[r] = out;
+}
+
+}  // namespace
+
+extern "C" int mhr_nce_shared_fwd_tokens(const void* p_rows, int io_dtype, int64_t n_p_rows, const int32_t* p_idx,
+                                         const int32_t* tok2row, int n_groups, const int32_t* n_tok_dev, int tok_cap,
+                                         int row_cap, const void* qn_row, const float* sum_row, const int32_t* n_valid_row,
+                                         const int32_t* rank_row, const void* negs, int n_neg, int dim,
+                                         const float* logit_scale_dev, const uint32_t* fix_words,
+                                         const int32_t* fix_slot_of_row, const int32_t* fix_any, void* pn_out, float* p_inv,
+                                         float* s_pos, float* sum_tok, int32_t* n_valid_tok, int32_t* rank_tok, void* stream) {
+  MHR_REQUIRE(p_rows && p_idx && tok2row && n_tok_dev && qn_row && sum_row && negs && logit_scale_dev && fix_words && fix_any,
+              "nce_shared_fwd_tokens: null input pointer");
+  MHR_REQUIRE(pn_out && p_inv && s_pos && sum_tok, "nce_shared_fwd_tokens: null output pointer");
+  MHR_REQUIRE((n_valid_row != nullptr) == (n_valid_tok != nullptr) && (rank_row != nullptr) == (rank_tok != nullptr),
+              "nce_shared_fwd_tokens: row / token log counters go together");
+  MHR_REQUIRE(dim > 0 && dim <= 256, "nce_shared_fwd_tokens: dim=%d unsupported (<= 256)", dim);
+  MHR_REQUIRE(tok_cap > 0 && row_cap > 0 && n_neg > 0 && n_p_rows > 0 && n_groups >= 1 && n_groups <= 65535,
+              "nce_shared_fwd_tokens: bad sizes");
+  const int n_rows_pad = (int)((n_p_rows + 255) / 256 * 256);
+  int blocks = (tok_cap + 15) / 16;                  // 4 waves x 4 tokens
+  if (blocks > 4096) blocks = 4096;
+  const dim3 grid(blocks, 1, n_groups);
+#define LAUNCH(IT)                                                                                                       \
+  hipLaunchKernelGGL((shared_tok_fwd_kernel<IT>), grid, dim3(256), 0, (hipStream_t)stream, (const IT*)p_rows, (int)n_p_rows, \
+                     p_idx, tok2row, n_tok_dev, tok_cap, row_cap, (const bf16_t*)qn_row, sum_row, n_valid_row, rank_row, \
+                     (const bf16_t*)negs, n_neg, dim, logit_scale_dev, fix_words, n_rows_pad, fix_slot_of_row, fix_any,  \
+                     (bf16_t*)pn_out, p_inv, s_pos, sum_tok, n_valid_tok, rank_tok)
+  if (io_dtype == MHR_BF16) LAUNCH(bf16_t);
+  else LAUNCH(float);
+#undef LAUNCH
+  MHR_CHECK_LAUNCH("nce_shared_fwd_tokens");
+  return MHR_OK;
+}
+
+extern "C" int mhr_nce_shared_bwd_tokens(const void* qn_row, const float* u_row, const float* q_inv_row, int row_cap,
+                                         const int32_t* tok2row, const void* pn, int dim, int n_groups,
+                                         const int32_t* n_tok_dev, int tok_cap, const float* logit_scale_dev,
+                                         const float* lse, const float* w, const float* p_inv, const float* s_pos,
+                                         const int32_t* q_idx, const int32_t* p_idx, float* dq_rows, float* dp_rows,
+                                         float* d_logit_scale, float* lw_out, const int32_t* w_bucket, int n_buckets,
+                                         const void* negs, int n_neg, const uint32_t* fix_words, int64_t n_p_rows,
+                                         const int32_t* fix_slot_of_row, const int32_t* fix_any, float* d_negs, void* stream) {
+  MHR_REQUIRE(qn_row && u_row && q_inv_row && tok2row && pn && n_tok_dev && logit_scale_dev && lse && w && p_inv && s_pos,
+              "nce_shared_bwd_tokens: null input pointer");
+  MHR_REQUIRE(q_idx && p_idx && dq_rows && dp_rows && lw_out && negs && fix_words && fix_any,
+              "nce_shared_bwd_tokens: null index/output pointer");
+  MHR_REQUIRE(dim > 0 && dim <= 256, "nce_shared_bwd_tokens: dim=%d unsupported (<= 256)", dim);
+  MHR_REQUIRE(tok_cap > 0 && row_cap > 0 && n_neg > 0 && n_p_rows > 0 && n_groups >= 1 && n_groups <= 65535,
+              "nce_shared_bwd_tokens: bad sizes");
+  const int n_rows_pad = (int)((n_p_rows + 255) / 256 * 256);
+  int blocks = (tok_cap + 31) / 32;                 // 4 waves x 8 tokens per pass
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(shared_tok_bwd_kernel, dim3(blocks, 1, n_groups), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)qn_row, u_row, q_inv_row, row_cap, tok2row, (const bf16_t*)pn, dim, n_tok_dev, tok_cap,
+                     logit_scale_dev, lse, w, p_inv, s_pos, q_idx, p_idx, dq_rows, dp_rows, d_logit_scale, lw_out, w_bucket,
+                     n_buckets, (const bf16_t*)negs, n_neg, fix_words, n_rows_pad, (int)n_p_rows, fix_slot_of_row, fix_any,
+                     d_negs);
+  MHR_CHECK_LAUNCH("nce_shared_bwd_tokens");
+  return MHR_OK;
+}
+
+extern "C" int mhr_nce_row_lw(const float* lw_tok, const int32_t* row_first, const int32_t* n_row_dev, int n_groups,
+                              int tok_cap, int row_cap, float* lw_row, void* stream) {
+  MHR_REQUIRE(lw_tok && row_first && n_row_dev && lw_row, "nce_row_lw: null pointer");
+  MHR_REQUIRE(tok_cap > 0 && row_cap > 1 && n_groups >= 1 && n_groups <= 65535, "nce_row_lw: bad sizes");
+  hipLaunchKernelGGL(row_lw_kernel, dim3((row_cap + 255) / 256, n_groups), dim3(256), 0, (hipStream_t)stream, lw_tok,
+                     row_first, n_row_dev, tok_cap, row_cap, lw_row);
+  MHR_CHECK_LAUNCH("nce_row_lw");
+  return MHR_OK;
+}

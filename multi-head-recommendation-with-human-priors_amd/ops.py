@@ -420,19 +420,123 @@ class NceSaved:
     """Tensors the forward keeps for the backward (all preallocated at token capacity)."""
     __slots__ = ("qn", "pn", "supp", "q_inv", "p_inv", "s_pos", "lse", "loss", "n_valid", "rank", "negs",
                  "n_tok_dev", "tok_cap", "cap", "thres", "dim", "n_neg", "groups", "q_idx", "p_idx", "bucket_idx", "n_buckets",
-                 "bucket_sum", "bucket_cnt", "u", "wide", "scale_dev", "cap_eff")
+                 "bucket_sum", "bucket_cnt", "u", "wide", "scale_dev", "cap_eff",
+                 # query-row sharing (nce_shared.hip): row-level state of the streaming kernels + the maps between rows and tokens
+                 "shared", "tok2row", "row_first", "n_row_dev", "row_cap", "fix_words", "fix_slot", "fix_any", "n_p_rows")
 
 
 _ROW_IOTA = {}
 
 
+SHARE_ROWS = os.environ.get("MHR_NCE_SHARE_ROWS", "1") != "0"
+_ZERO_FIX = {}
+
+
+def _row_maps(q_idx, n_tok_dev, cap, row_cap):
+    """Runs of equal query rows in the (offset-fastest) token lists -> (row list [G, row_cap], tok2row [G, cap],
+    row_first [G, row_cap], n_row [G]); all on the device, no host sync.  Column row_cap - 1 is a scratch slot."""
+    G = q_idx.shape[0]
+    dev = q_idx.device
+    ar = torch.arange(cap, dtype=torch.int32, device=dev)
+    live = ar[None] < n_tok_dev[:, None]
+    prev = torch.cat([q_idx.new_full((G, 1), -1), q_idx[:, :-1]], 1)
+    head = live & (q_idx != prev)
+    tok2row = torch.cumsum(head, 1, dtype=torch.int32) - 1
+    n_row = head.sum(1, dtype=torch.int32)
+    dst = torch.where(head, tok2row, torch.full_like(tok2row, row_cap - 1)).long()
+    r_q = torch.zeros(G, row_cap, dtype=torch.int32, device=dev)
+    r_first = torch.zeros(G, row_cap, dtype=torch.int32, device=dev)
+    r_q.scatter_(1, dst, q_idx)
+    r_first.scatter_(1, dst, ar[None].expand(G, -1))
+    r_first.scatter_(1, n_row[:, None].long(), n_tok_dev[:, None].clamp(max=cap))
+    tok2row = torch.where(live, tok2row, torch.zeros_like(tok2row)).contiguous()
+    return r_q, tok2row, r_first, n_row
+
+
+def _nce_fwd_shared(sv, q_rows, p_rows, negs, logit_scale, thres, want_logs, bucket_idx, n_buckets, log_group, p_row_mask, loss):
+    """Query-row sharing (csrc/nce_shared.hip): the streaming kernels see each distinct query row once."""
+    dev = negs.device
+    G, n_neg, D = sv.groups, sv.n_neg, sv.dim              # negs itself is padded to whole 32-row tiles
+    cap, tok_cap, n_tok_dev = sv.cap, sv.tok_cap, sv.n_tok_dev
+    q_idx, p_idx = sv.q_idx, sv.p_idx
+    row_cap = cap + 32
+    r_q, tok2row, r_first, n_row = _row_maps(q_idx, n_tok_dev, cap, row_cap)
+    n_p_rows = p_rows.shape[0]
+    rp_pad = (n_p_rows + 255) // 256 * 256
+    n_tiles = (n_neg + 31) // 32
+    st = _stream()
+    # (1) the real false-negative bit table, per target row
+    fix_words = torch.empty(G, n_tiles, rp_pad, dtype=torch.int32, device=dev)
+    fix_any = torch.zeros(G, rp_pad, dtype=torch.int32, device=dev)
+    row_list = n_list = slot_of_row = None
+    if p_row_mask is not None:
+        assert p_row_mask.shape == (G, n_p_rows)
+        key = (G, n_p_rows, str(dev))
+        if key not in _ROW_IOTA:
+            ar = torch.arange(n_p_rows, dtype=torch.int32, device=dev)
+            _ROW_IOTA[key] = (ar[None].expand(G, -1).contiguous(), ar)
+        iota_g, iota = _ROW_IOTA[key]
+        row_list, _, _, n_list = token_compact(p_row_mask.contiguous(), iota_g, iota, iota, tok_cap=rp_pad)
+        slot_of_row = torch.zeros(G, n_p_rows, dtype=torch.int32, device=dev)
+    lib.call("mhr_nce_fix_bits", p_rows.data_ptr(), _dt(p_rows), n_p_rows, negs.data_ptr(), n_neg, D, G, float(thres),
+             fix_words.data_ptr(), _ptr(row_list), _ptr(n_list), _ptr(slot_of_row), fix_any.data_ptr(), st)
+    # (2) the fused streaming forward over the ROWS, suppression off (an all-zero bit table that is never written); its
+    #     positive is the target of the row's first token, so the log counters of offset-0 tokens come out of this launch
+    zkey = (G, n_tiles, n_p_rows, str(dev))
+    if zkey not in _ZERO_FIX:
+        _ZERO_FIX.clear()
+        _ZERO_FIX[zkey] = (torch.zeros(G, n_tiles, rp_pad, dtype=torch.int32, device=dev),
+                           torch.zeros(G, rp_pad, dtype=torch.int32, device=dev), torch.zeros(G, dtype=torch.int32, device=dev),
+                           torch.zeros(G, n_p_rows, dtype=torch.int32, device=dev))
+    z_words, z_list, z_n, z_slot = _ZERO_FIX[zkey]
+    r_p = torch.gather(p_idx, 1, r_first.long().clamp_(max=cap - 1)).contiguous()
+    sum_row = torch.zeros(G, row_cap, dtype=torch.float32, device=dev)
+    nv_row = torch.zeros(G, row_cap, dtype=torch.int32, device=dev) if want_logs else None
+    rk_row = torch.zeros(G, row_cap, dtype=torch.int32, device=dev) if want_logs else None
+    qn_row = torch.empty(G, row_cap, D, dtype=torch.bfloat16, device=dev)
+    pn_row = torch.empty(G, row_cap, D, dtype=torch.bfloat16, device=dev)
+    supp_row = torch.empty(G, n_tiles, row_cap, dtype=torch.int32, device=dev)
+    q_inv_row = torch.empty(G, row_cap, dtype=torch.float32, device=dev)
+    p_inv_row = torch.empty(G, row_cap, dtype=torch.float32, device=dev)
+    s_pos_row = torch.empty(G, row_cap, dtype=torch.float32, device=dev)
+    u_row = torch.empty(G, row_cap, D, dtype=torch.float32, device=dev)
+    _timed_call("mhr_nce_fwd", q_rows.data_ptr(), r_q.data_ptr(), p_rows.data_ptr(), r_p.data_ptr(), _dt(q_rows),
+                negs.data_ptr(), n_neg, D, G, n_row.data_ptr(), row_cap, logit_scale.data_ptr(), float(thres),
+                sum_row.data_ptr(), _ptr(nv_row), _ptr(rk_row), qn_row.data_ptr(), pn_row.data_ptr(), supp_row.data_ptr(),
+                q_inv_row.data_ptr(), p_inv_row.data_ptr(), s_pos_row.data_ptr(), int(log_group), u_row.data_ptr(), n_p_rows,
+                z_words.data_ptr(), z_list.data_ptr(), z_n.data_ptr(), z_slot.data_ptr(), st)
+    # (3) per token: target, s+, sums and counters with the token's own suppressed negatives taken out
+    sv.pn = torch.empty(G, cap, D, dtype=torch.bfloat16, device=dev)
+    sv.p_inv = torch.empty(G, cap, dtype=torch.float32, device=dev)
+    ssum = torch.empty(G, cap, dtype=torch.float32, device=dev)
+    n_valid = torch.zeros(G, cap, dtype=torch.int32, device=dev) if want_logs else None
+    rank = torch.zeros(G, cap, dtype=torch.int32, device=dev) if want_logs else None
+    _timed_call("mhr_nce_shared_fwd_tokens", p_rows.data_ptr(), _dt(p_rows), n_p_rows, p_idx.data_ptr(), tok2row.data_ptr(), G,
+                n_tok_dev.data_ptr(), cap, row_cap, qn_row.data_ptr(), sum_row.data_ptr(), _ptr(nv_row), _ptr(rk_row),
+                negs.data_ptr(), n_neg, D, logit_scale.data_ptr(), fix_words.data_ptr(), _ptr(slot_of_row), fix_any.data_ptr(),
+                sv.pn.data_ptr(), sv.p_inv.data_ptr(), sv.s_pos.data_ptr(), ssum.data_ptr(), _ptr(n_valid), _ptr(rank), st)
+    lib.call("mhr_nce_finalize", ssum.data_ptr(), sv.s_pos.data_ptr(), G, n_tok_dev.data_ptr(), cap,
+             logit_scale.data_ptr(), loss.data_ptr(), sv.lse.data_ptr(), _ptr(n_valid), _ptr(bucket_idx), int(n_buckets),
+             _ptr(sv.bucket_sum), _ptr(sv.bucket_cnt), st)
+    sv.shared = True
+    sv.qn, sv.u, sv.q_inv, sv.supp = qn_row, u_row, q_inv_row, supp_row
+    sv.tok2row, sv.row_first, sv.n_row_dev, sv.row_cap = tok2row, r_first, n_row, row_cap
+    sv.fix_words, sv.fix_slot, sv.fix_any, sv.n_p_rows = fix_words, slot_of_row, fix_any, n_p_rows
+    sv.loss = loss[:, :tok_cap]
+    sv.n_valid = None if n_valid is None else n_valid[:, :tok_cap]
+    sv.rank = None if rank is None else rank[:, :tok_cap]
+    return sv
+
+
 def nce_fwd(q_rows, q_idx, p_rows, p_idx, negs, n_tok_dev, tok_cap, logit_scale, thres=0.99, want_logs=False,
-            for_backward=True, bucket_idx=None, n_buckets=0, log_group=-1, p_row_mask=None):
+            for_backward=True, bucket_idx=None, n_buckets=0, log_group=-1, p_row_mask=None, share_rows=False):
     """Grouped sampled softmax.  q_rows/p_rows [*, D] (bf16 or f32, same dtype, shared by all groups);
     q_idx/p_idx [G, tok_cap] int32; negs [G, n_neg, D] bf16 normalised; n_tok_dev [G] int32.
     (1-D q_idx / 2-D negs are accepted as a single group.)  Saved tensors carry the leading group axis.
     p_row_mask [G, p_rows.shape[0]] bool/uint8 (optional): per group, a superset of the rows of p_rows that live tokens
-    point at - the hoisted false-negative test then visits only those rows."""
+    point at - the hoisted false-negative test then visits only those rows.
+    share_rows: tokens with the same query row are neighbours in the lists (several prediction offsets of one position):
+    the negative-pool products run once per distinct row (csrc/nce_shared.hip).  Same results."""
     if q_idx.dim() == 1:
         q_idx, p_idx, negs, n_tok_dev = q_idx[None], p_idx[None], negs[None], n_tok_dev.view(1)
     _chk(negs, "negs", torch.bfloat16)
@@ -454,6 +558,7 @@ def nce_fwd(q_rows, q_idx, p_rows, p_idx, negs, n_tok_dev, tok_cap, logit_scale,
         if bucket_idx is not None:
             bucket_idx = torch.nn.functional.pad(bucket_idx, (0, cap - tok_cap)).contiguous()
     sv = NceSaved()
+    sv.shared = False
     sv.q_idx, sv.p_idx = q_idx, p_idx
     sv.wide = D not in STREAM_DIMS            # feature dims beyond the register-stationary kernels: wide.py (library GEMMs)
     sv.bucket_idx, sv.n_buckets, sv.bucket_sum, sv.bucket_cnt = bucket_idx, int(n_buckets), None, None
@@ -467,6 +572,11 @@ def nce_fwd(q_rows, q_idx, p_rows, p_idx, negs, n_tok_dev, tok_cap, logit_scale,
     n_valid = torch.zeros(G, cap, dtype=torch.int32, device=dev) if want_logs else None
     rank = torch.zeros(G, cap, dtype=torch.int32, device=dev) if want_logs else None
     sv.s_pos = torch.empty(G, cap, dtype=torch.float32, device=dev)
+    if share_rows and SHARE_ROWS and for_backward and not sv.wide:
+        sv.negs = negs
+        sv.n_tok_dev, sv.tok_cap, sv.cap, sv.thres, sv.dim, sv.n_neg, sv.groups = n_tok_dev, tok_cap, cap, float(thres), D, n_neg, G
+        return _nce_fwd_shared(sv, q_rows, p_rows, negs, logit_scale, thres, want_logs, bucket_idx, n_buckets, log_group,
+                               p_row_mask, loss)
     if for_backward or sv.wide:
         sv.qn = torch.empty(G, cap, D, dtype=torch.bfloat16, device=dev)
         sv.pn = torch.empty(G, cap, D, dtype=torch.bfloat16, device=dev)
@@ -545,8 +655,24 @@ def nce_bwd(sv, w, logit_scale, q_idx, p_idx, dq_rows, dp_rows, d_negs=None, d_l
         w_tok = torch.gather(w, 1, sv.bucket_idx.long().clamp(0, sv.n_buckets - 1)) if bucketed else w
         wide.nce_bwd_wide(sv, w_tok, logit_scale, dq_rows, dp_rows, d_negs, d_logit_scale)
         return d_negs, d_logit_scale
-    lw = torch.empty(G, cap, dtype=torch.float32, device=dev)     # lse log2e - log2 w: written by bwd_tokens, read by bwd_negs
     st = _stream()
+    if sv.shared:
+        lw_tok = torch.empty(G, cap, dtype=torch.float32, device=dev)
+        _timed_call("mhr_nce_shared_bwd_tokens", sv.qn.data_ptr(), sv.u.data_ptr(), sv.q_inv.data_ptr(), sv.row_cap,
+                    sv.tok2row.data_ptr(), sv.pn.data_ptr(), D, G, sv.n_tok_dev.data_ptr(), cap, logit_scale.data_ptr(),
+                    sv.lse.data_ptr(), w.data_ptr(), sv.p_inv.data_ptr(), sv.s_pos.data_ptr(), sv.q_idx.data_ptr(),
+                    sv.p_idx.data_ptr(), dq_rows.data_ptr(), dp_rows.data_ptr(), d_logit_scale.data_ptr(), lw_tok.data_ptr(),
+                    sv.bucket_idx.data_ptr() if bucketed else 0, sv.n_buckets if bucketed else 0, sv.negs.data_ptr(), sv.n_neg,
+                    sv.fix_words.data_ptr(), sv.n_p_rows, _ptr(sv.fix_slot), sv.fix_any.data_ptr(),
+                    d_negs.data_ptr() if want_negs else 0, st)
+        if want_negs:
+            lw_row = torch.full((G, sv.row_cap), float("inf"), dtype=torch.float32, device=dev)
+            lib.call("mhr_nce_row_lw", lw_tok.data_ptr(), sv.row_first.data_ptr(), sv.n_row_dev.data_ptr(), G, cap, sv.row_cap,
+                     lw_row.data_ptr(), st)
+            _timed_call("mhr_nce_bwd_negs", sv.qn.data_ptr(), sv.negs.data_ptr(), sv.supp.data_ptr(), sv.n_neg, D, G,
+                        sv.n_row_dev.data_ptr(), sv.row_cap, logit_scale.data_ptr(), lw_row.data_ptr(), d_negs.data_ptr(), st)
+        return d_negs, d_logit_scale
+    lw = torch.empty(G, cap, dtype=torch.float32, device=dev)     # lse log2e - log2 w: written by bwd_tokens, read by bwd_negs
     _timed_call("mhr_nce_bwd_tokens", sv.qn.data_ptr(), sv.pn.data_ptr(), sv.u.data_ptr(), D,
                 G, sv.n_tok_dev.data_ptr(), cap, logit_scale.data_ptr(), sv.lse.data_ptr(), w.data_ptr(), sv.q_inv.data_ptr(),
                 sv.p_inv.data_ptr(), sv.s_pos.data_ptr(), sv.q_idx.data_ptr(), sv.p_idx.data_ptr(), dq_rows.data_ptr(),

@@ -341,6 +341,70 @@ def test_nce_fwd_bwd(ops, D, n_tok, n_neg, dtype):
     assert abs(float(dls.cpu()) - float(lsr.grad)) < 2e-2 * abs(float(lsr.grad)) + 1e-4
 
 
+@pytest.mark.parametrize("D,n_pos,P,n_neg,dtype", [(64, 40, 4, 96, torch.float32), (256, 70, 8, 512, torch.bfloat16),
+                                                   (256, 33, 8, 8192, torch.float32), (32, 50, 3, 70, torch.bfloat16)])
+def test_nce_shared_query_rows_match_per_token_oracle(ops, D, n_pos, P, n_neg, dtype):
+    """Query-row sharing (nce_shared.hip): runs of tokens with the same query row (the offsets of one position) through
+    the row-level streaming kernels + per-token corrections vs the per-token oracle: loss 1e-4, log counters, gradients.
+    Planted false negatives hit single tokens of a run, first and later ones, so every correction path is exercised."""
+    g = torch.Generator().manual_seed(80 + D + P)
+    n_src = n_pos + 5
+    q_rows = (torch.randn(n_src, D, generator=g) * 2).to(dtype)
+    p_rows = torch.randn(n_pos * P + 7, D, generator=g).to(dtype)
+    q_l, p_l, o_l = [], [], []
+    for pos in range(n_pos):                        # each position keeps a random subset of its P offsets (category membership)
+        for off in range(P):
+            if torch.rand(1, generator=g).item() < 0.6:
+                q_l.append(pos + 2); p_l.append(pos * P + off); o_l.append(off)
+    n_tok = len(q_l)
+    q_idx, p_idx, o_idx = torch.tensor(q_l).int(), torch.tensor(p_l).int(), torch.tensor(o_l).int()
+    negs = bf(HO.l2n(torch.randn(n_neg, D, generator=g)))
+    for t in range(0, n_tok, 3):                    # false negatives: some negatives equal a token's positive
+        negs[(t * 11) % n_neg] = bf(HO.l2n(p_rows[p_idx[t]].float()[None]))[0]
+    ls = torch.tensor(math.log(20.0))
+    cap = (n_tok + 11 + 31) // 32 * 32
+    qi, pi, oi = (torch.zeros(cap, dtype=torch.int32) for _ in range(3))
+    qi[:n_tok], pi[:n_tok], oi[:n_tok] = q_idx, p_idx, o_idx
+    qi[n_tok:] = 12345                               # garbage beyond n_tok must not matter
+    ntd = torch.tensor([n_tok], dtype=torch.int32).cuda()
+    lsd = ls.reshape(1).cuda()
+    sv = ops.nce_fwd(dev(q_rows), dev(qi), dev(p_rows), dev(pi), dev(negs), ntd, cap, lsd, 0.99, want_logs=True, share_rows=True)
+    assert sv.shared and int(sv.n_row_dev[0]) == len(set(q_l)) < n_tok
+    torch.cuda.synchronize()
+    q = q_rows.float()[q_idx.long()].clone().requires_grad_(True)
+    p = p_rows.float()[p_idx.long()].clone().requires_grad_(True)
+    nn_ = negs.float().clone().requires_grad_(True)
+    lsr = ls.clone().requires_grad_(True)
+    loss, logits, keep, neg, pos = _nce_oracle(q, p, nn_, lsr, 0.99)
+    np.testing.assert_allclose(sv.loss.cpu().numpy()[0, :n_tok], loss.detach().numpy(), rtol=1e-4, atol=1e-4)
+    assert float(sv.loss[0, n_tok:].abs().max()) == 0.0
+    assert keep.sum() < keep.numel()
+    first = torch.ones(n_tok, dtype=torch.bool)
+    first[1:] = q_idx[1:] != q_idx[:-1]              # log counters are defined for the first token of a row (offset 0 in the model)
+    np.testing.assert_array_equal(sv.n_valid.cpu().numpy()[0, :n_tok][first.numpy()], (keep.sum(-1) + 1).numpy()[first.numpy()])
+    rank_ref = (keep & (neg > pos)).sum(-1)
+    assert int((sv.rank.cpu()[0, :n_tok] - rank_ref)[first].abs().max()) <= 1
+    w = torch.rand(cap, generator=g)
+    w[n_tok:] = 0
+    w[5] = 0                                         # a zero-weight token inside a run
+    (loss * w[:n_tok]).sum().backward()
+    dq_rows = torch.zeros(n_src, D).cuda()
+    dp_rows = torch.zeros(p_rows.shape[0], D).cuda()
+    dn, dls = ops.nce_bwd(sv, dev(w), lsd, dev(qi), dev(pi), dq_rows, dp_rows)
+    torch.cuda.synchronize()
+    dq_ref = torch.zeros(n_src, D).index_add_(0, q_idx.long(), q.grad)
+    dp_ref = torch.zeros(p_rows.shape[0], D).index_add_(0, p_idx.long(), p.grad)
+    for name, got, ref in (("dq", dq_rows.cpu(), dq_ref), ("dp", dp_rows.cpu(), dp_ref), ("dneg", dn.cpu()[0], nn_.grad)):
+        gs = float(ref.abs().max())
+        err = float((got - ref).abs().max())
+        assert err < 2e-2 * gs, (name, err, gs)
+    assert abs(float(dls.cpu()) - float(lsr.grad)) < 2e-2 * abs(float(lsr.grad)) + 1e-4
+    # and the same answers as the per-token kernels
+    sv2 = ops.nce_fwd(dev(q_rows), dev(qi), dev(p_rows), dev(pi), dev(negs), ntd, cap, lsd, 0.99, want_logs=True)
+    assert not sv2.shared
+    np.testing.assert_allclose(sv.loss.cpu().numpy(), sv2.loss.cpu().numpy(), rtol=2e-5, atol=2e-5)
+
+
 @pytest.mark.parametrize("rows,cols", [(16, 1024 * 256), (25600, 256), (3, 64), (1, 8), (4097, 1032)])
 def test_sum_rows_into(ops, rows, cols):
     """Split-K partial / bias-gradient reduction into an fp32 accumulator: exact fp32 sums of the bf16 inputs up to the
