@@ -163,7 +163,7 @@ def main():
 
     for i in range(args.warmup):
         step(i)
-    kernels = ["mhr_nce_fwd", "mhr_nce_bwd_tokens", "mhr_nce_bwd_negs", "mhr_catalog_score_emit", "mhr_catalog_score_emit_sliced",
+    kernels = ["mhr_nce_fwd", "mhr_nce_bwd_tokens", "mhr_nce_bwd_negs", "mhr_nce_shared_fwd_tokens", "mhr_nce_shared_bwd_tokens", "mhr_catalog_score_emit", "mhr_catalog_score_emit_sliced",
                "mhr_hstu_attn_fwd", "mhr_hstu_attn_bwd", "mhr_adam_rows", "mhr_embedding_gather_fwd", "mhr_sparse_rows_segment_sum",
                "mhr_topk_select", "mhr_topk_select_sliced"]
     if not args.no_kernel_events:
@@ -221,61 +221,78 @@ def main():
                     if cand_name in prof and prof[cand_name][0] > 0:
                         dom = (cand_name, prof[cand_name])
                         break
-            name, (launches, mean_ms, total_ms) = dom
             per_step = {k: round(v[2] / args.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][2])}
-            n_tok_total = None
-            if name.startswith("mhr_nce"):
-                # algorithmic flops per launch: ONE launch serves all groups (prior categories): sum over groups of
-                # live tokens x negatives x D; N_tok measured on the last batch of the timed region
-                items, _, mask, tags = batches[(args.warmup + args.steps - 1) % len(batches)]
-                idx = torch.arange(L, device=dev)[None, :] + 1 + torch.arange(P, device=dev)[:, None]
-                mb = mask.bool()
-                valid = mb[:, None, :L] & mb[:, idx]
-                if cfg["loss"] == "prior":
-                    n_tok = float((valid[..., None] & tags[:, idx].bool()).sum())          # summed over the C groups
-                    n_groups = C
+            # the dominant kernel of the step; if it is one of the small glue kernels without a roofline model, the next one
+            cands = [dom] + [kv for kv in sorted(prof.items(), key=lambda kv: -kv[1][2]) if kv[0] != dom[0]]
+            for name, (launches, mean_ms, total_ms) in cands:
+                if "roofline" in out:
+                    break
+                if name in ("mhr_nce_fwd", "mhr_nce_bwd_negs"):
+                    # algorithmic flops per launch: ONE launch serves all groups (prior categories): sum over groups of
+                    # live tokens x negatives x D; N_tok measured on the last batch of the timed region
+                    items, _, mask, tags = batches[(args.warmup + args.steps - 1) % len(batches)]
+                    idx = torch.arange(L, device=dev)[None, :] + 1 + torch.arange(P, device=dev)[:, None]
+                    mb = mask.bool()
+                    valid = mb[:, None, :L] & mb[:, idx]
+                    if cfg["loss"] == "prior":
+                        n_tok = float((valid[..., None] & tags[:, idx].bool()).sum())          # summed over the C groups
+                        n_groups = C
+                    else:
+                        n_tok = float(valid.sum())
+                        n_groups = 1
+                    n_neg = world * B * data.n_neg(B)
+                    # fused forward: neg logits + false-negative logits + the token-side gradient product = 3 x 2 N_tok N_neg D
+                    # ALGORITHMIC flop (what the reference's formulation computes per token; the false-negative
+                    # product is executed once per target row instead of once per token); negative-side backward: dN only (its
+                    # logit recompute is not counted)
+                    mult = 6.0 if name == "mhr_nce_fwd" else 2.0
+                    flops = mult * n_tok * n_neg * D
+                    ach = flops / (mean_ms * 1e-3) / 1e12
+                    out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS,
+                                       "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                                       "launch_ms": round(mean_ms, 4), "launches_per_step": launches / args.steps,
+                                       "algorithmic_flops_per_launch": flops, "tokens_per_launch": n_tok, "groups": n_groups,
+                                       "negatives_per_group": n_neg}
+                elif name in ("mhr_hstu_attn_fwd", "mhr_hstu_attn_bwd"):
+                    # one launch = one layer over the B sequences of the batch.  Algorithmic work: forward 4 L^2 D flop
+                    # per (sequence, layer) - the two products over the full L x L score matrix, half of it causally useful -
+                    # backward twice that (dV, dP, dQ, dK); algorithmic bytes 4 L D 2 B forward (q, k, v in, out), 7 L D 2 B backward
+                    bwd = name.endswith("bwd")
+                    flops = (8.0 if bwd else 4.0) * B * L * L * D
+                    nbytes = (7.0 if bwd else 4.0) * B * L * D * 2.0
+                    ach = flops / (mean_ms * 1e-3) / 1e12
+                    out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS,
+                                       "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                                       "launch_ms": round(mean_ms, 4), "launches_per_step": launches / args.steps,
+                                       "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": nbytes,
+                                       "algorithmic_GBps": round(nbytes / (mean_ms * 1e-3) / 1e9, 1),
+                                       "note": "L = 200, head_dim = 32: 7 x 7 tiles of 32 x 32 per (sequence, head); bound by the gate "
+                                               "arithmetic (sigmoid + derivative per score) and the per-workgroup prologue, not by MFMA or HBM"}
+                elif name in ("mhr_catalog_score_emit", "mhr_catalog_score_emit_sliced"):
+                    # the launch that scores the whole catalog (the two threshold-sample launches of a step score 1/14 + 1/222 of
+                    # it and are latency-sized): algorithmic flops of that launch / its own duration (the longest of the step)
+                    flops = 2.0 * B * model.medusa_num_heads * D * N
+                    full_ms = prof_max.get(name, mean_ms)
+                    ach = flops / (full_ms * 1e-3) / 1e12
+                    out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS,
+                                       "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                                       "launch_ms": round(full_ms, 4), "launches_per_step": launches / args.steps,
+                                       "algorithmic_flops_per_launch": flops,
+                                       "all_launches_ms_per_step": round(mean_ms * launches / args.steps, 4)}
                 else:
-                    n_tok = float(valid.sum())
-                    n_groups = 1
-                n_neg = world * B * data.n_neg(B)
-                # fused forward: neg logits + false-negative logits + the token-side gradient product = 3 x 2 N_tok N_neg D
-                # ALGORITHMIC flop (what the reference's formulation computes per token; the false-negative
-                # product is executed once per target row instead of once per token); negative-side backward: dN only (its
-                # logit recompute is not counted)
-                mult = 6.0 if name == "mhr_nce_fwd" else 2.0
-                flops = mult * n_tok * n_neg * D
-                ach = flops / (mean_ms * 1e-3) / 1e12
-                out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS,
-                                   "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                                   "launch_ms": round(mean_ms, 4), "launches_per_step": launches / args.steps,
-                                   "algorithmic_flops_per_launch": flops, "tokens_per_launch": n_tok, "groups": n_groups,
-                                   "negatives_per_group": n_neg}
-                # all three sampled-softmax kernels, same accounting (fwd 4x, bwd 2x each)
-                out["nce_kernels_TFLOPs"] = {k: round((6.0 if k == "mhr_nce_fwd" else 2.0) * n_tok * n_neg * D / (v[1] * 1e-3) / 1e12, 1)
-                                             for k, v in prof.items() if k in ("mhr_nce_fwd", "mhr_nce_bwd_negs")}
-            elif name in ("mhr_catalog_score_emit", "mhr_catalog_score_emit_sliced"):
-                # the launch that scores the whole catalog (the two threshold-sample launches of a step score 1/14 + 1/222 of
-                # it and are latency-sized): algorithmic flops of that launch / its own duration (the longest of the step)
-                flops = 2.0 * B * model.medusa_num_heads * D * N
-                full_ms = prof_max.get(name, mean_ms)
-                ach = flops / (full_ms * 1e-3) / 1e12
-                out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS,
-                                   "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                                   "launch_ms": round(full_ms, 4), "launches_per_step": launches / args.steps,
-                                   "algorithmic_flops_per_launch": flops,
-                                   "all_launches_ms_per_step": round(mean_ms * launches / args.steps, 4)}
-            else:
-                nbytes = {"mhr_adam_rows": N * D * 24.0, "mhr_embedding_gather_fwd": None}.get(name)
-                if nbytes:
-                    ach = nbytes / (mean_ms * 1e-3) / 1e9
-                    out["roofline"] = {"bound": "hbm", "kernel": name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                                       "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
-                                       "launch_ms": round(mean_ms, 4)}
+                    nbytes = {"mhr_adam_rows": N * D * 24.0, "mhr_embedding_gather_fwd": None}.get(name)
+                    if nbytes:
+                        ach = nbytes / (mean_ms * 1e-3) / 1e9
+                        out["roofline"] = {"bound": "hbm", "kernel": name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                                           "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                                           "launch_ms": round(mean_ms, 4)}
             # HBM bytes per launch of that kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE run on this same
             # command and condensed by tools/summarize_profiles.py; counters cannot be read from inside the process)
+            name = out["roofline"]["kernel"] if "roofline" in out else name
             if "roofline" in out and args.config == "cfg1" and not args.batch:
                 # one C-ABI call may be several launches (mhr_nce_fwd = false-negative bit table + fused forward): their sum
                 knames = {"mhr_nce_bwd_tokens": ["nce_bwd_rows_kernel"], "mhr_nce_bwd_negs": ["nce_bwd_n_kernel"],
+                          "mhr_hstu_attn_bwd": ["hstu_attn_bwd_kernel"], "mhr_hstu_attn_fwd": ["hstu_attn_fwd_kernel"],
                           "mhr_nce_fwd": ["nce_fwd_d_kernel", "nce_fix_bits_kernel"],
                           "mhr_catalog_score_emit": ["catalog_emit_kernel"], "mhr_catalog_score_emit_sliced": ["catalog_emit_sliced_kernel"],
                           "mhr_adam_rows": ["adam_rows_kernel"]}.get(name)
@@ -288,6 +305,25 @@ def main():
                         out["roofline"]["traffic"] = sum(r[key_] for r in recs if r)
                         out["roofline"]["traffic_source"] = os.path.relpath(files[-1], ROOT)
             out["kernel_ms_per_step"] = per_step
+            if args.mode == "train" and "mhr_nce_fwd" in prof and cfg["loss"] == "prior":
+                # sampled softmax: ALGORITHMIC = the reference's per-token formulation (3 products forward, dN backward);
+                # EXECUTED = what the row-sharing kernels run (2 products per distinct query row each way)
+                items_, _, mask_, tags_ = batches[(args.warmup + args.steps - 1) % len(batches)]
+                idx_ = torch.arange(L, device=dev)[None, :] + 1 + torch.arange(P, device=dev)[:, None]
+                mb_ = mask_.bool()
+                live_ = (mb_[:, None, :L] & mb_[:, idx_])[..., None] & tags_[:, idx_].bool()                 # [B, P, L, C]
+                n_tok_, n_row_ = float(live_.sum()), float(live_.any(dim=1).sum())
+                n_neg_ = world * B * data.n_neg(B)
+                shared = os.environ.get("MHR_NCE_SHARE_ROWS", "1") != "0" and P > 1
+                units = n_row_ if shared else n_tok_
+                out["sampled_softmax"] = {
+                    "tokens": n_tok_, "distinct_query_rows": n_row_, "row_sharing": shared,
+                    "fwd_ms": round(prof["mhr_nce_fwd"][1], 4), "bwd_negs_ms": round(prof["mhr_nce_bwd_negs"][1], 4),
+                    "fwd_algorithmic_TFLOPs": round(6.0 * n_tok_ * n_neg_ * D / (prof["mhr_nce_fwd"][1] * 1e-3) / 1e12, 1),
+                    "fwd_executed_TFLOPs": round(4.0 * units * n_neg_ * D / (prof["mhr_nce_fwd"][1] * 1e-3) / 1e12, 1),
+                    "bwd_negs_algorithmic_TFLOPs": round(2.0 * n_tok_ * n_neg_ * D / (prof["mhr_nce_bwd_negs"][1] * 1e-3) / 1e12, 1),
+                    "bwd_negs_executed_TFLOPs": round(4.0 * units * n_neg_ * D / (prof["mhr_nce_bwd_negs"][1] * 1e-3) / 1e12, 1),
+                    "mfma_peak_TFLOPs": MFMA_PEAK_TFLOPS}
             if "mhr_embedding_gather_fwd" in prof and args.mode == "train":
                 # item ids + negative-pool ids: table rows read and written as fp32, plus the position-added encoder input
                 n_pools = C if (cfg["loss"] == "prior" and cfg.get("neg_sample_by_cat")) else 1

@@ -89,54 +89,71 @@ __global__ __launch_bounds__(256) void shared_tok_fwd_kernel(
   const int wave_g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), n_waves = gridDim.x * (blockDim.x >> 6);
   const float scale = clamp_scale(logit_scale_dev);
   const float c1 = scale * LOG2E;
-  for (int tk = wave_g; tk < n_tok; tk += n_waves) {
-    const int r = tok2row[tk], pr = p_idx[tk];
-    const IT* ps = p_rows + (int64_t)pr * dim;
-    const bf16_t* qs = qn_row + (int64_t)r * dim;
-    float pv[NC], qv[NC];
-    float ss = 0.f;
+  constexpr int TB = 4;                               // tokens in flight per wave pass (independent row loads)
+  for (int t0 = wave_g * TB; t0 < n_tok; t0 += n_waves * TB) {
+    int rr[TB], prr[TB];
+    float pv[TB][NC], qv[TB][NC];
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      const int d = c * 64 + lane;
-      pv[c] = d < dim ? ld<IT>(ps + d) : 0.f;
-      qv[c] = d < dim ? (float)qs[d] : 0.f;
-      ss += pv[c] * pv[c];
+    for (int b = 0; b < TB; ++b) {
+      const int tk = min(t0 + b, n_tok - 1);
+      rr[b] = tok2row[tk];
+      prr[b] = p_idx[tk];
     }
-    ss = wave_sum(ss);
-    const float inv = 1.0f / sqrtf(ss);
-    float sp = 0.f;
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      const int d = c * 64 + lane;
-      const bf16_t pb = (bf16_t)(pv[c] * inv);
-      if (d < dim) pn_out[(int64_t)tk * dim + d] = pb;
-      sp += qv[c] * (float)pb;
-    }
-    sp = wave_sum(sp);
-    float corr = 0.f;
-    int hits = 0, above = 0;
-    const int slot = slot_of_row ? slot_of_row[pr] : pr;
-    if (fix_any[slot] != 0) {                                     // wave-uniform; a few percent of the tokens
-      for_each_hit(fixw, n_tiles, n_rows_pad, slot, n_neg, lane, [&](int j) {
-        const bf16_t* ns = negs + (int64_t)j * dim;
-        float s = 0.f;
+    for (int b = 0; b < TB; ++b) {
+      const IT* ps = p_rows + (int64_t)prr[b] * dim;
+      const bf16_t* qs = qn_row + (int64_t)rr[b] * dim;
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
-          const int d = c * 64 + lane;
-          s += d < dim ? qv[c] * (float)ns[d] : 0.f;
-        }
-        s = wave_sum(s);
-        corr += __builtin_amdgcn_exp2f(s * c1 - c1);
-        hits += 1;
-        above += s > sp ? 1 : 0;
-      });
+      for (int c = 0; c < NC; ++c) {
+        const int d = c * 64 + lane;
+        pv[b][c] = d < dim ? ld<IT>(ps + d) : 0.f;
+        qv[b][c] = d < dim ? (float)qs[d] : 0.f;
+      }
     }
-    if (lane == 0) {
-      p_inv[tk] = inv;
-      s_pos[tk] = sp;
-      sum_tok[tk] = fmaxf(sum_row[r] - corr, 0.f);
-      if (n_valid_row) n_valid_tok[tk] = n_valid_row[r] - hits;
-      if (rank_row) rank_tok[tk] = max(rank_row[r] - above, 0);
+#pragma unroll
+    for (int b = 0; b < TB; ++b) {
+      const int tk = t0 + b;
+      if (tk >= n_tok) break;
+      const int r = rr[b], pr = prr[b];
+      float ss = 0.f;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) ss += pv[b][c] * pv[b][c];
+      ss = wave_sum(ss);
+      const float inv = 1.0f / sqrtf(ss);
+      float sp = 0.f;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const int d = c * 64 + lane;
+        const bf16_t pb = (bf16_t)(pv[b][c] * inv);
+        if (d < dim) pn_out[(int64_t)tk * dim + d] = pb;
+        sp += qv[b][c] * (float)pb;
+      }
+      sp = wave_sum(sp);
+      float corr = 0.f;
+      int hits = 0, above = 0;
+      const int slot = slot_of_row ? slot_of_row[pr] : pr;
+      if (fix_any[slot] != 0) {                                     // wave-uniform; a few percent of the tokens
+        for_each_hit(fixw, n_tiles, n_rows_pad, slot, n_neg, lane, [&](int j) {
+          const bf16_t* ns = negs + (int64_t)j * dim;
+          float s = 0.f;
+#pragma unroll
+          for (int c = 0; c < NC; ++c) {
+            const int d = c * 64 + lane;
+            s += d < dim ? qv[b][c] * (float)ns[d] : 0.f;
+          }
+          s = wave_sum(s);
+          corr += __builtin_amdgcn_exp2f(s * c1 - c1);
+          hits += 1;
+          above += s > sp ? 1 : 0;
+        });
+      }
+      if (lane == 0) {
+        p_inv[tk] = inv;
+        s_pos[tk] = sp;
+        sum_tok[tk] = fmaxf(sum_row[r] - corr, 0.f);
+        if (n_valid_row) n_valid_tok[tk] = n_valid_row[r] - hits;
+        if (rank_row) rank_tok[tk] = max(rank_row[r] - above, 0);
+      }
     }
   }
 }

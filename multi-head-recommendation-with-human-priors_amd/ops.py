@@ -441,8 +441,14 @@ def _row_maps(q_idx, n_tok_dev, cap, row_cap):
     live = ar[None] < n_tok_dev[:, None]
     prev = torch.cat([q_idx.new_full((G, 1), -1), q_idx[:, :-1]], 1)
     head = live & (q_idx != prev)
-    tok2row = torch.cumsum(head, 1, dtype=torch.int32) - 1
-    n_row = head.sum(1, dtype=torch.int32)
+    # inclusive scan of the run heads in two levels (torch's one-pass scan over a 200 k-long innermost dim takes 0.46 ms)
+    blk = 1024
+    pad = (-cap) % blk
+    h = torch.nn.functional.pad(head, (0, pad)).view(G, -1, blk).to(torch.int32)
+    inner = torch.cumsum(h, 2, dtype=torch.int32)
+    outer = torch.cumsum(inner[:, :, -1], 1, dtype=torch.int32)
+    tok2row = (inner + (outer - inner[:, :, -1])[:, :, None]).view(G, -1)[:, :cap] - 1
+    n_row = outer[:, -1].contiguous()
     dst = torch.where(head, tok2row, torch.full_like(tok2row, row_cap - 1)).long()
     r_q = torch.zeros(G, row_cap, dtype=torch.int32, device=dev)
     r_first = torch.zeros(G, row_cap, dtype=torch.int32, device=dev)

@@ -34,7 +34,11 @@ for e in ka:
     rows.append((dt / 3, e.count / 3, e.self_cpu_time_total / 3, e.key, [str(e.input_shapes)[:110]]))
 rows.sort(key=lambda r: -r[0])
 print("device us/step | calls/step | host us/step | op | python frames")
+kern = [r for r in rows if not r[3].startswith('aten::') and r[2] == 0]
+print('--- device kernels'); [print(f'{r[0]:9.1f} {r[1]:6.1f}  {r[3][:110]}') for r in kern[:45]]
+print('kernel total us/step', sum(r[0] for r in kern))
+print('--- aten ops by input shape')
 rows = [r for r in rows if r[3].startswith('aten::')]
-for r in rows[:60]:
+for r in rows[:45]:
     print(f"{r[0]:9.1f} {r[1]:6.1f} {r[2]:9.1f}  {r[3][:60]:60s} {' <- '.join(x.split('/')[-1][:70] for x in r[4])}")
 print("total device us/step", sum(r[0] for r in rows), " host self us/step", sum(r[2] for r in rows))
