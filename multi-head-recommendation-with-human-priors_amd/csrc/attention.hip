@@ -19,6 +19,9 @@
 #include "stream_gemm.h"
 #include "attn_tiles.h"
 
+#ifndef ATTN_BWD_WG
+#define ATTN_BWD_WG 3
+#endif
 namespace {
 
 using namespace attn;
@@ -139,7 +142,7 @@ __global__ __launch_bounds__(256) void hstu_attn_fwd_kernel(const bf16_t* __rest
 // backward
 // ------------------------------------------------------------------------------------------
 template <int NKS, int ND>
-__global__ __launch_bounds__(256, NKS <= 2 ? 3 : 1) void hstu_attn_bwd_kernel(
+__global__ __launch_bounds__(256, NKS <= 2 ? ATTN_BWD_WG : 1) void hstu_attn_bwd_kernel(
     const bf16_t* __restrict__ q_pre, const bf16_t* __restrict__ k_pre, const bf16_t* __restrict__ v_pre, int64_t stride,
     const bf16_t* __restrict__ act_q, const bf16_t* __restrict__ act_k, const bf16_t* __restrict__ act_v, int64_t act_stride,
     const uint8_t* __restrict__ key_valid, const bf16_t* __restrict__ d_out, int64_t do_stride, bf16_t* __restrict__ dq,

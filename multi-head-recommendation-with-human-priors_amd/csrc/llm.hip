@@ -142,7 +142,16 @@ __global__ __launch_bounds__(256) void sum_rows_into_kernel(const bf16_t* __rest
   const int64_t r0 = (int64_t)blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (c0 < cols) {
-    for (int64_t r = r0 + ty; r < r1; r += 8) {
+    int64_t r = r0 + ty;
+    for (; r + 24 < r1; r += 32) {                       // four independent 16-byte loads in flight per thread
+      const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(x + r * cols + c0);
+      const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(x + (r + 8) * cols + c0);
+      const bf16x8 v2 = *reinterpret_cast<const bf16x8*>(x + (r + 16) * cols + c0);
+      const bf16x8 v3 = *reinterpret_cast<const bf16x8*>(x + (r + 24) * cols + c0);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += ((float)v0[e] + (float)v1[e]) + ((float)v2[e] + (float)v3[e]);
+    }
+    for (; r < r1; r += 8) {
       const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + r * cols + c0);
 #pragma unroll
       for (int e = 0; e < 8; ++e) acc[e] += (float)v[e];
@@ -181,8 +190,10 @@ extern "C" int mhr_sum_rows_into(const void* x_bf16, int64_t rows, int64_t cols,
   if (rows == 0) return MHR_OK;
   const int64_t col_blocks = (cols / 8 + 31) / 32;
   MHR_REQUIRE(col_blocks < (1ll << 31), "sum_rows_into: too many columns");
-  int64_t splits = 1;        // a few row ranges when there are few columns (many would only contend on the same atomics)
-  while (splits < 32 && col_blocks * splits < 512 && rows / (splits * 2) >= 64) splits *= 2;
+  // a few row ranges when there are few columns (many would only contend on the same atomics: 512 ranges adding into the
+  // 256 floats of a bias gradient cost far more than they saved); the row loop keeps four loads in flight instead
+  int64_t splits = 1;
+  while (splits < 64 && col_blocks * splits < 512 && rows / (splits * 2) >= 64) splits *= 2;
   const int64_t rpb = (rows + splits - 1) / splits;
   hipLaunchKernelGGL(sum_rows_into_kernel, dim3((unsigned)col_blocks, (unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0,
                      (hipStream_t)stream, (const bf16_t*)x_bf16, rows, cols, out, rpb);
