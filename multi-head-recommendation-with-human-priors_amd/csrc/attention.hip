@@ -44,6 +44,24 @@ __device__ unsigned long long g_attn_stamps[16];
 // ------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------
+// Workgroups are dealt to the 8 XCDs round-robin (workgroup i runs on XCD i % 8) and every XCD has its own L2.  A head's
+// q / k / v / dO slice of a row is head_dim * 2 bytes - 64 B at head_dim 32, HALF a 128-byte line whose other half belongs
+// to the neighbouring head - so with the natural order (b * n_heads + head, n_heads = 8) the heads of one sequence land on
+// eight different XCDs and every line is fetched from HBM once per head that touches it.  This decode keeps all heads of a
+// sequence on one XCD (b = 8 * (slot / n_heads) + xcd): the neighbours' halves are L2 hits.
+__device__ __forceinline__ void decode_seq_head(int n_heads, int& b, int& head) {
+  const int n_wg = gridDim.x, i = blockIdx.x;
+  const int full = (n_wg / (8 * n_heads)) * (8 * n_heads);          // whole groups of 8 sequences; the remainder keeps the plain order
+  if (i < full) {
+    const int xcd = i & 7, slot = i >> 3;
+    head = slot % n_heads;
+    b = (slot / n_heads) * 8 + xcd;
+  } else {
+    b = i / n_heads;
+    head = i % n_heads;
+  }
+}
+
 template <int NKS, int ND>
 __global__ __launch_bounds__(256) void hstu_attn_fwd_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                             const bf16_t* __restrict__ v, int64_t stride,
@@ -58,7 +76,8 @@ __global__ __launch_bounds__(256) void hstu_attn_fwd_kernel(const bf16_t* __rest
   unsigned char* Vt = smem + nb * T::BYTES;       // nb tiles: activated V
   uint32_t* vmask = reinterpret_cast<uint32_t*>(Vt + nb * T::BYTES);
 
-  const int b = blockIdx.x / n_heads, head = blockIdx.x % n_heads;
+  int b, head;
+  decode_seq_head(n_heads, b, head);
   const int64_t row0 = (int64_t)b * L;
   const bf16_t* qp = q + row0 * stride + head * hd;
   const bf16_t* kp = k + row0 * stride + head * hd;
@@ -155,7 +174,8 @@ __global__ __launch_bounds__(256, NKS <= 2 ? ATTN_BWD_WG : 1) void hstu_attn_bwd
   unsigned char* T1 = smem + nb * T::BYTES;      // dO tiles in pass A, V tiles in pass B
   uint32_t* vmask = reinterpret_cast<uint32_t*>(T1 + nb * T::BYTES);
 
-  const int b = blockIdx.x / n_heads, head = blockIdx.x % n_heads;
+  int b, head;
+  decode_seq_head(n_heads, b, head);
   const int64_t row0 = (int64_t)b * L;
   const int hoff = head * hd;
   // without saved activations (act_q == nullptr) silu(q), silu(k), silu(v) are recomputed from the pre-activation values
