@@ -215,7 +215,9 @@ int mhr_softmax_attn_bwd(const void* q, const void* k, const void* v, int64_t ro
  * ---------------------------------------------------------------------------------------- */
 int mhr_token_compact(const uint8_t* mask, const int32_t* q_all, const int32_t* p_all, const int32_t* o_all,
                       int n_groups, int n_slots, int tok_cap, int32_t* q_idx, int32_t* p_idx, int32_t* o_idx,
-                      int32_t* n_tok, int32_t* scratch, void* stream);
+                      int32_t* n_tok, int32_t* scratch, int32_t* tok_of_slot, void* stream);
+/* tok_of_slot (may be NULL) [n_groups, n_slots] int32: the inverse map - position of a live slot in its group's list,
+ * -1 for slots that are not live (or fell beyond tok_cap). */
 
 /* ------------------------------------------------------------------------------------------
  * Sampled softmax with false-negative suppression (model/IDNet/hstu.py:600-619 + F.cross_entropy 697/833).
@@ -332,6 +334,25 @@ int mhr_nce_shared_bwd_tokens(const void* qn_row, const float* u_row, const floa
                               float* d_logit_scale, float* lw_out, const int32_t* w_bucket, int n_buckets,
                               const void* negs, int n_neg, const uint32_t* fix_words, int64_t n_p_rows,
                               const int32_t* fix_slot_of_row, const int32_t* fix_any, float* d_negs, void* stream);
+/* Window-structured lists (slots (b, l, p), p fastest; target row of a slot = b (seq_len + pred_len) + l + 1 + p; tok_of_slot
+ * from mhr_token_compact): the backward without per-token atomics.
+ * mhr_nce_shared_bwd_rows: one wave per (group, row): dq_rows[row_q[r]] += the row's gradient (chain rule once per row, one
+ *   float-atomic set per row), lw_row[r] written, d(logit_scale) added, suppressed pairs taken out of u and of d_negs.
+ * mhr_nce_shared_bwd_targets: one wave per row of p_rows: dp_rows[m] += the gradient of every token of every group that
+ *   points at it, gathered through tok_of_slot (plain read-modify-write, no atomics, bitwise reproducible). */
+int mhr_nce_shared_bwd_rows(const void* qn_row, const float* u_row, const float* q_inv_row, const int32_t* row_q,
+                            const int32_t* row_first, const int32_t* n_row_dev, int row_cap, const void* pn, int dim,
+                            int n_groups, int tok_cap, const float* logit_scale_dev, const float* lse,
+                            const float* w, const float* s_pos, const int32_t* p_idx, float* dq_rows,
+                            float* d_logit_scale, float* lw_row, const int32_t* w_bucket, int n_buckets,
+                            const void* negs, int n_neg, const uint32_t* fix_words, int64_t n_p_rows,
+                            const int32_t* fix_slot_of_row, const int32_t* fix_any, float* d_negs, void* stream);
+int mhr_nce_shared_bwd_targets(const void* qn_row, int row_cap, const int32_t* tok2row, const int32_t* tok_of_slot,
+                               const int32_t* n_tok_dev, int n_groups, int n_slots, int tok_cap, int seq_len,
+                               int pred_len, const void* pn, const float* p_inv, int dim,
+                               const float* logit_scale_dev, const float* lse, const float* w, const float* s_pos,
+                               const int32_t* w_bucket, int n_buckets, int64_t n_p_rows, float* dp_rows,
+                               void* stream);
 int mhr_nce_row_lw(const float* lw_tok, const int32_t* row_first, const int32_t* n_row_dev, int n_groups,
                    int tok_cap, int row_cap, float* lw_row, void* stream);
 

@@ -214,6 +214,13 @@ class MultiHeadDecoding:
     # ------------------------------------------------------------------------------------------
     # training loss
     # ------------------------------------------------------------------------------------------
+    def _const(self, values, device, dtype):
+        """Small constant vector on the device, uploaded once (a `torch.tensor(list, device=...)` per step is a blocking copy)."""
+        key = ("const", tuple(values), str(device), dtype)
+        if key not in self._tok_cache:
+            self._tok_cache[key] = torch.tensor(values, device=device, dtype=dtype)
+        return self._tok_cache[key]
+
     def _token_tables(self, B, device, head_for_p):
         """Static index tables for G groups: query row in head_embs.view(-1,D) [G, B*P*L], target row in
         e.view(-1,D) [B*P*L], prediction offset [B*P*L].  head_for_p: [G, P] long (head used by group g at offset p)."""
@@ -246,25 +253,32 @@ class MultiHeadDecoding:
         q_static, p_all, o_all = self._token_tables(B, dev, head_for_p)
         q_all = q_static if q_all is None else q_all          # (a model may pick the query row per token itself: ComiRec)
         from mhr_amd import ops
-        q_idx, p_idx, o_idx, n_tok = ops.token_compact(valid_g.reshape(G, n_slots), q_all, p_all, o_all)
+        share = P > 1 and q_all is q_static      # the P offsets of a position share their query row (csrc/nce_shared.hip)
+        window = None
+        if share:
+            q_idx, p_idx, o_idx, n_tok, tos = ops.token_compact(valid_g.reshape(G, n_slots), q_all, p_all, o_all, slot_map=True)
+            window = (tos, L, P)
+        else:
+            q_idx, p_idx, o_idx, n_tok = ops.token_compact(valid_g.reshape(G, n_slots), q_all, p_all, o_all)
         cap = q_idx.shape[1]
         want_logs = log_group is not None
         logs = {} if want_logs else None
         mean_p = NceLossFn.apply(head_rows, e_rows, negs_g, self.logit_scale, q_idx, p_idx, n_tok, cap,
                                  float(self.nce_thres), want_logs, logs, o_idx, P,
-                                 log_group if want_logs else -1, p_row_mask,
-                                 P > 1 and q_all is q_static)     # the P offsets of a position share their query row   [G, P]
-        live = (torch.arange(cap, device=dev)[None, :] < n_tok[:, None]).float() if want_logs else None
+                                 log_group if want_logs else -1, p_row_mask, share, window)                 # [G, P]
         out_logs = None
-        if want_logs:
+        if want_logs:                                   # all counters of the logged group in ONE masked reduction
             g = log_group
-            first = live[g] * (o_idx[g] == 0).float()                     # tokens of prediction offset 0
-            n0 = first.sum().clamp_min(1.0)
-            out_logs = {'nce_samples': (logs["n_valid"][g].float() * first).sum() / n0}
-            for k in (1, 5, 10, 50, 100):
-                if k > negs_g.shape[1] + 1:
-                    break
-                out_logs[f'nce_top{k}_acc'] = ((logs["rank"][g] < k).float() * first).sum() / n0
+            first = ((torch.arange(cap, device=dev) < n_tok[g]) & (o_idx[g] == 0)).float()      # tokens of prediction offset 0
+            ks = [k for k in (1, 5, 10, 50, 100) if k <= negs_g.shape[1] + 1]
+            rank = logs["rank"][g]
+            cols = torch.cat([torch.ones_like(first)[None], logs["n_valid"][g].float()[None],
+                              (rank[None, :] < self._const(ks, dev, rank.dtype)[:, None]).float()])
+            sums = cols @ first                                                                  # [2 + len(ks)]
+            n0 = sums[0].clamp_min(1.0)
+            out_logs = {'nce_samples': sums[1] / n0}
+            for i, k in enumerate(ks):
+                out_logs[f'nce_top{k}_acc'] = sums[2 + i] / n0
         return mean_p, out_logs
 
     def _clamp_logit_scale(self):
@@ -325,7 +339,7 @@ class MultiHeadDecoding:
         log_group = max(i for i, g in enumerate(groups) if g[4] == 'nce' or g[5] == 0)
         p_row_mask = torch.stack(row_masks).reshape(len(groups), -1)
         mean_gp, logs = self._grouped_loss(head_rows, e_rows, negs_g.contiguous(), valid_g, head_for_p_g, log_group, p_row_mask)
-        per_gp = mean_gp * self.horizon_discount.float()[None, :] * torch.tensor([g[3] for g in groups], device=dev)[:, None]
+        per_gp = mean_gp * self.horizon_discount.float()[None, :] * self._const([g[3] for g in groups], dev, torch.float32)[:, None]
 
         model_out = defaultdict(float)
         total = per_gp.sum()

@@ -291,6 +291,227 @@ __global__ __launch_bounds__(256) void shared_tok_bwd_kernel(
   if (lane == 0 && d_logit_scale && dls != 0.f) atomicAdd(d_logit_scale, dls * scale);   // d/d(param), scale = exp(param)
 }
 
+// ------------------------------------------------------------------------------------------
+// backward without per-token atomics (window-structured token lists: slot (b, l, p) -> target row b (L + P) + l + 1 + p)
+// ------------------------------------------------------------------------------------------
+// Everything the token-side backward adds is linear in the per-token vectors, so it is summed where it lands:
+//   * per ROW (one wave per (group, row)): dq - its tokens share the query row, so A = sum a_t, sum coef_t pn_t and the
+//     suppressed-pair corrections are formed in registers and the L2-normalisation chain rule runs ONCE per row; one
+//     256-byte-shaped float-atomic set per row (heads can be shared between groups); also lw_row, d(logit_scale) and the
+//     d_negs corrections;
+//   * per TARGET row (one wave per row of p_rows): dp - the tokens that point at target (b, pos) are (l = pos - 1 - p, p) in
+//     every group, found through the inverse slot map of mhr_token_compact; their pn is the same vector, so
+//     A = sum scale coef_t qn_row(t) is gathered and the chain rule runs once; plain read-modify-write, no atomics,
+//     bitwise reproducible.
+// (The per-token form, shared_tok_bwd_kernel above, adds 1 KiB of float atomics per token for dp: 275 MB at cfg1.)
+__global__ __launch_bounds__(256) void shared_bwd_rows_kernel(
+    const bf16_t* __restrict__ qn_row, const float* __restrict__ u_row, const float* __restrict__ q_inv_row,
+    const int32_t* __restrict__ row_q, const int32_t* __restrict__ row_first, const int32_t* __restrict__ n_row_dev, int row_cap,
+    const bf16_t* __restrict__ pn, int dim, int tok_cap, const float* __restrict__ logit_scale_dev,
+    const float* __restrict__ lse, const float* __restrict__ w, const float* __restrict__ s_pos,
+    const int32_t* __restrict__ p_idx, float* __restrict__ dq_rows, float* __restrict__ d_logit_scale,
+    float* __restrict__ lw_row, const int32_t* __restrict__ w_bucket, int n_buckets, const bf16_t* __restrict__ negs, int n_neg,
+    const uint32_t* __restrict__ fixw, int n_rows_pad, int n_p_rows, const int32_t* __restrict__ slot_of_row,
+    const int32_t* __restrict__ fix_any, float* __restrict__ d_negs) {
+  const int n_tiles = (n_neg + 31) >> 5;
+  {
+    const int64_t grp = blockIdx.z, to = grp * tok_cap, ro = grp * row_cap;
+    qn_row += ro * dim; u_row += ro * dim; q_inv_row += ro; row_q += ro; row_first += ro; lw_row += ro; n_row_dev += grp;
+    pn += to * dim; lse += to; s_pos += to; p_idx += to;
+    if (w_bucket) { w_bucket += to; w += grp * n_buckets; } else { w += to; }
+    negs += grp * (int64_t)((n_neg + 31) & ~31) * dim;
+    fixw += grp * (int64_t)n_tiles * n_rows_pad;
+    fix_any += grp * (int64_t)n_rows_pad;
+    if (slot_of_row) slot_of_row += grp * (int64_t)n_p_rows;
+    if (d_negs) d_negs += grp * (int64_t)n_neg * dim;
+  }
+  const int n_row = min(*n_row_dev, row_cap - 1);
+  const int lane = threadIdx.x & 63;
+  const int wave_g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), n_waves = gridDim.x * (blockDim.x >> 6);
+  const float scale = clamp_scale(logit_scale_dev);
+  const float c1 = scale * LOG2E;
+  float dls = 0.f;
+  for (int r = wave_g; r < n_row; r += n_waves) {
+    const int t0 = row_first[r], t1 = min(row_first[r + 1], tok_cap);
+    float qv[NC], uv[NC], accp[NC] = {0.f, 0.f, 0.f, 0.f}, accu[NC] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int d = c * 64 + lane;
+      qv[c] = d < dim ? (float)qn_row[(int64_t)r * dim + d] : 0.f;
+      uv[c] = d < dim ? u_row[(int64_t)r * dim + d] : 0.f;
+    }
+    float a_sum = 0.f, lw_m = INFINITY, lw_s = 0.f;
+    for (int c0 = t0; c0 < t1; c0 += 64) {
+      // lane = token of the row: every per-token scalar (and the dependent slot / hit-flag look-ups) in ONE round of loads
+      const int tk = c0 + lane;
+      const bool live = tk < t1;
+      float wi = 0.f, sp = 0.f, ls = 0.f;
+      int slot = 0;
+      bool hit = false;
+      if (live) {
+        wi = w_bucket ? w[w_bucket[tk]] : w[tk];
+        sp = s_pos[tk];
+        ls = lse[tk];
+        const int pi = p_idx[tk];
+        slot = slot_of_row ? slot_of_row[pi] : pi;
+        hit = fix_any[slot] != 0;
+      }
+      const float a = live ? wi * __expf(scale - ls) : 0.f;
+      const float coef = live ? wi * (__expf(scale * sp - ls) - 1.0f) : 0.f;
+      const float lw = (live && wi > 0.f) ? ls * LOG2E - __log2f(wi) : INFINITY;
+      a_sum += wave_sum(a);
+      dls += wave_sum(coef * sp);
+      const float m = -wave_max(-lw);                          // min over the chunk
+      if (m < INFINITY) {                                      // running max-shifted sum of 2^(-lw), merged chunk by chunk
+        const float sc = wave_sum(lw < INFINITY ? __builtin_amdgcn_exp2f(m - lw) : 0.f);
+        if (m < lw_m) {
+          lw_s = (lw_m < INFINITY ? lw_s * __builtin_amdgcn_exp2f(m - lw_m) : 0.f) + sc;
+          lw_m = m;
+        } else {
+          lw_s += sc * __builtin_amdgcn_exp2f(lw_m - m);
+        }
+      }
+      const int cnt = min(64, t1 - c0);
+      for (int i = 0; i < cnt; ++i) {                          // independent row loads: the compiler keeps several in flight
+        const float cf = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, coef), i));
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          const int d = c * 64 + lane;
+          accp[c] += d < dim ? cf * (float)pn[(int64_t)(c0 + i) * dim + d] : 0.f;
+        }
+      }
+      uint64_t hm = __ballot(hit);
+      while (hm) {                                             // tokens with suppressed negatives: a few percent
+        const int i = __builtin_ctzll(hm);
+        hm &= hm - 1;
+        const int slot_u = __builtin_amdgcn_readlane(slot, i);
+        const float a_u = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a), i));
+        const float wi_u = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wi), i));
+        const float ls_u = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ls), i));
+        for_each_hit(fixw, n_tiles, n_rows_pad, slot_u, n_neg, lane, [&](int j) {
+          const bf16_t* ns = negs + (int64_t)j * dim;
+          float nv[NC];
+          float s = 0.f;
+#pragma unroll
+          for (int c = 0; c < NC; ++c) {
+            const int d = c * 64 + lane;
+            nv[c] = d < dim ? (float)ns[d] : 0.f;
+            s += qv[c] * nv[c];
+          }
+          s = wave_sum(s);
+          const float eb = (float)(bf16_t)__builtin_amdgcn_exp2f(s * c1 - c1);
+          const float gneg = -scale * wi_u * __expf(scale * s - ls_u);
+#pragma unroll
+          for (int c = 0; c < NC; ++c) {
+            const int d = c * 64 + lane;
+            accu[c] += a_u * eb * nv[c];
+            if (d_negs && d < dim && wi_u != 0.f) atomicAdd(d_negs + (int64_t)j * dim + d, gneg * qv[c]);
+          }
+        });
+      }
+    }
+    float dqn[NC];
+    float dot_q = 0.f, dot_raw = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const float raw = a_sum * uv[c] - accu[c];
+      dqn[c] = scale * (raw + accp[c]);
+      dot_raw += qv[c] * raw;
+      dot_q += qv[c] * dqn[c];
+    }
+    dot_q = wave_sum(dot_q);
+    dls += wave_sum(dot_raw);
+    const float iq = q_inv_row[r];
+    float* qdst = dq_rows + (int64_t)row_q[r] * dim;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int d = c * 64 + lane;
+      if (d < dim) atomicAdd(qdst + d, (dqn[c] - qv[c] * dot_q) * iq);
+    }
+    if (lane == 0) lw_row[r] = lw_m < INFINITY ? lw_m - __log2f(lw_s) : INFINITY;
+  }
+  // d(logit_scale): ONE atomic per workgroup (every wave adding to the same address serialises: 61 k adds cost 0.6 ms)
+  __shared__ float s_dls[4];
+  if (lane == 0) s_dls[threadIdx.x >> 6] = dls;
+  __syncthreads();
+  if (threadIdx.x == 0 && d_logit_scale) {
+    const float t = (s_dls[0] + s_dls[1]) + (s_dls[2] + s_dls[3]);
+    if (t != 0.f) atomicAdd(d_logit_scale, t * scale);       // d/d(param), scale = exp(param)
+  }
+}
+
+__global__ __launch_bounds__(256) void shared_bwd_targets_kernel(
+    const bf16_t* __restrict__ qn_row, int row_cap, const int32_t* __restrict__ tok2row, const int32_t* __restrict__ tok_of_slot,
+    const int32_t* __restrict__ n_tok_dev, int n_groups, int n_slots, int tok_cap, int L, int P, const bf16_t* __restrict__ pn,
+    const float* __restrict__ p_inv, int dim, const float* __restrict__ logit_scale_dev, const float* __restrict__ lse,
+    const float* __restrict__ w, const float* __restrict__ s_pos, const int32_t* __restrict__ w_bucket, int n_buckets,
+    int n_p_rows, float* __restrict__ dp_rows) {
+  const int lane = threadIdx.x & 63;
+  const int wave_g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), n_waves = gridDim.x * (blockDim.x >> 6);
+  const float scale = clamp_scale(logit_scale_dev);
+  const int W = L + P, n_cand = n_groups * P;
+  for (int m = wave_g; m < n_p_rows; m += n_waves) {
+    const int b = m / W, pos = m - b * W;
+    float acc[NC] = {0.f, 0.f, 0.f, 0.f};
+    int t_any = -1, g_any = 0;
+    for (int c0 = 0; c0 < n_cand; c0 += 64) {
+      // lane = candidate (group, offset): the token (l = pos - 1 - p, p) of that group, if it is live
+      const int cand = c0 + lane;
+      int tk = -1, g = 0;
+      float coef = 0.f;
+      if (cand < n_cand) {
+        g = cand / P;
+        const int p = cand - g * P, l = pos - 1 - p;
+        if (l >= 0 && l < L) {
+          const int64_t slot = ((int64_t)b * L + l) * P + p;
+          if (slot < n_slots) tk = tok_of_slot[(int64_t)g * n_slots + slot];
+          if (tk >= min(n_tok_dev[g], tok_cap)) tk = -1;
+        }
+        if (tk >= 0) {
+          const int64_t o = (int64_t)g * tok_cap + tk;
+          const float wi = w_bucket ? w[(int64_t)g * n_buckets + w_bucket[o]] : w[o];
+          coef = wi * (__expf(scale * s_pos[o] - lse[o]) - 1.0f);
+        }
+      }
+      uint64_t live = __ballot(tk >= 0);
+      while (live) {
+        const int ln = __builtin_ctzll(live);
+        live &= live - 1;
+        const int tk_u = __builtin_amdgcn_readlane(tk, ln), g_u = __builtin_amdgcn_readlane(g, ln);
+        const float cf = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, coef), ln));
+        const int r = tok2row[(int64_t)g_u * tok_cap + tk_u];
+        const bf16_t* qs = qn_row + ((int64_t)g_u * row_cap + r) * dim;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          const int d = c * 64 + lane;
+          acc[c] += d < dim ? cf * (float)qs[d] : 0.f;
+        }
+        t_any = tk_u;
+        g_any = g_u;
+      }
+    }
+    if (t_any < 0) continue;                                 // no live token points at this row: its gradient stays as it is
+    const int64_t o = (int64_t)g_any * tok_cap + t_any;
+    const float ip = p_inv[o];
+    float pv[NC], dpn[NC];
+    float dot = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int d = c * 64 + lane;
+      pv[c] = d < dim ? (float)pn[o * dim + d] : 0.f;
+      dpn[c] = scale * acc[c];
+      dot += pv[c] * dpn[c];
+    }
+    dot = wave_sum(dot);
+    float* dst = dp_rows + (int64_t)m * dim;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int d = c * 64 + lane;
+      if (d < dim) dst[d] += (dpn[c] - pv[c] * dot) * ip;
+    }
+  }
+}
+
 // lw_row[r] = -log2 sum_{t in row r} 2^(-lw_tok[t]), max-shifted; +inf when every token of the row has zero weight
 __global__ __launch_bounds__(256) void row_lw_kernel(const float* __restrict__ lw_tok, const int32_t* __restrict__ row_first,
                                                      const int32_t* __restrict__ n_row_dev, int tok_cap, int row_cap,
@@ -369,6 +590,53 @@ extern "C" int mhr_nce_shared_bwd_tokens(const void* qn_row, const float* u_row,
                      n_buckets, (const bf16_t*)negs, n_neg, fix_words, n_rows_pad, (int)n_p_rows, fix_slot_of_row, fix_any,
                      d_negs);
   MHR_CHECK_LAUNCH("nce_shared_bwd_tokens");
+  return MHR_OK;
+}
+
+extern "C" int mhr_nce_shared_bwd_rows(const void* qn_row, const float* u_row, const float* q_inv_row, const int32_t* row_q,
+                                       const int32_t* row_first, const int32_t* n_row_dev, int row_cap, const void* pn, int dim,
+                                       int n_groups, int tok_cap, const float* logit_scale_dev, const float* lse,
+                                       const float* w, const float* s_pos, const int32_t* p_idx, float* dq_rows,
+                                       float* d_logit_scale, float* lw_row, const int32_t* w_bucket, int n_buckets,
+                                       const void* negs, int n_neg, const uint32_t* fix_words, int64_t n_p_rows,
+                                       const int32_t* fix_slot_of_row, const int32_t* fix_any, float* d_negs, void* stream) {
+  MHR_REQUIRE(qn_row && u_row && q_inv_row && row_q && row_first && n_row_dev && pn && logit_scale_dev && lse && w && s_pos,
+              "nce_shared_bwd_rows: null input pointer");
+  MHR_REQUIRE(p_idx && dq_rows && lw_row && negs && fix_words && fix_any, "nce_shared_bwd_rows: null index/output pointer");
+  MHR_REQUIRE(dim > 0 && dim <= 256, "nce_shared_bwd_rows: dim=%d unsupported (<= 256)", dim);
+  MHR_REQUIRE(tok_cap > 0 && row_cap > 1 && n_neg > 0 && n_p_rows > 0 && n_groups >= 1 && n_groups <= 65535,
+              "nce_shared_bwd_rows: bad sizes");
+  const int n_rows_pad = (int)((n_p_rows + 255) / 256 * 256);
+  int blocks = (row_cap + 15) / 16;                 // 4 waves x 4 rows; few enough workgroups that their closing atomics stay cheap
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(shared_bwd_rows_kernel, dim3(blocks, 1, n_groups), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)qn_row, u_row, q_inv_row, row_q, row_first, n_row_dev, row_cap, (const bf16_t*)pn, dim, tok_cap,
+                     logit_scale_dev, lse, w, s_pos, p_idx, dq_rows, d_logit_scale, lw_row, w_bucket, n_buckets,
+                     (const bf16_t*)negs, n_neg, fix_words, n_rows_pad, (int)n_p_rows, fix_slot_of_row, fix_any, d_negs);
+  MHR_CHECK_LAUNCH("nce_shared_bwd_rows");
+  return MHR_OK;
+}
+
+extern "C" int mhr_nce_shared_bwd_targets(const void* qn_row, int row_cap, const int32_t* tok2row, const int32_t* tok_of_slot,
+                                          const int32_t* n_tok_dev, int n_groups, int n_slots, int tok_cap, int seq_len,
+                                          int pred_len, const void* pn, const float* p_inv, int dim,
+                                          const float* logit_scale_dev, const float* lse, const float* w, const float* s_pos,
+                                          const int32_t* w_bucket, int n_buckets, int64_t n_p_rows, float* dp_rows,
+                                          void* stream) {
+  MHR_REQUIRE(qn_row && tok2row && tok_of_slot && n_tok_dev && pn && p_inv && logit_scale_dev && lse && w && s_pos && dp_rows,
+              "nce_shared_bwd_targets: null pointer");
+  MHR_REQUIRE(dim > 0 && dim <= 256, "nce_shared_bwd_targets: dim=%d unsupported (<= 256)", dim);
+  MHR_REQUIRE(seq_len > 0 && pred_len > 0 && n_slots > 0 && n_slots % (seq_len * pred_len) == 0 &&
+                  n_p_rows == (int64_t)(n_slots / (seq_len * pred_len)) * (seq_len + pred_len),
+              "nce_shared_bwd_targets: slots must be (b, l, p) windows and p_rows the [B, L + P] targets (n_slots=%d L=%d P=%d "
+              "n_p_rows=%lld)", n_slots, seq_len, pred_len, (long long)n_p_rows);
+  MHR_REQUIRE(tok_cap > 0 && row_cap > 0 && n_groups >= 1 && n_groups <= 65535, "nce_shared_bwd_targets: bad sizes");
+  int blocks = (int)((n_p_rows + 3) / 4);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(shared_bwd_targets_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qn_row, row_cap,
+                     tok2row, tok_of_slot, n_tok_dev, n_groups, n_slots, tok_cap, seq_len, pred_len, (const bf16_t*)pn, p_inv, dim,
+                     logit_scale_dev, lse, w, s_pos, w_bucket, n_buckets, (int)n_p_rows, dp_rows);
+  MHR_CHECK_LAUNCH("nce_shared_bwd_targets");
   return MHR_OK;
 }
 

@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void token_scatter_kernel(const uint8_t* __res
                                                             int n_slots, int n_chunks, int tok_cap,
                                                             const int32_t* __restrict__ chunk_cnt, int32_t* __restrict__ q_idx,
                                                             int32_t* __restrict__ p_idx, int32_t* __restrict__ o_idx,
-                                                            int32_t* __restrict__ n_tok) {
+                                                            int32_t* __restrict__ n_tok, int32_t* __restrict__ tok_of_slot) {
   const int chunk = blockIdx.x, grp = blockIdx.y;
   const uint8_t* m = mask + (int64_t)grp * n_slots;
   const int32_t* cc = chunk_cnt + grp * n_chunks;
@@ -78,6 +78,18 @@ __global__ __launch_bounds__(256) void token_scatter_kernel(const uint8_t* __res
   int32_t* pd = p_idx + (int64_t)grp * tok_cap;
   int32_t* od = o_idx + (int64_t)grp * tok_cap;
   const int32_t* qa = q_all + (int64_t)grp * n_slots;
+  if (tok_of_slot) {                                       // inverse map: list position of a live slot, -1 for the others
+    int32_t* ts = tok_of_slot + (int64_t)grp * n_slots;
+    int o2 = off;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      if (base + i < n_slots) {
+        const bool on = (bits >> i) & 1u;
+        ts[base + i] = (on && o2 < tok_cap) ? o2 : -1;
+        o2 += on ? 1 : 0;
+      }
+    }
+  }
   while (bits) {
     const int i = __ffs(bits) - 1;
     bits &= bits - 1;
@@ -94,14 +106,14 @@ __global__ __launch_bounds__(256) void token_scatter_kernel(const uint8_t* __res
 
 extern "C" int mhr_token_compact(const uint8_t* mask, const int32_t* q_all, const int32_t* p_all, const int32_t* o_all,
                                  int n_groups, int n_slots, int tok_cap, int32_t* q_idx, int32_t* p_idx, int32_t* o_idx,
-                                 int32_t* n_tok, int32_t* scratch, void* stream) {
+                                 int32_t* n_tok, int32_t* scratch, int32_t* tok_of_slot, void* stream) {
   MHR_REQUIRE(mask && q_all && p_all && o_all && q_idx && p_idx && o_idx && n_tok && scratch, "token_compact: null pointer");
   MHR_REQUIRE(n_groups >= 1 && n_groups <= 65535 && n_slots > 0 && tok_cap > 0, "token_compact: bad sizes");
   const int n_chunks = (n_slots + CHUNK - 1) / CHUNK;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(token_count_kernel, dim3(n_chunks, n_groups), dim3(256), 0, s, mask, n_slots, n_chunks, scratch);
   hipLaunchKernelGGL(token_scatter_kernel, dim3(n_chunks, n_groups), dim3(256), 0, s, mask, q_all, p_all, o_all, n_slots,
-                     n_chunks, tok_cap, scratch, q_idx, p_idx, o_idx, n_tok);
+                     n_chunks, tok_cap, scratch, q_idx, p_idx, o_idx, n_tok, tok_of_slot);
   MHR_CHECK_LAUNCH("token_compact");
   return MHR_OK;
 }

@@ -386,10 +386,11 @@ def softmax_attn_bwd(qkv, out, d_out, lse, n_seqs, max_len, n_heads, n_kv_heads,
 # ------------------------------------------------------------------------------------------------
 # sampled softmax
 # ------------------------------------------------------------------------------------------------
-def token_compact(mask, q_all, p_all, o_all, tok_cap=None):
+def token_compact(mask, q_all, p_all, o_all, tok_cap=None, slot_map=False):
     """Ordered compaction of live (group, slot) pairs.  mask [G, n_slots] bool/uint8; q_all [G, n_slots] int32;
     p_all, o_all [n_slots] int32.  Returns (q_idx, p_idx, o_idx [G, cap] int32 - entries beyond n_tok undefined -,
-    n_tok [G] int32) with cap = tok_cap (default n_slots) rounded up to a multiple of 32.  No host sync."""
+    n_tok [G] int32) with cap = tok_cap (default n_slots) rounded up to a multiple of 32.  No host sync.
+    slot_map: also return tok_of_slot [G, n_slots] int32 (list position of a live slot, -1 otherwise)."""
     if mask.dtype == torch.bool:
         mask = mask.view(torch.uint8)
     _chk(mask, "mask", torch.uint8)
@@ -405,8 +406,11 @@ def token_compact(mask, q_all, p_all, o_all, tok_cap=None):
     o_idx = torch.empty(G, cap, dtype=torch.int32, device=dev)
     n_tok = torch.empty(G, dtype=torch.int32, device=dev)
     scratch = torch.empty(G, (n_slots + 4095) // 4096, dtype=torch.int32, device=dev)
+    tos = torch.empty(G, n_slots, dtype=torch.int32, device=dev) if slot_map else None
     lib.call("mhr_token_compact", mask.data_ptr(), q_all.data_ptr(), p_all.data_ptr(), o_all.data_ptr(), G, n_slots, cap,
-             q_idx.data_ptr(), p_idx.data_ptr(), o_idx.data_ptr(), n_tok.data_ptr(), scratch.data_ptr(), _stream())
+             q_idx.data_ptr(), p_idx.data_ptr(), o_idx.data_ptr(), n_tok.data_ptr(), scratch.data_ptr(), _ptr(tos), _stream())
+    if slot_map:
+        return q_idx, p_idx, o_idx, n_tok, tos
     return q_idx, p_idx, o_idx, n_tok
 
 
@@ -422,7 +426,8 @@ class NceSaved:
                  "n_tok_dev", "tok_cap", "cap", "thres", "dim", "n_neg", "groups", "q_idx", "p_idx", "bucket_idx", "n_buckets",
                  "bucket_sum", "bucket_cnt", "u", "wide", "scale_dev", "cap_eff",
                  # query-row sharing (nce_shared.hip): row-level state of the streaming kernels + the maps between rows and tokens
-                 "shared", "tok2row", "row_first", "n_row_dev", "row_cap", "fix_words", "fix_slot", "fix_any", "n_p_rows")
+                 "shared", "tok2row", "row_first", "n_row_dev", "row_cap", "fix_words", "fix_slot", "fix_any", "n_p_rows", "row_q",
+                 "window")
 
 
 _ROW_IOTA = {}
@@ -459,7 +464,8 @@ def _row_maps(q_idx, n_tok_dev, cap, row_cap):
     return r_q, tok2row, r_first, n_row
 
 
-def _nce_fwd_shared(sv, q_rows, p_rows, negs, logit_scale, thres, want_logs, bucket_idx, n_buckets, log_group, p_row_mask, loss):
+def _nce_fwd_shared(sv, q_rows, p_rows, negs, logit_scale, thres, want_logs, bucket_idx, n_buckets, log_group, p_row_mask, loss,
+                    window=None):
     """Query-row sharing (csrc/nce_shared.hip): the streaming kernels see each distinct query row once."""
     dev = negs.device
     G, n_neg, D = sv.groups, sv.n_neg, sv.dim              # negs itself is padded to whole 32-row tiles
@@ -526,7 +532,8 @@ def _nce_fwd_shared(sv, q_rows, p_rows, negs, logit_scale, thres, want_logs, buc
              _ptr(sv.bucket_sum), _ptr(sv.bucket_cnt), st)
     sv.shared = True
     sv.qn, sv.u, sv.q_inv, sv.supp = qn_row, u_row, q_inv_row, supp_row
-    sv.tok2row, sv.row_first, sv.n_row_dev, sv.row_cap = tok2row, r_first, n_row, row_cap
+    sv.tok2row, sv.row_first, sv.n_row_dev, sv.row_cap, sv.row_q = tok2row, r_first, n_row, row_cap, r_q
+    sv.window = window                      # (tok_of_slot [G, n_slots], L, P) of window-structured lists, or None
     sv.fix_words, sv.fix_slot, sv.fix_any, sv.n_p_rows = fix_words, slot_of_row, fix_any, n_p_rows
     sv.loss = loss[:, :tok_cap]
     sv.n_valid = None if n_valid is None else n_valid[:, :tok_cap]
@@ -535,14 +542,16 @@ def _nce_fwd_shared(sv, q_rows, p_rows, negs, logit_scale, thres, want_logs, buc
 
 
 def nce_fwd(q_rows, q_idx, p_rows, p_idx, negs, n_tok_dev, tok_cap, logit_scale, thres=0.99, want_logs=False,
-            for_backward=True, bucket_idx=None, n_buckets=0, log_group=-1, p_row_mask=None, share_rows=False):
+            for_backward=True, bucket_idx=None, n_buckets=0, log_group=-1, p_row_mask=None, share_rows=False, window=None):
     """Grouped sampled softmax.  q_rows/p_rows [*, D] (bf16 or f32, same dtype, shared by all groups);
     q_idx/p_idx [G, tok_cap] int32; negs [G, n_neg, D] bf16 normalised; n_tok_dev [G] int32.
     (1-D q_idx / 2-D negs are accepted as a single group.)  Saved tensors carry the leading group axis.
     p_row_mask [G, p_rows.shape[0]] bool/uint8 (optional): per group, a superset of the rows of p_rows that live tokens
     point at - the hoisted false-negative test then visits only those rows.
     share_rows: tokens with the same query row are neighbours in the lists (several prediction offsets of one position):
-    the negative-pool products run once per distinct row (csrc/nce_shared.hip).  Same results."""
+    the negative-pool products run once per distinct row (csrc/nce_shared.hip).  Same results.
+    window = (tok_of_slot, L, P) (with share_rows): the lists are the compaction of (b, l, p) window slots with
+    p_idx = b (L + P) + l + 1 + p (token_compact(slot_map=True)): the backward then needs no per-token atomics."""
     if q_idx.dim() == 1:
         q_idx, p_idx, negs, n_tok_dev = q_idx[None], p_idx[None], negs[None], n_tok_dev.view(1)
     _chk(negs, "negs", torch.bfloat16)
@@ -582,7 +591,7 @@ def nce_fwd(q_rows, q_idx, p_rows, p_idx, negs, n_tok_dev, tok_cap, logit_scale,
         sv.negs = negs
         sv.n_tok_dev, sv.tok_cap, sv.cap, sv.thres, sv.dim, sv.n_neg, sv.groups = n_tok_dev, tok_cap, cap, float(thres), D, n_neg, G
         return _nce_fwd_shared(sv, q_rows, p_rows, negs, logit_scale, thres, want_logs, bucket_idx, n_buckets, log_group,
-                               p_row_mask, loss)
+                               p_row_mask, loss, window)
     if for_backward or sv.wide:
         sv.qn = torch.empty(G, cap, D, dtype=torch.bfloat16, device=dev)
         sv.pn = torch.empty(G, cap, D, dtype=torch.bfloat16, device=dev)
@@ -663,18 +672,32 @@ def nce_bwd(sv, w, logit_scale, q_idx, p_idx, dq_rows, dp_rows, d_negs=None, d_l
         return d_negs, d_logit_scale
     st = _stream()
     if sv.shared:
-        lw_tok = torch.empty(G, cap, dtype=torch.float32, device=dev)
-        _timed_call("mhr_nce_shared_bwd_tokens", sv.qn.data_ptr(), sv.u.data_ptr(), sv.q_inv.data_ptr(), sv.row_cap,
-                    sv.tok2row.data_ptr(), sv.pn.data_ptr(), D, G, sv.n_tok_dev.data_ptr(), cap, logit_scale.data_ptr(),
-                    sv.lse.data_ptr(), w.data_ptr(), sv.p_inv.data_ptr(), sv.s_pos.data_ptr(), sv.q_idx.data_ptr(),
-                    sv.p_idx.data_ptr(), dq_rows.data_ptr(), dp_rows.data_ptr(), d_logit_scale.data_ptr(), lw_tok.data_ptr(),
-                    sv.bucket_idx.data_ptr() if bucketed else 0, sv.n_buckets if bucketed else 0, sv.negs.data_ptr(), sv.n_neg,
-                    sv.fix_words.data_ptr(), sv.n_p_rows, _ptr(sv.fix_slot), sv.fix_any.data_ptr(),
-                    d_negs.data_ptr() if want_negs else 0, st)
+        wb_ptr, nb = (sv.bucket_idx.data_ptr(), sv.n_buckets) if bucketed else (0, 0)
+        dn_ptr = d_negs.data_ptr() if want_negs else 0
+        lw_row = torch.full((G, sv.row_cap), float("inf"), dtype=torch.float32, device=dev)
+        if sv.window is not None:            # window-structured lists: sums formed where they land, no per-token atomics
+            tos, L_, P_ = sv.window
+            _timed_call("mhr_nce_shared_bwd_rows", sv.qn.data_ptr(), sv.u.data_ptr(), sv.q_inv.data_ptr(), sv.row_q.data_ptr(),
+                        sv.row_first.data_ptr(), sv.n_row_dev.data_ptr(), sv.row_cap, sv.pn.data_ptr(), D, G, cap,
+                        logit_scale.data_ptr(), sv.lse.data_ptr(), w.data_ptr(), sv.s_pos.data_ptr(), sv.p_idx.data_ptr(),
+                        dq_rows.data_ptr(), d_logit_scale.data_ptr(), lw_row.data_ptr(), wb_ptr, nb, sv.negs.data_ptr(), sv.n_neg,
+                        sv.fix_words.data_ptr(), sv.n_p_rows, _ptr(sv.fix_slot), sv.fix_any.data_ptr(), dn_ptr, st)
+            _timed_call("mhr_nce_shared_bwd_targets", sv.qn.data_ptr(), sv.row_cap, sv.tok2row.data_ptr(), tos.data_ptr(),
+                        sv.n_tok_dev.data_ptr(), G, tos.shape[1], cap, int(L_), int(P_), sv.pn.data_ptr(), sv.p_inv.data_ptr(), D,
+                        logit_scale.data_ptr(), sv.lse.data_ptr(), w.data_ptr(), sv.s_pos.data_ptr(), wb_ptr, nb, sv.n_p_rows,
+                        dp_rows.data_ptr(), st)
+        else:
+            lw_tok = torch.empty(G, cap, dtype=torch.float32, device=dev)
+            _timed_call("mhr_nce_shared_bwd_tokens", sv.qn.data_ptr(), sv.u.data_ptr(), sv.q_inv.data_ptr(), sv.row_cap,
+                        sv.tok2row.data_ptr(), sv.pn.data_ptr(), D, G, sv.n_tok_dev.data_ptr(), cap, logit_scale.data_ptr(),
+                        sv.lse.data_ptr(), w.data_ptr(), sv.p_inv.data_ptr(), sv.s_pos.data_ptr(), sv.q_idx.data_ptr(),
+                        sv.p_idx.data_ptr(), dq_rows.data_ptr(), dp_rows.data_ptr(), d_logit_scale.data_ptr(), lw_tok.data_ptr(),
+                        wb_ptr, nb, sv.negs.data_ptr(), sv.n_neg, sv.fix_words.data_ptr(), sv.n_p_rows, _ptr(sv.fix_slot),
+                        sv.fix_any.data_ptr(), dn_ptr, st)
+            if want_negs:
+                lib.call("mhr_nce_row_lw", lw_tok.data_ptr(), sv.row_first.data_ptr(), sv.n_row_dev.data_ptr(), G, cap, sv.row_cap,
+                         lw_row.data_ptr(), st)
         if want_negs:
-            lw_row = torch.full((G, sv.row_cap), float("inf"), dtype=torch.float32, device=dev)
-            lib.call("mhr_nce_row_lw", lw_tok.data_ptr(), sv.row_first.data_ptr(), sv.n_row_dev.data_ptr(), G, cap, sv.row_cap,
-                     lw_row.data_ptr(), st)
             _timed_call("mhr_nce_bwd_negs", sv.qn.data_ptr(), sv.negs.data_ptr(), sv.supp.data_ptr(), sv.n_neg, D, G,
                         sv.n_row_dev.data_ptr(), sv.row_cap, logit_scale.data_ptr(), lw_row.data_ptr(), d_negs.data_ptr(), st)
         return d_negs, d_logit_scale

@@ -405,6 +405,75 @@ def test_nce_shared_query_rows_match_per_token_oracle(ops, D, n_pos, P, n_neg, d
     np.testing.assert_allclose(sv.loss.cpu().numpy(), sv2.loss.cpu().numpy(), rtol=2e-5, atol=2e-5)
 
 
+@pytest.mark.parametrize("D,B,L,P,G,n_neg", [(64, 3, 9, 4, 2, 96), (256, 2, 13, 8, 3, 256)])
+def test_nce_window_backward_without_token_atomics(ops, D, B, L, P, G, n_neg):
+    """Window-structured lists ((b, l, p) slots, target row b (L + P) + l + 1 + p): the row-wise / target-wise backward
+    (mhr_nce_shared_bwd_rows + _targets, driven by token_compact's inverse slot map) against the per-token oracle, with
+    per-(group, offset) bucket weights, planted false negatives and two groups pointing at the same target rows."""
+    g = torch.Generator().manual_seed(5 + D + P)
+    H = G
+    head_rows = (torch.randn(B * H * L, D, generator=g) * 2)
+    e_rows = torch.randn(B * (L + P), D, generator=g)
+    valid = torch.rand(G, B, L, P, generator=g) < 0.5
+    b_ = torch.arange(B)[None, :, None, None]
+    l_ = torch.arange(L)[None, None, :, None]
+    p_ = torch.arange(P)[None, None, None, :]
+    h_ = torch.arange(G)[:, None, None, None]
+    q_all = ((b_ * H + h_) * L + l_).expand(G, B, L, P).reshape(G, -1).int().contiguous()
+    p_all = (b_ * (L + P) + l_ + 1 + p_).expand(1, B, L, P).reshape(-1).int().contiguous()
+    o_all = p_.expand(1, B, L, P).reshape(-1).int().contiguous()
+    n_slots = B * L * P
+    q_idx, p_idx, o_idx, n_tok, tos = ops.token_compact(dev(valid.reshape(G, n_slots)), dev(q_all), dev(p_all), dev(o_all), slot_map=True)
+    cap = q_idx.shape[1]
+    for gi in range(G):                                   # the inverse map is consistent with the lists
+        live = valid[gi].reshape(-1)
+        t = tos[gi].cpu()
+        assert bool((t[~live] == -1).all()) and t[live].tolist() == list(range(int(live.sum())))
+    negs = bf(HO.l2n(torch.randn(G, n_neg, D, generator=g)))
+    for gi in range(G):
+        for k in range(0, int(n_tok[gi]), 4):
+            negs[gi, (k * 5) % n_neg] = bf(HO.l2n(e_rows[p_idx[gi, k].cpu().long()][None]))[0]
+    ls = torch.tensor(math.log(15.0))
+    lsd = ls.reshape(1).cuda()
+    sv = ops.nce_fwd(dev(head_rows), q_idx, dev(e_rows), p_idx, dev(negs), n_tok, cap, lsd, 0.99, bucket_idx=o_idx, n_buckets=P,
+                     share_rows=True, window=(tos, L, P))
+    assert sv.shared and sv.window is not None
+    w_gp = torch.rand(G, P, generator=g)
+    w_gp[0, 1] = 0.0
+    dq = torch.zeros(B * H * L, D).cuda()
+    dp = torch.zeros(B * (L + P), D).cuda()
+    dn, dls = ops.nce_bwd(sv, dev(w_gp), lsd, q_idx, p_idx, dq, dp)
+    torch.cuda.synchronize()
+    # oracle: every token on its own
+    hq = head_rows.clone().requires_grad_(True)
+    ep = e_rows.clone().requires_grad_(True)
+    nn_ = negs.float().clone().requires_grad_(True)
+    lsr = ls.clone().requires_grad_(True)
+    total = 0.0
+    for gi in range(G):
+        n = int(n_tok[gi])
+        qi, pi, oi = q_idx[gi, :n].cpu().long(), p_idx[gi, :n].cpu().long(), o_idx[gi, :n].cpu().long()
+        loss, *_ = _nce_oracle(hq[qi], ep[pi], nn_[gi], lsr, 0.99)
+        np.testing.assert_allclose(sv.loss.cpu().numpy()[gi, :n], loss.detach().numpy(), rtol=1e-4, atol=1e-4)
+        total = total + (loss * w_gp[gi][oi]).sum()
+    total.backward()
+    for name, got, ref in (("dq", dq.cpu(), hq.grad), ("dp", dp.cpu(), ep.grad), ("dneg", dn.cpu(), nn_.grad)):
+        gs = float(ref.abs().max())
+        assert float((got - ref).abs().max()) < 2e-2 * gs, (name, float((got - ref).abs().max()), gs)
+    assert abs(float(dls.cpu()) - float(lsr.grad)) < 2e-2 * abs(float(lsr.grad)) + 1e-4
+    # same numbers from the generic (per-token atomics) form of the shared path
+    sv2 = ops.nce_fwd(dev(head_rows), q_idx, dev(e_rows), p_idx, dev(negs), n_tok, cap, lsd, 0.99, bucket_idx=o_idx, n_buckets=P,
+                      share_rows=True)
+    dq2, dp2 = torch.zeros_like(dq), torch.zeros_like(dp)
+    dn2, dls2 = ops.nce_bwd(sv2, dev(w_gp), lsd, q_idx, p_idx, dq2, dp2)
+    for a, b2, tol in ((dq, dq2, 1e-4), (dp, dp2, 1e-4), (dn, dn2, 1e-2)):      # dn: the row weights feed a bf16 tile (2^-9 steps)
+        assert float((a - b2).abs().max()) <= tol * float(b2.abs().max()) + 1e-7
+    # the target-row gather has no atomics: bitwise reproducible
+    dq3, dp3 = torch.zeros_like(dq), torch.zeros_like(dp)
+    ops.nce_bwd(sv, dev(w_gp), lsd, q_idx, p_idx, dq3, dp3)
+    assert torch.equal(dp3, dp)
+
+
 @pytest.mark.parametrize("rows,cols", [(16, 1024 * 256), (25600, 256), (3, 64), (1, 8), (4097, 1032)])
 def test_sum_rows_into(ops, rows, cols):
     """Split-K partial / bias-gradient reduction into an fp32 accumulator: exact fp32 sums of the bf16 inputs up to the
