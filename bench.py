@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--mode", default="train", choices=["train", "eval"])
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override (0 = config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-probe", action="store_true", help="skip the 5 untimed steps that measure the host's issue time (profiler runs)")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-kernel HIP events (pure wall-clock run)")
     return ap.parse_args()
 
@@ -177,13 +178,15 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     host_alone = []                                   # host cost of issuing ONE step into an idle queue (outside the timed region)
-    for i in range(5):
+    prof_keep, ops.PROFILE = ops.PROFILE, None        # (and outside the per-kernel event collection)
+    for i in range(0 if args.no_host_probe else 5):
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         step(args.warmup + args.steps + i)
         host_alone.append(time.perf_counter() - t1)
     sync()
-    host_alone = sorted(host_alone)[len(host_alone) // 2]
+    host_alone = sorted(host_alone)[len(host_alone) // 2] if host_alone else float('nan')
+    ops.PROFILE = prof_keep
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -210,7 +213,8 @@ def main():
                        "global_batch": world * B, "seq_len": L, "parallelism": f"dp{world}"},
         }
         out["host_enqueue_ms_per_step"] = round(1000 * host_enqueue / args.steps, 3)
-        out["host_issue_ms_idle_queue"] = round(1000 * host_alone, 3)
+        if host_alone == host_alone:
+            out["host_issue_ms_idle_queue"] = round(1000 * host_alone, 3)
         if last is not None and args.mode == "train":
             out["loss"] = round(float(last["loss"].detach()), 4)
         # ---- roofline of the dominant kernel ----

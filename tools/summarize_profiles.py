@@ -129,10 +129,13 @@ rocprofv3 kernel stats, per step (25 steps traced):
 HIP-event durations measured inside `bench.py` for the library's kernels (ms/step): `{json.dumps(bt["kernel_ms_per_step"])}` -
 they agree with the rocprofv3 averages above to within a few per cent (rocprofv3 serialises a little).
 
-Sampled-softmax kernels, algorithmic TFLOP/s (bench): `{json.dumps(bt.get("nce_kernels_TFLOPs"))}`.  `mhr_nce_fwd` is the fused
-forward (query logits + false-negative logits + token-side gradient product = 6 N_tok N_neg D flop); `mhr_nce_bwd_negs` executes
-2x its algorithmic flops (the logits are recomputed).  The same MFMA at full chip load sustains about 1.8-2.2 PFLOP/s in a bare
-loop (`tools/mfma_rate.hip`: the shader clock drops from 2.39 GHz to about 1.85 GHz), so 2.5 PFLOP/s is not reachable even in principle.
+Sampled softmax (bench `sampled_softmax`): `{json.dumps(bt.get("sampled_softmax"))}`.  With query-row sharing
+(`csrc/nce_shared.hip`) the two streaming MFMA kernels (`nce_fwd_d_kernel`, `nce_bwd_n_kernel`) run once per distinct query row
+instead of once per token; *algorithmic* rates are quoted on the reference's per-token formulation (6 N_tok N_neg D flop forward,
+2 N_tok N_neg D for dN), *executed* rates on what the kernels run (two products per row each way).  The same MFMA at full chip
+load sustains about 1.8-2.2 PFLOP/s in a bare loop (`tools/mfma_rate.hip`: the shader clock drops from 2.39 GHz to about 1.85 GHz).
+The roofline object of the bench line is quoted on whichever library kernel takes most of the step (now `hstu_attn_bwd`):
+`{json.dumps(bt.get("roofline"))}`.
 
 ## Eval step (bench: {be["value"]} users/s, {be["ms_per_step"]} ms/step of 256 users x 4 heads over 453 938 items)
 
