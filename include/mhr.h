@@ -219,6 +219,13 @@ int mhr_token_compact(const uint8_t* mask, const int32_t* q_all, const int32_t* 
 /* tok_of_slot (may be NULL) [n_groups, n_slots] int32: the inverse map - position of a live slot in its group's list,
  * -1 for slots that are not live (or fell beyond tok_cap). */
 
+/* Row maps of compacted token lists (query-row sharing): a row = a run of consecutive live tokens with the same q_idx.
+ * q_idx [n_groups, tok_cap], n_tok_dev [n_groups] -> tok2row [n_groups, tok_cap] (0 beyond n_tok), row_q / row_first
+ * [n_groups, row_cap] (query row and first token of row r; row_first[n_row] = n_tok; rows >= n_row untouched: the caller
+ * zeroes them), n_row [n_groups].  scratch: [n_groups, ceil(tok_cap / 4096)] int32.  row_cap > the largest row count.  Two launches. */
+int mhr_row_maps(const int32_t* q_idx, const int32_t* n_tok_dev, int n_groups, int tok_cap, int row_cap,
+                 int32_t* row_q, int32_t* row_first, int32_t* tok2row, int32_t* n_row, int32_t* scratch, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Sampled softmax with false-negative suppression (model/IDNet/hstu.py:600-619 + F.cross_entropy 697/833).
  * Tokens are described by row indices instead of compacted copies: token t uses query row

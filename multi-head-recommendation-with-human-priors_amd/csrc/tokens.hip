@@ -102,6 +102,104 @@ __global__ __launch_bounds__(256) void token_scatter_kernel(const uint8_t* __res
   }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Row maps of the compacted token lists (query-row sharing, nce_shared.hip): a ROW is a run of consecutive live tokens with
+// the same query row.  Same two-launch structure as the compaction: heads per 4096-token chunk, then prefix + in-workgroup scan.
+//   tok2row[t] = row of token t (0 beyond n_tok), row_q[r] = the run's query row, row_first[r] = its first token,
+//   row_first[n_row] = n_tok, n_row[g] = number of rows.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t head_bits(const int32_t* __restrict__ q, int n_tok, int base) {
+  uint32_t bits = 0;
+  if (base < n_tok) {
+    int prev = base > 0 ? q[base - 1] : -1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      if (base + i < n_tok) {
+        const int cur = q[base + i];
+        bits |= (base + i == 0 || cur != prev) ? (1u << i) : 0u;
+        prev = cur;
+      }
+    }
+  }
+  return bits;
+}
+
+__global__ __launch_bounds__(256) void row_count_kernel(const int32_t* __restrict__ q_idx, const int32_t* __restrict__ n_tok_dev,
+                                                        int tok_cap, int n_chunks, int32_t* __restrict__ chunk_cnt) {
+  const int chunk = blockIdx.x, grp = blockIdx.y;
+  const int n_tok = min(n_tok_dev[grp], tok_cap);
+  int c = __popc(head_bits(q_idx + (int64_t)grp * tok_cap, n_tok, chunk * CHUNK + threadIdx.x * 16));
+  c = wave_sum_i(c);
+  __shared__ int s[4];
+  if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) chunk_cnt[grp * n_chunks + chunk] = s[0] + s[1] + s[2] + s[3];
+}
+
+__global__ __launch_bounds__(256) void row_scatter_kernel(const int32_t* __restrict__ q_idx, const int32_t* __restrict__ n_tok_dev,
+                                                          int tok_cap, int row_cap, int n_chunks,
+                                                          const int32_t* __restrict__ chunk_cnt, int32_t* __restrict__ row_q,
+                                                          int32_t* __restrict__ row_first, int32_t* __restrict__ tok2row,
+                                                          int32_t* __restrict__ n_row) {
+  const int chunk = blockIdx.x, grp = blockIdx.y;
+  const int n_tok = min(n_tok_dev[grp], tok_cap);
+  const int32_t* q = q_idx + (int64_t)grp * tok_cap;
+  const int32_t* cc = chunk_cnt + grp * n_chunks;
+  int32_t* rq = row_q + (int64_t)grp * row_cap;
+  int32_t* rf = row_first + (int64_t)grp * row_cap;
+  int32_t* t2r = tok2row + (int64_t)grp * tok_cap;
+  __shared__ int s_wave[4];
+  __shared__ int s_start;
+  if (threadIdx.x < 64) {
+    int before = 0, total = 0;
+    for (int c = threadIdx.x; c < n_chunks; c += 64) {
+      const int v = cc[c];
+      total += v;
+      before += c < chunk ? v : 0;
+    }
+    before = wave_sum_i(before);
+    total = wave_sum_i(total);
+    if (threadIdx.x == 0) {
+      s_start = before;
+      if (chunk == 0) {
+        n_row[grp] = min(total, row_cap - 1);
+        if (total < row_cap) rf[total] = n_tok;
+      }
+    }
+  }
+  const int base = chunk * CHUNK + threadIdx.x * 16;
+  const uint32_t bits = head_bits(q, n_tok, base);
+  const int mine = __popc(bits);
+  int incl = mine;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int v = __shfl_up(incl, o, 64);
+    if ((threadIdx.x & 63) >= o) incl += v;
+  }
+  if ((threadIdx.x & 63) == 63) s_wave[threadIdx.x >> 6] = incl;
+  __syncthreads();
+  int rid = s_start + incl - mine - 1;                   // row of the token in front of my first one
+  for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) rid += s_wave[w];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int t = base + i;
+    if (t >= tok_cap) break;
+    if (t < n_tok) {
+      if ((bits >> i) & 1u) {
+        ++rid;
+        if (rid < row_cap - 1) {
+          rq[rid] = q[t];
+          rf[rid] = t;
+        }
+      }
+      t2r[t] = min(rid, row_cap - 2);
+    } else {
+      t2r[t] = 0;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int mhr_token_compact(const uint8_t* mask, const int32_t* q_all, const int32_t* p_all, const int32_t* o_all,
@@ -115,5 +213,19 @@ extern "C" int mhr_token_compact(const uint8_t* mask, const int32_t* q_all, cons
   hipLaunchKernelGGL(token_scatter_kernel, dim3(n_chunks, n_groups), dim3(256), 0, s, mask, q_all, p_all, o_all, n_slots,
                      n_chunks, tok_cap, scratch, q_idx, p_idx, o_idx, n_tok, tok_of_slot);
   MHR_CHECK_LAUNCH("token_compact");
+  return MHR_OK;
+}
+
+extern "C" int mhr_row_maps(const int32_t* q_idx, const int32_t* n_tok_dev, int n_groups, int tok_cap, int row_cap,
+                            int32_t* row_q, int32_t* row_first, int32_t* tok2row, int32_t* n_row, int32_t* scratch,
+                            void* stream) {
+  MHR_REQUIRE(q_idx && n_tok_dev && row_q && row_first && tok2row && n_row && scratch, "row_maps: null pointer");
+  MHR_REQUIRE(n_groups >= 1 && n_groups <= 65535 && tok_cap > 0 && row_cap > 1, "row_maps: bad sizes");
+  const int n_chunks = (tok_cap + CHUNK - 1) / CHUNK;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(row_count_kernel, dim3(n_chunks, n_groups), dim3(256), 0, s, q_idx, n_tok_dev, tok_cap, n_chunks, scratch);
+  hipLaunchKernelGGL(row_scatter_kernel, dim3(n_chunks, n_groups), dim3(256), 0, s, q_idx, n_tok_dev, tok_cap, row_cap, n_chunks,
+                     scratch, row_q, row_first, tok2row, n_row);
+  MHR_CHECK_LAUNCH("row_maps");
   return MHR_OK;
 }

@@ -439,28 +439,16 @@ _ZERO_FIX = {}
 
 def _row_maps(q_idx, n_tok_dev, cap, row_cap):
     """Runs of equal query rows in the (offset-fastest) token lists -> (row list [G, row_cap], tok2row [G, cap],
-    row_first [G, row_cap], n_row [G]); all on the device, no host sync.  Column row_cap - 1 is a scratch slot."""
+    row_first [G, row_cap], n_row [G]); all on the device, no host sync (mhr_row_maps: count + scan, like the compaction)."""
     G = q_idx.shape[0]
     dev = q_idx.device
-    ar = torch.arange(cap, dtype=torch.int32, device=dev)
-    live = ar[None] < n_tok_dev[:, None]
-    prev = torch.cat([q_idx.new_full((G, 1), -1), q_idx[:, :-1]], 1)
-    head = live & (q_idx != prev)
-    # inclusive scan of the run heads in two levels (torch's one-pass scan over a 200 k-long innermost dim takes 0.46 ms)
-    blk = 1024
-    pad = (-cap) % blk
-    h = torch.nn.functional.pad(head, (0, pad)).view(G, -1, blk).to(torch.int32)
-    inner = torch.cumsum(h, 2, dtype=torch.int32)
-    outer = torch.cumsum(inner[:, :, -1], 1, dtype=torch.int32)
-    tok2row = (inner + (outer - inner[:, :, -1])[:, :, None]).view(G, -1)[:, :cap] - 1
-    n_row = outer[:, -1].contiguous()
-    dst = torch.where(head, tok2row, torch.full_like(tok2row, row_cap - 1)).long()
     r_q = torch.zeros(G, row_cap, dtype=torch.int32, device=dev)
     r_first = torch.zeros(G, row_cap, dtype=torch.int32, device=dev)
-    r_q.scatter_(1, dst, q_idx)
-    r_first.scatter_(1, dst, ar[None].expand(G, -1))
-    r_first.scatter_(1, n_row[:, None].long(), n_tok_dev[:, None].clamp(max=cap))
-    tok2row = torch.where(live, tok2row, torch.zeros_like(tok2row)).contiguous()
+    tok2row = torch.empty(G, cap, dtype=torch.int32, device=dev)
+    n_row = torch.empty(G, dtype=torch.int32, device=dev)
+    scratch = torch.empty(G, (cap + 4095) // 4096, dtype=torch.int32, device=dev)
+    lib.call("mhr_row_maps", q_idx.data_ptr(), n_tok_dev.data_ptr(), G, cap, row_cap, r_q.data_ptr(), r_first.data_ptr(),
+             tok2row.data_ptr(), n_row.data_ptr(), scratch.data_ptr(), _stream())
     return r_q, tok2row, r_first, n_row
 
 

@@ -14,8 +14,19 @@ cfg["int_to_category"] = data.int_to_category
 torch.manual_seed(2020)
 model = get_model("HSTU")(cfg, data).to(dev)
 tr = Trainer(cfg); tr.setup_model(model); tr.train_step = 3000
-batches = [data.train_batch(128) for _ in range(4)]
-model.train()
+EVAL = len(sys.argv) > 1 and sys.argv[1] == "eval"
+if EVAL:
+    batches = [data.eval_batch(256) for _ in range(4)]
+    tr.compute_item_feature(data.item_tags)
+
+    def step(b):
+        with torch.no_grad():
+            fused, pu, pi, tt, _ = tr._full_sort_batch_eval(b)
+            tr.eval_collector.eval_batch_collect(fused, pu, pi)
+    tr.train_step_fn = step
+else:
+    batches = [data.train_batch(128) for _ in range(4)]
+    model.train()
 for i in range(6):
     tr.train_step_fn(batches[i % 4])
 torch.cuda.synchronize()
