@@ -219,6 +219,16 @@ int mhr_token_compact(const uint8_t* mask, const int32_t* q_all, const int32_t* 
 /* tok_of_slot (may be NULL) [n_groups, n_slots] int32: the inverse map - position of a live slot in its group's list,
  * -1 for slots that are not live (or fell beyond tok_cap). */
 
+/* ------------------------------------------------------------------------------------------
+ * Decoding heads after their one concatenated GEMM (model/llm_heads.py:5-40, stacked and permuted by hstu.py:665-667):
+ *   out[b, h, l, :] = x[b, l, :] + silu(z[b, l, h, :]),  x [n_tok, dim] f32 (n_tok = B seq_len), z [n_tok, n_heads dim] bf16,
+ *   out [B, n_heads, seq_len, dim] f32 - the layout the loss reads.  Backward: dz = d_out silu'(z) (bf16), dx = sum_h d_out (f32).
+ * ---------------------------------------------------------------------------------------- */
+int mhr_heads_residual_fwd(const float* x, const void* z_bf16, float* out, int64_t n_tok, int seq_len, int n_heads,
+                           int dim, void* stream);
+int mhr_heads_residual_bwd(const float* d_out, const void* z_bf16, void* dz_bf16, float* dx, int64_t n_tok,
+                           int seq_len, int n_heads, int dim, void* stream);
+
 /* Row maps of compacted token lists (query-row sharing): a row = a run of consecutive live tokens with the same q_idx.
  * q_idx [n_groups, tok_cap], n_tok_dev [n_groups] -> tok2row [n_groups, tok_cap] (0 beyond n_tok), row_q / row_first
  * [n_groups, row_cap] (query row and first token of row r; row_first[n_row] = n_tok; rows >= n_row untouched: the caller

@@ -118,6 +118,24 @@ class SplitKLinearFn(Function):
         return dx, dw, db, None, None
 
 
+class HeadsResidualFn(Function):
+    """out[b, h, l] = x[b, l] + silu(z[b, l, h]) in the [B, H, L, D] layout the loss reads (reference llm_heads.py:5-40 per
+    head + the stack / permute of hstu.py:665-667); x [B*L, D] fp32, z [B*L, H*D] bf16 (the heads' one concatenated GEMM)."""
+
+    @staticmethod
+    def forward(ctx, x, z, B, L, H):
+        ctx.save_for_backward(z)
+        ctx.cfg = (B, L, H)
+        return ops.heads_residual_fwd(x.contiguous(), z.contiguous(), B, L, H)
+
+    @staticmethod
+    def backward(ctx, d_out):
+        (z,) = ctx.saved_tensors
+        B, L, H = ctx.cfg
+        dz, dx = ops.heads_residual_bwd(d_out.contiguous().float(), z, B, L, H)
+        return dx, dz, None, None, None
+
+
 class FusedParamLinearFn(Function):
     """y = x @ [W0; W1; ...]^T for parameters the fused optimizer laid out back to back (mhr_amd.optim.fused_views): the
     operand is the bf16 shadow view of the flat weight buffer and the weight gradient goes straight into the flat gradient

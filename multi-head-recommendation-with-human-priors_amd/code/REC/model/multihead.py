@@ -163,6 +163,12 @@ class MultiHeadDecoding:
             w = torch.cat([h[0].linear.weight for h in heads], 0)
             b = torch.cat([h[0].linear.bias for h in heads], 0)
             z = SplitKLinearFn.apply(x.reshape(-1, D).to(torch.bfloat16), w, b, True, None)
+            if x.dim() == 3 and x.dtype == torch.float32 and D % 4 == 0:
+                # bias-added GEMM output -> SiLU + residual written straight in the [B, H, L, D] layout of the loss
+                # (csrc/heads.hip); returned as the [B, L, H, D] view every caller expects
+                from REC.model.hstu_functional import HeadsResidualFn
+                Bq, Lq = x.shape[0], x.shape[1]
+                return HeadsResidualFn.apply(x.reshape(-1, D), z, Bq, Lq, H).permute(0, 2, 1, 3)
             return torch.add(x.unsqueeze(-2), F.silu(z.view(*x.shape[:-1], H, D)))
         with torch.autocast(device_type=x.device.type, dtype=torch.bfloat16, enabled=x.is_cuda):
             if self.medusa_num_layers > 0 and self.head_interaction == 'hierarchical':

@@ -131,6 +131,26 @@ def adam_flat(w, g, m, v, step, lr, grad_scale=1.0, betas=(0.9, 0.999), eps=1e-8
              betas[0], betas[1], eps, weight_decay, step, _ptr(w_bf16), _stream())
 
 
+def heads_residual_fwd(x, z, B, L, H):
+    """out [B, H, L, D] f32 = x[b, l] + silu(z[b, l, h]);  x [B*L, D] f32, z [B*L, H*D] bf16."""
+    _chk(x, "x", torch.float32)
+    _chk(z, "z", torch.bfloat16)
+    D = x.shape[-1]
+    out = torch.empty(B, H, L, D, dtype=torch.float32, device=x.device)
+    lib.call("mhr_heads_residual_fwd", x.data_ptr(), z.data_ptr(), out.data_ptr(), B * L, L, H, D, _stream())
+    return out
+
+
+def heads_residual_bwd(d_out, z, B, L, H):
+    """(dz [B*L, H*D] bf16, dx [B*L, D] f32) from d_out [B, H, L, D] f32."""
+    _chk(d_out, "d_out", torch.float32)
+    D = d_out.shape[-1]
+    dz = torch.empty_like(z)
+    dx = torch.empty(B * L, D, dtype=torch.float32, device=z.device)
+    lib.call("mhr_heads_residual_bwd", d_out.data_ptr(), z.data_ptr(), dz.data_ptr(), dx.data_ptr(), B * L, L, H, D, _stream())
+    return dz, dx
+
+
 def sum_rows_into(x, out):
     """out [cols] fp32 += column sums of x [rows, cols] bf16 (contiguous)."""
     _chk(x, "x", torch.bfloat16)

@@ -747,3 +747,22 @@ def test_end_to_end_decode_matches_oracle(ops):
     items_ref, vals_ref, src_ref = DO.merge_dedup(rv, ri, k)
     assert np.array_equal(mi.cpu().numpy(), items_ref)
     assert np.array_equal(ms.cpu().numpy(), src_ref)
+
+
+@pytest.mark.parametrize("B,L,H,D", [(3, 7, 4, 64), (2, 200, 4, 256), (5, 1, 16, 128)])
+def test_heads_residual_fwd_bwd(ops, B, L, H, D):
+    """out[b, h, l] = x[b, l] + silu(z[b, l, h]) in the [B, H, L, D] layout (llm_heads.py:5-40 + hstu.py:665-667) and its backward
+    vs torch on the same bf16 z: forward to fp32 rounding, dz within one bf16 rounding, dx exact up to summation order."""
+    g = torch.Generator().manual_seed(B * 100 + L)
+    x = torch.randn(B * L, D, generator=g)
+    z = bf(torch.randn(B * L, H * D, generator=g) * 2)
+    out = ops.heads_residual_fwd(dev(x), dev(z), B, L, H)
+    zr = z.float().requires_grad_(True)
+    xr = x.clone().requires_grad_(True)
+    ref = (xr.view(B, L, 1, D) + torch.nn.functional.silu(zr.view(B, L, H, D))).permute(0, 2, 1, 3)
+    assert rel_err(out.cpu(), ref.detach()) < 1e-6
+    d_out = torch.randn(B, H, L, D, generator=g)
+    dz, dx = ops.heads_residual_bwd(dev(d_out), dev(z), B, L, H)
+    ref.backward(d_out)
+    assert float((dz.float().cpu() - zr.grad).abs().max()) <= 2 ** -7 * float(zr.grad.abs().max())
+    assert rel_err(dx.cpu(), xr.grad) < 1e-6
