@@ -126,6 +126,8 @@ int mhr_ln_gate_bwd(const void* d_o, int do_dtype, const void* u_base, int64_t u
 
 /* y[r,:] = x[r,:] / ||x[r,:]||_2  (hstu.py:605-606, 672, 966, 975, 1021); optional norms out ([rows] f32). */
 int mhr_l2norm_rows(const void* x, int x_dtype, void* y, int y_dtype, float* norms, int64_t rows, int dim, void* stream);
+/* backward of y = x / |x| (autograd of hstu.py:672, 754): dx = (dy - n (n . dy)) / |x| with n = x / |x|; all f32, norms from the forward */
+int mhr_l2norm_rows_bwd(const float* dy, const float* x, const float* norms, float* dx, int64_t rows, int dim, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * HSTU pointwise-gated attention (model/IDNet/hstu.py:137-160), fused, never materialises [L,L].

@@ -80,13 +80,14 @@ class ComiRec(HSTU):
         n_item_ids = B * (L + P)
         ids_all = torch.cat([items.reshape(-1), pool_ids]).contiguous()
         fused_pos = isinstance(self.item_id_proj_tower, nn.Identity)
-        rows_all, x = EmbeddingGatherFn.apply(self.item_embedding.weight, self.position_embedding.weight if fused_pos else None,
+        rows_items, rows_negs, x = EmbeddingGatherFn.apply(self.item_embedding.weight, self.position_embedding.weight if fused_pos else None,
                                               ids_all, n_item_ids, L, L + P, self)
         if not fused_pos:
-            rows_all = self.item_id_proj_tower(rows_all)
-            x = rows_all[:n_item_ids].view(B, L + P, D)[:, :L] + self.position_embedding.weight[:L][None]
-        e_rows = rows_all[:n_item_ids]
-        negs = L2NormFn.apply(rows_all[n_item_ids:].contiguous()).view(1, -1, D)
+            rows_all = self.item_id_proj_tower(torch.cat([rows_items, rows_negs]))
+            rows_items, rows_negs = rows_all[:n_item_ids], rows_all[n_item_ids:]
+            x = rows_items.view(B, L + P, D)[:, :L] + self.position_embedding.weight[:L][None]
+        e_rows = rows_items
+        negs = L2NormFn.apply(rows_negs.contiguous()).view(1, -1, D)
         out = self._encode(x, mask[:, :L].to(torch.uint8).contiguous())                        # [B,L,D] fp32
         interests = self._causal_interests(out, mask[:, :L])                                   # [B,L,K,D]
         # hard read-out (comirec.py:265-288): the interest with the largest dot product with the target of (l, p)

@@ -203,16 +203,17 @@ class HSTU(MultiHeadDecoding, BaseModel):
         n_item_ids = B * (L + P)
         ids_all = torch.cat([items.reshape(-1)] + pool_ids).contiguous()
         fused_pos = isinstance(self.item_id_proj_tower, nn.Identity)
-        rows_all, x = EmbeddingGatherFn.apply(self.item_embedding.weight,
+        rows_items, rows_negs, x = EmbeddingGatherFn.apply(self.item_embedding.weight,
                                               self.position_embedding.weight if fused_pos else None, ids_all,
                                               n_item_ids, L, L + P, self)
         if not fused_pos:
-            rows_all = self.item_id_proj_tower(rows_all)
-            x = rows_all[:n_item_ids].view(B, L + P, D)[:, :L] + self.position_embedding.weight[:L][None]
-        e_rows = rows_all[:n_item_ids]                                   # targets, [B*(L+P), D] fp32
+            rows_all = self.item_id_proj_tower(torch.cat([rows_items, rows_negs]))
+            rows_items, rows_negs = rows_all[:n_item_ids], rows_all[n_item_ids:]
+            x = rows_items.view(B, L + P, D)[:, :L] + self.position_embedding.weight[:L][None]
+        e_rows = rows_items                                   # targets, [B*(L+P), D] fp32
         # data parallel: the negatives' gradient rows leave for their all-reduce from inside this backward (fused_pos:
         # they are rows of the table itself), underneath the encoder backward
-        negs_pools = L2NormFn.apply(rows_all[n_item_ids:].contiguous(), self if fused_pos else None).view(len(pools), n_pool, D)
+        negs_pools = L2NormFn.apply(rows_negs.contiguous(), self if fused_pos else None).view(len(pools), n_pool, D)
 
         key_valid = mask[:, :L].to(torch.uint8).contiguous()
         out = self._encode(x, key_valid)                                 # [B,L,D] fp32

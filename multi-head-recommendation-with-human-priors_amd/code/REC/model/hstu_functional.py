@@ -234,14 +234,19 @@ class EmbeddingGatherFn(Function):
             x = torch.zeros(1, device=table.device)
         ctx.save_for_backward(ids_all)
         ctx.meta = (n_item_ids, L, window, holder, table.shape[0], D)
-        return rows, x
+        # two outputs over ONE buffer (item windows | negative pools): their gradients arrive as two tensors, so the backward
+        # has no slice-backward zero fills and no accumulate pass over the [rows, D] gradient
+        return rows[:n_item_ids], rows[n_item_ids:], x
 
     @staticmethod
-    def backward(ctx, d_rows, d_x):
+    def backward(ctx, d_items, d_negs, d_x):
         (ids_all,) = ctx.saved_tensors
         n_item_ids, L, window, holder, n_rows, D = ctx.meta
         dev = ids_all.device
-        d_rows = d_rows.contiguous() if d_rows is not None else torch.zeros(ids_all.numel(), D, device=dev)
+        n_neg_ids = ids_all.numel() - n_item_ids
+        d_items = d_items.contiguous() if d_items is not None else torch.zeros(n_item_ids, D, device=dev)
+        if n_neg_ids:
+            d_negs = d_negs.contiguous() if d_negs is not None else torch.zeros(n_neg_ids, D, device=dev)
         d_x = d_x.contiguous() if (d_x is not None and d_x.dim() == 3) else None
         d_pos = None
         if d_x is not None:
@@ -249,7 +254,9 @@ class EmbeddingGatherFn(Function):
             d_pos[:L] = d_x.sum(dim=0)
         if getattr(holder, "dense_embedding_grad", False):
             gt = torch.zeros(n_rows, D, dtype=torch.float32, device=dev)
-            ops.embedding_scatter_add(d_rows, ids_all, gt)
+            ops.embedding_scatter_add(d_items, ids_all[:n_item_ids].contiguous(), gt)
+            if n_neg_ids:
+                ops.embedding_scatter_add(d_negs, ids_all[n_item_ids:].contiguous(), gt)
             if d_x is not None:
                 ops.embedding_scatter_add(d_x.view(-1, D), ids_all[:n_item_ids].view(-1, window)[:, :L].contiguous().view(-1), gt)
             return gt, d_pos, None, None, None, None, None
@@ -260,6 +267,7 @@ class EmbeddingGatherFn(Function):
             # data parallel / gradient accumulation: fold the input-side gradient into the rows and defer the reduction
             # until the optimizer asks for it (HSTU.finish_sparse_grad: cross-rank exchange, then ONE segment-sum over the
             # rows of every micro-batch since the last step)
+            d_rows = torch.cat([d_items, d_negs]) if n_neg_ids else d_items
             if d_x is not None:
                 d_rows[:n_item_ids].view(-1, window, D)[:, :L] += d_x
             shared, holder._shared_pending = getattr(holder, "_shared_pending", None), None
@@ -270,8 +278,7 @@ class EmbeddingGatherFn(Function):
             return None, d_pos, None, None, None, None, None
         sorted_ids, perm = torch.sort(ids_all)
         out_rows = torch.zeros(ids_all.numel(), D, dtype=torch.float32, device=dev)
-        ga, gb = d_rows[:n_item_ids], (d_rows[n_item_ids:] if ids_all.numel() > n_item_ids else None)
-        ops.sparse_rows_segment_sum(sorted_ids, perm, ga, gb, d_x, L, window, out_rows, holder._row_slot)
+        ops.sparse_rows_segment_sum(sorted_ids, perm, d_items, d_negs if n_neg_ids else None, d_x, L, window, out_rows, holder._row_slot)
         holder.sparse_grad = SparseRowGrad(sorted_ids, out_rows, holder._row_slot, n_rows)
         return None, d_pos, None, None, None, None, None
 
@@ -334,9 +341,12 @@ class L2NormFn(Function):
     @staticmethod
     def backward(ctx, dy):
         x, norms = ctx.saved_tensors
-        n = x / norms[:, None]
-        dy = dy.float()
-        g = (dy - n * (n * dy).sum(-1, keepdim=True)) / norms[:, None]
+        if x.dtype == torch.float32 and x.is_contiguous():
+            g = ops.l2norm_rows_bwd(dy.reshape(x.shape).float().contiguous(), x, norms)
+        else:
+            n = x / norms[:, None]
+            dy = dy.float()
+            g = (dy - n * (n * dy).sum(-1, keepdim=True)) / norms[:, None]
         from mhr_amd import distributed as dist_
         if ctx.holder is not None and dist_.world_size() > 1 and dist_.OVERLAP:
             ctx.holder._shared_pending = (g, dist_.allreduce_sum_begin(g))

@@ -449,6 +449,47 @@ __global__ __launch_bounds__(256) void l2norm_kernel(const XT* __restrict__ x, Y
   }
 }
 
+// backward of y = x / |x|:  dx = (dy - n (n . dy)) / |x|,  n = x / |x|  (fp32; one wave per row)
+template <int NC>
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                         const float* __restrict__ norms, float* __restrict__ dx, int64_t rows,
+                                                         int dim) {
+  WAVE_ROW_LOOP(rows) {
+    RowRegs<NC> rx, rg;
+    load_row<float, NC>(x + row * dim, dim, lane, rx);
+    load_row<float, NC>(dy + row * dim, dim, lane, rg);
+    const float inv = 1.0f / norms[row];
+    float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; ++i)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        rx.v[i][k] *= inv;
+        dot += rx.v[i][k] * rg.v[i][k];
+      }
+    dot = wave_sum(dot);
+#pragma unroll
+    for (int i = 0; i < NC; ++i)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) rg.v[i][k] = (rg.v[i][k] - rx.v[i][k] * dot) * inv;
+    store_row<float, NC>(dx + row * dim, dim, lane, rg);
+  }
+}
+
+extern "C" int mhr_l2norm_rows_bwd(const float* dy, const float* x, const float* norms, float* dx, int64_t rows, int dim,
+                                   void* stream) {
+  MHR_REQUIRE(dy && x && norms && dx, "l2norm_rows_bwd: null pointer");
+  MHR_REQUIRE(dim > 0 && dim % 4 == 0 && dim <= 2048, "l2norm_rows_bwd: dim=%d unsupported", dim);
+  if (rows == 0) return MHR_OK;
+  hipStream_t s = (hipStream_t)stream;
+  int grid = mhr_grid_for(rows, 4);
+#define LB(NC) hipLaunchKernelGGL((l2norm_bwd_kernel<NC>), dim3(grid), dim3(256), 0, s, dy, x, norms, dx, rows, dim)
+  DISPATCH_NC(dim, LB);
+#undef LB
+  MHR_CHECK_LAUNCH("l2norm_rows_bwd");
+  return MHR_OK;
+}
+
 extern "C" int mhr_l2norm_rows(const void* x, int x_dtype, void* y, int y_dtype, float* norms, int64_t rows, int dim,
                                void* stream) {
   MHR_REQUIRE(x && (y || norms), "l2norm_rows: null pointer");

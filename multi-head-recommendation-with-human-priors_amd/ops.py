@@ -246,6 +246,16 @@ def l2norm_rows(x, out_dtype=torch.bfloat16, want_norms=False):
     return (y, norms) if want_norms else y
 
 
+def l2norm_rows_bwd(dy, x, norms):
+    """dx of y = x / |x| (fp32 rows)."""
+    _chk(dy, "dy", torch.float32)
+    _chk(x, "x", torch.float32)
+    D = x.shape[-1]
+    dx = torch.empty_like(x)
+    lib.call("mhr_l2norm_rows_bwd", dy.data_ptr(), x.data_ptr(), norms.data_ptr(), dx.data_ptr(), x.numel() // D, D, _stream())
+    return dx
+
+
 # ------------------------------------------------------------------------------------------------
 # attention
 # ------------------------------------------------------------------------------------------------
