@@ -88,6 +88,18 @@ int mhr_adam_rows(float* w, float* m, float* v, int64_t n_rows, int dim,
  * per-step cast kernels (the reference's autocast re-casts every weight every step). */
 int mhr_adam_flat(float* w, const float* g, float* m, float* v, int64_t n, float grad_scale,
                   float lr, float beta1, float beta2, float eps, float weight_decay, int step, void* w_bf16, void* stream);
+/* Lazy form of mhr_adam_rows (same arithmetic, bitwise the same weights once a row is up to date): rows are replayed through
+ * the gradient-free steps they missed when they are next needed.  last_step [n_rows] int32 (zeros at start): last step applied
+ * to a row; hist [hist_len, 4] f32: the constants of step s at row s % hist_len as filled by mhr_adam_consts (a host helper,
+ * no launch); the caller flushes (mode 2) at least every hist_len steps.  mode 0: bring the rows of `ids` (duplicates allowed) up
+ * to step - 1 (before the forward reads them); mode 1: ids = the sorted ids of a SparseRowGrad, grad_rows its rows: every
+ * segment head is replayed to step - 1 and gets step `step` with its gradient (row_slot of the row is reset to -1); mode 2: all
+ * rows through `step`. */
+int mhr_adam_consts(float lr, float beta1, float beta2, float eps, float weight_decay, int step, float* out4);
+int mhr_adam_rows_lazy(float* w, float* m, float* v, int64_t n_rows, int dim, const int64_t* ids, int64_t n_ids,
+                       const float* grad_rows, int32_t* row_slot, int32_t* last_step, const float* hist,
+                       int hist_len, int step, float grad_scale, float beta1, float beta2, float eps, int mode,
+                       void* stream);
 
 /* out[c] += sum_r x[r, c]: x bf16 [rows, cols] (cols % 8 == 0), out fp32 [cols].  The reduction of split-K weight-gradient
  * partials and of bias gradients straight into the flat gradient buffer (autograd's accumulate semantics: the caller

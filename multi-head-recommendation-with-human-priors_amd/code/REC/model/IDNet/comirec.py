@@ -79,6 +79,7 @@ class ComiRec(HSTU):
         pool_ids = all_gather_ids(neg_items[:, -1].contiguous()).reshape(-1)                   # comirec.py:222-224
         n_item_ids = B * (L + P)
         ids_all = torch.cat([items.reshape(-1), pool_ids]).contiguous()
+        self._table_catch_up(ids_all)
         fused_pos = isinstance(self.item_id_proj_tower, nn.Identity)
         rows_items, rows_negs, x = EmbeddingGatherFn.apply(self.item_embedding.weight, self.position_embedding.weight if fused_pos else None,
                                               ids_all, n_item_ids, L, L + P, self)

@@ -146,7 +146,25 @@ class HSTU(MultiHeadDecoding, BaseModel):
                                          layer._o.bias.to(torch.bfloat16))
         return hit
 
+    def _table_catch_up(self, ids):
+        opt = getattr(self, "_table_optimizer", None)
+        if opt is not None:
+            opt.catch_up(ids)
+
+    def sync_table(self):
+        """With the lazy table optimizer (mhr_amd.optim.FusedAdamW(lazy_table=True)) rows lag behind until they are read by a
+        training forward; this brings the whole table up to date.  Called on eval(), state_dict() and by the Trainer."""
+        opt = getattr(self, "_table_optimizer", None)
+        if opt is not None:
+            opt.flush_table()
+
+    def state_dict(self, *args, **kwargs):
+        self.sync_table()
+        return super().state_dict(*args, **kwargs)
+
     def train(self, mode=True):
+        if not mode:
+            self.sync_table()
         self._bf16_cache = {}
         self._item_cache = None            # keyed on the feature tensor's address: a new table may reuse a freed one's
         return super().train(mode)
@@ -154,7 +172,11 @@ class HSTU(MultiHeadDecoding, BaseModel):
     def load_state_dict(self, *args, **kwargs):
         self._bf16_cache = {}
         self._item_cache = None
-        return super().load_state_dict(*args, **kwargs)
+        out = super().load_state_dict(*args, **kwargs)
+        opt = getattr(self, "_table_optimizer", None)
+        if opt is not None:                              # loaded rows are current: nothing to replay
+            opt.last_step.fill_(opt.step_count)
+        return out
 
     def _encode(self, x, key_valid, training=None):
         """x [B,L,D] fp32, key_valid [B,L] uint8 -> [B,L,D] fp32 (reference hstu.py:221-328)."""
@@ -202,6 +224,7 @@ class HSTU(MultiHeadDecoding, BaseModel):
         n_pool = pool_ids[0].numel()
         n_item_ids = B * (L + P)
         ids_all = torch.cat([items.reshape(-1)] + pool_ids).contiguous()
+        self._table_catch_up(ids_all)                      # lazy table optimizer: the rows this step reads, up to date first
         fused_pos = isinstance(self.item_id_proj_tower, nn.Identity)
         rows_items, rows_negs, x = EmbeddingGatherFn.apply(self.item_embedding.weight,
                                               self.position_embedding.weight if fused_pos else None, ids_all,

@@ -56,7 +56,11 @@ class Trainer(object):
     def setup_model(self, model):
         from mhr_amd.optim import FusedAdamW
         self.model = model
-        self.optimizer = FusedAdamW(model, lr=self.optim_args['learning_rate'], weight_decay=self.optim_args['weight_decay'])
+        # lazy table update: only the rows a step touches are written, the gradient-free steps of the others are replayed
+        # when they are next read (bitwise the dense result; `lazy_table_adam: False` restores the dense pass per step)
+        lazy = self.config.get('lazy_table_adam', True) and not getattr(model, "dense_embedding_grad", False)
+        self.optimizer = FusedAdamW(model, lr=self.optim_args['learning_rate'], weight_decay=self.optim_args['weight_decay'],
+                                    lazy_table=bool(lazy))
         self._micro_step = 0
         if self.accumulate_grad > 1:                # the item-table gradient rows of all micro-batches are reduced at the step
             model.accumulate_rows = True

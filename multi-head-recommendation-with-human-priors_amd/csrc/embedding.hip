@@ -233,15 +233,18 @@ static AdamConst make_adam(float lr, float beta1, float beta2, float eps, float 
   return a;
 }
 
+// Every operation is spelled with a rounding-explicit intrinsic: under -ffp-contract=fast the compiler may fuse
+// (w * decay) - step * q either way round, and it chose differently in different kernels - the lazy replay
+// (adam_rows_lazy_kernel) must reproduce the dense kernel's bits, so the order is fixed here once for all of them.
 __device__ __forceinline__ void adam_update4(f32x4& w, f32x4& m, f32x4& v, f32x4 g, const AdamConst& a) {
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    float gk = g[k] * a.grad_scale;
-    float wk = w[k] * a.decay_mul;
-    float mk = a.beta1 * m[k] + a.one_m_beta1 * gk;
-    float vk = a.beta2 * v[k] + a.one_m_beta2 * gk * gk;
-    float denom = sqrtf(vk) * a.inv_sqrt_bc2 + a.eps;
-    w[k] = wk - a.step_size * (mk / denom);
+    const float gk = __fmul_rn(g[k], a.grad_scale);
+    const float wk = __fmul_rn(w[k], a.decay_mul);
+    const float mk = __fmaf_rn(a.beta1, m[k], __fmul_rn(a.one_m_beta1, gk));
+    const float vk = __fmaf_rn(a.beta2, v[k], __fmul_rn(__fmul_rn(a.one_m_beta2, gk), gk));
+    const float denom = __fmaf_rn(__fsqrt_rn(vk), a.inv_sqrt_bc2, a.eps);
+    w[k] = __fmaf_rn(-a.step_size, __fdiv_rn(mk, denom), wk);
     m[k] = mk;
     v[k] = vk;
   }
@@ -281,6 +284,104 @@ extern "C" int mhr_adam_rows(float* w, float* m, float* v, int64_t n_rows, int d
   hipLaunchKernelGGL(adam_rows_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, m, v, n_rows, dim, grad_rows,
                      row_slot, a);
   MHR_CHECK_LAUNCH("adam_rows");
+  return MHR_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Lazy form of the dense table update.  The reference updates EVERY row every step (dense gradient, trainer.py:292-299): a
+// row without gradient still decays its moments and moves by its momentum.  That update needs no gradient, so it can be
+// replayed later: last_step[row] remembers the last step applied to a row and `hist` keeps the per-step constants of the last
+// `hist_len` steps.  A row is brought up to date (same adam_update4, same constants, same order: bitwise the dense result)
+//   * before the forward reads it  (mode 0: the ids of the batch, up to step - 1),
+//   * when its gradient is applied (mode 1: the touched rows = segment heads of the sorted ids, through step),
+//   * when everything is flushed   (mode 2: all rows through step; evaluation, checkpoints, every hist_len steps).
+// Per step this touches the ~60 k rows of the batch instead of all 454 k (2.8 GB of HBM traffic at cfg1).
+// ------------------------------------------------------------------------------------------
+struct AdamLazy {
+  float beta1, beta2, one_m_beta1, one_m_beta2, eps, grad_scale;
+  int hist_len, step, mode;
+};
+
+__device__ __forceinline__ AdamConst lazy_consts(const AdamLazy& a, const float* __restrict__ hist, int s, float grad_scale) {
+  const float* h = hist + (int64_t)(s % a.hist_len) * 4;
+  AdamConst c;
+  c.beta1 = a.beta1; c.beta2 = a.beta2; c.one_m_beta1 = a.one_m_beta1; c.one_m_beta2 = a.one_m_beta2; c.eps = a.eps;
+  c.decay_mul = h[0]; c.step_size = h[1]; c.inv_sqrt_bc2 = h[2]; c.grad_scale = grad_scale;
+  return c;
+}
+
+__global__ __launch_bounds__(256) void adam_rows_lazy_kernel(float* __restrict__ w, float* __restrict__ m, float* __restrict__ v,
+                                                             int64_t n_rows, int dim, const int64_t* __restrict__ ids,
+                                                             int64_t n_ids, const float* __restrict__ grad_rows,
+                                                             int32_t* __restrict__ row_slot, int32_t* __restrict__ last_step,
+                                                             const float* __restrict__ hist, AdamLazy a) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  const int64_t n_work = a.mode == 2 ? n_rows : n_ids;
+  for (int64_t i = wave; i < n_work; i += n_waves) {
+    int64_t row = i;
+    if (a.mode != 2) {
+      row = ids[i];
+      if (row < 0 || row >= n_rows) continue;
+      if (a.mode == 1 && i > 0 && ids[i - 1] == row) continue;          // not the head of its segment
+    }
+    const int target = a.mode == 0 ? a.step - 1 : a.step;               // last step this visit leaves applied
+    int last = last_step[row];
+    if (last >= target) continue;
+    if (a.mode == 0) {                                                  // duplicates in the id list: one wave claims the row
+      int won = 0;
+      if (lane == 0) won = atomicCAS(last_step + row, last, target) == last ? 1 : 0;
+      won = __builtin_amdgcn_readfirstlane(won);
+      if (!won) continue;
+    }
+    for (int c = lane * 4; c < dim; c += 256) {
+      const int64_t o = row * dim + c;
+      f32x4 wv = *reinterpret_cast<const f32x4*>(w + o);
+      f32x4 mv = *reinterpret_cast<const f32x4*>(m + o);
+      f32x4 vv = *reinterpret_cast<const f32x4*>(v + o);
+      const int replay_to = a.mode == 1 ? a.step - 1 : target;          // steps without gradient
+      for (int s = last + 1; s <= replay_to; ++s) {
+        const AdamConst cs = lazy_consts(a, hist, s, 1.0f);
+        adam_update4(wv, mv, vv, f32x4{0.f, 0.f, 0.f, 0.f}, cs);
+      }
+      if (a.mode == 1) {
+        const f32x4 g = *reinterpret_cast<const f32x4*>(grad_rows + i * dim + c);   // the segment head holds the summed row
+        const AdamConst cs = lazy_consts(a, hist, a.step, a.grad_scale);
+        adam_update4(wv, mv, vv, g, cs);
+      }
+      *reinterpret_cast<f32x4*>(w + o) = wv;
+      *reinterpret_cast<f32x4*>(m + o) = mv;
+      *reinterpret_cast<f32x4*>(v + o) = vv;
+    }
+    if (a.mode != 0 && lane == 0) last_step[row] = target;
+    if (a.mode == 1 && row_slot && lane == 0) row_slot[row] = -1;
+  }
+}
+
+extern "C" int mhr_adam_consts(float lr, float beta1, float beta2, float eps, float weight_decay, int step, float* out4) {
+  MHR_REQUIRE(out4 && step >= 1, "adam_consts: bad arguments");
+  const AdamConst a = make_adam(lr, beta1, beta2, eps, weight_decay, step, 1.0f);     // host only: the constants of one step
+  out4[0] = a.decay_mul; out4[1] = a.step_size; out4[2] = a.inv_sqrt_bc2; out4[3] = lr;
+  return MHR_OK;
+}
+
+extern "C" int mhr_adam_rows_lazy(float* w, float* m, float* v, int64_t n_rows, int dim, const int64_t* ids, int64_t n_ids,
+                                  const float* grad_rows, int32_t* row_slot, int32_t* last_step, const float* hist,
+                                  int hist_len, int step, float grad_scale, float beta1, float beta2, float eps, int mode,
+                                  void* stream) {
+  MHR_REQUIRE(w && m && v && last_step && hist, "adam_rows_lazy: null pointer");
+  MHR_REQUIRE(mode >= 0 && mode <= 2 && (mode == 2 || ids) && (mode != 1 || grad_rows), "adam_rows_lazy: bad mode / inputs");
+  MHR_REQUIRE(dim > 0 && dim % 4 == 0 && n_rows > 0 && hist_len > 0 && step >= 0, "adam_rows_lazy: bad sizes");
+  const int64_t n_work = mode == 2 ? n_rows : n_ids;
+  if (n_work <= 0) return MHR_OK;
+  AdamLazy a;
+  a.beta1 = beta1; a.beta2 = beta2; a.one_m_beta1 = 1.0f - beta1; a.one_m_beta2 = 1.0f - beta2; a.eps = eps;
+  a.grad_scale = grad_scale; a.hist_len = hist_len; a.step = step; a.mode = mode;
+  int grid = mhr_grid_for(n_work, 4 * 4);
+  hipLaunchKernelGGL(adam_rows_lazy_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, m, v, n_rows, dim, ids, n_ids,
+                     grad_rows, row_slot, last_step, hist, a);
+  MHR_CHECK_LAUNCH("adam_rows_lazy");
   return MHR_OK;
 }
 

@@ -32,8 +32,15 @@ def fused_views(params):
     return (torch.as_strided(params[0]._mhr_bf16, (rows, k), (k, 1)), torch.as_strided(params[0].grad, (rows, k), (k, 1)))
 
 
+LAZY_HIST = 64        # steps a table row may lag behind before everything is flushed (= length of the constants' history)
+
+
 class FusedAdamW:
-    def __init__(self, model, lr=1e-3, weight_decay=0.0, betas=(0.9, 0.999), eps=1e-8):
+    def __init__(self, model, lr=1e-3, weight_decay=0.0, betas=(0.9, 0.999), eps=1e-8, lazy_table=False):
+        """lazy_table: update only the rows a step touches and replay the gradient-free steps of a row when it is next read
+        (`catch_up`, called by the model's training forward) or flushed (`flush_table`: evaluation, checkpoints, state_dict,
+        every LAZY_HIST steps).  Bitwise the same weights as the dense update; the model must read the table through those
+        hooks (HSTU does) - leave it off for code that reads `item_embedding.weight` directly while training."""
         self.model = model
         self.lr, self.weight_decay, self.betas, self.eps = lr, weight_decay, betas, eps
         self.step_count = 0
@@ -70,6 +77,12 @@ class FusedAdamW:
             p._mhr_direct_grad = os.environ.get("MHR_OPT_DIRECT", "1") != "0"   # backward kernels may write p.grad in place
             off += sz
         self.param_groups = [{"lr": lr}]                                 # scheduler-facing view
+        self.lazy = bool(lazy_table) and self.table is not None and os.environ.get("MHR_LAZY_ADAM", "1") != "0"
+        if self.lazy:
+            self.last_step = torch.zeros(self.table.shape[0], dtype=torch.int32, device=dev)
+            self.hist = torch.zeros(LAZY_HIST, 4, dtype=torch.float32, device=dev)
+            self._hist_host = torch.zeros(LAZY_HIST, 4, dtype=torch.float32).pin_memory()
+            model._table_optimizer = self                                # the model's forward / eval hooks find us here
 
     def zero_grad(self):
         global GRAD_EPOCH
@@ -98,7 +111,12 @@ class FusedAdamW:
         if self.table is None:
             return
         sg = self.model.finish_sparse_grad() if hasattr(self.model, "finish_sparse_grad") else self.model.sparse_grad
-        if sg is not None:
+        if sg is not None and self.lazy:
+            self._push_consts(self.step_count, lr)
+            self._lazy_call(1, sg.sorted_ids, sg.rows, sg.row_slot, 1.0 / W)
+            if self.step_count % LAZY_HIST == 0:                         # nobody lags further than the history reaches
+                self.flush_table()
+        elif sg is not None:
             ops.adam_rows(self.table, self.t_m, self.t_v, sg.rows, sg.row_slot, self.step_count, lr, 1.0 / W, self.betas,
                           self.eps, self.weight_decay)
         elif self.table.grad is not None:                                # dense_embedding_grad mode
@@ -107,7 +125,34 @@ class FusedAdamW:
             ops.adam_rows(self.table, self.t_m, self.t_v, g, None, self.step_count, lr, 1.0, self.betas, self.eps,
                           self.weight_decay)
 
+    # ---- lazy table update -------------------------------------------------------------------
+    def _push_consts(self, step, lr):
+        """The step's Adam constants into the device-side history (pinned staging row, asynchronous copy: no host stall)."""
+        from . import lib
+        row = step % LAZY_HIST
+        lib.call("mhr_adam_consts", float(lr), self.betas[0], self.betas[1], self.eps, self.weight_decay, int(step),
+                 self._hist_host[row].data_ptr())
+        self.hist[row].copy_(self._hist_host[row], non_blocking=True)
+
+    def _lazy_call(self, mode, ids, grad_rows, row_slot, grad_scale, step=None):
+        t = self.table
+        ops._timed_call("mhr_adam_rows_lazy", t.data_ptr(), self.t_m.data_ptr(), self.t_v.data_ptr(), t.shape[0], t.shape[1],
+                 ops._ptr(ids), 0 if ids is None else ids.numel(), ops._ptr(grad_rows), ops._ptr(row_slot),
+                 self.last_step.data_ptr(), self.hist.data_ptr(), LAZY_HIST, self.step_count if step is None else step,
+                 float(grad_scale), self.betas[0], self.betas[1], self.eps, mode, ops._stream())
+
+    def catch_up(self, ids):
+        """Bring the rows of `ids` (int64, duplicates allowed) up to the last optimizer step before they are read."""
+        if self.lazy and self.step_count > 0:
+            self._lazy_call(0, ids.contiguous(), None, None, 1.0, step=self.step_count + 1)
+
+    def flush_table(self):
+        """Every row up to the last optimizer step (no-op when nothing lags)."""
+        if self.lazy and self.step_count > 0:
+            self._lazy_call(2, None, None, None, 1.0)
+
     def state_dict(self):
+        self.flush_table()
         sd = {"step": self.step_count, "flat_m": self.flat_m, "flat_v": self.flat_v}
         if self.table is not None:
             sd.update(t_m=self.t_m, t_v=self.t_v)
@@ -117,3 +162,5 @@ class FusedAdamW:
         self.step_count = int(sd["step"])
         for k in ("flat_m", "flat_v") + (("t_m", "t_v") if self.table is not None else ()):
             getattr(self, k).copy_(sd[k])
+        if self.lazy:                                    # a checkpoint is a flushed state: every row stands at `step`
+            self.last_step.fill_(self.step_count)

@@ -3,6 +3,7 @@ fixtures generated from the reference (fp32 CPU).  Tolerances are bf16-mixed tra
 loss within 2e-2 relative, gradients within 6e-2 of their max-abs; eval scores within 2e-2 absolute on cosines,
 ranking metrics of the fused decode equal to the oracle decode of the same scores."""
 import json
+import math
 import os
 import sys
 
@@ -517,6 +518,7 @@ opt.zero_grad()
 sg.row_slot.fill_(-1)
 for _ in range(3):
     tr.train_step_fn(data.train_batch(8))
+model.sync_table()                       # lazy table optimizer: rows lag until read; compare the flushed tables
 torch.cuda.synchronize()
 np.savez(os.path.join(out_dir, f"after{rank}.npz"), table=model.item_embedding.weight.detach().cpu().numpy(),
          flat=opt.flat_w.cpu().numpy())
@@ -636,3 +638,60 @@ def test_gradient_accumulation_matches_separate_micro_batches(rec):
     assert float((seen["flat"] - flat).abs().max()) <= 1e-3 * float(flat.abs().max())
     assert float((seen["table"] - table).abs().max()) <= 1e-3 * float(table.abs().max())
     assert int((seen["table"].abs().sum(1) > 0).sum()) == int((table.abs().sum(1) > 0).sum())
+
+
+def test_lazy_table_adam_is_bitwise_the_dense_update(rec):
+    """Lazy table optimizer (rows replayed through their gradient-free steps when next read) against the dense per-step
+    update of the whole table, fed the SAME sparse gradients: 150 steps under a varying learning rate with weight decay
+    (crosses two 64-step flushes).  Rows read after `catch_up` equal the dense rows bit for bit at every step; after a flush
+    the table and both moments are bitwise identical."""
+    from mhr_amd import ops
+    from mhr_amd.optim import FusedAdamW, LAZY_HIST
+    from REC.model.hstu_functional import SparseRowGrad
+    dev = torch.device("cuda", 0)
+    N, D = 3000, 64
+
+    class Tiny(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.item_embedding = torch.nn.Embedding(N, D)
+            self.other = torch.nn.Parameter(torch.zeros(8))
+            self.sparse_grad = None
+
+    torch.manual_seed(4)
+    m_lazy, m_dense = Tiny().to(dev), Tiny().to(dev)
+    m_dense.load_state_dict(m_lazy.state_dict())
+    o_lazy = FusedAdamW(m_lazy, lr=1e-3, weight_decay=0.01, lazy_table=True)
+    o_dense = FusedAdamW(m_dense, lr=1e-3, weight_decay=0.01, lazy_table=False)
+    assert o_lazy.lazy and not o_dense.lazy
+    g = torch.Generator(device="cuda").manual_seed(8)
+    slot_l = torch.full((N,), -1, dtype=torch.int32, device=dev)
+    slot_d = torch.full((N,), -1, dtype=torch.int32, device=dev)
+    lagging_seen = 0
+    for t in range(150):
+        # Zipf-ish ids with duplicates: a few hot rows every step, most rows rarely
+        ids = (torch.rand(96, device=dev, generator=g) ** 4 * (N - 1)).long() + 1
+        ids = ids.clamp_(max=N - 1)
+        o_lazy.catch_up(ids)                                            # what the training forward does before its gather
+        assert torch.equal(m_lazy.item_embedding.weight[ids], m_dense.item_embedding.weight[ids]), t
+        rows = torch.randn(ids.numel(), D, device=dev, generator=g)
+        sorted_ids, perm = torch.sort(ids)
+        out_rows = torch.zeros(ids.numel(), D, device=dev)               # ONE reduction, shared: both optimizers see the same bits
+        ops.sparse_rows_segment_sum(sorted_ids, perm, rows, None, None, 0, 0, out_rows, slot_l)
+        slot_d.copy_(slot_l)
+        m_lazy.sparse_grad = SparseRowGrad(sorted_ids, out_rows, slot_l, N)
+        m_dense.sparse_grad = SparseRowGrad(sorted_ids, out_rows.clone(), slot_d, N)
+        lr = 1e-3 * (0.5 + 0.5 * math.cos(t / 40.0))
+        for opt in (o_lazy, o_dense):
+            opt.param_groups[0]["lr"] = lr
+            opt.step()
+            opt.zero_grad()
+        lagging_seen = max(lagging_seen, int((o_lazy.last_step < o_lazy.step_count).sum()))
+        if (t + 1) % LAZY_HIST == 0:
+            assert int((o_lazy.last_step < o_lazy.step_count).sum()) == 0            # the periodic flush happened
+    assert lagging_seen > N // 2                                                     # most rows really were lagging
+    o_lazy.flush_table()
+    torch.cuda.synchronize()
+    assert torch.equal(m_lazy.item_embedding.weight, m_dense.item_embedding.weight)
+    assert torch.equal(o_lazy.t_m, o_dense.t_m) and torch.equal(o_lazy.t_v, o_dense.t_v)
+    assert int((slot_l != -1).sum()) == 0 and int((slot_d != -1).sum()) == 0
