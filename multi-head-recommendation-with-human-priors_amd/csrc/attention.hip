@@ -96,8 +96,10 @@ __global__ __launch_bounds__(256) void hstu_attn_fwd_kernel(const bf16_t* __rest
   sg::LaneAddr<NKS> la;
   la.init(lane);
   for (int it = 0; it * 4 < nb; ++it) {
-    const int qb = (it & 1) ? it * 4 + (3 - wave) : it * 4 + wave;   // zig-zag: balances the causal triangle
-    if (qb >= nb) continue;
+    // snake from the HEAVY end (query block qb costs qb + 1 tile pairs): blocks nb-1 .. nb-4 to waves 0..3, the next four to
+    // waves 3..0, ...  Dealt from the light end, nb = 7 (L = 200) came out as 1 / 9 / 9 / 9 pairs per wave instead of 7 each.
+    const int qb = nb - 1 - ((it & 1) ? it * 4 + (3 - wave) : it * 4 + wave);
+    if (qb < 0) continue;
     const int qrow = qb * 32 + r;
     bf16x8 qf[NKS];
 #pragma unroll
@@ -297,8 +299,8 @@ __global__ __launch_bounds__(256, NKS <= 2 ? ATTN_BWD_WG : 1) void hstu_attn_bwd
   __syncthreads();
   ASTAMP(4)
   for (int it = 0; it * 4 < nb; ++it) {
-    const int qb = (it & 1) ? it * 4 + (3 - wave) : it * 4 + wave;
-    if (qb >= nb) continue;
+    const int qb = nb - 1 - ((it & 1) ? it * 4 + (3 - wave) : it * 4 + wave);     // snake from the heavy end (see the forward)
+    if (qb < 0) continue;
     const int qcol = qb * 32 + r;
     bf16x8 qf[NKS], dof[NKS];
 #pragma unroll

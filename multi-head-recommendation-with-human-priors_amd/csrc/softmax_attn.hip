@@ -67,8 +67,8 @@ __global__ __launch_bounds__(256) void softmax_attn_fwd_kernel(const bf16_t* __r
   sg::LaneAddr<NKS> la;
   la.init(lane);
   for (int it = 0; it * nw < nb; ++it) {
-    const int qb = (it & 1) ? it * nw + (nw - 1 - wave) : it * nw + wave;   // zig-zag over the causal triangle
-    if (qb >= nb) continue;
+    const int qb = nb - 1 - ((it & 1) ? it * nw + (nw - 1 - wave) : it * nw + wave);   // snake over the causal triangle from its heavy end
+    if (qb < 0) continue;
     const int qrow = qb * 32 + r;
     bf16x8 qf[NKS];
 #pragma unroll
@@ -265,8 +265,8 @@ __global__ __launch_bounds__(256) void softmax_attn_bwd_kernel(
   stage_tiles<NKS>(T1, vp, stride, L, Lp, hd, false, nullptr, 0);
   __syncthreads();
   for (int it = 0; it * nw < nb; ++it) {
-    const int qb = (it & 1) ? it * nw + (nw - 1 - wave) : it * nw + wave;
-    if (qb >= nb) continue;
+    const int qb = nb - 1 - ((it & 1) ? it * nw + (nw - 1 - wave) : it * nw + wave);
+    if (qb < 0) continue;
     const int qcol = qb * 32 + r;
     bf16x8 qf[NKS], dof[NKS];
 #pragma unroll
