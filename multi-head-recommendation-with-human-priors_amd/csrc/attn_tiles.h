@@ -47,15 +47,29 @@ template <int NKS>
 __device__ __forceinline__ void stage_tiles(unsigned char* dst, const bf16_t* src, int64_t stride, int L, int Lp, int hd,
                                             bool do_silu, bf16_t* act, int64_t act_stride) {
   using T = sg::Tile<NKS>;
-  for (int c = threadIdx.x; c < Lp * T::CH; c += blockDim.x) {
-    const int m = c / T::CH, j = c % T::CH;
-    bf16x8 val = zero8();
-    if (m < L && j * 8 < hd) {
-      val = *reinterpret_cast<const bf16x8*>(src + (int64_t)m * stride + j * 8);
-      if (do_silu) val = silu8(val);
-      if (act) *reinterpret_cast<bf16x8*>(act + (int64_t)m * act_stride + j * 8) = val;
+  // four 16-byte chunks per thread in flight: all loads of a batch are issued before the first SiLU / LDS store (one chunk per
+  // iteration left every staging at 3-4 dependent global round trips, and a backward workgroup stages four operands)
+  constexpr int U = 4;
+  const int total = Lp * T::CH, nt = blockDim.x;
+  for (int c0 = threadIdx.x; c0 < total; c0 += U * nt) {
+    bf16x8 val[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int c = c0 + u * nt;
+      const int m = c / T::CH, j = c % T::CH;
+      val[u] = zero8();
+      if (c < total && m < L && j * 8 < hd) val[u] = *reinterpret_cast<const bf16x8*>(src + (int64_t)m * stride + j * 8);
     }
-    *reinterpret_cast<bf16x8*>(dst + (m >> 5) * T::BYTES + T::off(m & 31, j)) = val;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int c = c0 + u * nt;
+      if (c >= total) break;
+      const int m = c / T::CH, j = c % T::CH;
+      const bool in = m < L && j * 8 < hd;
+      if (in && do_silu) val[u] = silu8(val[u]);
+      if (in && act) *reinterpret_cast<bf16x8*>(act + (int64_t)m * act_stride + j * 8) = val[u];
+      *reinterpret_cast<bf16x8*>(dst + (m >> 5) * T::BYTES + T::off(m & 31, j)) = val[u];
+    }
   }
 }
 
