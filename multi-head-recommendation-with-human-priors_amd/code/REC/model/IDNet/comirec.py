@@ -111,6 +111,7 @@ class ComiRec(HSTU):
     def _interest_heads(self, item_seq):
         """[B,L] ids (front zero padded) -> L2-normalised interests [B,K,D] fp32 (comirec.py:330-384)."""
         from mhr_amd import ops
+        self.sync_table()                                   # lazy table optimizer: a read outside the training forward
         B, L = item_seq.shape
         if isinstance(self.item_id_proj_tower, nn.Identity):
             _, x = ops.embedding_gather(self.item_embedding.weight, item_seq.contiguous(), torch.float32,

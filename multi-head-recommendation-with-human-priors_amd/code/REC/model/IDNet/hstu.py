@@ -263,6 +263,7 @@ class HSTU(MultiHeadDecoding, BaseModel):
     @torch.no_grad()
     def compute_item_all(self):
         """L2-normalised (projected) item table, fp32 [N, D] (reference hstu.py:1018-1021)."""
+        self.sync_table()                                   # lazy table optimizer: a read outside the training forward
         from mhr_amd import ops
         self._item_cache = None
         w = self.item_id_proj_tower(self.item_embedding.weight)
@@ -271,6 +272,7 @@ class HSTU(MultiHeadDecoding, BaseModel):
     @torch.no_grad()
     def _last_hidden(self, item_seq):
         """[B,L] ids (front zero padded) -> encoder output at the last position [B,D] fp32 (reference hstu.py:879-913)."""
+        self.sync_table()                                   # lazy table optimizer: a read outside the training forward
         from mhr_amd import ops
         B, L = item_seq.shape
         if isinstance(self.item_id_proj_tower, nn.Identity):

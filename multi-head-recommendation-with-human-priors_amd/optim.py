@@ -83,6 +83,7 @@ class FusedAdamW:
             self.hist = torch.zeros(LAZY_HIST, 4, dtype=torch.float32, device=dev)
             self._hist_host = torch.zeros(LAZY_HIST, 4, dtype=torch.float32).pin_memory()
             model._table_optimizer = self                                # the model's forward / eval hooks find us here
+            self._lagging = False                                        # rows behind step_count exist (host-side flag)
 
     def zero_grad(self):
         global GRAD_EPOCH
@@ -114,6 +115,7 @@ class FusedAdamW:
         if sg is not None and self.lazy:
             self._push_consts(self.step_count, lr)
             self._lazy_call(1, sg.sorted_ids, sg.rows, sg.row_slot, 1.0 / W)
+            self._lagging = True
             if self.step_count % LAZY_HIST == 0:                         # nobody lags further than the history reaches
                 self.flush_table()
         elif sg is not None:
@@ -147,9 +149,10 @@ class FusedAdamW:
             self._lazy_call(0, ids.contiguous(), None, None, 1.0, step=self.step_count + 1)
 
     def flush_table(self):
-        """Every row up to the last optimizer step (no-op when nothing lags)."""
-        if self.lazy and self.step_count > 0:
+        """Every row up to the last optimizer step (no launch when nothing lags)."""
+        if self.lazy and self.step_count > 0 and self._lagging:
             self._lazy_call(2, None, None, None, 1.0)
+            self._lagging = False
 
     def state_dict(self):
         self.flush_table()
