@@ -11,7 +11,7 @@ user sequences and the item -> category multi-hot:
   eval batch  = (user_ids, item_seq [B,L] front zero-padded, item_target [B,E], (history_u, history_i), positive_u,
                  time_seq, target_tags [B,E,C], outlier_users)
 
-Same distributions as the reference (category_by = 'item', uniform negative sampling):
+Same distributions as the reference:
   * windows: `valid_sample_locations` as built by `dataload.py:163-195` (one window per short user, non-overlapping
     windows for long users), context front-padded, prediction part end-padded; with `pad_random_sample` the pad slots
     hold uniformly drawn real ids that are not in the user's window (mask 0), else 0;
@@ -20,8 +20,15 @@ Same distributions as the reference (category_by = 'item', uniform negative samp
     here every negative respects the blacklist); `neg_sample_mix_ratio` flips one coin per (sample, category);
   * sharding: train - a shared permutation per epoch, rank r takes positions r, r+W, ... (DistributedSampler);
     eval - users r, r+W, ... in order (`NonConsecutiveSequentialDistributedSampler`, data/utils.py:95-121).
-Out of scope here (data layer): parquet loading, id remapping, timestamps (`time_seq` is returned empty),
-weighted negative sampling (`neg_sample_mode`), category_by = 'user' / 'event'.
+  * categories (`category_by`): 'item' - the item's multi-hot tags per position (`process_item`); 'user' - the user's
+    cluster one-hot on EVERY position of the window, pads included (trainset.py:168-169, evalset.py:119-121); 'event' - the
+    one-hot of the interaction's event type on the real positions, zeros on the pads (`process_event`, 143-153; eval:
+    the target interactions' event types, evalset.py:144-149, outlier users by unseen target events 126-141).  Per-category
+    negative pools exist for 'item' only (trainset.py:33);
+  * weighted negatives (`neg_sample_mode`, trainset.py:99-107): draws WITH replacement from the pool with the weight list
+    the reference hands to `random.choices(..., weights=...)`, items of the window rejected, repeats allowed.
+Out of scope here (data layer): parquet loading, id remapping, timestamps (`time_seq` is returned empty), building the
+weight lists from interaction counts (dataload.py:263-327) and the user clustering.
 """
 import math
 
@@ -33,7 +40,12 @@ class SeqStore:
     `train_seq_len[uid]` the length of the training prefix (dataload.py: the rest is held out), `item_tags` [N, C] bool
     (row 0 = pad item, all False)."""
 
-    def __init__(self, user_seq, train_seq_len, item_tags, device="cpu"):
+    def __init__(self, user_seq, train_seq_len, item_tags, device="cpu", user_cluster=None, event_seq=None, item_weights=None,
+                 item_weights_by_cat=None):
+        """user_cluster [U] ints (category_by = 'user': `dataload.user_cluster_list`); event_seq: per user, the event type of
+        every interaction (category_by = 'event': `dataload.event_seq`, parallel to user_seq); item_weights [N] /
+        item_weights_by_cat (list of per-category weight vectors parallel to the category's item list): the lists the
+        reference passes as `weights=` when `neg_sample_mode` is set (`dataload.item_interact_weights`, `item_weights_by_cat`)."""
         lens = torch.tensor([len(s) for s in user_seq], dtype=torch.int64)
         self.ptr = torch.zeros(len(user_seq) + 1, dtype=torch.int64)
         self.ptr[1:] = torch.cumsum(lens, 0)
@@ -45,6 +57,15 @@ class SeqStore:
         self.item_num = self.item_tags.shape[0]
         self.user_num = len(user_seq)
         self.device = torch.device(device)
+        self.user_cluster = None if user_cluster is None else torch.as_tensor(user_cluster, dtype=torch.int64).to(device)
+        self.events = None
+        if event_seq is not None:
+            if [len(e) for e in event_seq] != [len(s_) for s_ in user_seq]:
+                raise ValueError("event_seq must be parallel to user_seq")
+            self.events = torch.tensor([e for es in event_seq for e in es], dtype=torch.int64).to(device)
+        self.item_weights = None if item_weights is None else torch.as_tensor(item_weights, dtype=torch.float64).to(device)
+        self.item_weights_by_cat = None if item_weights_by_cat is None else [torch.as_tensor(w, dtype=torch.float64).to(device)
+                                                                             for w in item_weights_by_cat]
 
     def sample_locations(self, max_len, pred_len, sample_last_only=False):
         """[n, 2] (uid, context_end) exactly as dataload.py:163-195."""
@@ -106,6 +127,30 @@ def _draw_without_replacement(pool, n_draw, black, gen, slack=16):
                      "(pool minus window too small)")
 
 
+def _draw_weighted(pool, weights, n_draw, black, gen):
+    """[B, n_draw] items of `pool` drawn WITH replacement with probability proportional to `weights` (parallel to pool), items
+    in `black` [B, W] rejected, repeats allowed - the reference's weighted path (trainset.py:99-107: `random.choices` in a
+    loop until k accepted)."""
+    B, dev = black.shape[0], black.device
+    out = torch.zeros(B, n_draw, dtype=torch.int64, device=dev)
+    have = torch.zeros(B, dtype=torch.int64, device=dev)
+    p = (weights / weights.sum()).float()
+    for _ in range(256):
+        need = n_draw - have
+        todo = torch.nonzero(need > 0).flatten()
+        if todo.numel() == 0:
+            return out
+        m = int(need.max()) + 16
+        pick = torch.multinomial(p, todo.numel() * m, replacement=True, generator=gen).view(todo.numel(), m)
+        cand = pool[pick]
+        ok = ~(cand[:, :, None] == black[todo][:, None, :]).any(-1)
+        slot = have[todo, None] + torch.cumsum(ok, 1) - 1
+        put = ok & (slot < n_draw)
+        out[todo[:, None].expand_as(cand)[put], slot[put]] = cand[put]
+        have[todo] += put.sum(1)
+    raise ValueError("weighted negative sampling did not find enough items outside the window")
+
+
 class SeqTrainBatcher:
     """Iterable over train batches for one rank (reference SEQTrainDataset + DistributedSampler + default collate)."""
 
@@ -114,7 +159,18 @@ class SeqTrainBatcher:
         self.L, self.P = config['MAX_ITEM_LIST_LENGTH'], config['pred_len']
         self.B = batch_size or config['train_batch_size']
         self.return_tags = config['loss'] == 'prior'
-        self.by_cat = self.return_tags and bool(config['neg_sample_by_cat']) and (config['category_by'] or 'item') == 'item'
+        self.category_by = config['category_by'] or 'item'
+        if self.category_by not in ('item', 'user', 'event'):
+            raise ValueError(f"category_by = {self.category_by} is not defined.")
+        self.by_cat = self.return_tags and bool(config['neg_sample_by_cat']) and self.category_by == 'item'
+        self.weighted = config['neg_sample_mode'] is not None
+        if self.weighted and store.item_weights is None:
+            raise ValueError("neg_sample_mode needs SeqStore(item_weights=...) (dataload.item_interact_weights)")
+        if self.return_tags and self.category_by == 'user' and store.user_cluster is None:
+            raise ValueError("category_by = 'user' needs SeqStore(user_cluster=...)")
+        if self.return_tags and self.category_by == 'event' and store.events is None:
+            raise ValueError("category_by = 'event' needs SeqStore(event_seq=...)")
+        self.n_cats = config['eval_num_cats'] or store.item_tags.shape[1]
         self.mix = config['neg_sample_mix_ratio'] or 0.0
         self.random_pad = bool(config['pad_random_sample'])
         nn_ = config['num_negatives']
@@ -147,18 +203,33 @@ class SeqTrainBatcher:
         if self.random_pad:                                     # pad slots: random real ids outside the user's window
             pads = _draw_without_replacement(self.all_items, W, items, self.gen)
             items = torch.where(real, items, pads)
+        def draw(pool, weights):
+            if self.weighted:
+                return _draw_weighted(pool, weights, self.n_neg, items, self.gen)
+            return _draw_without_replacement(pool, self.n_neg, items, self.gen)
+
+        w_all = st.item_weights[1:] if self.weighted else None
         pools = []
         if self.by_cat:
             for c in range(self.C):
-                neg = _draw_without_replacement(self.cat_items[c], self.n_neg, items, self.gen)
+                neg = draw(self.cat_items[c], st.item_weights_by_cat[c] if (self.weighted and st.item_weights_by_cat) else
+                           (st.item_weights[self.cat_items[c]] if self.weighted else None))
                 if self.mix > 0.0:                              # one coin per (sample, category): global pool instead
-                    glob = _draw_without_replacement(self.all_items, self.n_neg, items, self.gen)
+                    glob = draw(self.all_items, w_all)
                     coin = torch.rand(items.shape[0], device=dev, generator=self.gen) <= self.mix
                     neg = torch.where(coin[:, None], glob, neg)
                 pools.append(neg)
-        pools.append(_draw_without_replacement(self.all_items, self.n_neg, items, self.gen))
+        pools.append(draw(self.all_items, w_all))
         neg_items = torch.stack(pools, dim=1)
-        tags = st.item_tags[items].long() if self.return_tags else torch.zeros(items.shape[0], 0, dtype=torch.int64, device=dev)
+        if not self.return_tags:
+            tags = torch.zeros(items.shape[0], 0, dtype=torch.int64, device=dev)
+        elif self.category_by == 'item':
+            tags = st.item_tags[items].long()
+        elif self.category_by == 'user':                        # the user's cluster on every position, pads included
+            tags = torch.nn.functional.one_hot(st.user_cluster[uid], self.n_cats)[:, None, :].expand(-1, W, -1).contiguous()
+        else:                                                   # the interaction's event type; zeros on the pads
+            ev = st.events[src.clamp(0, st.events.numel() - 1)]
+            tags = torch.nn.functional.one_hot(ev.clamp(0, self.n_cats - 1), self.n_cats) * real[..., None].long()
         return items, neg_items, real.long(), tags
 
     def __iter__(self):
@@ -182,6 +253,12 @@ class SeqEvalBatcher:
         self.B = batch_size or config['eval_batch_size']
         self.return_tags = (config['eval_num_cats'] or 1) > 1
         self.outlier = config['outlier_user_metrics']
+        self.category_by = config['category_by'] or 'item'
+        self.n_cats = config['eval_num_cats'] or store.item_tags.shape[1]
+        if self.return_tags and self.category_by == 'user' and store.user_cluster is None:
+            raise ValueError("category_by = 'user' needs SeqStore(user_cluster=...)")
+        if self.category_by == 'event' and (self.return_tags or self.outlier == 'event') and store.events is None:
+            raise ValueError("category_by = 'event' needs SeqStore(event_seq=...)")
         need = (store.train_len if phase == 'valid' else store.lens - self.E) + self.E
         if bool((need[1:] > store.lens[1:]).any()) or bool(((store.lens - self.E)[1:] < 0).any()):
             raise ValueError("every user needs eval_pred_len held-out items after the history (evalset.py:80-90)")
@@ -207,8 +284,19 @@ class SeqEvalBatcher:
         off = torch.arange(int(n_hist.sum()), device=dev) - torch.repeat_interleave(torch.cumsum(n_hist, 0) - n_hist, n_hist)
         hi = st.items[torch.repeat_interleave(base, n_hist) + off]
         positive_u = torch.arange(B, device=dev)[:, None].repeat(1, E)
-        tt = st.item_tags[item_target].long() if self.return_tags else torch.zeros(B, 0, dtype=torch.int64, device=dev)
+        tgt_pos = (base[:, None] + n_hist[:, None] + e).clamp(0, st.items.numel() - 1)
+        if not self.return_tags:
+            tt = torch.zeros(B, 0, dtype=torch.int64, device=dev)
+        elif self.category_by == 'item':
+            tt = st.item_tags[item_target].long()
+        elif self.category_by == 'user':
+            tt = torch.nn.functional.one_hot(st.user_cluster[uid], self.n_cats)[:, None, :].expand(-1, E, -1).contiguous()
+        else:
+            tt = torch.nn.functional.one_hot(st.events[tgt_pos].clamp(0, self.n_cats - 1), self.n_cats)
         outlier = torch.zeros(B, dtype=torch.bool, device=dev)
+        if self.outlier == 'event' and self.category_by == 'event':     # a target event type the last L history events never showed
+            h_ev = torch.where(pos >= 0, st.events[(base[:, None] + pos).clamp(0, st.events.numel() - 1)], torch.full_like(pos, -1))
+            outlier = ~(st.events[tgt_pos][:, :, None] == h_ev[:, None, :]).any(-1).all(-1)
         if self.outlier == 'category':                        # a target category the whole history never showed (evalset.py:101-109)
             def fixed(t):                                     # items tagged with EVERY category count as untagged
                 return t & ~t.all(-1, keepdim=True)

@@ -156,3 +156,87 @@ def test_sharding_matches_the_reference_samplers():
     u0 = torch.cat([b[0] for b in ev[0]]).tolist()
     u1 = torch.cat([b[0] for b in ev[1]]).tolist()
     assert u0 == list(range(1, 34, 2)) and u1 == list(range(2, 34, 2)) and ev[0].num_total_examples == 33
+
+
+def _toy_events(user_seq, n_ev, seed=5):
+    rng = np.random.default_rng(seed)
+    return [[int(rng.integers(0, n_ev)) for _ in s] for s in user_seq]
+
+
+def test_user_and_event_categories_match_the_reference_construction():
+    """category_by = 'user': the user's cluster one-hot on every window position, pads included (trainset.py:168-169), and on
+    every eval target (evalset.py:119-121); category_by = 'event': the interaction's event one-hot on the real positions, zeros
+    on the pads (process_event, trainset.py:143-153), the targets' event types in eval (evalset.py:144-149) and outlier users =
+    a target event the last L history events never showed (126-141).  No per-category negative pools (trainset.py:33)."""
+    from REC.data import SeqEvalBatcher, SeqStore, SeqTrainBatcher
+    user_seq, train_len, tags = _data()
+    tags = torch.from_numpy(tags)
+    C = tags.shape[1]
+    U = len(user_seq)
+    clusters = [u % C for u in range(U)]
+    events = _toy_events(user_seq, C)
+    st = SeqStore(user_seq, train_len, tags, user_cluster=clusters, event_seq=events)
+    L, P = 6, 3
+    for cb in ("user", "event"):
+        cfg = _cfg(MAX_ITEM_LIST_LENGTH=L, pred_len=P, loss="prior", category_by=cb, neg_sample_by_cat=True, eval_num_cats=C,
+                   num_negatives=0, eval_pred_len=2, outlier_user_metrics="event" if cb == "event" else None)
+        tb = SeqTrainBatcher(cfg, st, batch_size=5, seed=3)
+        idx = torch.arange(min(5, tb.loc.shape[0]))
+        items, neg, mask, tg = tb.batch(idx)
+        assert neg.shape[1] == 1                                           # no category pools outside category_by = 'item'
+        assert tg.shape == (idx.numel(), L + P, C)
+        for b, row in enumerate(idx.tolist()):
+            uid, end = tb.loc[row].tolist()
+            start = max(0, end - L)
+            ctx_pad = L - (end - start)
+            n_pred = min(train_len[uid] - end, P)
+            if cb == "user":
+                want = torch.nn.functional.one_hot(torch.tensor(clusters[uid]), C)[None].expand(L + P, -1)
+            else:
+                want = torch.zeros(L + P, C, dtype=torch.int64)
+                ev = events[uid][start:end + n_pred]
+                for j, e in enumerate(ev):
+                    want[ctx_pad + j, e] = 1
+            assert torch.equal(tg[b], want), (cb, b)
+        eb = SeqEvalBatcher(cfg, st, phase="valid", batch_size=4)
+        uid, item_seq, item_target, hist, pos_u, _, tt, outlier = eb.batch(eb.users[:4])
+        for b, u in enumerate(uid.tolist()):
+            n_hist = train_len[u]
+            if cb == "user":
+                want = torch.nn.functional.one_hot(torch.tensor(clusters[u]), C)[None].expand(2, -1)
+            else:
+                tgt_ev = events[u][n_hist:n_hist + 2]
+                want = torch.nn.functional.one_hot(torch.tensor(tgt_ev), C)
+                ctx = set(events[u][:n_hist][-L:])
+                assert bool(outlier[b]) == any(e not in ctx for e in tgt_ev)
+            assert torch.equal(tt[b], want), (cb, b)
+
+
+def test_weighted_negative_sampling_follows_the_weight_list():
+    """neg_sample_mode (trainset.py:99-107): `random.choices(pool, weights=w)` until k accepted - draws WITH replacement,
+    proportional to the weights, window items rejected.  Frequencies over many draws follow w (chi-square-free check: the
+    heaviest decile is drawn far more often than the lightest), repeats occur, no negative is in its window."""
+    from REC.data import SeqStore, SeqTrainBatcher
+    user_seq, train_len, tags = _data()
+    tags = torch.from_numpy(tags)
+    N = tags.shape[0]
+    w = np.zeros(N)
+    w[1:] = np.linspace(0.01, 1.0, N - 1) ** 2
+    by_cat = [w[np.nonzero(tags[:, c].numpy())[0]] for c in range(tags.shape[1])]
+    st = SeqStore(user_seq, train_len, tags, item_weights=w, item_weights_by_cat=by_cat)
+    cfg = _cfg(MAX_ITEM_LIST_LENGTH=6, pred_len=2, loss="prior", category_by="item", neg_sample_by_cat=True,
+               eval_num_cats=tags.shape[1], num_negatives=64 * 8, neg_sample_mode="sqrt")
+    tb = SeqTrainBatcher(cfg, st, batch_size=8, seed=1)
+    counts = torch.zeros(N)
+    repeats = 0
+    for _ in range(30):
+        items, neg, mask, tg = tb.batch(torch.arange(8) % tb.loc.shape[0])
+        assert neg.shape == (8, tags.shape[1] + 1, 64)
+        for c in range(tags.shape[1]):
+            assert bool(tags[neg[:, c].reshape(-1), c].all())                                  # category pools respected
+        assert not bool((neg[:, :, :, None] == items[:, None, None, :]).any())                 # window items rejected
+        glob = neg[:, -1]
+        counts += torch.bincount(glob.reshape(-1), minlength=N).float()
+        repeats += sum(int(r.numel() - r.unique().numel()) for r in glob)
+    lo, hi = counts[1:1 + (N - 1) // 10].sum(), counts[-((N - 1) // 10):].sum()
+    assert hi > 20 * max(float(lo), 1.0) and repeats > 0
