@@ -457,6 +457,47 @@ def run_comirec_cases():
     print("wrote comirec_nce loss", float(out["loss"]))
 
 
+def run_remi_cases():
+    """REMI (REC/model/IDNet/remi.py: ComiRec + routing regularisation + interest-aware hard negatives) on the reference
+    itself: one training step with every model_out key and gradients, and one predict call."""
+    import numpy as np
+    import torch
+    from REC.model.IDNet.remi import REMI
+    N, B, L, P, n_neg = 301, 5, 12, 3, 9
+    cfg = base_cfg(pred_len=P, eval_pred_len=P, interest_num=3, interest_hidden=8, loss="nce", n_layers=2, n_heads=2,
+                   lambda_rr=3.0e4, beta_ihn=1.0)
+    torch.manual_seed(43)
+    model = REMI(cfg, FakeData(N, 1))
+    model._verbose = False
+    model.eval()
+    with torch.no_grad():
+        for n_, p_ in model.named_parameters():
+            if n_.startswith("attention_net"):
+                p_.mul_(120.0)       # peaky routing: the regulariser and its gradient become visible
+    g = torch.Generator().manual_seed(44)
+    items, neg, mask, tags = make_batch(g, N, B, L, P, 1, n_neg, 1, None)
+    neg[0, -1, 0] = items[0, L]                      # a false negative: a sampled negative equal to a target
+    out = model((items, neg, mask, tags))
+    out["loss"].backward()
+    save = np_state(model)
+    save.update({"in/items": items.numpy(), "in/neg_items": neg.numpy(), "in/mask": mask.numpy(), "cfg/json": np.array(cfg_json(cfg, N, 1))})
+    for k, v in out.items():
+        save["out/" + k] = np.float64(float(v))
+    grads = dict(model.named_parameters())
+    for k in ("attention_net.0.weight", "attention_net.3.weight", "_hstu._attention_layers.0._uvqk", "logit_scale"):
+        save["grad/" + k] = grads[k].grad.numpy()
+    save["grad/item_embedding.weight"] = grads["item_embedding.weight"].grad.numpy()
+    seq = torch.randint(1, N, (4, L), generator=g)
+    seq[0, :5] = 0
+    seq[2, :1] = 0
+    with torch.no_grad():
+        feat = model.compute_item_all()
+        scores, _, _, _ = model.predict(seq, None, feat, None, None)
+    save.update({"in/item_seq": seq.numpy(), "out/item_feature": feat.numpy(), "out/scores": scores.numpy()})
+    np.savez_compressed(os.path.join(OUT, "remi_nce.npz"), **save)
+    print("wrote remi_nce", {k: float(v) for k, v in out.items()})
+
+
 def main():
     _setup()
     os.makedirs(OUT, exist_ok=True)
@@ -465,6 +506,9 @@ def main():
         return
     if len(sys.argv) > 1 and sys.argv[1] == "baichuan":
         run_baichuan_cases()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "remi":
+        run_remi_cases()
         return
     if len(sys.argv) > 1 and sys.argv[1] == "llama":
         run_llama_cases()
@@ -513,6 +557,7 @@ def main():
     run_llama_cases()
     run_baichuan_cases()
     run_comirec_cases()
+    run_remi_cases()
 
 
 if __name__ == "__main__":

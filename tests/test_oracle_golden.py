@@ -214,3 +214,29 @@ def test_comirec_oracle_matches_reference():
         np.testing.assert_allclose(feat.numpy(), g["out/item_feature"], rtol=1e-5, atol=1e-6)
         scores = CO.predict_scores(w, cfg, torch.from_numpy(g["in/item_seq"]), feat)
     np.testing.assert_allclose(scores.numpy(), g["out/scores"], rtol=2e-5, atol=2e-6)
+
+
+def test_remi_oracle_matches_reference():
+    """REMI (ComiRec + routing regulariser + interest-aware hard negatives): the restatement against the reference's own
+    remi.py - every model_out key, gradients, predict scores."""
+    from oracle import remi_oracle as RO
+    g = load_golden("remi_nce")
+    cfg = cfg_of(g)
+    w = weights_of(g, requires_grad=True)
+    batch = tuple(torch.from_numpy(g["in/" + k]) for k in ("items", "neg_items", "mask")) + (None,)
+    out = RO.train_forward(w, cfg, batch)
+    n = 0
+    for k, v in g.items():
+        if k.startswith("out/") and k not in ("out/item_feature", "out/scores"):
+            assert abs(float(out[k[4:]]) - float(v)) <= 2e-5 * max(1.0, abs(float(v))) + (1e-9 if "rr" in k else 0), k
+            n += 1
+    assert n >= 5 and float(g["out/rr_loss"]) * cfg["lambda_rr"] > 0.5                      # the regulariser is a visible part of the loss
+    out["loss"].backward()
+    for k, v in g.items():
+        if k.startswith("grad/"):
+            got = w[k[5:]].grad
+            ref = torch.from_numpy(v)
+            assert float((got - ref).abs().max()) <= 3e-5 * float(ref.abs().max()) + 1e-8, k
+    with torch.no_grad():
+        sc = RO.predict_scores({k: t.detach() for k, t in w.items()}, cfg, torch.from_numpy(g["in/item_seq"]), torch.from_numpy(g["out/item_feature"]))
+    assert float((sc - torch.from_numpy(g["out/scores"])).abs().max()) <= 2e-5
