@@ -453,6 +453,18 @@ int mhr_nce_dense_fwd(const float* neg_logits, const float* fix_logits, int64_t 
 int mhr_nce_dense_bwd(const float* neg_logits, const float* fix_logits, int64_t ld, int n_neg, const float* lse,
                       const float* w, const float* scale_dev, float thres, const int32_t* n_live_dev, int64_t row_base,
                       int64_t rows, void* g_bf16, int64_t ldg, void* stream);
+/* REMI's interest-aware hard-negative loss over the same dense chunks (model/IDNet/remi.py:203-288): with l = scale s,
+ *   loss = logaddexp(l+, A - (Z - log n_neg)) - l+,  A = logsumexp_j((beta + 1) l_j),  Z = logsumexp_j(beta l_j)  over the kept
+ * negatives (beta > 0; beta <= 0 is mhr_nce_dense_fwd).  Saves lse (the logaddexp), log_num = A, log_imp = Z per row; the
+ * backward writes g = w sigma_neg ((beta + 1) exp((beta + 1) l - A) - beta exp(beta l - Z)) as the bf16 tile of the dQ / dN GEMMs. */
+int mhr_ihn_dense_fwd(const float* neg_logits, const float* fix_logits, int64_t ld, int n_neg, const float* s_pos,
+                      const float* scale_dev, float thres, float beta, const int32_t* n_live_dev, int64_t row_base,
+                      int64_t rows, float* lse, float* log_num, float* log_imp, float* loss, int32_t* n_valid,
+                      int32_t* rank, void* stream);
+int mhr_ihn_dense_bwd(const float* neg_logits, const float* fix_logits, int64_t ld, int n_neg, const float* lse,
+                      const float* log_num, const float* log_imp, const float* w, const float* scale_dev, float thres,
+                      float beta, const int32_t* n_live_dev, int64_t row_base, int64_t rows, void* g_bf16, int64_t ldg,
+                      void* stream);
 
 /* Catalog masks on a dense score chunk (model/IDNet/hstu.py:982-999, trainer.py:724): column j is item
  * item_begin + j * item_stride; scores[r, j] = -inf unless (tag_bits[item] & row_bits[r]) != 0 and item != 0

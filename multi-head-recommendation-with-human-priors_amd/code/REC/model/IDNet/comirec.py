@@ -55,14 +55,23 @@ class ComiRec(HSTU):
         with torch.autocast(device_type=out.device.type, dtype=torch.bfloat16, enabled=out.is_cuda):
             return self.attention_net(out).float()                                            # [B,L,K]
 
-    def _causal_interests(self, out, valid):
-        """[B,L,D] fp32, valid [B,L] bool -> [B,L,K,D] fp32 by prefix sums (see the module docstring)."""
+    _ihn_beta = 0.0                                   # REMI: interest-aware hard negatives (plain sampled softmax here)
+
+    def _causal_interests(self, out, valid, want_stats=False):
+        """[B,L,D] fp32, valid [B,L] bool -> [B,L,K,D] fp32 by prefix sums (see the module docstring); want_stats: also the
+        routing scores a [B,L,K] (-inf at padded positions; the routing weight of m in window t is softmax_{m <= t}(a)) and the
+        running sums den [B,L,K]."""
         a = self._interest_scores(out).masked_fill(~valid[..., None], float("-inf"))
         m = a.max(dim=1, keepdim=True).values
         e = torch.exp(a - torch.where(torch.isfinite(m), m, torch.zeros_like(m)))             # 0 at padded positions
         den = torch.cumsum(e, dim=1)
         num = torch.cumsum(e[..., None] * out[:, :, None, :], dim=1)
-        return num / den.clamp_min(1e-30)[..., None]
+        interests = num / den.clamp_min(1e-30)[..., None]
+        return (interests, a, den) if want_stats else interests
+
+    def _routing_loss(self, a, den, valid, model_out):
+        """Extra loss on the routing weights (REMI's regulariser); ComiRec has none."""
+        return 0.0
 
     def forward(self, interaction):
         from REC.model.basemodel import all_gather_ids
@@ -90,7 +99,7 @@ class ComiRec(HSTU):
         e_rows = rows_items
         negs = L2NormFn.apply(rows_negs.contiguous()).view(1, -1, D)
         out = self._encode(x, mask[:, :L].to(torch.uint8).contiguous())                        # [B,L,D] fp32
-        interests = self._causal_interests(out, mask[:, :L])                                   # [B,L,K,D]
+        interests, e_w, den_w = self._causal_interests(out, mask[:, :L], want_stats=True)      # [B,L,K,D]
         # hard read-out (comirec.py:265-288): the interest with the largest dot product with the target of (l, p)
         idx = torch.arange(L, device=dev)[:, None] + 1 + torch.arange(P, device=dev)[None, :]  # [L,P]
         with torch.no_grad():
@@ -102,9 +111,11 @@ class ComiRec(HSTU):
             q_all = (((b_i * L + l_i) * K) + best).reshape(1, -1).int().contiguous()
         base_valid = (mask[:, :L, None] & mask[:, idx])[None]                                   # [1,B,L,P]
         mean_gp, logs = self._grouped_loss(interests.reshape(-1, D), e_rows, negs.contiguous(), base_valid,
-                                           torch.zeros(1, P, dtype=torch.long), 0, mask.reshape(1, -1), q_all=q_all)
+                                           torch.zeros(1, P, dtype=torch.long), 0, mask.reshape(1, -1), q_all=q_all,
+                                           ihn_beta=self._ihn_beta)
         model_out = dict(logs)
-        model_out["loss"] = (mean_gp[0] * self.horizon_discount.float()).sum()
+        extra = self._routing_loss(e_w, den_w, mask[:, :L], model_out)
+        model_out["loss"] = extra + (mean_gp[0] * self.horizon_discount.float()).sum()
         return model_out
 
     @torch.no_grad()

@@ -370,10 +370,10 @@ class NceLossFn(Function):
 
     @staticmethod
     def forward(ctx, q_rows, p_rows, negs, logit_scale, q_idx, p_idx, n_tok_dev, tok_cap, thres, want_logs, logs_out,
-                bucket_idx=None, n_buckets=0, log_group=-1, p_row_mask=None, share_rows=False, window=None):
+                bucket_idx=None, n_buckets=0, log_group=-1, p_row_mask=None, share_rows=False, window=None, ihn_beta=0.0):
         sv = ops.nce_fwd(q_rows, q_idx, p_rows, p_idx, negs, n_tok_dev, tok_cap, logit_scale.detach().view(1), thres,
                          want_logs=want_logs, for_backward=True, bucket_idx=bucket_idx, n_buckets=n_buckets,
-                         log_group=log_group, p_row_mask=p_row_mask, share_rows=share_rows, window=window)
+                         log_group=log_group, p_row_mask=p_row_mask, share_rows=share_rows, window=window, ihn_beta=ihn_beta)
         ctx.sv = sv
         ctx.save_for_backward(q_idx, p_idx, logit_scale)
         ctx.shapes = (q_rows.shape, p_rows.shape)
@@ -397,4 +397,4 @@ class NceLossFn(Function):
             w = w / sv.bucket_cnt.clamp_min(1.0)                      # d(mean)/d(loss_t) = 1 / count of the bucket
         d_negs, d_ls = ops.nce_bwd(sv, w, logit_scale.detach().view(1), q_idx, p_idx, dq, dp, want_negs=ctx.needs_input_grad[2])
         ctx.sv = None
-        return dq, dp, d_negs, d_ls.view(logit_scale.shape), None, None, None, None, None, None, None, None, None, None, None, None, None
+        return dq, dp, d_negs, d_ls.view(logit_scale.shape), None, None, None, None, None, None, None, None, None, None, None, None, None, None

@@ -246,7 +246,7 @@ class MultiHeadDecoding:
             self._tok_cache[key] = (q_all, p_all, o_all)
         return self._tok_cache[key]
 
-    def _grouped_loss(self, head_rows, e_rows, negs_g, valid_g, head_for_p, log_group, p_row_mask=None, q_all=None):
+    def _grouped_loss(self, head_rows, e_rows, negs_g, valid_g, head_for_p, log_group, p_row_mask=None, q_all=None, ihn_beta=0.0):
         """Sampled-softmax loss of G (token mask, negative pool) groups in ONE fused launch per kernel.
         valid_g [G,B,L,P] bool (offset fastest), negs_g [G,n_neg,D] bf16, head_for_p [G,P].  Returns (mean loss per (group, offset)
         [G,P] fp32, logs of `log_group` or None).  No host sync: tokens are compacted by scatter at fixed capacity
@@ -271,7 +271,7 @@ class MultiHeadDecoding:
         logs = {} if want_logs else None
         mean_p = NceLossFn.apply(head_rows, e_rows, negs_g, self.logit_scale, q_idx, p_idx, n_tok, cap,
                                  float(self.nce_thres), want_logs, logs, o_idx, P,
-                                 log_group if want_logs else -1, p_row_mask, share, window)                 # [G, P]
+                                 log_group if want_logs else -1, p_row_mask, share, window, float(ihn_beta))       # [G, P]
         out_logs = None
         if want_logs:                                   # all counters of the logged group in ONE masked reduction
             g = log_group

@@ -118,6 +118,102 @@ __global__ __launch_bounds__(256) void nce_dense_bwd_kernel(const float* __restr
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// REMI's interest-aware hard-negative loss over a dense logit chunk (reference model/IDNet/remi.py:203-288):
+//   l_j = scale s_j, false negatives (fix_j > thres) dropped;  A = logsumexp_j((beta + 1) l_j),  Z = logsumexp_j(beta l_j);
+//   log Neg = A - (Z - log n_neg)   (the mean runs over ALL n_neg sampled negatives, dropped ones counted);
+//   lse = logaddexp(l+, log Neg),  loss = lse - l+.   Counters as in nce_dense_fwd (standard logits).
+// Two passes per row (max, then shifted sums - the exact logsumexp of the reference, whatever the temperature); the row is
+// 32 KiB and comes back from L2.  Backward: g_j = w sigma_neg ((beta + 1) exp((beta + 1) l_j - A) - beta exp(beta l_j - Z)),
+// sigma_neg = exp(log Neg - lse): the bf16 tile the dQ / dN GEMMs of the wide path consume (same contract as nce_dense_bwd).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ihn_dense_fwd_kernel(const float* __restrict__ s, const float* __restrict__ fix, int64_t ld,
+                                                            int n_neg, const float* __restrict__ s_pos,
+                                                            const float* __restrict__ scale_p, float thres, float beta,
+                                                            const int32_t* __restrict__ n_live_p, int64_t row_base, int64_t rows,
+                                                            float* __restrict__ lse, float* __restrict__ log_num,
+                                                            float* __restrict__ log_imp, float* __restrict__ loss,
+                                                            int32_t* __restrict__ n_valid, int32_t* __restrict__ rank) {
+  const float scale = scale_p[0];
+  const int64_t n_live = n_live_p ? (int64_t)n_live_p[0] : row_base + rows;
+  WAVE_ROWS(rows) {
+    const float* sr = s + row * ld;
+    const float* fr = fix + row * ld;
+    const float sp = s_pos[row];
+    float mx = -INFINITY;
+    int nv = 0, rk = 0;
+    for (int j = lane; j < n_neg; j += 64) {
+      const bool keep = !(fr[j] > thres);
+      mx = keep ? fmaxf(mx, sr[j]) : mx;
+      nv += keep;
+      rk += keep && sr[j] > sp;
+    }
+    mx = wave_max(mx);
+    nv = wave_sum_i(nv);
+    rk = wave_sum_i(rk);
+    float t1 = 0.f, t0 = 0.f;
+    if (mx > -INFINITY) {
+      const float c1 = (beta + 1.0f) * scale * LOG2E, c0 = beta * scale * LOG2E;
+      for (int j = lane; j < n_neg; j += 64) {
+        if (!(fr[j] > thres)) {
+          const float d = sr[j] - mx;
+          t1 += __builtin_amdgcn_exp2f(d * c1);
+          t0 += __builtin_amdgcn_exp2f(d * c0);
+        }
+      }
+    }
+    t1 = wave_sum(t1);
+    t0 = wave_sum(t0);
+    if (lane == 0) {
+      const bool live = row_base + row < n_live;
+      const float lp = scale * sp;
+      float a = -INFINITY, z = -INFINITY, ln = -INFINITY;
+      if (mx > -INFINITY) {
+        a = (beta + 1.0f) * scale * mx + __logf(t1);
+        z = beta * scale * mx + __logf(t0);
+        ln = a - (z - __logf((float)n_neg));
+      }
+      const float hi = fmaxf(lp, ln);
+      const float l = hi + __logf(__expf(lp - hi) + (ln > -INFINITY ? __expf(ln - hi) : 0.f));
+      lse[row] = l;
+      log_num[row] = a;
+      log_imp[row] = z;
+      loss[row] = live ? l - lp : 0.f;
+      if (n_valid) n_valid[row] = live ? nv + 1 : 0;
+      if (rank) rank[row] = live ? rk : 0;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void ihn_dense_bwd_kernel(const float* __restrict__ s, const float* __restrict__ fix, int64_t ld,
+                                                            int n_neg, const float* __restrict__ lse,
+                                                            const float* __restrict__ log_num, const float* __restrict__ log_imp,
+                                                            const float* __restrict__ w, const float* __restrict__ scale_p,
+                                                            float thres, float beta, const int32_t* __restrict__ n_live_p,
+                                                            int64_t row_base, int64_t rows, bf16_t* __restrict__ g, int64_t ldg) {
+  const float scale = scale_p[0];
+  const int64_t n_live = n_live_p ? (int64_t)n_live_p[0] : row_base + rows;
+  WAVE_ROWS(rows) {
+    const float* sr = s + row * ld;
+    const float* fr = fix + row * ld;
+    bf16_t* gr = g + row * ldg;
+    const bool live = row_base + row < n_live;
+    const float a = log_num[row], z = log_imp[row];
+    const bool any = a > -INFINITY;
+    const float ln = any ? a - (z - __logf((float)n_neg)) : -INFINITY;
+    const float wn = (live && any) ? w[row] * __expf(ln - lse[row]) : 0.f;         // w sigma_neg
+    const float b1 = beta + 1.0f;
+    for (int j = lane; j < n_neg; j += 64) {
+      float v = 0.f;
+      if (wn != 0.f && !(fr[j] > thres)) {
+        const float l = scale * sr[j];
+        v = wn * (b1 * __expf(b1 * l - a) - beta * __expf(beta * l - z));
+      }
+      gr[j] = (bf16_t)v;
+    }
+  }
+}
+
 __device__ __forceinline__ bool item_ok(int item, const int32_t* tag_bits, int rb) {
   if (item == 0) return false;                                  // pad id (trainer.py:724)
   const int tb = tag_bits ? tag_bits[item] : (int)0x80000000;
@@ -192,6 +288,32 @@ extern "C" int mhr_nce_dense_bwd(const float* neg_logits, const float* fix_logit
   hipLaunchKernelGGL(nce_dense_bwd_kernel, dim3(mhr_grid_for(rows, 4)), dim3(256), 0, (hipStream_t)stream, neg_logits, fix_logits,
                      ld, n_neg, lse, w, scale_dev, thres, n_live_dev, row_base, rows, (bf16_t*)g_bf16, ldg);
   MHR_CHECK_LAUNCH("nce_dense_bwd");
+  return MHR_OK;
+}
+
+extern "C" int mhr_ihn_dense_fwd(const float* neg_logits, const float* fix_logits, int64_t ld, int n_neg, const float* s_pos,
+                                 const float* scale_dev, float thres, float beta, const int32_t* n_live_dev, int64_t row_base,
+                                 int64_t rows, float* lse, float* log_num, float* log_imp, float* loss, int32_t* n_valid,
+                                 int32_t* rank, void* stream) {
+  MHR_REQUIRE(neg_logits && fix_logits && s_pos && scale_dev && lse && log_num && log_imp && loss, "ihn_dense_fwd: null pointer");
+  MHR_REQUIRE(n_neg > 0 && ld >= n_neg && rows >= 0 && beta > 0.f, "ihn_dense_fwd: bad sizes / beta");
+  if (rows == 0) return MHR_OK;
+  hipLaunchKernelGGL(ihn_dense_fwd_kernel, dim3(mhr_grid_for(rows, 4)), dim3(256), 0, (hipStream_t)stream, neg_logits, fix_logits,
+                     ld, n_neg, s_pos, scale_dev, thres, beta, n_live_dev, row_base, rows, lse, log_num, log_imp, loss, n_valid, rank);
+  MHR_CHECK_LAUNCH("ihn_dense_fwd");
+  return MHR_OK;
+}
+
+extern "C" int mhr_ihn_dense_bwd(const float* neg_logits, const float* fix_logits, int64_t ld, int n_neg, const float* lse,
+                                 const float* log_num, const float* log_imp, const float* w, const float* scale_dev, float thres,
+                                 float beta, const int32_t* n_live_dev, int64_t row_base, int64_t rows, void* g_bf16, int64_t ldg,
+                                 void* stream) {
+  MHR_REQUIRE(neg_logits && fix_logits && lse && log_num && log_imp && w && scale_dev && g_bf16, "ihn_dense_bwd: null pointer");
+  MHR_REQUIRE(n_neg > 0 && ld >= n_neg && ldg >= n_neg && rows >= 0 && beta > 0.f, "ihn_dense_bwd: bad sizes / beta");
+  if (rows == 0) return MHR_OK;
+  hipLaunchKernelGGL(ihn_dense_bwd_kernel, dim3(mhr_grid_for(rows, 4)), dim3(256), 0, (hipStream_t)stream, neg_logits, fix_logits,
+                     ld, n_neg, lse, log_num, log_imp, w, scale_dev, thres, beta, n_live_dev, row_base, rows, (bf16_t*)g_bf16, ldg);
+  MHR_CHECK_LAUNCH("ihn_dense_bwd");
   return MHR_OK;
 }
 

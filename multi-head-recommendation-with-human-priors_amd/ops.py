@@ -457,7 +457,9 @@ class NceSaved:
                  "bucket_sum", "bucket_cnt", "u", "wide", "scale_dev", "cap_eff",
                  # query-row sharing (nce_shared.hip): row-level state of the streaming kernels + the maps between rows and tokens
                  "shared", "tok2row", "row_first", "n_row_dev", "row_cap", "fix_words", "fix_slot", "fix_any", "n_p_rows", "row_q",
-                 "window")
+                 "window",
+                 # REMI's interest-aware hard-negative loss (dense path): beta and the two saved log-sums per token
+                 "ihn_beta", "ihn_num", "ihn_imp")
 
 
 _ROW_IOTA = {}
@@ -560,7 +562,8 @@ def _nce_fwd_shared(sv, q_rows, p_rows, negs, logit_scale, thres, want_logs, buc
 
 
 def nce_fwd(q_rows, q_idx, p_rows, p_idx, negs, n_tok_dev, tok_cap, logit_scale, thres=0.99, want_logs=False,
-            for_backward=True, bucket_idx=None, n_buckets=0, log_group=-1, p_row_mask=None, share_rows=False, window=None):
+            for_backward=True, bucket_idx=None, n_buckets=0, log_group=-1, p_row_mask=None, share_rows=False, window=None,
+            ihn_beta=0.0):
     """Grouped sampled softmax.  q_rows/p_rows [*, D] (bf16 or f32, same dtype, shared by all groups);
     q_idx/p_idx [G, tok_cap] int32; negs [G, n_neg, D] bf16 normalised; n_tok_dev [G] int32.
     (1-D q_idx / 2-D negs are accepted as a single group.)  Saved tensors carry the leading group axis.
@@ -569,7 +572,9 @@ def nce_fwd(q_rows, q_idx, p_rows, p_idx, negs, n_tok_dev, tok_cap, logit_scale,
     share_rows: tokens with the same query row are neighbours in the lists (several prediction offsets of one position):
     the negative-pool products run once per distinct row (csrc/nce_shared.hip).  Same results.
     window = (tok_of_slot, L, P) (with share_rows): the lists are the compaction of (b, l, p) window slots with
-    p_idx = b (L + P) + l + 1 + p (token_compact(slot_map=True)): the backward then needs no per-token atomics."""
+    p_idx = b (L + P) + l + 1 + p (token_compact(slot_map=True)): the backward then needs no per-token atomics.
+    ihn_beta > 0: REMI's interest-aware hard-negative loss (remi.py:203-288) instead of the plain sampled softmax; runs on the
+    dense path (library GEMM + the ihn_dense epilogues of csrc/wide.hip) at every feature dim."""
     if q_idx.dim() == 1:
         q_idx, p_idx, negs, n_tok_dev = q_idx[None], p_idx[None], negs[None], n_tok_dev.view(1)
     _chk(negs, "negs", torch.bfloat16)
@@ -593,7 +598,8 @@ def nce_fwd(q_rows, q_idx, p_rows, p_idx, negs, n_tok_dev, tok_cap, logit_scale,
     sv = NceSaved()
     sv.shared = False
     sv.q_idx, sv.p_idx = q_idx, p_idx
-    sv.wide = D not in STREAM_DIMS            # feature dims beyond the register-stationary kernels: wide.py (library GEMMs)
+    sv.ihn_beta = float(ihn_beta)
+    sv.wide = D not in STREAM_DIMS or sv.ihn_beta > 0     # feature dims beyond the register-stationary kernels (and the IHN loss): wide.py
     sv.bucket_idx, sv.n_buckets, sv.bucket_sum, sv.bucket_cnt = bucket_idx, int(n_buckets), None, None
     if bucket_idx is not None:       # per-(group, bucket) loss sums and token counts come out of the finalize kernel
         _chk(bucket_idx, "bucket_idx", torch.int32)
@@ -605,6 +611,9 @@ def nce_fwd(q_rows, q_idx, p_rows, p_idx, negs, n_tok_dev, tok_cap, logit_scale,
     n_valid = torch.zeros(G, cap, dtype=torch.int32, device=dev) if want_logs else None
     rank = torch.zeros(G, cap, dtype=torch.int32, device=dev) if want_logs else None
     sv.s_pos = torch.empty(G, cap, dtype=torch.float32, device=dev)
+    if sv.ihn_beta > 0:
+        sv.ihn_num = torch.zeros(G, cap, dtype=torch.float32, device=dev)
+        sv.ihn_imp = torch.zeros(G, cap, dtype=torch.float32, device=dev)
     if share_rows and SHARE_ROWS and for_backward and not sv.wide:
         sv.negs = negs
         sv.n_tok_dev, sv.tok_cap, sv.cap, sv.thres, sv.dim, sv.n_neg, sv.groups = n_tok_dev, tok_cap, cap, float(thres), D, n_neg, G

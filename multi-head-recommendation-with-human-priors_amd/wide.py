@@ -40,7 +40,7 @@ def _scale(logit_scale):
 
 def _norm_rows(rows, idx):
     x = rows.float()[idx.long().clamp(0, rows.shape[0] - 1)]        # slots past the live count hold arbitrary indices
-    inv = 1.0 / x.norm(dim=-1)
+    inv = 1.0 / x.norm(dim=-1).clamp_min(1e-30)                       # (... possibly of all-zero rows: keep them finite)
     return (x * inv[:, None]).to(torch.bfloat16), inv
 
 
@@ -73,6 +73,13 @@ def nce_fwd_wide(sv, q_rows, p_rows, negs, logit_scale, want_logs, bucket_idx, l
             c1 = min(cap_eff, c0 + CHUNK)
             s = _mm(qn[c0:c1], ngt)                               # cos(query, negative)
             fx = _mm(pn[c0:c1], ngt)                              # cos(target, negative): false-negative test
+            if sv.ihn_beta > 0:                                   # REMI's hard-negative loss: same chunks, its own epilogue
+                lib.call("mhr_ihn_dense_fwd", s.data_ptr(), fx.data_ptr(), s.shape[1], sv.n_neg, s_pos[c0:c1].data_ptr(),
+                         scale.data_ptr(), float(thres), float(sv.ihn_beta), sv.n_tok_dev[g:g + 1].data_ptr(), c0, c1 - c0,
+                         sv.lse[g, c0:c1].data_ptr(), sv.ihn_num[g, c0:c1].data_ptr(), sv.ihn_imp[g, c0:c1].data_ptr(),
+                         loss[g, c0:c1].data_ptr(), n_valid[g, c0:c1].data_ptr() if want_logs else 0,
+                         rank[g, c0:c1].data_ptr() if want_logs else 0, st)
+                continue
             lib.call("mhr_nce_dense_fwd", s.data_ptr(), fx.data_ptr(), s.shape[1], sv.n_neg, s_pos[c0:c1].data_ptr(),
                      scale.data_ptr(), float(thres), sv.n_tok_dev[g:g + 1].data_ptr(), c0, c1 - c0, sv.lse[g, c0:c1].data_ptr(),
                      loss[g, c0:c1].data_ptr(), n_valid[g, c0:c1].data_ptr() if want_logs else 0,
@@ -103,9 +110,15 @@ def nce_bwd_wide(sv, w_tok, logit_scale, dq_rows, dp_rows, d_negs, d_logit_scale
             s = _mm(qn, ngt)
             fx = _mm(pn, ngt)
             gmat = torch.empty(c1 - c0, sv.n_neg, dtype=torch.bfloat16, device=dev)
-            lib.call("mhr_nce_dense_bwd", s.data_ptr(), fx.data_ptr(), s.shape[1], sv.n_neg, sv.lse[g, c0:c1].data_ptr(),
-                     w_tok[g, c0:c1].data_ptr(), scale.data_ptr(), float(thres), sv.n_tok_dev[g:g + 1].data_ptr(), c0, c1 - c0,
-                     gmat.data_ptr(), sv.n_neg, st)
+            if sv.ihn_beta > 0:
+                lib.call("mhr_ihn_dense_bwd", s.data_ptr(), fx.data_ptr(), s.shape[1], sv.n_neg, sv.lse[g, c0:c1].data_ptr(),
+                         sv.ihn_num[g, c0:c1].data_ptr(), sv.ihn_imp[g, c0:c1].data_ptr(), w_tok[g, c0:c1].data_ptr(),
+                         scale.data_ptr(), float(thres), float(sv.ihn_beta), sv.n_tok_dev[g:g + 1].data_ptr(), c0, c1 - c0,
+                         gmat.data_ptr(), sv.n_neg, st)
+            else:
+                lib.call("mhr_nce_dense_bwd", s.data_ptr(), fx.data_ptr(), s.shape[1], sv.n_neg, sv.lse[g, c0:c1].data_ptr(),
+                         w_tok[g, c0:c1].data_ptr(), scale.data_ptr(), float(thres), sv.n_tok_dev[g:g + 1].data_ptr(), c0, c1 - c0,
+                         gmat.data_ptr(), sv.n_neg, st)
             del s, fx
             dq_raw = _mm(gmat, ng)                                                               # sum_j g_ij n_j
             if d_negs is not None:

@@ -766,3 +766,52 @@ def test_heads_residual_fwd_bwd(ops, B, L, H, D):
     ref.backward(d_out)
     assert float((dz.float().cpu() - zr.grad).abs().max()) <= 2 ** -7 * float(zr.grad.abs().max())
     assert rel_err(dx.cpu(), xr.grad) < 1e-6
+
+
+@pytest.mark.parametrize("D,n_tok,n_neg,beta", [(64, 150, 96, 1.0), (256, 70, 513, 0.5)])
+def test_ihn_loss_fwd_bwd(ops, D, n_tok, n_neg, beta):
+    """REMI's interest-aware hard-negative loss (remi.py:203-288) through ops.nce_fwd(ihn_beta=...) - dense logit chunks + the
+    ihn_dense epilogue kernels - against the oracle restatement on the same bf16-rounded operands: loss 1e-4, counters,
+    gradients of queries / targets / negatives / temperature; false negatives planted."""
+    from oracle import remi_oracle as RO
+    g = torch.Generator().manual_seed(31 + D)
+    n_src = 2 * n_tok
+    q_rows = torch.randn(n_src, D, generator=g) * 2
+    p_rows = torch.randn(n_src, D, generator=g)
+    q_idx = torch.randint(0, n_src, (n_tok,), generator=g).int()
+    p_idx = torch.randint(0, n_src, (n_tok,), generator=g).int()
+    negs = bf(HO.l2n(torch.randn(n_neg, D, generator=g)))
+    for t in range(0, n_tok, 6):
+        negs[(t * 7) % n_neg] = bf(HO.l2n(p_rows[p_idx[t]].float()[None]))[0]
+    ls = torch.tensor(math.log(20.0))
+    cap = (n_tok + 9 + 31) // 32 * 32
+    qi, pi = torch.zeros(cap, dtype=torch.int32), torch.zeros(cap, dtype=torch.int32)
+    qi[:n_tok], pi[:n_tok] = q_idx, p_idx
+    ntd = torch.tensor([n_tok], dtype=torch.int32).cuda()
+    lsd = ls.reshape(1).cuda()
+    sv = ops.nce_fwd(dev(q_rows), dev(qi), dev(p_rows), dev(pi), dev(negs), ntd, cap, lsd, 0.99, want_logs=True, ihn_beta=beta)
+    assert sv.wide and sv.ihn_beta == beta
+
+    def r(t):
+        return t + (bf(t).float() - t).detach()
+    q = q_rows[q_idx.long()].clone().requires_grad_(True)
+    p = p_rows[p_idx.long()].clone().requires_grad_(True)
+    nn_ = negs.float().clone().requires_grad_(True)
+    lsr = ls.clone().requires_grad_(True)
+    loss, logits = RO.ihn_loss(r(HO.l2n(q)), r(HO.l2n(p)), nn_, lsr, 0.99, beta, normalized=True)   # the kernel's operand precision
+    np.testing.assert_allclose(sv.loss.cpu().numpy()[0, :n_tok], loss.detach().numpy(), rtol=1e-4, atol=1e-4)
+    keep = logits[:, 1:] > torch.finfo(torch.float32).min / 100
+    assert keep.sum() < keep.numel()
+    np.testing.assert_array_equal(sv.n_valid.cpu().numpy()[0, :n_tok], (keep.sum(-1) + 1).numpy())
+    w = torch.rand(cap, generator=g)
+    w[n_tok:] = 0
+    (loss * w[:n_tok]).sum().backward()
+    dq_rows, dp_rows = torch.zeros(n_src, D).cuda(), torch.zeros(n_src, D).cuda()
+    dn, dls = ops.nce_bwd(sv, dev(w), lsd, dev(qi), dev(pi), dq_rows, dp_rows)
+    torch.cuda.synchronize()
+    dq_ref = torch.zeros(n_src, D).index_add_(0, q_idx.long(), q.grad)
+    dp_ref = torch.zeros(n_src, D).index_add_(0, p_idx.long(), p.grad)
+    for name, got, ref in (("dq", dq_rows.cpu(), dq_ref), ("dp", dp_rows.cpu(), dp_ref), ("dneg", dn.cpu()[0], nn_.grad)):
+        gs = float(ref.abs().max())
+        assert float((got - ref).abs().max()) < 2e-2 * gs, (name, float((got - ref).abs().max()), gs)
+    assert abs(float(dls.cpu()) - float(lsr.grad)) < 2e-2 * abs(float(lsr.grad)) + 1e-4

@@ -364,6 +364,46 @@ def test_fit_and_evaluate_on_the_device_batchers(rec):
     assert after[key]["recall@20"] > before[key]["recall@20"] + 0.1, (before[key], after[key])
 
 
+def test_remi_vs_reference_golden(rec):
+    """REMI (ComiRec + routing regulariser + interest-aware hard-negative loss through the ihn_dense kernels)
+    against the reference's own remi.py outputs: loss, the regulariser, top-k logs, gradients, predict scores."""
+    from REC.config.configurator import Config
+    from REC.utils import get_model
+    g = load_golden("remi_nce")
+    c = json.loads(str(g["cfg/json"]))
+    c["int_to_category"] = {int(k): v for k, v in c["int_to_category"].items()}
+    model = get_model("REMI")(Config(config_dict=c), FakeData(c))
+    sd = {k[2:]: torch.from_numpy(np.array(v)) for k, v in g.items() if k.startswith("w/")}
+    model.load_state_dict(sd, strict=True)
+    model = model.cuda().train()
+    assert model._ihn_beta == 1.0 and model.lambda_rr == c["lambda_rr"]
+    batch = tuple(torch.from_numpy(g["in/" + k]).cuda() for k in ("items", "neg_items", "mask")) + (None,)
+    out = model(batch)
+    assert abs(float(out["loss"]) - float(g["out/loss"])) <= 2e-2 * abs(float(g["out/loss"])) + 2e-3
+    assert abs(float(out["rr_loss"]) - float(g["out/rr_loss"])) <= 6e-2 * float(g["out/rr_loss"])     # bf16 encoder under a peaky routing
+    for k, v in g.items():
+        if k.startswith("out/nce_top") or k == "out/nce_samples":
+            assert abs(float(out[k[4:]]) - float(v)) <= 0.15 * max(1.0, abs(float(v))), k
+    out["loss"].backward()
+    dense = model.finish_sparse_grad().to_dense().cpu().numpy()
+    ref = g["grad/item_embedding.weight"]
+    assert np.abs(dense - ref).max() < 8e-2 * np.abs(ref).max()
+    named = dict(model.named_parameters())
+    for k, v in g.items():
+        if k.startswith("grad/") and k != "grad/item_embedding.weight":
+            got = named[k[5:]].grad
+            assert got is not None, k
+            # (the fixture's routing scores are scaled x120 to make the regulariser visible: bf16 noise of the encoder is amplified
+            #  accordingly - 0.12 of max-abs here against 0.06 for ComiRec's x20)
+            assert float((got.cpu() - torch.from_numpy(v)).abs().max()) < 1.2e-1 * float(np.abs(v).max()) + 1e-5, k
+    model.eval()
+    seq = torch.from_numpy(g["in/item_seq"]).cuda()
+    feat = model.compute_item_all()
+    np.testing.assert_allclose(feat.cpu().numpy(), g["out/item_feature"], rtol=1e-5, atol=1e-6)
+    scores, _, _, _ = model.predict(seq, None, feat, None, None)
+    assert np.abs(scores.cpu().numpy() - g["out/scores"]).max() < 2e-2
+
+
 def test_comirec_vs_reference_golden(rec):
     """ComiRec baseline on the shared kernels against the reference's own comirec.py outputs."""
     from REC.config.configurator import Config
