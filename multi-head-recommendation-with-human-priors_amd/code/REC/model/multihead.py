@@ -302,23 +302,17 @@ class MultiHeadDecoding:
             pools += list(range(self.num_prior_head))
         return pools
 
-    def _multihead_loss(self, out, e_rows, negs_pools, pools, mask, pos_tags):
-        """Everything of the training forward after the sequence encoder (reference hstu.py:648-872 / hllm.py:506-763).
-        out [B,L,D] fp32 encoder output; e_rows [B*(L+P), D] fp32 target-item rows; negs_pools [len(pools), n_pool, D]
-        bf16 L2-normalised; mask [B,L+P] bool; pos_tags [B,L+P,C]."""
-        dev = out.device
-        B = out.shape[0]
-        L, P, D = self.max_seq_length, self.pred_len, self._head_dim
+    def _loss_plan(self, negs_pools, pools, mask, pos_tags):
+        """Everything of the loss that depends on the BATCH only, not on the encoder output: the token masks of the groups
+        (one group per (token mask, head assignment, negative pool): the nce branch and every prior category), their heads /
+        pools / weights, the rows of the target table each group can point at."""
+        dev = mask.device
+        L, P = self.max_seq_length, self.pred_len
         S, C = self.num_segment_head, self.num_prior_head
         additive = self.head_interaction == 'additive'
         pool_slot = {p: i for i, p in enumerate(pools)}
-        head_embs = self._heads(out).permute(0, 2, 1, 3).contiguous()     # [B,H,L,D]
-        head_rows = head_embs.view(-1, D)
-
         idx = torch.arange(L, device=dev)[:, None] + 1 + torch.arange(P, device=dev)[None, :]      # [L,P]: target of (l, p)
         base_valid = mask[:, :L, None] & mask[:, idx]                                              # [B,L,P]
-
-        # one group per (token mask, head assignment, negative pool): the nce branch and every prior category
         groups = []                       # (valid [B,L,P], head_for_p [P], pool slot, weight, kind, index)
         row_masks = []                    # per group: the target rows (b, j) its tokens can point at (a superset is enough)
         if self.loss == 'nce' or (self.loss == 'prior' and additive):
@@ -337,13 +331,29 @@ class MultiHeadDecoding:
                 pool = pool_slot[c] if self.neg_sample_by_cat else pool_slot[pools[0]]
                 groups.append((valid, head_for_p, pool, float(self.prior_loss_weight[c]), 'prior', c))
                 row_masks.append(mask if self.pos_sample_mix_ratio > 0.0 else mask & pos_tags[..., c].bool())
-        valid_g = torch.stack([g[0] for g in groups])
-        head_for_p_g = torch.stack([g[1] for g in groups])
         slots = [g[2] for g in groups]
-        negs_g = negs_pools if slots == list(range(len(pools))) else negs_pools[torch.tensor(slots, device=dev)]
-        # reference: top-k logs come from the nce branch, then are overwritten by prior category 0 (hstu.py:723, 863)
-        log_group = max(i for i, g in enumerate(groups) if g[4] == 'nce' or g[5] == 0)
-        p_row_mask = torch.stack(row_masks).reshape(len(groups), -1)
+        negs_g = negs_pools if slots == list(range(len(pools))) else negs_pools[self._const(slots, dev, torch.int64)]
+        return dict(groups=groups, tag_win=tag_win, valid_g=torch.stack([g[0] for g in groups]),
+                    head_for_p_g=torch.stack([g[1] for g in groups]), negs_g=negs_g.contiguous(),
+                    # reference: top-k logs come from the nce branch, then are overwritten by prior category 0 (hstu.py:723, 863)
+                    log_group=max(i for i, g in enumerate(groups) if g[4] == 'nce' or g[5] == 0),
+                    p_row_mask=torch.stack(row_masks).reshape(len(groups), -1))
+
+    def _multihead_loss(self, out, e_rows, negs_pools, pools, mask, pos_tags, plan=None):
+        """Everything of the training forward after the sequence encoder (reference hstu.py:648-872 / hllm.py:506-763).
+        out [B,L,D] fp32 encoder output; e_rows [B*(L+P), D] fp32 target-item rows; negs_pools [len(pools), n_pool, D]
+        bf16 L2-normalised; mask [B,L+P] bool; pos_tags [B,L+P,C]; plan: `_loss_plan(...)` when the caller built it early."""
+        dev = out.device
+        B = out.shape[0]
+        L, P, D = self.max_seq_length, self.pred_len, self._head_dim
+        S, C = self.num_segment_head, self.num_prior_head
+        additive = self.head_interaction == 'additive'
+        head_embs = self._heads(out).permute(0, 2, 1, 3).contiguous()     # [B,H,L,D]
+        head_rows = head_embs.view(-1, D)
+        if plan is None:
+            plan = self._loss_plan(negs_pools, pools, mask, pos_tags)
+        groups, tag_win, valid_g, head_for_p_g = plan["groups"], plan["tag_win"], plan["valid_g"], plan["head_for_p_g"]
+        negs_g, log_group, p_row_mask = plan["negs_g"], plan["log_group"], plan["p_row_mask"]
         mean_gp, logs = self._grouped_loss(head_rows, e_rows, negs_g.contiguous(), valid_g, head_for_p_g, log_group, p_row_mask)
         per_gp = mean_gp * self.horizon_discount.float()[None, :] * self._const([g[3] for g in groups], dev, torch.float32)[:, None]
 

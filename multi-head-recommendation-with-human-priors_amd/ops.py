@@ -59,6 +59,8 @@ def _stream():
     return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
 
 
+
+
 def _chk(t, name, dtype=None):
     if not t.is_cuda:
         raise RuntimeError(f"{name}: expected a GPU tensor; the MI355X path has no CPU fallback")
@@ -484,6 +486,33 @@ def _row_maps(q_idx, n_tok_dev, cap, row_cap):
     return r_q, tok2row, r_first, n_row
 
 
+def _fix_bits_launch(p_rows, negs, n_neg, D, G, thres, p_row_mask):
+    dev = negs.device
+    n_p_rows = p_rows.shape[0]
+    rp_pad = (n_p_rows + 255) // 256 * 256
+    n_tiles = (n_neg + 31) // 32
+    fix_words = torch.empty(G, n_tiles, rp_pad, dtype=torch.int32, device=dev)
+    fix_any = torch.zeros(G, rp_pad, dtype=torch.int32, device=dev)
+    row_list = n_list = slot_of_row = None
+    if p_row_mask is not None:
+        assert p_row_mask.shape == (G, n_p_rows)
+        key = (G, n_p_rows, str(dev))
+        if key not in _ROW_IOTA:
+            ar = torch.arange(n_p_rows, dtype=torch.int32, device=dev)
+            _ROW_IOTA[key] = (ar[None].expand(G, -1).contiguous(), ar)
+        iota_g, iota = _ROW_IOTA[key]
+        row_list, _, _, n_list = token_compact(p_row_mask.contiguous(), iota_g, iota, iota, tok_cap=rp_pad)
+        slot_of_row = torch.zeros(G, n_p_rows, dtype=torch.int32, device=dev)
+    lib.call("mhr_nce_fix_bits", p_rows.data_ptr(), _dt(p_rows), n_p_rows, negs.data_ptr(), n_neg, D, G, float(thres),
+             fix_words.data_ptr(), _ptr(row_list), _ptr(n_list), _ptr(slot_of_row), fix_any.data_ptr(), _stream())
+    return fix_words, fix_any, slot_of_row, (row_list, n_list)
+
+
+def _fix_bits_tables(p_rows, negs, n_neg, D, G, thres, p_row_mask):
+    tabs = _fix_bits_launch(p_rows, negs, n_neg, D, G, thres, p_row_mask)
+    return tabs[0], tabs[1], tabs[2]
+
+
 def _nce_fwd_shared(sv, q_rows, p_rows, negs, logit_scale, thres, want_logs, bucket_idx, n_buckets, log_group, p_row_mask, loss,
                     window=None):
     """Query-row sharing (csrc/nce_shared.hip): the streaming kernels see each distinct query row once."""
@@ -498,20 +527,7 @@ def _nce_fwd_shared(sv, q_rows, p_rows, negs, logit_scale, thres, want_logs, buc
     n_tiles = (n_neg + 31) // 32
     st = _stream()
     # (1) the real false-negative bit table, per target row
-    fix_words = torch.empty(G, n_tiles, rp_pad, dtype=torch.int32, device=dev)
-    fix_any = torch.zeros(G, rp_pad, dtype=torch.int32, device=dev)
-    row_list = n_list = slot_of_row = None
-    if p_row_mask is not None:
-        assert p_row_mask.shape == (G, n_p_rows)
-        key = (G, n_p_rows, str(dev))
-        if key not in _ROW_IOTA:
-            ar = torch.arange(n_p_rows, dtype=torch.int32, device=dev)
-            _ROW_IOTA[key] = (ar[None].expand(G, -1).contiguous(), ar)
-        iota_g, iota = _ROW_IOTA[key]
-        row_list, _, _, n_list = token_compact(p_row_mask.contiguous(), iota_g, iota, iota, tok_cap=rp_pad)
-        slot_of_row = torch.zeros(G, n_p_rows, dtype=torch.int32, device=dev)
-    lib.call("mhr_nce_fix_bits", p_rows.data_ptr(), _dt(p_rows), n_p_rows, negs.data_ptr(), n_neg, D, G, float(thres),
-             fix_words.data_ptr(), _ptr(row_list), _ptr(n_list), _ptr(slot_of_row), fix_any.data_ptr(), st)
+    fix_words, fix_any, slot_of_row = _fix_bits_tables(p_rows, negs, n_neg, D, G, thres, p_row_mask)
     # (2) the fused streaming forward over the ROWS, suppression off (an all-zero bit table that is never written); its
     #     positive is the target of the row's first token, so the log counters of offset-0 tokens come out of this launch
     zkey = (G, n_tiles, n_p_rows, str(dev))
