@@ -123,6 +123,11 @@ class FusedAdamW:
                           self.eps, self.weight_decay)
         elif self.table.grad is not None:                                # dense_embedding_grad mode
             g = self.table.grad
+            if self.lazy:                      # a dense step in between lazy ones: everything up to date first, and after it
+                self.step_count -= 1
+                self.flush_table()
+                self.step_count += 1
+                self.last_step.fill_(self.step_count)
             D.allreduce_mean_(g)
             ops.adam_rows(self.table, self.t_m, self.t_v, g, None, self.step_count, lr, 1.0, self.betas, self.eps,
                           self.weight_decay)
