@@ -259,3 +259,72 @@ def test_embedding_paths_full_table(ops):
     ops.adam_rows(table, m, v, out_rows, none, 1, 0.0, 1.0)
     torch.cuda.synchronize()
     assert torch.equal(table, w0) and float(m.abs().max()) == 0.0 and float(v.abs().max()) == 0.0
+
+
+def test_lazy_table_adam_full_table(ops):
+    """The lazy table update at cfg1's table size (453 938 x 256 rows, three 465 MB buffers per optimizer) against the dense
+    kernel on identical gradients: 5 steps of ~59 k touched ids (Zipf-like duplicates), catch-up reads in between, one flush -
+    bitwise equal tables and moments."""
+    import os
+    import sys
+    from conftest import ROOT
+    code = os.path.join(ROOT, "multi-head-recommendation-with-human-priors_amd", "code")
+    if code not in sys.path:
+        sys.path.insert(0, code)
+    from mhr_amd.optim import FusedAdamW
+    from REC.model.hstu_functional import SparseRowGrad
+    dev = torch.device("cuda", 0)
+
+    class Tiny(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.item_embedding = torch.nn.Embedding(N_ITEMS, D)
+            self.other = torch.nn.Parameter(torch.zeros(8))
+            self.sparse_grad = None
+
+    torch.manual_seed(2)
+    m_l = Tiny().to(dev)
+    m_d = Tiny().to(dev)
+    m_d.load_state_dict(m_l.state_dict())
+    o_l, o_d = FusedAdamW(m_l, lr=1e-4, lazy_table=True), FusedAdamW(m_d, lr=1e-4, lazy_table=False)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    slot_l = torch.full((N_ITEMS,), -1, dtype=torch.int32, device=dev)
+    slot_d = torch.full((N_ITEMS,), -1, dtype=torch.int32, device=dev)
+    for t in range(5):
+        ids = ((torch.rand(59392, device=dev, generator=g) ** 3) * (N_ITEMS - 2)).long() + 1
+        o_l.catch_up(ids)
+        assert torch.equal(m_l.item_embedding.weight[ids[:4096]], m_d.item_embedding.weight[ids[:4096]])
+        rows = torch.randn(ids.numel(), D, device=dev, generator=g)
+        sorted_ids, perm = torch.sort(ids)
+        out_rows = torch.zeros(ids.numel(), D, device=dev)
+        ops.sparse_rows_segment_sum(sorted_ids, perm, rows, None, None, 0, 0, out_rows, slot_l)
+        slot_d.copy_(slot_l)
+        m_l.sparse_grad = SparseRowGrad(sorted_ids, out_rows, slot_l, N_ITEMS)
+        m_d.sparse_grad = SparseRowGrad(sorted_ids, out_rows.clone(), slot_d, N_ITEMS)
+        for o in (o_l, o_d):
+            o.param_groups[0]["lr"] = 1e-4 * (1 + t)
+            o.step()
+            o.zero_grad()
+    assert int((o_l.last_step < o_l.step_count).sum()) > N_ITEMS // 2          # most of the table is lagging
+    o_l.flush_table()
+    torch.cuda.synchronize()
+    assert torch.equal(m_l.item_embedding.weight, m_d.item_embedding.weight)
+    assert torch.equal(o_l.t_m, o_d.t_m) and torch.equal(o_l.t_v, o_d.t_v)
+
+
+def test_heads_residual_full_size(ops):
+    """cfg1's head tensor ([128, 4, 200, 256] fp32): the fused SiLU + residual + layout kernel and its backward vs torch."""
+    B, L, H = 128, 200, 4
+    g = torch.Generator(device="cuda").manual_seed(4)
+    x = torch.randn(B * L, D, device="cuda", generator=g)
+    z = (torch.randn(B * L, H * D, device="cuda", generator=g) * 2).bfloat16()
+    out = ops.heads_residual_fwd(x, z, B, L, H)
+    zr = z.float().requires_grad_(True)
+    xr = x.clone().requires_grad_(True)
+    ref = (xr.view(B, L, 1, D) + torch.nn.functional.silu(zr.view(B, L, H, D))).permute(0, 2, 1, 3)
+    assert float((out - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    d_out = torch.randn(B, H, L, D, device="cuda", generator=g)
+    dz, dx = ops.heads_residual_bwd(d_out, z, B, L, H)
+    ref.backward(d_out)
+    assert float((dz.float() - zr.grad).abs().max()) <= 2 ** -7 * float(zr.grad.abs().max())
+    assert float((dx - xr.grad).abs().max()) <= 1e-5 * float(xr.grad.abs().max())
