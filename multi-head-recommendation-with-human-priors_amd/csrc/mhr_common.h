@@ -47,11 +47,19 @@ static inline int mhr_grid_for(int64_t work_items, int per_block, int max_blocks
 __device__ __forceinline__ float bf2f(bf16_t x) { return (float)x; }
 __device__ __forceinline__ bf16_t f2bf(float x) { return (bf16_t)x; }   // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// sigmoid by one v_exp_f32 and one v_rcp_f32 (1 ulp; an IEEE division costs a Newton step and a fix-up on top)
+__device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float silu_f(float x) { return x * sigmoid_f(x); }
 // d/dx silu(x) = sig * (1 + x * (1 - sig))
 __device__ __forceinline__ float dsilu_f(float x) {
-  float s = 1.0f / (1.0f + __expf(-x));
+  const float s = sigmoid_f(x);
   return s * (1.0f + x * (1.0f - s));
+}
+// silu and its derivative from ONE sigmoid
+__device__ __forceinline__ void silu_both(float x, float& y, float& dy) {
+  const float s = sigmoid_f(x);
+  y = x * s;
+  dy = s * (1.0f + x * (1.0f - s));
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

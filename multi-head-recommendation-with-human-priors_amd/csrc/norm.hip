@@ -349,9 +349,10 @@ __global__ __launch_bounds__(256) void ln_gate_bwd_kernel(const GT* __restrict__
           }
           float xh = (av.v[i][k] - mean) * rstd;
           float up = uv.v[i][k];
-          float su = silu_f(up);
+          float su, dsu;
+          silu_both(up, su, dsu);             // one sigmoid for both
           float gy = gk * su;                 // grad w.r.t. LN(a)
-          uv.v[i][k] = gk * xh * dsilu_f(up);  // grad w.r.t. pre-activation u
+          uv.v[i][k] = gk * xh * dsu;          // grad w.r.t. pre-activation u
           av.v[i][k] = xh;
           g.v[i][k] = gy;
           s1 += gy;
