@@ -336,7 +336,9 @@ int mhr_nce_bwd_negs(const void* qn, const void* negs, const uint32_t* supp, int
  *   [n_groups, tok_cap(, dim)];  row_first [n_groups, row_cap] int32: first token of row r (entry n_row = n_tok).
  * mhr_nce_fix_bits: the false-negative bit table of mhr_nce_fwd as a launch of its own (same arguments), plus
  *   fix_any [n_groups, round_up(n_p_rows, 256)] int32 (caller zeroes): != 0 where a target row has any suppressed negative.
- * mhr_nce_shared_fwd_tokens: per token: pn_out = bf16(target / |target|), p_inv, s_pos = qn_row . pn,
+ * The normalised targets are a property of the TARGET ROW: pn_rows [n_p_rows, dim] bf16 = bf16(p_rows / |p_rows|) and p_inv
+ *   [n_p_rows] f32 (mhr_l2norm_rows, once per step) are shared by all tokens and groups; `pn` / `p_inv` below are these tables.
+ * mhr_nce_shared_fwd_tokens: per token: s_pos = qn_row . pn_rows[p_idx],
  *   sum_tok = sum_row - sum over the token's suppressed negatives of exp(scale (s_j - 1)); with log counters:
  *   n_valid_tok = n_valid_row - #suppressed, rank_tok = rank_row - #suppressed with s_j > s_pos (rank_row must have been
  *   counted against this token's target: the caller gives the row kernel the target of the row's first token).
@@ -350,12 +352,12 @@ int mhr_nce_bwd_negs(const void* qn, const void* negs, const uint32_t* supp, int
 int mhr_nce_fix_bits(const void* p_rows, int io_dtype, int64_t n_p_rows, const void* negs, int n_neg, int dim,
                      int n_groups, float thres, uint32_t* fix_words, const int32_t* fix_row_list,
                      const int32_t* fix_n_rows, int32_t* fix_slot_of_row, int32_t* fix_any, void* stream);
-int mhr_nce_shared_fwd_tokens(const void* p_rows, int io_dtype, int64_t n_p_rows, const int32_t* p_idx,
+int mhr_nce_shared_fwd_tokens(const void* pn_rows, int64_t n_p_rows, const int32_t* p_idx,
                               const int32_t* tok2row, int n_groups, const int32_t* n_tok_dev, int tok_cap,
                               int row_cap, const void* qn_row, const float* sum_row, const int32_t* n_valid_row,
                               const int32_t* rank_row, const void* negs, int n_neg, int dim,
                               const float* logit_scale_dev, const uint32_t* fix_words,
-                              const int32_t* fix_slot_of_row, const int32_t* fix_any, void* pn_out, float* p_inv,
+                              const int32_t* fix_slot_of_row, const int32_t* fix_any,
                               float* s_pos, float* sum_tok, int32_t* n_valid_tok, int32_t* rank_tok, void* stream);
 int mhr_nce_shared_bwd_tokens(const void* qn_row, const float* u_row, const float* q_inv_row, int row_cap,
                               const int32_t* tok2row, const void* pn, int dim, int n_groups,

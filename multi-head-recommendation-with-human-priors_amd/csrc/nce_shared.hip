@@ -34,9 +34,6 @@ __device__ __forceinline__ float clamp_scale(const float* logit_scale_dev) {
   return __expf(ls);
 }
 
-template <typename IT>
-__device__ __forceinline__ float ld(const IT* p) { return (float)*p; }
-
 // Visits the suppressed negatives of one target row (wave-uniform control flow): f(j) for every set bit of the row's
 // column of the bit table.  fixw: [n_tiles, n_rows_pad] words of this group, bit b of word [tile, slot] = negative 32 tile + b.
 template <typename F>
@@ -63,19 +60,18 @@ __device__ __forceinline__ void for_each_hit(const uint32_t* __restrict__ fixw, 
 // ------------------------------------------------------------------------------------------
 // forward, per token: normalised target, s+, the row's sum minus this token's suppressed negatives, log counters
 // ------------------------------------------------------------------------------------------
-template <typename IT>
 __global__ __launch_bounds__(256) void shared_tok_fwd_kernel(
-    const IT* __restrict__ p_rows, int n_p_rows, const int32_t* __restrict__ p_idx, const int32_t* __restrict__ tok2row,
+    const bf16_t* __restrict__ pn_rows, int n_p_rows, const int32_t* __restrict__ p_idx, const int32_t* __restrict__ tok2row,
     const int32_t* __restrict__ n_tok_dev, int tok_cap, int row_cap, const bf16_t* __restrict__ qn_row,
     const float* __restrict__ sum_row, const int32_t* __restrict__ n_valid_row, const int32_t* __restrict__ rank_row,
     const bf16_t* __restrict__ negs, int n_neg, int dim, const float* __restrict__ logit_scale_dev,
     const uint32_t* __restrict__ fixw, int n_rows_pad, const int32_t* __restrict__ slot_of_row,
-    const int32_t* __restrict__ fix_any, bf16_t* __restrict__ pn_out, float* __restrict__ p_inv, float* __restrict__ s_pos,
+    const int32_t* __restrict__ fix_any, float* __restrict__ s_pos,
     float* __restrict__ sum_tok, int32_t* __restrict__ n_valid_tok, int32_t* __restrict__ rank_tok) {
   const int n_tiles = (n_neg + 31) >> 5;
   {
     const int64_t grp = blockIdx.z, to = grp * tok_cap, ro = grp * row_cap;
-    p_idx += to; tok2row += to; n_tok_dev += grp; pn_out += to * dim; p_inv += to; s_pos += to; sum_tok += to;
+    p_idx += to; tok2row += to; n_tok_dev += grp; s_pos += to; sum_tok += to;
     qn_row += ro * dim; sum_row += ro;
     if (n_valid_row) { n_valid_row += ro; n_valid_tok += to; }
     if (rank_row) { rank_row += ro; rank_tok += to; }
@@ -101,12 +97,12 @@ __global__ __launch_bounds__(256) void shared_tok_fwd_kernel(
     }
 #pragma unroll
     for (int b = 0; b < TB; ++b) {
-      const IT* ps = p_rows + (int64_t)prr[b] * dim;
+      const bf16_t* ps = pn_rows + (int64_t)prr[b] * dim;       // the target's normalised row: a property of the target row, shared by its tokens
       const bf16_t* qs = qn_row + (int64_t)rr[b] * dim;
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
         const int d = c * 64 + lane;
-        pv[b][c] = d < dim ? ld<IT>(ps + d) : 0.f;
+        pv[b][c] = d < dim ? (float)ps[d] : 0.f;
         qv[b][c] = d < dim ? (float)qs[d] : 0.f;
       }
     }
@@ -115,19 +111,9 @@ __global__ __launch_bounds__(256) void shared_tok_fwd_kernel(
       const int tk = t0 + b;
       if (tk >= n_tok) break;
       const int r = rr[b], pr = prr[b];
-      float ss = 0.f;
-#pragma unroll
-      for (int c = 0; c < NC; ++c) ss += pv[b][c] * pv[b][c];
-      ss = wave_sum(ss);
-      const float inv = 1.0f / sqrtf(ss);
       float sp = 0.f;
 #pragma unroll
-      for (int c = 0; c < NC; ++c) {
-        const int d = c * 64 + lane;
-        const bf16_t pb = (bf16_t)(pv[b][c] * inv);
-        if (d < dim) pn_out[(int64_t)tk * dim + d] = pb;
-        sp += qv[b][c] * (float)pb;
-      }
+      for (int c = 0; c < NC; ++c) sp += qv[b][c] * pv[b][c];
       sp = wave_sum(sp);
       float corr = 0.f;
       int hits = 0, above = 0;
@@ -148,7 +134,6 @@ __global__ __launch_bounds__(256) void shared_tok_fwd_kernel(
         });
       }
       if (lane == 0) {
-        p_inv[tk] = inv;
         s_pos[tk] = sp;
         sum_tok[tk] = fmaxf(sum_row[r] - corr, 0.f);
         if (n_valid_row) n_valid_tok[tk] = n_valid_row[r] - hits;
@@ -175,7 +160,7 @@ __global__ __launch_bounds__(256) void shared_tok_bwd_kernel(
   {
     const int64_t grp = blockIdx.z, to = grp * tok_cap, ro = grp * row_cap;
     qn_row += ro * dim; u_row += ro * dim; q_inv_row += ro;
-    tok2row += to; pn += to * dim; n_tok_dev += grp; lse += to; p_inv += to; s_pos += to; q_idx += to; p_idx += to;
+    tok2row += to; n_tok_dev += grp; lse += to; s_pos += to; q_idx += to; p_idx += to;      // pn / p_inv: per target row, shared by the groups
     lw_out += to;
     if (w_bucket) { w_bucket += to; w += grp * n_buckets; } else { w += to; }
     negs += grp * (int64_t)((n_neg + 31) & ~31) * dim;
@@ -221,13 +206,14 @@ __global__ __launch_bounds__(256) void shared_tok_bwd_kernel(
         }
       }
       const float wi = w_bucket ? w[w_bucket[tk]] : w[tk];
-      const float sp = s_pos[tk], ls = lse[tk], ip = p_inv[tk];
+      const float sp = s_pos[tk], ls = lse[tk];
       const int qi = q_idx[tk], pi = p_idx[tk];
+      const float ip = p_inv[pi];
       float pv[NC];
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
         const int d = c * 64 + lane;
-        pv[c] = d < dim ? (float)pn[(int64_t)tk * dim + d] : 0.f;
+        pv[c] = d < dim ? (float)pn[(int64_t)pi * dim + d] : 0.f;
       }
       const float a = wi * __expf(scale - ls);                          // G_ij = a * E_ij
       const float coef = wi * (__expf(scale * sp - ls) - 1.0f);         // w (p_pos - 1)
@@ -317,7 +303,7 @@ __global__ __launch_bounds__(256) void shared_bwd_rows_kernel(
   {
     const int64_t grp = blockIdx.z, to = grp * tok_cap, ro = grp * row_cap;
     qn_row += ro * dim; u_row += ro * dim; q_inv_row += ro; row_q += ro; row_first += ro; lw_row += ro; n_row_dev += grp;
-    pn += to * dim; lse += to; s_pos += to; p_idx += to;
+    lse += to; s_pos += to; p_idx += to;
     if (w_bucket) { w_bucket += to; w += grp * n_buckets; } else { w += to; }
     negs += grp * (int64_t)((n_neg + 31) & ~31) * dim;
     fixw += grp * (int64_t)n_tiles * n_rows_pad;
@@ -346,13 +332,13 @@ __global__ __launch_bounds__(256) void shared_bwd_rows_kernel(
       const int tk = c0 + lane;
       const bool live = tk < t1;
       float wi = 0.f, sp = 0.f, ls = 0.f;
-      int slot = 0;
+      int slot = 0, pi = 0;
       bool hit = false;
       if (live) {
         wi = w_bucket ? w[w_bucket[tk]] : w[tk];
         sp = s_pos[tk];
         ls = lse[tk];
-        const int pi = p_idx[tk];
+        pi = p_idx[tk];
         slot = slot_of_row ? slot_of_row[pi] : pi;
         hit = fix_any[slot] != 0;
       }
@@ -374,10 +360,11 @@ __global__ __launch_bounds__(256) void shared_bwd_rows_kernel(
       const int cnt = min(64, t1 - c0);
       for (int i = 0; i < cnt; ++i) {                          // independent row loads: the compiler keeps several in flight
         const float cf = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, coef), i));
+        const bf16_t* ps = pn + (int64_t)__builtin_amdgcn_readlane(pi, i) * dim;        // the token's target row (L2-resident table)
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
           const int d = c * 64 + lane;
-          accp[c] += d < dim ? cf * (float)pn[(int64_t)(c0 + i) * dim + d] : 0.f;
+          accp[c] += d < dim ? cf * (float)ps[d] : 0.f;
         }
       }
       uint64_t hm = __ballot(hit);
@@ -453,7 +440,7 @@ __global__ __launch_bounds__(256) void shared_bwd_targets_kernel(
   for (int m = wave_g; m < n_p_rows; m += n_waves) {
     const int b = m / W, pos = m - b * W;
     float acc[NC] = {0.f, 0.f, 0.f, 0.f};
-    int t_any = -1, g_any = 0;
+    int t_any = -1;
     for (int c0 = 0; c0 < n_cand; c0 += 64) {
       // lane = candidate (group, offset): the token (l = pos - 1 - p, p) of that group, if it is live
       const int cand = c0 + lane;
@@ -487,18 +474,16 @@ __global__ __launch_bounds__(256) void shared_bwd_targets_kernel(
           acc[c] += d < dim ? cf * (float)qs[d] : 0.f;
         }
         t_any = tk_u;
-        g_any = g_u;
       }
     }
     if (t_any < 0) continue;                                 // no live token points at this row: its gradient stays as it is
-    const int64_t o = (int64_t)g_any * tok_cap + t_any;
-    const float ip = p_inv[o];
+    const float ip = p_inv[m];
     float pv[NC], dpn[NC];
     float dot = 0.f;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       const int d = c * 64 + lane;
-      pv[c] = d < dim ? (float)pn[o * dim + d] : 0.f;
+      pv[c] = d < dim ? (float)pn[(int64_t)m * dim + d] : 0.f;
       dpn[c] = scale * acc[c];
       dot += pv[c] * dpn[c];
     }
@@ -535,16 +520,16 @@ __global__ __launch_bounds__(256) void row_lw_kernel(const float* __restrict__ l
 
 }  // namespace
 
-extern "C" int mhr_nce_shared_fwd_tokens(const void* p_rows, int io_dtype, int64_t n_p_rows, const int32_t* p_idx,
+extern "C" int mhr_nce_shared_fwd_tokens(const void* pn_rows, int64_t n_p_rows, const int32_t* p_idx,
                                          const int32_t* tok2row, int n_groups, const int32_t* n_tok_dev, int tok_cap,
                                          int row_cap, const void* qn_row, const float* sum_row, const int32_t* n_valid_row,
                                          const int32_t* rank_row, const void* negs, int n_neg, int dim,
                                          const float* logit_scale_dev, const uint32_t* fix_words,
-                                         const int32_t* fix_slot_of_row, const int32_t* fix_any, void* pn_out, float* p_inv,
+                                         const int32_t* fix_slot_of_row, const int32_t* fix_any,
                                          float* s_pos, float* sum_tok, int32_t* n_valid_tok, int32_t* rank_tok, void* stream) {
-  MHR_REQUIRE(p_rows && p_idx && tok2row && n_tok_dev && qn_row && sum_row && negs && logit_scale_dev && fix_words && fix_any,
+  MHR_REQUIRE(pn_rows && p_idx && tok2row && n_tok_dev && qn_row && sum_row && negs && logit_scale_dev && fix_words && fix_any,
               "nce_shared_fwd_tokens: null input pointer");
-  MHR_REQUIRE(pn_out && p_inv && s_pos && sum_tok, "nce_shared_fwd_tokens: null output pointer");
+  MHR_REQUIRE(s_pos && sum_tok, "nce_shared_fwd_tokens: null output pointer");
   MHR_REQUIRE((n_valid_row != nullptr) == (n_valid_tok != nullptr) && (rank_row != nullptr) == (rank_tok != nullptr),
               "nce_shared_fwd_tokens: row / token log counters go together");
   MHR_REQUIRE(dim > 0 && dim <= 256, "nce_shared_fwd_tokens: dim=%d unsupported (<= 256)", dim);
@@ -553,15 +538,10 @@ extern "C" int mhr_nce_shared_fwd_tokens(const void* p_rows, int io_dtype, int64
   const int n_rows_pad = (int)((n_p_rows + 255) / 256 * 256);
   int blocks = (tok_cap + 15) / 16;                  // 4 waves x 4 tokens
   if (blocks > 4096) blocks = 4096;
-  const dim3 grid(blocks, 1, n_groups);
-#define LAUNCH(IT)                                                                                                       \
-  hipLaunchKernelGGL((shared_tok_fwd_kernel<IT>), grid, dim3(256), 0, (hipStream_t)stream, (const IT*)p_rows, (int)n_p_rows, \
-                     p_idx, tok2row, n_tok_dev, tok_cap, row_cap, (const bf16_t*)qn_row, sum_row, n_valid_row, rank_row, \
-                     (const bf16_t*)negs, n_neg, dim, logit_scale_dev, fix_words, n_rows_pad, fix_slot_of_row, fix_any,  \
-                     (bf16_t*)pn_out, p_inv, s_pos, sum_tok, n_valid_tok, rank_tok)
-  if (io_dtype == MHR_BF16) LAUNCH(bf16_t);
-  else LAUNCH(float);
-#undef LAUNCH
+  hipLaunchKernelGGL(shared_tok_fwd_kernel, dim3(blocks, 1, n_groups), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)pn_rows, (int)n_p_rows, p_idx, tok2row, n_tok_dev, tok_cap, row_cap, (const bf16_t*)qn_row,
+                     sum_row, n_valid_row, rank_row, (const bf16_t*)negs, n_neg, dim, logit_scale_dev, fix_words, n_rows_pad,
+                     fix_slot_of_row, fix_any, s_pos, sum_tok, n_valid_tok, rank_tok);
   MHR_CHECK_LAUNCH("nce_shared_fwd_tokens");
   return MHR_OK;
 }

@@ -553,16 +553,17 @@ def _nce_fwd_shared(sv, q_rows, p_rows, negs, logit_scale, thres, want_logs, buc
                 sum_row.data_ptr(), _ptr(nv_row), _ptr(rk_row), qn_row.data_ptr(), pn_row.data_ptr(), supp_row.data_ptr(),
                 q_inv_row.data_ptr(), p_inv_row.data_ptr(), s_pos_row.data_ptr(), int(log_group), u_row.data_ptr(), n_p_rows,
                 z_words.data_ptr(), z_list.data_ptr(), z_n.data_ptr(), z_slot.data_ptr(), st)
-    # (3) per token: target, s+, sums and counters with the token's own suppressed negatives taken out
-    sv.pn = torch.empty(G, cap, D, dtype=torch.bfloat16, device=dev)
-    sv.p_inv = torch.empty(G, cap, dtype=torch.float32, device=dev)
+    # (3) per token: s+, sums and counters with the token's own suppressed negatives taken out.  The normalised target is a
+    #     property of the TARGET ROW (shared by every token and group that points at it): one l2norm pass over p_rows
+    pn_rows, p_norm = l2norm_rows(p_rows.contiguous(), torch.bfloat16, want_norms=True)
+    sv.pn, sv.p_inv = pn_rows, (1.0 / p_norm)
     ssum = torch.empty(G, cap, dtype=torch.float32, device=dev)
     n_valid = torch.zeros(G, cap, dtype=torch.int32, device=dev) if want_logs else None
     rank = torch.zeros(G, cap, dtype=torch.int32, device=dev) if want_logs else None
-    _timed_call("mhr_nce_shared_fwd_tokens", p_rows.data_ptr(), _dt(p_rows), n_p_rows, p_idx.data_ptr(), tok2row.data_ptr(), G,
+    _timed_call("mhr_nce_shared_fwd_tokens", pn_rows.data_ptr(), n_p_rows, p_idx.data_ptr(), tok2row.data_ptr(), G,
                 n_tok_dev.data_ptr(), cap, row_cap, qn_row.data_ptr(), sum_row.data_ptr(), _ptr(nv_row), _ptr(rk_row),
                 negs.data_ptr(), n_neg, D, logit_scale.data_ptr(), fix_words.data_ptr(), _ptr(slot_of_row), fix_any.data_ptr(),
-                sv.pn.data_ptr(), sv.p_inv.data_ptr(), sv.s_pos.data_ptr(), ssum.data_ptr(), _ptr(n_valid), _ptr(rank), st)
+                sv.s_pos.data_ptr(), ssum.data_ptr(), _ptr(n_valid), _ptr(rank), st)
     lib.call("mhr_nce_finalize", ssum.data_ptr(), sv.s_pos.data_ptr(), G, n_tok_dev.data_ptr(), cap,
              logit_scale.data_ptr(), loss.data_ptr(), sv.lse.data_ptr(), _ptr(n_valid), _ptr(bucket_idx), int(n_buckets),
              _ptr(sv.bucket_sum), _ptr(sv.bucket_cnt), st)
