@@ -11,7 +11,7 @@
 
 namespace {
 
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// (sigmoid_f: mhr_common.h - one v_exp and one v_rcp)
 
 // a[r, c] = silu(gu[r, c]) * gu[r, F + c]
 __global__ __launch_bounds__(256) void swiglu_fwd_kernel(const bf16_t* __restrict__ gu, bf16_t* __restrict__ a, int64_t rows,
