@@ -735,3 +735,14 @@ def test_lazy_table_adam_is_bitwise_the_dense_update(rec):
     assert torch.equal(m_lazy.item_embedding.weight, m_dense.item_embedding.weight)
     assert torch.equal(o_lazy.t_m, o_dense.t_m) and torch.equal(o_lazy.t_v, o_dense.t_v)
     assert int((slot_l != -1).sum()) == 0 and int((slot_d != -1).sum()) == 0
+
+
+def test_rccl_collectives_one_rank_rehearsal(rec):
+    """The exact torch.distributed calls of the data-parallel step on the nccl (= RCCL) backend with one rank - a one-GPU box
+    cannot host two RCCL ranks on its card (the two-rank tests above run on gloo): sliced all_gather_into_tensor outputs, bf16
+    rows, asynchronous handles and wait() ordering the compute stream (tools/nccl_api_probe.py)."""
+    import subprocess
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29655", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "nccl_api_probe.py")], env=env, capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0 and "nccl api probe ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
