@@ -66,14 +66,16 @@ int mhr_embedding_scatter_add_bwd(const void* grad_rows, int grad_dtype, const i
  * ([n_a/window_len, seq_len, dim] f32): the gradient of the fused position-added copy, added to
  * source row r < n_a when (r % window_len) < seq_len.
  * Output: for every segment head position i (first occurrence of an id) out_rows[i,:] = sum of the
- * segment's source rows (f32), and row_slot[id] = i.  out_rows ([n_ids, dim] f32) must be ZEROED by the caller
- * (segments longer than a 32-row chunk are combined with float atomics); non-head rows stay zero.
- * row_slot ([n_rows] int32) must hold -1 everywhere on entry; mhr_adam_rows restores that. */
+ * segment's source rows (f32), and row_slot[id] = i.  out_rows ([n_ids, dim] f32) must be ZEROED by the caller;
+ * non-head rows are zero on return.  No atomics: a segment cut by the 32-position work chunks is summed from one
+ * partial per chunk in chunk order by a second launch, so the result is bitwise reproducible (and identical on every
+ * data-parallel replica).  row_slot ([n_rows] int32) must hold -1 everywhere on entry; mhr_adam_rows restores that.
+ * Ids outside [0, n_rows) get no slot (their rows are left out of the update). */
 int mhr_sparse_rows_segment_sum(const int64_t* sorted_ids, const int64_t* perm, int64_t n_ids,
                                 const void* grad_a, int a_dtype, int64_t n_a,
                                 const void* grad_b, int b_dtype, int64_t n_b,
                                 const float* x_grad, int seq_len, int window_len,
-                                float* out_rows, int32_t* row_slot, int dim, void* stream);
+                                float* out_rows, int32_t* row_slot, int64_t n_rows, int dim, void* stream);
 
 /* Dense AdamW over an embedding table whose gradient is given sparsely (trainer.py:292-299 semantics:
  * every row is updated every step, untouched rows with g = 0).  For each row: slot = row_slot[row];
@@ -85,21 +87,25 @@ int mhr_adam_rows(float* w, float* m, float* v, int64_t n_rows, int dim,
 
 /* Dense AdamW over a flat parameter buffer (all non-table parameters live in one flat buffer).  w_bf16 (optional, [n]):
  * bf16 copy of the updated weights, written in the same pass - the operand of the next step's bf16 GEMMs, so no
- * per-step cast kernels (the reference's autocast re-casts every weight every step). */
+ * per-step cast kernels (the reference's autocast re-casts every weight every step).
+ * step_dev (optional, device int64[1]) + hist [hist_len, 4] f32 (rows of mhr_adam_consts): a step replayed from a hipGraph
+ * has its kernel arguments frozen at capture, so the step's constants (lr decay, bias corrections) are read from
+ * hist[step_dev[0] % hist_len] instead of being derived from `lr` / `step`; NULL: the arguments as given. */
 int mhr_adam_flat(float* w, const float* g, float* m, float* v, int64_t n, float grad_scale,
-                  float lr, float beta1, float beta2, float eps, float weight_decay, int step, void* w_bf16, void* stream);
+                  float lr, float beta1, float beta2, float eps, float weight_decay, int step, void* w_bf16,
+                  const float* hist, int hist_len, const int64_t* step_dev, void* stream);
 /* Lazy form of mhr_adam_rows (same arithmetic, bitwise the same weights once a row is up to date): rows are replayed through
  * the gradient-free steps they missed when they are next needed.  last_step [n_rows] int32 (zeros at start): last step applied
  * to a row; hist [hist_len, 4] f32: the constants of step s at row s % hist_len as filled by mhr_adam_consts (a host helper,
  * no launch); the caller flushes (mode 2) at least every hist_len steps.  mode 0: bring the rows of `ids` (duplicates allowed) up
  * to step - 1 (before the forward reads them); mode 1: ids = the sorted ids of a SparseRowGrad, grad_rows its rows: every
  * segment head is replayed to step - 1 and gets step `step` with its gradient (row_slot of the row is reset to -1); mode 2: all
- * rows through `step`. */
+ * rows through `step`.  step_dev (optional, device int64[1]): overrides `step` (hipGraph-replayed steps). */
 int mhr_adam_consts(float lr, float beta1, float beta2, float eps, float weight_decay, int step, float* out4);
 int mhr_adam_rows_lazy(float* w, float* m, float* v, int64_t n_rows, int dim, const int64_t* ids, int64_t n_ids,
                        const float* grad_rows, int32_t* row_slot, int32_t* last_step, const float* hist,
                        int hist_len, int step, float grad_scale, float beta1, float beta2, float eps, int mode,
-                       void* stream);
+                       const int64_t* step_dev, void* stream);
 
 /* out[c] += sum_r x[r, c]: x bf16 [rows, cols] (cols % 8 == 0), out fp32 [cols].  The reduction of split-K weight-gradient
  * partials and of bias gradients straight into the flat gradient buffer (autograd's accumulate semantics: the caller
@@ -126,15 +132,17 @@ int mhr_add_layernorm_bwd(const void* d_xn_bf16, const float* x_out, const float
 
 /* o = silu(u) * LayerNorm(a) * dropmask   (hstu.py:277-285).  u is a column block of the uvqk GEMM
  * output: u[r,c] = u_base[r*u_stride + c] (pre-activation; SiLU applied here).  a [rows, dim].
- * dropout: keep-mask from a counter hash of (seed, r*dim+c), scaled by 1/(1-p); p = 0 disables. */
+ * dropout: keep-mask from a counter hash of (seed, r*dim+c), scaled by 1/(1-p); p = 0 disables.
+ * step_seed (optional, device int64[1]): the step counter of a hipGraph-replayed step, whose kernel arguments are frozen
+ * at capture: the effective seed is (step_seed[0] * 1000003 + seed) & (2^63 - 1), NULL: `seed` as given. */
 int mhr_ln_gate_fwd(const void* u_base, int64_t u_stride, const void* a, int dtype, void* o, int o_dtype,
                     float* mean, float* rstd, int64_t rows, int dim, float eps,
-                    float dropout_p, uint64_t seed, void* stream);
+                    float dropout_p, uint64_t seed, const int64_t* step_seed, void* stream);
 /* Backward of the above: given d_o, writes du (pre-activation gradient, into a column block with
  * row stride du_stride) and da. */
 int mhr_ln_gate_bwd(const void* d_o, int do_dtype, const void* u_base, int64_t u_stride, const void* a, int dtype,
                     const float* mean, const float* rstd, void* du_base, int64_t du_stride, void* da,
-                    int64_t rows, int dim, float dropout_p, uint64_t seed, void* stream);
+                    int64_t rows, int dim, float dropout_p, uint64_t seed, const int64_t* step_seed, void* stream);
 
 /* y[r,:] = x[r,:] / ||x[r,:]||_2  (hstu.py:605-606, 672, 966, 975, 1021); optional norms out ([rows] f32). */
 int mhr_l2norm_rows(const void* x, int x_dtype, void* y, int y_dtype, float* norms, int64_t rows, int dim, void* stream);

@@ -73,6 +73,13 @@ class HSTUJagged(nn.Module):
 class HSTU(MultiHeadDecoding, BaseModel):
     input_type = InputType.SEQ
 
+    @property
+    def graph_capable(self):
+        """The training step can be replayed from a hipGraph: the streaming path (feature dims up to 256) never synchronises
+        with the host and reads its dropout step counter from `_seed_dev`; the wide path bounds a chunk loop on the host."""
+        from mhr_amd import ops
+        return type(self).__name__ == "HSTU" and self._hstu_embedding_dim in ops.STREAM_DIMS
+
     def __init__(self, config, dataload):
         super().__init__()
         self.logger = getLogger()
@@ -116,6 +123,7 @@ class HSTU(MultiHeadDecoding, BaseModel):
         self._row_exchange = None
         self._bf16_cache = {}
         self._step_seed = 0
+        self._seed_dev = None              # device int64[1] while the Trainer captures the step as a hipGraph
 
     # ------------------------------------------------------------------------------------------
     def reset_params(self):
@@ -189,10 +197,14 @@ class HSTU(MultiHeadDecoding, BaseModel):
         xn = LayerNormFn.apply(x2, layers[0]._eps)
         for i, layer in enumerate(layers):
             cached = self._layer_weights_bf16(i, layer)
-            seed = (self._step_seed * 1000003 + i * 7919 + self.rank * 104729) & 0x7FFFFFFFFFFFFFFF
+            # dropout seed = (step * 1000003 + layer part) & (2^63 - 1); a hipGraph-replayed step reads the step counter from
+            # device memory (self._seed_dev, set by the Trainer's step graph) and passes only the layer part
+            seed_dev = getattr(self, "_seed_dev", None) if training else None
+            layer_part = i * 7919 + self.rank * 104729
+            seed = layer_part if seed_dev is not None else (self._step_seed * 1000003 + layer_part) & 0x7FFFFFFFFFFFFFFF
             if cached is None:
                 h = SplitKLinearFn.apply(xn, layer._uvqk, None, False, None)
-                o = HSTUCoreFn.apply(h, key_valid, B, L, self._num_heads, self._dqk, layer._eps, p, seed)
+                o = HSTUCoreFn.apply(h, key_valid, B, L, self._num_heads, self._dqk, layer._eps, p, seed, seed_dev)
                 y = SplitKLinearFn.apply(o, layer._o.weight, layer._o.bias, True, None)
             else:
                 h = xn @ cached[0]

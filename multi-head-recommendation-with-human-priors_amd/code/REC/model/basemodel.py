@@ -28,13 +28,9 @@ def all_gather_ids(ids, group=None):
     reduction - and moves D*4/8 times fewer bytes over xGMI with no backward collective."""
     if _world() > 1:
         ids = ids.contiguous()
-        if dist.get_backend(group) == "nccl":              # straight into the stacked output
-            out = torch.empty((_world(),) + tuple(ids.shape), dtype=ids.dtype, device=ids.device)
-            dist.all_gather_into_tensor(out, ids, group=group)
-            return out
-        out = [torch.empty_like(ids) for _ in range(_world())]
-        dist.all_gather(out, ids, group=group)
-        return torch.stack(out, dim=0)
+        out = torch.empty((_world(),) + tuple(ids.shape), dtype=ids.dtype, device=ids.device)
+        dist.all_gather_into_tensor(out.view(-1), ids.view(-1), group=group)      # straight into the stacked output (RCCL and gloo alike)
+        return out
     return ids.unsqueeze(0)
 
 

@@ -172,24 +172,24 @@ class HSTUCoreFn(Function):
     """
 
     @staticmethod
-    def forward(ctx, h, key_valid, B, L, n_heads, head_dim, eps, dropout_p, seed):
+    def forward(ctx, h, key_valid, B, L, n_heads, head_dim, eps, dropout_p, seed, seed_dev=None):
         D = n_heads * head_dim
         # the activated q / k / v are NOT saved: the backward recomputes silu() while it stages them (h is kept anyway)
         a, _ = ops.hstu_attn_fwd(h, key_valid, B, L, n_heads, head_dim, apply_silu=True, save_act=False)
-        o, mean, rstd = ops.ln_gate_fwd(h, a, D, torch.bfloat16, eps, dropout_p, seed)
+        o, mean, rstd = ops.ln_gate_fwd(h, a, D, torch.bfloat16, eps, dropout_p, seed, seed_dev)
         ctx.save_for_backward(h, key_valid, a, mean, rstd)
-        ctx.cfg = (B, L, n_heads, head_dim, dropout_p, seed)
+        ctx.cfg = (B, L, n_heads, head_dim, dropout_p, seed, seed_dev)
         return o
 
     @staticmethod
     def backward(ctx, d_o):
         h, key_valid, a, mean, rstd = ctx.saved_tensors
-        B, L, n_heads, head_dim, dropout_p, seed = ctx.cfg
+        B, L, n_heads, head_dim, dropout_p, seed, seed_dev = ctx.cfg
         D = n_heads * head_dim
         dh = torch.empty_like(h)
-        da = ops.ln_gate_bwd(d_o.contiguous(), h, a, mean, rstd, dh, D, dropout_p, seed)
+        da = ops.ln_gate_bwd(d_o.contiguous(), h, a, mean, rstd, dh, D, dropout_p, seed, seed_dev)
         ops.hstu_attn_bwd(h, None, key_valid, da, dh, B, L, n_heads, head_dim, apply_silu=True)
-        return dh, None, None, None, None, None, None, None, None
+        return dh, None, None, None, None, None, None, None, None, None
 
 
 class SparseRowGrad:

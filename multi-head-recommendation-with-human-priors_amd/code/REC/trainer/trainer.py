@@ -21,6 +21,83 @@ from REC.utils import early_stopping
 from REC.utils.lr_scheduler import cosine_warmup_factor
 
 
+class _StepGraph:
+    """One optimisation step captured as a hipGraph (torch.cuda.CUDAGraph over the C-ABI launches, the library GEMMs and the
+    torch glue of the step) and replayed with ONE host call per step.
+
+    What changes from step to step cannot be a kernel argument of a replayed launch, so it lives in device memory:
+      * the batch: static input tensors, refreshed by device-to-device copies in front of the replay;
+      * `ctrl` int64[2] = (dropout step counter, optimizer step): the ln_gate kernels derive their seeds from ctrl[0]
+        (`mhr_ln_gate_*`'s step_seed), the Adam kernels read ctrl[1] (`step_dev`);
+      * the step's Adam constants (lr schedule, bias corrections): row `step % 64` of the optimizer's device-side history,
+        uploaded from a pinned ring in front of the replay (`FusedAdamW.begin_replayed_step`).
+    The host may run ahead of the GPU by at most ~48 replays (an event every 16 replays, the third-youngest waited for), so the
+    64-row pinned rings are never overwritten while a copy from them is pending."""
+    WARM, RING = 3, 64
+
+    def __init__(self, trainer, sig):
+        self.tr, self.sig = trainer, sig
+        self.warm, self.graph, self.static, self.out = 0, None, None, None
+        self.n, self.events = 0, []
+
+    def release(self):
+        self.graph = self.static = self.out = None
+
+    def _capture(self, data):
+        tr = self.tr
+        model, opt, dev = tr.model, tr.optimizer, data[0].device
+        self.ctrl = torch.zeros(2, dtype=torch.int64, device=dev)
+        self.ctrl_host = torch.zeros(self.RING, 2, dtype=torch.int64).pin_memory()
+        self.static = tuple(t.clone() for t in data)
+        keep = (model._step_seed, opt.step_count, tr.train_step, tr._micro_step, opt.param_groups[0]["lr"])
+        graph = torch.cuda.CUDAGraph()
+        model._seed_dev, opt.step_dev, opt.in_graph = self.ctrl[0:1], self.ctrl[1:2], True
+        try:
+            with torch.cuda.graph(graph):
+                out = tr._eager_step(self.static)
+        finally:
+            model._seed_dev, opt.step_dev, opt.in_graph = None, None, False
+            # the capture ran the Python of one step (counters moved) and launched nothing: put the counters back
+            model._step_seed, opt.step_count, tr.train_step, tr._micro_step, opt.param_groups[0]["lr"] = keep
+        self.graph, self.out = graph, out
+
+    def step(self, data):
+        tr = self.tr
+        if self.graph is None:
+            if self.warm < self.WARM:          # host-issued steps first: caches, bf16 weight shadows, allocator pools
+                self.warm += 1
+                return tr._eager_step(data)
+            try:
+                self._capture(data)
+            except Exception as e:  # noqa: BLE001 - a step that cannot be captured still trains, launch by launch
+                tr._graph_failed = True
+                tr.logger.warning(f"hipGraph capture of the train step failed ({type(e).__name__}: {e}); continuing with host-issued launches")
+                self.release()
+                return tr._eager_step(data)
+        model, opt = tr.model, tr.optimizer
+        for s_, t in zip(self.static, data):
+            if s_ is not t:
+                s_.copy_(t, non_blocking=True)
+        if self.n % 16 == 0:
+            ev = torch.cuda.Event()
+            ev.record()
+            self.events.append(ev)
+            if len(self.events) > 3:
+                self.events.pop(0).synchronize()
+        model._step_seed += 1
+        lr = tr._lr_at(tr.train_step)
+        tr.train_step += 1
+        tr._micro_step += 1
+        opt.begin_replayed_step(lr)
+        h = self.ctrl_host[self.n % self.RING]
+        h[0], h[1] = model._step_seed, opt.step_count
+        self.ctrl.copy_(h, non_blocking=True)
+        self.n += 1
+        self.graph.replay()
+        opt.end_replayed_step()
+        return self.out
+
+
 class Trainer(object):
     def __init__(self, config):
         self.config = config
@@ -76,9 +153,19 @@ class Trainer(object):
         if torch.isnan(loss):
             raise ValueError('Training loss is nan')
 
-    def train_step_fn(self, data):
+    def train_step_fn(self, data, graph=None):
         """One forward / backward; every `accumulate_grad`-th call also exchanges the gradients and runs the fused Adam
-        (reference trainer.py:511-536).  Returns the model_out dict (device tensors)."""
+        (reference trainer.py:511-536).  Returns the model_out dict (device tensors).
+
+        `hip_graph` (config, default on): after three host-issued steps on a batch signature the whole step - forward,
+        backward, fused Adam, zero_grad: about 300 launches - is captured ONCE as a hipGraph and every later step of that
+        signature is one graph launch (`_StepGraph`).  The returned tensors are then the graph's static outputs: they are
+        overwritten by the next step (copy what must outlive it).  `graph=False` forces a host-issued step."""
+        if graph is not False and self._graph_ok(data):
+            return self._graph_step(data)
+        return self._eager_step(data)
+
+    def _eager_step(self, data):
         model_out = self.model(data)
         loss = model_out["loss"]
         (loss / self.accumulate_grad).backward()
@@ -89,6 +176,29 @@ class Trainer(object):
             self.optimizer.step()
             self.optimizer.zero_grad()
         return model_out
+
+    # ---- hipGraph replay of the step -------------------------------------------------------------
+    def _graph_ok(self, data):
+        m = self.model
+        return (self.config.get("hip_graph", True) and os.environ.get("MHR_HIP_GRAPH", "1") != "0"
+                and self.accumulate_grad == 1 and self.world == 1 and getattr(m, "graph_capable", False)
+                and self.optimizer.graph_capable() and isinstance(data, (tuple, list))
+                and all(torch.is_tensor(t) and t.is_cuda for t in data) and m.training
+                and not getattr(m, "dense_embedding_grad", False) and not getattr(self, "_graph_failed", False))
+
+    def _graph_step(self, data):
+        sig = tuple((tuple(t.shape), t.dtype) for t in data)
+        st = getattr(self, "_step_graph", None)
+        if st is None or st.sig != sig:
+            if st is not None:
+                st.release()
+            st = self._step_graph = _StepGraph(self, sig)
+        return st.step(data)
+
+    @property
+    def graph_active(self):
+        st = getattr(self, "_step_graph", None)
+        return st is not None and st.graph is not None
 
     def fit(self, train_data, valid_data=None, verbose=True, saved=True, show_progress=False, callback_fn=None):
         self.model.train()

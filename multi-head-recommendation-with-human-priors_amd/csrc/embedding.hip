@@ -120,8 +120,11 @@ extern "C" int mhr_embedding_scatter_add_bwd(const void* grad_rows, int grad_dty
 // ------------------------------------------------------------------------------------------
 // One wave per CHUNK of 32 consecutive sorted positions (not per segment: under Zipf-distributed ids one item can own
 // thousands of rows and a wave per segment serialises them - measured 1.1 ms of a 21 ms step).  Runs of equal ids
-// inside a chunk are summed in registers; a run that is cut by a chunk border adds its partial sum to the segment
-// head's row with float atomics (256-byte shape), every other run is a plain store.  out_rows must be zeroed.
+// inside a chunk are summed in registers (in list order) and stored once.  A run that is cut by chunk borders leaves one
+// partial sum per chunk - at the run's head in its first chunk, at the chunk's first position in every later one (a
+// position no other wave writes) - and a second pass adds a run's partials to its head IN CHUNK ORDER and zeroes them:
+// no atomics, so the sum of a hot id (hundreds of duplicates per step under Zipf ids) has one fixed order and the
+// data-parallel replicas, which each run this reduction on the same exchanged list, stay bitwise identical.
 constexpr int SEG_CHUNK = 32;
 
 template <typename AT, typename BT>
@@ -131,7 +134,7 @@ __global__ __launch_bounds__(256) void segment_sum_kernel(const int64_t* __restr
                                                           const BT* __restrict__ gb, int64_t n_b,
                                                           const float* __restrict__ xg, int seq_len, int window_len,
                                                           float* __restrict__ out_rows, int32_t* __restrict__ row_slot,
-                                                          int dim) {
+                                                          int64_t n_rows, int dim) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
@@ -143,19 +146,9 @@ __global__ __launch_bounds__(256) void segment_sum_kernel(const int64_t* __restr
       int64_t e = j + 1;
       while (e < i1 && sorted_ids[e] == id) ++e;
       const bool from_before = (j == i0) && i0 > 0 && sorted_ids[i0 - 1] == id;
-      const bool goes_on = (e == i1) && i1 < n_ids && sorted_ids[i1] == id;
-      int64_t head = j;
-      if (from_before) {                                   // first occurrence of id: lower bound in the sorted list
-        int64_t lo = 0, hi = i0;
-        while (lo < hi) {
-          const int64_t mid = (lo + hi) >> 1;
-          if (sorted_ids[mid] < id) lo = mid + 1;
-          else hi = mid;
-        }
-        head = lo;
-      } else if (lane == 0) {
-        row_slot[id] = (int32_t)j;
-      }
+      // ids outside the table (a data-layer bug; nn.Embedding would have raised in the forward) get no slot: their
+      // rows stay out of the update instead of writing row_slot out of bounds
+      if (!from_before && lane == 0 && id >= 0 && id < n_rows) row_slot[id] = (int32_t)j;
       for (int c = lane * 4; c < dim; c += 256) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         for (int64_t q = j; q < e; ++q) {
@@ -171,15 +164,46 @@ __global__ __launch_bounds__(256) void segment_sum_kernel(const int64_t* __restr
             acc += Vec4IO<BT>::load(gb + (r - n_a) * dim + c);
           }
         }
-        float* dst = out_rows + head * dim + c;
-        if (from_before || goes_on) {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) atomicAdd(dst + k, acc[k]);
-        } else {
-          *reinterpret_cast<f32x4*>(dst) = acc;
-        }
+        *reinterpret_cast<f32x4*>(out_rows + j * dim + c) = acc;     // whole run, or this chunk's partial of a cut run
       }
       j = e;
+    }
+  }
+}
+
+// Second pass: the wave of the chunk in which a cut run STARTS walks the run's later chunks in order, adds their partials
+// (stored at the chunks' first positions) to the head row and clears them, so non-head rows are zero again.
+__global__ __launch_bounds__(256) void segment_fixup_kernel(const int64_t* __restrict__ sorted_ids, int64_t n_ids,
+                                                            float* __restrict__ out_rows, int dim) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  const int64_t n_chunks = (n_ids + SEG_CHUNK - 1) / SEG_CHUNK;
+  for (int64_t ch = wave; ch + 1 < n_chunks; ch += n_waves) {
+    const int64_t i0 = ch * SEG_CHUNK, i1 = i0 + SEG_CHUNK;
+    const int64_t id = sorted_ids[i1 - 1];
+    if (sorted_ids[i1] != id) continue;                          // the chunk's last run ends with the chunk
+    if (sorted_ids[i0] == id && i0 > 0 && sorted_ids[i0 - 1] == id) continue;   // the run started earlier: not ours
+    int64_t head = i1 - 1;
+    while (head > i0 && sorted_ids[head - 1] == id) --head;
+    int64_t last = ch + 1;                                       // chunks ch + 1 .. last hold partials of this run
+    while (last + 1 < n_chunks && sorted_ids[(last + 1) * SEG_CHUNK] == id) ++last;
+    constexpr int U = 4;                                         // partial rows in flight
+    for (int c = lane * 4; c < dim; c += 256) {
+      f32x4 acc = *reinterpret_cast<const f32x4*>(out_rows + head * dim + c);
+      for (int64_t k0 = ch + 1; k0 <= last; k0 += U) {
+        f32x4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (k0 + u <= last) v[u] = *reinterpret_cast<const f32x4*>(out_rows + (k0 + u) * SEG_CHUNK * dim + c);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (k0 + u <= last) {
+            acc += v[u];
+            *reinterpret_cast<f32x4*>(out_rows + (k0 + u) * SEG_CHUNK * dim + c) = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+      }
+      *reinterpret_cast<f32x4*>(out_rows + head * dim + c) = acc;
     }
   }
 }
@@ -187,9 +211,9 @@ __global__ __launch_bounds__(256) void segment_sum_kernel(const int64_t* __restr
 extern "C" int mhr_sparse_rows_segment_sum(const int64_t* sorted_ids, const int64_t* perm, int64_t n_ids,
                                            const void* grad_a, int a_dtype, int64_t n_a, const void* grad_b, int b_dtype,
                                            int64_t n_b, const float* x_grad, int seq_len, int window_len, float* out_rows,
-                                           int32_t* row_slot, int dim, void* stream) {
+                                           int32_t* row_slot, int64_t n_rows, int dim, void* stream) {
   MHR_REQUIRE(sorted_ids && perm && out_rows && row_slot, "sparse_rows_segment_sum: null pointer");
-  MHR_REQUIRE(dim > 0 && dim % 4 == 0, "sparse_rows_segment_sum: dim=%d must be a multiple of 4", dim);
+  MHR_REQUIRE(dim > 0 && dim % 4 == 0 && n_rows > 0, "sparse_rows_segment_sum: dim=%d must be a multiple of 4", dim);
   MHR_REQUIRE((n_a == 0 || grad_a) && (n_b == 0 || grad_b), "sparse_rows_segment_sum: null gradient buffer");
   MHR_REQUIRE(n_a + n_b >= n_ids, "sparse_rows_segment_sum: n_a+n_b < n_ids");
   if (x_grad) MHR_REQUIRE(window_len > 0 && seq_len > 0 && n_a % window_len == 0, "sparse_rows_segment_sum: bad window");
@@ -199,7 +223,8 @@ extern "C" int mhr_sparse_rows_segment_sum(const int64_t* sorted_ids, const int6
   int grid = mhr_grid_for((n_ids + SEG_CHUNK - 1) / SEG_CHUNK, 4);
 #define LAUNCH(AT, BT)                                                                                               \
   hipLaunchKernelGGL((segment_sum_kernel<AT, BT>), dim3(grid), dim3(256), 0, s, sorted_ids, perm, n_ids,             \
-                     (const AT*)grad_a, n_a, (const BT*)grad_b, n_b, x_grad, seq_len, window_len, out_rows, row_slot, dim)
+                     (const AT*)grad_a, n_a, (const BT*)grad_b, n_b, x_grad, seq_len, window_len, out_rows, row_slot, \
+                     n_rows, dim)
   bool ab = a_dtype == MHR_BF16, bb = b_dtype == MHR_BF16;
   if (ab && bb) LAUNCH(bf16_t, bf16_t);
   else if (ab) LAUNCH(bf16_t, float);
@@ -207,6 +232,10 @@ extern "C" int mhr_sparse_rows_segment_sum(const int64_t* sorted_ids, const int6
   else LAUNCH(float, float);
 #undef LAUNCH
   MHR_CHECK_LAUNCH("sparse_rows_segment_sum");
+  if (n_ids > SEG_CHUNK) {
+    hipLaunchKernelGGL(segment_fixup_kernel, dim3(grid), dim3(256), 0, s, sorted_ids, n_ids, out_rows, dim);
+    MHR_CHECK_LAUNCH("sparse_rows_segment_sum (fix-up)");
+  }
   return MHR_OK;
 }
 
@@ -314,7 +343,9 @@ __global__ __launch_bounds__(256) void adam_rows_lazy_kernel(float* __restrict__
                                                              int64_t n_rows, int dim, const int64_t* __restrict__ ids,
                                                              int64_t n_ids, const float* __restrict__ grad_rows,
                                                              int32_t* __restrict__ row_slot, int32_t* __restrict__ last_step,
-                                                             const float* __restrict__ hist, AdamLazy a) {
+                                                             const float* __restrict__ hist, AdamLazy a,
+                                                             const int64_t* __restrict__ step_dev) {
+  if (step_dev) a.step = (int)step_dev[0];      // hipGraph-replayed step: the step number lives in device memory
   const int lane = threadIdx.x & 63;
   const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
@@ -369,7 +400,7 @@ extern "C" int mhr_adam_consts(float lr, float beta1, float beta2, float eps, fl
 extern "C" int mhr_adam_rows_lazy(float* w, float* m, float* v, int64_t n_rows, int dim, const int64_t* ids, int64_t n_ids,
                                   const float* grad_rows, int32_t* row_slot, int32_t* last_step, const float* hist,
                                   int hist_len, int step, float grad_scale, float beta1, float beta2, float eps, int mode,
-                                  void* stream) {
+                                  const int64_t* step_dev, void* stream) {
   MHR_REQUIRE(w && m && v && last_step && hist, "adam_rows_lazy: null pointer");
   MHR_REQUIRE(mode >= 0 && mode <= 2 && (mode == 2 || ids) && (mode != 1 || grad_rows), "adam_rows_lazy: bad mode / inputs");
   MHR_REQUIRE(dim > 0 && dim % 4 == 0 && n_rows > 0 && hist_len > 0 && step >= 0, "adam_rows_lazy: bad sizes");
@@ -380,14 +411,20 @@ extern "C" int mhr_adam_rows_lazy(float* w, float* m, float* v, int64_t n_rows, 
   a.grad_scale = grad_scale; a.hist_len = hist_len; a.step = step; a.mode = mode;
   int grid = mhr_grid_for(n_work, 4 * 4);
   hipLaunchKernelGGL(adam_rows_lazy_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, m, v, n_rows, dim, ids, n_ids,
-                     grad_rows, row_slot, last_step, hist, a);
+                     grad_rows, row_slot, last_step, hist, a, step_dev);
   MHR_CHECK_LAUNCH("adam_rows_lazy");
   return MHR_OK;
 }
 
 __global__ __launch_bounds__(256) void adam_flat_kernel(float* __restrict__ w, const float* __restrict__ g,
                                                         float* __restrict__ m, float* __restrict__ v, int64_t n,
-                                                        AdamConst a, bf16_t* __restrict__ w16) {
+                                                        AdamConst a, bf16_t* __restrict__ w16,
+                                                        const float* __restrict__ hist, int hist_len,
+                                                        const int64_t* __restrict__ step_dev) {
+  if (step_dev) {       // hipGraph-replayed step: this step's constants from the device-side history (mhr_adam_consts rows)
+    const float* h = hist + (step_dev[0] % hist_len) * 4;
+    a.decay_mul = h[0]; a.step_size = h[1]; a.inv_sqrt_bc2 = h[2];
+  }
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t nt = (int64_t)gridDim.x * blockDim.x;
   const int64_t n4 = n / 4;
@@ -413,8 +450,10 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(float* __restrict__ w, c
 }
 
 extern "C" int mhr_adam_flat(float* w, const float* g, float* m, float* v, int64_t n, float grad_scale, float lr,
-                             float beta1, float beta2, float eps, float weight_decay, int step, void* w_bf16, void* stream) {
+                             float beta1, float beta2, float eps, float weight_decay, int step, void* w_bf16,
+                             const float* hist, int hist_len, const int64_t* step_dev, void* stream) {
   MHR_REQUIRE(w && g && m && v, "adam_flat: null pointer");
+  MHR_REQUIRE(!step_dev || (hist && hist_len > 0), "adam_flat: step_dev needs the constants' history");
   MHR_REQUIRE(!w_bf16 || (uintptr_t)w_bf16 % 8 == 0, "adam_flat: the bf16 shadow must be 8-byte aligned");
   MHR_REQUIRE(n >= 0 && step >= 1, "adam_flat: bad sizes");
   MHR_REQUIRE(((uintptr_t)w % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)m % 16 == 0) && ((uintptr_t)v % 16 == 0),
@@ -422,7 +461,8 @@ extern "C" int mhr_adam_flat(float* w, const float* g, float* m, float* v, int64
   if (n == 0) return MHR_OK;
   AdamConst a = make_adam(lr, beta1, beta2, eps, weight_decay, step, grad_scale);
   int grid = mhr_grid_for(n / 4 + 1, 256, 2048);
-  hipLaunchKernelGGL(adam_flat_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, g, m, v, n, a, (bf16_t*)w_bf16);
+  hipLaunchKernelGGL(adam_flat_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, g, m, v, n, a, (bf16_t*)w_bf16,
+                     hist, hist_len, step_dev);
   MHR_CHECK_LAUNCH("adam_flat");
   return MHR_OK;
 }

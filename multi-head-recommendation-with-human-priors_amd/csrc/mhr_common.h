@@ -96,6 +96,14 @@ template <> struct Vec4IO<bf16_t> {
   }
 };
 
+// Dropout seed of a launch.  Host-issued steps pass the whole seed as a kernel argument; a step replayed from a hipGraph
+// cannot (arguments are frozen at capture), so it passes the per-layer constant part and a pointer to the step counter in
+// device memory.  Both give (step * 1000003 + layer_part) & (2^63 - 1) - the host formula of REC/model/IDNet/hstu.py:_encode.
+__device__ __forceinline__ uint64_t mhr_step_seed(uint64_t seed, const int64_t* __restrict__ step_seed) {
+  if (!step_seed) return seed;
+  return ((uint64_t)step_seed[0] * 1000003ull + seed) & 0x7FFFFFFFFFFFFFFFull;
+}
+
 // counter-based uniform in [0,1) for the dropout masks: murmur3's 32-bit finaliser over (index, seed) folded to 32 bits - a
 // dozen 32-bit operations per element (the 64-bit splitmix finaliser used before cost three 64-bit multiplies per element:
 // about 7 us of a 16 us ln_gate launch at cfg1).  Forward and backward regenerate the same mask from (seed, index).

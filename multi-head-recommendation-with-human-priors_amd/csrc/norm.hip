@@ -295,7 +295,9 @@ template <typename T, typename OT, int NC>
 __global__ __launch_bounds__(256) void ln_gate_fwd_kernel(const T* __restrict__ u, int64_t u_stride, const T* __restrict__ a,
                                                           OT* __restrict__ o, float* __restrict__ mean_o,
                                                           float* __restrict__ rstd_o, int64_t rows, int dim, float eps,
-                                                          float p, float keep_scale, uint64_t seed) {
+                                                          float p, float keep_scale, uint64_t seed,
+                                                          const int64_t* __restrict__ step_seed) {
+  seed = mhr_step_seed(seed, step_seed);
   WAVE_ROW_LOOP(rows) {
     RowRegs<NC> av, uv;
     load_row<T, NC>(a + row * dim, dim, lane, av);
@@ -328,7 +330,9 @@ __global__ __launch_bounds__(256) void ln_gate_bwd_kernel(const GT* __restrict__
                                                           int64_t u_stride, const T* __restrict__ a,
                                                           const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
                                                           T* __restrict__ du, int64_t du_stride, T* __restrict__ da,
-                                                          int64_t rows, int dim, float p, float keep_scale, uint64_t seed) {
+                                                          int64_t rows, int dim, float p, float keep_scale, uint64_t seed,
+                                                          const int64_t* __restrict__ step_seed) {
+  seed = mhr_step_seed(seed, step_seed);
   WAVE_ROW_LOOP(rows) {
     RowRegs<NC> g, uv, av;
     load_row<GT, NC>(d_o + row * dim, dim, lane, g);
@@ -373,7 +377,7 @@ __global__ __launch_bounds__(256) void ln_gate_bwd_kernel(const GT* __restrict__
 
 extern "C" int mhr_ln_gate_fwd(const void* u_base, int64_t u_stride, const void* a, int dtype, void* o, int o_dtype,
                                float* mean, float* rstd, int64_t rows, int dim, float eps, float dropout_p, uint64_t seed,
-                               void* stream) {
+                               const int64_t* step_seed, void* stream) {
   MHR_REQUIRE(u_base && a && o && mean && rstd, "ln_gate_fwd: null pointer");
   MHR_REQUIRE(dim > 0 && dim % 4 == 0 && dim <= 2048 && u_stride >= dim, "ln_gate_fwd: dim=%d / stride unsupported", dim);
   MHR_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "ln_gate_fwd: dropout_p out of range");
@@ -385,15 +389,15 @@ extern "C" int mhr_ln_gate_fwd(const void* u_base, int64_t u_stride, const void*
 #define L(NC)                                                                                                             \
   if (tb && ob) hipLaunchKernelGGL((ln_gate_fwd_kernel<bf16_t, bf16_t, NC>), dim3(grid), dim3(256), 0, s,                 \
                                    (const bf16_t*)u_base, u_stride, (const bf16_t*)a, (bf16_t*)o, mean, rstd, rows, dim,  \
-                                   eps, dropout_p, ks, seed);                                                            \
+                                   eps, dropout_p, ks, seed, step_seed);                                                            \
   else if (tb) hipLaunchKernelGGL((ln_gate_fwd_kernel<bf16_t, float, NC>), dim3(grid), dim3(256), 0, s,                   \
                                   (const bf16_t*)u_base, u_stride, (const bf16_t*)a, (float*)o, mean, rstd, rows, dim,    \
-                                  eps, dropout_p, ks, seed);                                                             \
+                                  eps, dropout_p, ks, seed, step_seed);                                                             \
   else if (ob) hipLaunchKernelGGL((ln_gate_fwd_kernel<float, bf16_t, NC>), dim3(grid), dim3(256), 0, s,                   \
                                   (const float*)u_base, u_stride, (const float*)a, (bf16_t*)o, mean, rstd, rows, dim,     \
-                                  eps, dropout_p, ks, seed);                                                             \
+                                  eps, dropout_p, ks, seed, step_seed);                                                             \
   else hipLaunchKernelGGL((ln_gate_fwd_kernel<float, float, NC>), dim3(grid), dim3(256), 0, s, (const float*)u_base,      \
-                          u_stride, (const float*)a, (float*)o, mean, rstd, rows, dim, eps, dropout_p, ks, seed)
+                          u_stride, (const float*)a, (float*)o, mean, rstd, rows, dim, eps, dropout_p, ks, seed, step_seed)
   DISPATCH_NC(dim, L);
 #undef L
   MHR_CHECK_LAUNCH("ln_gate_fwd");
@@ -402,7 +406,7 @@ extern "C" int mhr_ln_gate_fwd(const void* u_base, int64_t u_stride, const void*
 
 extern "C" int mhr_ln_gate_bwd(const void* d_o, int do_dtype, const void* u_base, int64_t u_stride, const void* a, int dtype,
                                const float* mean, const float* rstd, void* du_base, int64_t du_stride, void* da,
-                               int64_t rows, int dim, float dropout_p, uint64_t seed, void* stream) {
+                               int64_t rows, int dim, float dropout_p, uint64_t seed, const int64_t* step_seed, void* stream) {
   MHR_REQUIRE(d_o && u_base && a && mean && rstd && du_base && da, "ln_gate_bwd: null pointer");
   MHR_REQUIRE(dim > 0 && dim % 4 == 0 && dim <= 2048 && u_stride >= dim && du_stride >= dim, "ln_gate_bwd: bad dims");
   if (rows <= 0) return MHR_OK;
@@ -412,7 +416,7 @@ extern "C" int mhr_ln_gate_bwd(const void* d_o, int do_dtype, const void* u_base
   bool tb = dtype == MHR_BF16, gb = do_dtype == MHR_BF16;
 #define LK(GT, T, NC)                                                                                                  \
   hipLaunchKernelGGL((ln_gate_bwd_kernel<GT, T, NC>), dim3(grid), dim3(256), 0, s, (const GT*)d_o, (const T*)u_base,    \
-                     u_stride, (const T*)a, mean, rstd, (T*)du_base, du_stride, (T*)da, rows, dim, dropout_p, ks, seed)
+                     u_stride, (const T*)a, mean, rstd, (T*)du_base, du_stride, (T*)da, rows, dim, dropout_p, ks, seed, step_seed)
 #define L(NC)                          \
   if (gb && tb) LK(bf16_t, bf16_t, NC); \
   else if (gb) LK(bf16_t, float, NC);   \

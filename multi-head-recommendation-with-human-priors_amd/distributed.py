@@ -54,17 +54,15 @@ def allreduce_sum_begin(t):
 class RowExchange:
     """In-flight exchange of a step's embedding-gradient rows (see `begin_row_exchange`)."""
 
-    def __init__(self, ids, rows_priv, rows_shared, w_ids=(), w_rows=(), finish=None):
+    def __init__(self, ids, rows_priv, rows_shared, w_ids=(), w_rows=()):
         self._ids, self._rows_priv, self._rows_shared = ids, rows_priv, rows_shared
-        self._w_ids, self._w_rows, self._finish = list(w_ids), list(w_rows), finish
+        self._w_ids, self._w_rows = list(w_ids), list(w_rows)
 
     def wait_ids(self):
         """ids [W*n_private + n_shared] (private ids in rank order, then the shared ids)."""
         for w in self._w_ids:
             w.wait()
         self._w_ids = []
-        if self._finish is not None:
-            self._finish[0]()
         return self._ids
 
     def wait_rows(self):
@@ -72,8 +70,6 @@ class RowExchange:
         for w in self._w_rows:
             w.wait()
         self._w_rows = []
-        if self._finish is not None:
-            self._finish[1]()
         return self._rows_priv, self._rows_shared
 
 
@@ -98,12 +94,10 @@ def begin_row_exchange(ids_all, d_rows, n_private, wire_dtype=None, shared_pendi
     ids_out = torch.empty(W * n_private + n_sh, dtype=ids_all.dtype, device=ids_all.device)
     rows_priv = torch.empty(W * n_private, d_rows.shape[1], dtype=wire, device=d_rows.device)
     ids_out[W * n_private:] = shared_ids
-    w_ids, w_rows, finish = [], [], None
-    if dist.get_backend() == "nccl":          # gather straight into the output (no per-rank list + concatenation)
-        w_ids.append(dist.all_gather_into_tensor(ids_out[:W * n_private], priv_ids, async_op=True))
-    else:
-        g_ids = [torch.empty_like(priv_ids) for _ in range(W)]
-        w_ids.append(dist.all_gather(g_ids, priv_ids, async_op=True))
+    # gathers go straight into the output (no per-rank list + concatenation); gloo implements all_gather_into_tensor too, so
+    # the two-rank CPU / one-card tests run exactly the layout and wait-ordering code that ships over RCCL
+    w_ids = [dist.all_gather_into_tensor(ids_out[:W * n_private], priv_ids, async_op=True)]
+    w_rows = []
     if shared_pending is not None:
         shared_rows, w_sh = shared_pending
         if w_sh is not None:
@@ -112,13 +106,8 @@ def begin_row_exchange(ids_all, d_rows, n_private, wire_dtype=None, shared_pendi
         shared_rows = d_rows[n_private:].contiguous()
         if n_sh:
             w_rows.append(dist.all_reduce(shared_rows, op=dist.ReduceOp.SUM, async_op=True))
-    if dist.get_backend() == "nccl":
-        w_rows.append(dist.all_gather_into_tensor(rows_priv, priv_rows, async_op=True))
-    else:
-        g_rows = [torch.empty_like(priv_rows) for _ in range(W)]
-        w_rows.append(dist.all_gather(g_rows, priv_rows, async_op=True))
-        finish = (lambda: ids_out[:W * n_private].copy_(torch.cat(g_ids)), lambda: rows_priv.copy_(torch.cat(g_rows)))
-    return RowExchange(ids_out, rows_priv, shared_rows, w_ids, w_rows, finish)
+    w_rows.append(dist.all_gather_into_tensor(rows_priv.view(-1), priv_rows.view(-1), async_op=True))
+    return RowExchange(ids_out, rows_priv, shared_rows, w_ids, w_rows)
 
 
 def exchange_sparse_rows(ids_all, d_rows, n_private, wire_dtype=None, shared_pending=None):

@@ -120,7 +120,7 @@ def sparse_rows_segment_sum(sorted_ids, perm, grad_a, grad_b, x_grad, seq_len, w
     _timed_call("mhr_sparse_rows_segment_sum", sorted_ids.data_ptr(), perm.data_ptr(), sorted_ids.numel(),
              _ptr(grad_a), _dt(grad_a) if grad_a is not None else F32, n_a,
              _ptr(grad_b), _dt(grad_b) if grad_b is not None else F32, n_b,
-             _ptr(x_grad), seq_len, window_len, out_rows.data_ptr(), row_slot.data_ptr(), D, _stream())
+             _ptr(x_grad), seq_len, window_len, out_rows.data_ptr(), row_slot.data_ptr(), row_slot.numel(), D, _stream())
 
 
 def adam_rows(w, m, v, grad_rows, row_slot, step, lr, grad_scale=1.0, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
@@ -128,9 +128,12 @@ def adam_rows(w, m, v, grad_rows, row_slot, step, lr, grad_scale=1.0, betas=(0.9
              _ptr(row_slot), grad_scale, lr, betas[0], betas[1], eps, weight_decay, step, _stream())
 
 
-def adam_flat(w, g, m, v, step, lr, grad_scale=1.0, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, w_bf16=None):
+def adam_flat(w, g, m, v, step, lr, grad_scale=1.0, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, w_bf16=None,
+              hist=None, step_dev=None):
+    """hist [hist_len, 4] f32 + step_dev int64[1] (device): the step's constants come from device memory (hipGraph replay)."""
     lib.call("mhr_adam_flat", w.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), w.numel(), grad_scale, lr,
-             betas[0], betas[1], eps, weight_decay, step, _ptr(w_bf16), _stream())
+             betas[0], betas[1], eps, weight_decay, step, _ptr(w_bf16), _ptr(hist), 0 if hist is None else hist.shape[0],
+             _ptr(step_dev), _stream())
 
 
 def heads_residual_fwd(x, z, B, L, H):
@@ -217,24 +220,25 @@ def add_layernorm_bwd(d_xn, x_out, mean, rstd, d_xout):
     return dx, dy
 
 
-def ln_gate_fwd(h, a, dim, out_dtype=None, eps=1e-6, dropout_p=0.0, seed=0):
-    """o = silu(h[:, :dim]) * LN(a) * dropmask.  h [rows, stride] pre-activation, a [rows, dim]."""
+def ln_gate_fwd(h, a, dim, out_dtype=None, eps=1e-6, dropout_p=0.0, seed=0, seed_dev=None):
+    """o = silu(h[:, :dim]) * LN(a) * dropmask.  h [rows, stride] pre-activation, a [rows, dim].
+    seed_dev (device int64[1], optional): step counter of a hipGraph-replayed step; `seed` is then the per-layer part."""
     rows = a.numel() // dim
     o = torch.empty(rows, dim, dtype=out_dtype or a.dtype, device=a.device)
     mean = torch.empty(rows, dtype=torch.float32, device=a.device)
     rstd = torch.empty(rows, dtype=torch.float32, device=a.device)
     assert h.dtype == a.dtype
     lib.call("mhr_ln_gate_fwd", h.data_ptr(), h.stride(0), a.data_ptr(), _dt(a), o.data_ptr(), _dt(o), mean.data_ptr(),
-             rstd.data_ptr(), rows, dim, eps, dropout_p, seed, _stream())
+             rstd.data_ptr(), rows, dim, eps, dropout_p, seed, _ptr(seed_dev), _stream())
     return o, mean, rstd
 
 
-def ln_gate_bwd(d_o, h, a, mean, rstd, dh, dim, dropout_p=0.0, seed=0):
+def ln_gate_bwd(d_o, h, a, mean, rstd, dh, dim, dropout_p=0.0, seed=0, seed_dev=None):
     """writes du into dh[:, :dim]; returns da."""
     rows = a.numel() // dim
     da = torch.empty_like(a)
     lib.call("mhr_ln_gate_bwd", d_o.data_ptr(), _dt(d_o), h.data_ptr(), h.stride(0), a.data_ptr(), _dt(a), mean.data_ptr(),
-             rstd.data_ptr(), dh.data_ptr(), dh.stride(0), da.data_ptr(), rows, dim, dropout_p, seed, _stream())
+             rstd.data_ptr(), dh.data_ptr(), dh.stride(0), da.data_ptr(), rows, dim, dropout_p, seed, _ptr(seed_dev), _stream())
     return da
 
 

@@ -49,13 +49,14 @@ class FusedAdamW:
         dev = next(model.parameters()).device
         self.t_m = torch.zeros_like(self.table) if self.table is not None else None
         self.t_v = torch.zeros_like(self.table) if self.table is not None else None
-        self.dense = [p for n, p in model.named_parameters() if p.requires_grad and p is not self.table]
-        seen, uniq = set(), []
-        for p in self.dense:
-            if id(p) not in seen:
+        seen, uniq, names = set(), [], []
+        for n, p in model.named_parameters():
+            if p.requires_grad and p is not self.table and id(p) not in seen:
                 seen.add(id(p))
                 uniq.append(p)
+                names.append(n)
         self.dense = uniq
+        self.layout = [[n, p.numel()] for n, p in zip(names, uniq)]     # order of the flat buffers (checked on load)
         sizes = [(p.numel() + 3) // 4 * 4 for p in self.dense]          # keep every view 16-byte aligned
         total = sum(sizes)
         self.flat_w = torch.zeros(total, dtype=torch.float32, device=dev)
@@ -78,10 +79,17 @@ class FusedAdamW:
             off += sz
         self.param_groups = [{"lr": lr}]                                 # scheduler-facing view
         self.lazy = bool(lazy_table) and self.table is not None and os.environ.get("MHR_LAZY_ADAM", "1") != "0"
+        # per-step constants (lr decay, bias corrections) of the last LAZY_HIST steps on the device: the lazy table replay
+        # reads them, and so does every Adam kernel of a step replayed from a hipGraph (`step_dev`, set by the Trainer's
+        # step graph: the step number in device memory, because a replayed launch cannot take it as an argument)
+        self.hist = torch.zeros(LAZY_HIST, 4, dtype=torch.float32, device=dev)
+        self._hist_host = torch.zeros(LAZY_HIST, 4, dtype=torch.float32)
+        if dev.type == "cuda":
+            self._hist_host = self._hist_host.pin_memory()
+        self.step_dev = None
+        self.in_graph = False                                            # True while a step is being captured
         if self.lazy:
             self.last_step = torch.zeros(self.table.shape[0], dtype=torch.int32, device=dev)
-            self.hist = torch.zeros(LAZY_HIST, 4, dtype=torch.float32, device=dev)
-            self._hist_host = torch.zeros(LAZY_HIST, 4, dtype=torch.float32).pin_memory()
             model._table_optimizer = self                                # the model's forward / eval hooks find us here
             self._lagging = False                                        # rows behind step_count exist (host-side flag)
 
@@ -92,6 +100,24 @@ class FusedAdamW:
         if self.table is not None:
             self.table.grad = None
         self.model.sparse_grad = None
+
+    def graph_capable(self):
+        """A step can be replayed from a hipGraph when every per-step scalar can come from device memory: the flat Adam and
+        the lazy table Adam can; the dense table pass (`mhr_adam_rows`) takes its constants as arguments."""
+        return self.table is None or self.lazy
+
+    def begin_replayed_step(self, lr):
+        """Host side of a step that is replayed from a hipGraph: advance the counters the captured Python would have advanced
+        and upload the step's constants (stream-ordered in front of the replay)."""
+        self.step_count += 1
+        self.param_groups[0]["lr"] = lr
+        self._push_consts(self.step_count, lr)
+        if self.lazy:
+            self._lagging = True
+
+    def end_replayed_step(self):
+        if self.lazy and self.step_count % LAZY_HIST == 0:               # nobody lags further than the history reaches
+            self.flush_table()
 
     def step(self):
         self.step_count += 1
@@ -104,19 +130,21 @@ class FusedAdamW:
             self.model.begin_sparse_exchange()
         if dense_work is not None:
             dense_work.wait()
+        sd = self.step_dev if self.in_graph else None
         ops.adam_flat(self.flat_w, self.flat_g, self.flat_m, self.flat_v, self.step_count, lr, 1.0 / W, self.betas, self.eps,
-                      self.weight_decay, w_bf16=self.flat_w16)
+                      self.weight_decay, w_bf16=self.flat_w16, hist=self.hist if sd is not None else None, step_dev=sd)
         for p in self.dense:
             if hasattr(p, "_mhr_bf16"):
                 p._mhr_ver = p._version
         if self.table is None:
             return
         sg = self.model.finish_sparse_grad() if hasattr(self.model, "finish_sparse_grad") else self.model.sparse_grad
+        if self.lazy and not self.in_graph:          # every step has its constants in the history, with or without a gradient
+            self._push_consts(self.step_count, lr)   # (a captured step gets them from begin_replayed_step at every replay)
         if sg is not None and self.lazy:
-            self._push_consts(self.step_count, lr)
             self._lazy_call(1, sg.sorted_ids, sg.rows, sg.row_slot, 1.0 / W)
             self._lagging = True
-            if self.step_count % LAZY_HIST == 0:                         # nobody lags further than the history reaches
+            if self.step_count % LAZY_HIST == 0 and not self.in_graph:   # nobody lags further than the history reaches
                 self.flush_table()
         elif sg is not None:
             ops.adam_rows(self.table, self.t_m, self.t_v, sg.rows, sg.row_slot, self.step_count, lr, 1.0 / W, self.betas,
@@ -143,10 +171,11 @@ class FusedAdamW:
 
     def _lazy_call(self, mode, ids, grad_rows, row_slot, grad_scale, step=None):
         t = self.table
+        sd = self.step_dev if (self.in_graph and mode != 2) else None     # captured launches read the step from the device
         ops._timed_call("mhr_adam_rows_lazy", t.data_ptr(), self.t_m.data_ptr(), self.t_v.data_ptr(), t.shape[0], t.shape[1],
                  ops._ptr(ids), 0 if ids is None else ids.numel(), ops._ptr(grad_rows), ops._ptr(row_slot),
                  self.last_step.data_ptr(), self.hist.data_ptr(), LAZY_HIST, self.step_count if step is None else step,
-                 float(grad_scale), self.betas[0], self.betas[1], self.eps, mode, ops._stream())
+                 float(grad_scale), self.betas[0], self.betas[1], self.eps, mode, ops._ptr(sd), ops._stream())
 
     def catch_up(self, ids):
         """Bring the rows of `ids` (int64, duplicates allowed) up to the last optimizer step before they are read."""
@@ -161,12 +190,16 @@ class FusedAdamW:
 
     def state_dict(self):
         self.flush_table()
-        sd = {"step": self.step_count, "flat_m": self.flat_m, "flat_v": self.flat_v}
+        sd = {"step": self.step_count, "flat_m": self.flat_m, "flat_v": self.flat_v, "layout": self.layout}
         if self.table is not None:
             sd.update(t_m=self.t_m, t_v=self.t_v)
         return sd
 
     def load_state_dict(self, sd):
+        lay = sd.get("layout")
+        if lay is not None and [list(x) for x in lay] != self.layout:
+            raise RuntimeError("optimizer state was saved for a different parameter layout (names / sizes / order of the flat "
+                               "moment buffers differ): refusing to load it onto the wrong parameters")
         self.step_count = int(sd["step"])
         for k in ("flat_m", "flat_v") + (("t_m", "t_v") if self.table is not None else ()):
             getattr(self, k).copy_(sd[k])

@@ -71,13 +71,15 @@ def silu(x):
     return x * torch.sigmoid(x)
 
 
-def hstu_attention(q, k, v, key_valid, n_heads):
+def hstu_attention(q, k, v, key_valid, n_heads, operand_round=None):
     """Pointwise-gated causal attention. model/IDNet/hstu.py:137-160.
 
     q,k: [B,L,Hh*dqk]  v: [B,L,Hh*dv]  key_valid: [B,L] bool.
     A[b,n,h,:] = sum_{m<=n, key_valid[b,m]} silu(q[b,n,h].k[b,m,h]) / L * v[b,m,h,:]
     The normaliser is the padded length L (hstu.py:146,153), and padded *query*
     rows still produce an output.
+    operand_round (tests only; None = the reference's fp32): rounding applied to the gate tile where the GPU kernel
+    feeds it to its second matrix product as a bf16 operand (the caller rounds q, k, v the same way).
     """
     B, L, _ = q.shape
     dqk = q.shape[-1] // n_heads
@@ -89,6 +91,8 @@ def hstu_attention(q, k, v, key_valid, n_heads):
     causal = torch.ones(L, L, dtype=torch.bool).tril()
     m = causal[None, None] & key_valid[:, None, None, :]
     s = s * m
+    if operand_round is not None:
+        s = operand_round(s)
     out = s @ vh                                                  # [B,Hh,L,dv]
     return out.permute(0, 2, 1, 3).reshape(B, L, n_heads * dv)
 
@@ -220,8 +224,10 @@ def l2n(x):
     return x / x.norm(dim=-1, keepdim=True)
 
 
-def nce_logits(q, p, negs_n, logit_scale, thres):
+def nce_logits(q, p, negs_n, logit_scale, thres, operand_round=None):
     """model/IDNet/hstu.py:600-619.  q,p: [T,D] raw; negs_n: [Nn,D] already L2-normalised.
+    operand_round (tests only; None = the reference's fp32): rounding applied to the normalised rows, which the GPU kernels
+    feed to the matrix cores as bf16 operands.
 
     Returns logits [T, 1+Nn] (label 0).  False negatives (cos(p, neg) > thres) are
     suppressed to -inf (finfo.min * exp(scale) overflows to -inf, as in the reference).
@@ -229,6 +235,8 @@ def nce_logits(q, p, negs_n, logit_scale, thres):
     """
     scale = torch.clamp(logit_scale, 0.0, math.log(100.0)).exp()
     qn, pn = l2n(q), l2n(p)
+    if operand_round is not None:
+        qn, pn = operand_round(qn), operand_round(pn)
     pos = (qn * pn).sum(-1, keepdim=True)
     neg = qn @ negs_n.T
     fix = pn @ negs_n.T

@@ -232,3 +232,36 @@ def test_data_parallel_exchange_two_gloo_ranks(tmp_path, built_lib):
     for p, (o, e) in zip(procs, outs):
         assert p.returncode == 0, (o, e[-2000:])
         assert json.loads(o.strip().splitlines()[-1])["ok"]
+
+
+def test_kernel_oracles_are_the_pinned_oracle_functions():
+    """The oracles the GPU kernel tests compare with (tests/kernel_oracles.py) are the fixture-pinned `HO.hstu_attention` /
+    `HO.nce_logits` / `HO.token_ce` with a rounding hook for the kernels' bf16 operands: with the hook off they return the
+    pinned functions' values bit for bit, and the hook moves them by no more than bf16 rounding can."""
+    import math
+    import torch
+    from kernel_oracles import attn_oracle, bf16_round, nce_oracle
+    from oracle import hstu_oracle as HO
+    g = torch.Generator().manual_seed(0)
+    B, L, Hh, hd = 2, 19, 2, 8
+    D = Hh * hd
+    h = torch.randn(B * L, 4 * D, generator=g).to(torch.bfloat16)
+    valid = torch.rand(B, L, generator=g) > 0.2
+    out, _ = attn_oracle(h, valid, B, L, Hh, hd, operand_round=None)
+    u, v, q, k = torch.split(HO.silu(h.float()), [D, D, D, D], dim=-1)
+    want = HO.hstu_attention(q.view(B, L, D), k.view(B, L, D), v.view(B, L, D), valid, Hh).reshape(B * L, D)
+    assert torch.equal(out, want)
+    out_r, _ = attn_oracle(h, valid, B, L, Hh, hd)
+    assert 0 < float((out_r - want).abs().max()) <= 2 ** -6 * float(want.abs().max())
+    T, Nn = 23, 40
+    qq, pp = torch.randn(T, D, generator=g) * 2, torch.randn(T, D, generator=g)
+    negs = HO.l2n(torch.randn(Nn, D, generator=g))
+    negs[3] = HO.l2n(pp[5][None])[0]                                       # a false negative
+    ls = torch.tensor(math.log(20.0))
+    loss, logits, keep, neg, pos = nce_oracle(qq, pp, negs, ls, 0.99, operand_round=None)
+    want_logits = HO.nce_logits(qq, pp, negs, ls, 0.99)
+    assert torch.equal(logits, want_logits) and torch.equal(loss, HO.token_ce(want_logits))
+    assert not bool(keep[5, 3]) and int((~keep).sum()) >= 1 and bool(torch.isinf(neg[5, 3]))
+    loss_r, *_ = nce_oracle(qq, pp, negs, ls, 0.99)
+    assert 0 < float((loss_r - loss).abs().max()) <= 0.25
+    assert float((bf16_round(qq) - qq).abs().max()) <= 2 ** -8 * float(qq.abs().max())

@@ -1,0 +1,138 @@
+"""The train step replayed from a hipGraph (REC/trainer/trainer.py:_StepGraph) against the same step issued launch by launch.
+
+What a replayed launch cannot take as a kernel argument comes from device memory: the dropout step counter
+(`mhr_ln_gate_*`'s step_seed), the optimizer step and its constants (`mhr_adam_flat` / `mhr_adam_rows_lazy`'s step_dev +
+the constants' history).  These tests pin (a) that the device-side forms give the bits of the host-side forms, and
+(b) that a trainer whose steps are replayed follows the trajectory of one whose steps are host-issued - same dropout
+masks, same lr schedule, same lazy-table bookkeeping - on the reference's step semantics (trainer.py:494-536)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+CODE = os.path.join(ROOT, "multi-head-recommendation-with-human-priors_amd", "code")
+
+
+@pytest.fixture(scope="module")
+def rec():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    if CODE not in sys.path:
+        sys.path.insert(0, CODE)
+    import REC  # noqa: F401
+    return REC
+
+
+def test_device_side_seed_and_step_give_the_host_side_bits(rec):
+    from mhr_amd import ops
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(0)
+    rows, D = 300, 256
+    h = torch.randn(rows, 4 * D, generator=g, device=dev).bfloat16()
+    a = torch.randn(rows, D, generator=g, device=dev).bfloat16()
+    d_o = torch.randn(rows, D, generator=g, device=dev).bfloat16()
+    step, layer_part = 4321, 3 * 7919 + 2 * 104729
+    host_seed = (step * 1000003 + layer_part) & 0x7FFFFFFFFFFFFFFF
+    ctr = torch.tensor([step], dtype=torch.int64, device=dev)
+    o1, m1, r1 = ops.ln_gate_fwd(h, a, D, torch.bfloat16, 1e-6, 0.25, host_seed)
+    o2, m2, r2 = ops.ln_gate_fwd(h, a, D, torch.bfloat16, 1e-6, 0.25, layer_part, ctr)
+    assert torch.equal(o1, o2) and 0.15 < float((o1 == 0).float().mean()) < 0.35
+    dh1, dh2 = torch.zeros_like(h), torch.zeros_like(h)
+    da1 = ops.ln_gate_bwd(d_o, h, a, m1, r1, dh1, D, 0.25, host_seed)
+    da2 = ops.ln_gate_bwd(d_o, h, a, m2, r2, dh2, D, 0.25, layer_part, ctr)
+    assert torch.equal(da1, da2) and torch.equal(dh1, dh2)
+    # flat Adam: constants from the device-side history == constants derived from the arguments
+    from mhr_amd import lib
+    n = 10007
+    w = torch.randn(n, generator=g, device=dev)
+    gr = torch.randn(n, generator=g, device=dev)
+    wa, ma, va = w.clone(), torch.zeros_like(w), torch.zeros_like(w)
+    wb, mb, vb = w.clone(), torch.zeros_like(w), torch.zeros_like(w)
+    hist_h = torch.zeros(64, 4)
+    hist = torch.zeros(64, 4, device=dev)
+    sd = torch.zeros(1, dtype=torch.int64, device=dev)
+    for s in (1, 2, 70):
+        lr = 1e-3 / s
+        ops.adam_flat(wa, gr, ma, va, s, lr, 0.5, weight_decay=0.01)
+        lib.call("mhr_adam_consts", lr, 0.9, 0.999, 1e-8, 0.01, s, hist_h[s % 64].data_ptr())
+        hist.copy_(hist_h)
+        sd.fill_(s)
+        ops.adam_flat(wb, gr, mb, vb, 999, 123.0, 0.5, weight_decay=0.01, hist=hist, step_dev=sd)     # arguments ignored
+    assert torch.equal(wa, wb) and torch.equal(ma, mb) and torch.equal(va, vb)
+
+
+def _trainer(rec, graph, dev, **over):
+    import mhr_amd.synth as synth
+    from REC.config.configurator import Config, apply_run_fixups
+    from REC.trainer import Trainer
+    from REC.utils import get_model
+    kw = dict(MAX_ITEM_LIST_LENGTH=24, pred_len=4, eval_pred_len=4, n_layers=2, n_heads=2, item_embedding_size=64,
+              hstu_embedding_size=64, loss='prior', num_prior_head=3, medusa_num_layers=1, eval_num_cats=3, num_negatives=256,
+              device=dev, total_iters=200, eval_interval=0, checkpoint_dir=None, save_model_note="t",
+              scheduler_args={'type': 'cosine', 'warmup': 0.05}, optim_args={'learning_rate': 2e-3, 'weight_decay': 0.01},
+              hidden_dropout_prob=0.2, hip_graph=graph)
+    kw.update(over)
+    cfg = apply_run_fixups(Config(config_dict=synth.base_config(**kw)))
+    data = synth.SyntheticData(cfg, 2000, dev, seed=7)
+    cfg["int_to_category"] = data.int_to_category
+    torch.manual_seed(11)
+    model = get_model("HSTU")(cfg, data).to(dev)
+    tr = Trainer(cfg)
+    tr.setup_model(model)
+    return tr, model, data
+
+
+@pytest.mark.parametrize("loss", ["prior", "nce"])
+def test_replayed_steps_follow_the_host_issued_trajectory(rec, loss):
+    dev = torch.device("cuda", 0)
+    over = dict(loss=loss) if loss == "prior" else dict(loss="nce", num_prior_head=1, medusa_num_layers=0, eval_num_cats=1, pred_len=1,
+                                                        eval_pred_len=1)
+    tr_e, m_e, data = _trainer(rec, False, dev, **over)
+    tr_g, m_g, _ = _trainer(rec, True, dev, **over)
+    assert all(torch.equal(a, b) for a, b in zip(m_e.state_dict().values(), m_g.state_dict().values()))
+    batches = [data.train_batch(16) for _ in range(6)]
+    n_steps = 70                                   # crosses the lazy table's 64-step flush
+    le, lg = [], []
+    for i in range(n_steps):
+        b = batches[i % len(batches)]
+        le.append(float(tr_e.train_step_fn(b)["loss"]))
+        lg.append(float(tr_g.train_step_fn(b)["loss"]))
+    assert tr_g.graph_active and not tr_e.graph_active
+    assert tr_g._step_graph.n == n_steps - 3       # three host-issued warm-up steps, everything else replayed
+    assert tr_g.train_step == tr_e.train_step == n_steps and tr_g.optimizer.step_count == tr_e.optimizer.step_count == n_steps
+    assert m_g._step_seed == m_e._step_seed == n_steps
+    # same dropout masks, same schedule: the two runs differ by the order of float atomics in the loss backward only
+    le, lg = np.array(le), np.array(lg)
+    assert np.all(np.isfinite(lg))
+    np.testing.assert_allclose(lg, le, rtol=5e-3)
+    assert le[-1] < le[0]
+    sd_e, sd_g = m_e.state_dict(), m_g.state_dict()                 # state_dict() flushes the lazy table
+    for k in sd_e:
+        a, b = sd_e[k].float(), sd_g[k].float()
+        assert float((a - b).abs().max()) <= 2e-2 * float(a.abs().max()) + 1e-6, k
+    # a different dropout mask would show: replaying with a frozen step counter must NOT reproduce the trajectory
+    assert abs(lg[10] - lg[4]) > 0 or loss == "nce"
+
+
+def test_host_issued_steps_interleave_with_replays(rec):
+    """bench.py's evented pass issues steps from the host between replays: counters, lazy-table state and the constants'
+    history are shared, so the run is the same run."""
+    dev = torch.device("cuda", 0)
+    tr_a, m_a, data = _trainer(rec, True, dev, hidden_dropout_prob=0.0)
+    tr_b, m_b, _ = _trainer(rec, True, dev, hidden_dropout_prob=0.0)
+    batches = [data.train_batch(16) for _ in range(4)]
+    for i in range(24):
+        b = batches[i % 4]
+        tr_a.train_step_fn(b)
+        tr_b.train_step_fn(b, graph=False if 8 <= i < 14 else None)
+    assert tr_a.graph_active and tr_b.graph_active and tr_b._step_graph.n == 24 - 3 - 6
+    sd_a, sd_b = m_a.state_dict(), m_b.state_dict()
+    for k in sd_a:
+        a, b = sd_a[k].float(), sd_b[k].float()
+        assert float((a - b).abs().max()) <= 1e-2 * float(a.abs().max()) + 1e-6, k
+    assert torch.equal(tr_a.optimizer.last_step, tr_b.optimizer.last_step)

@@ -81,6 +81,7 @@ def test_segment_sum_and_adam_rows(ops):
     ids_a = torch.randint(1, N, (B * W,), generator=g)
     ids_a[:50] = 5                                        # a hot row spanning several 32-row chunks
     ids_b = torch.randint(1, N, (nneg,), generator=g)
+    ids_b[:40] = 9                                        # a second one, fed from the other gradient buffer
     ga = bf(torch.randn(B * W, D, generator=g))
     gb = torch.randn(nneg, D, generator=g)
     xg = torch.randn(B, L, D, generator=g)
@@ -100,12 +101,28 @@ def test_segment_sum_and_adam_rows(ops):
     got = torch.zeros(N, D)
     got[touched] = out_rows.cpu()[slot[touched].long()]
     np.testing.assert_allclose(got.numpy(), dense.numpy(), rtol=1e-5, atol=2e-5)
-    # rows whose segment fits one chunk are bitwise reproducible (only chunk-spanning hot rows use atomics)
+    # no atomics anywhere: EVERY row - the chunk-spanning hot ones included - is bitwise reproducible, and the sum of a run
+    # has one fixed order (list order inside a chunk, chunks in order); non-head rows are zero on return
     out2 = torch.zeros_like(out_rows)
     slot2 = torch.full((N,), -1, dtype=torch.int32).cuda()
     ops.sparse_rows_segment_sum(dev(sorted_ids), dev(perm), dev(ga), dev(gb), dev(xg), L, W, out2, slot2)
-    cold = touched[touched != 5]
-    assert torch.equal(out2.cpu()[slot[cold].long()], out_rows.cpu()[slot[cold].long()])
+    assert torch.equal(out2.cpu(), out_rows.cpu()) and torch.equal(slot2.cpu(), slot)
+    head = torch.ones_like(sorted_ids, dtype=torch.bool)
+    head[1:] = sorted_ids[1:] != sorted_ids[:-1]
+    assert float(out_rows.cpu()[~head].abs().max()) == 0.0
+    src = torch.cat([full.view(-1, D), gb])                      # the fixed order, restated: chunk partials, then chunk order
+    for hot in (5, 9):
+        pos = torch.nonzero(sorted_ids == hot).flatten()
+        acc = None
+        for c0 in range(int(pos[0]) // 32 * 32, int(pos[-1]) + 1, 32):
+            part = torch.zeros(D)
+            for q in pos[(pos >= c0) & (pos < c0 + 32)].tolist():
+                r = int(perm[q])
+                part = part + (ga[r].float() if r < B * W else gb[r - B * W])
+                if r < B * W and r % W < L:
+                    part = part + xg[r // W, r % W]
+            acc = part if acc is None else acc + part
+        assert torch.equal(out_rows.cpu()[int(slot[hot])], acc), f"hot row {hot}: order of the sum is not the documented one"
     # AdamW over the table, two steps, untouched rows move too (dense semantics)
     w = torch.randn(N, D, generator=g)
     m = torch.zeros(N, D)
@@ -200,27 +217,7 @@ def _attn_case(B, L, Hh, hd, seed):
     return h, valid, d_out
 
 
-def _attn_oracle(h, valid, B, L, Hh, hd, d_out=None):
-    """Oracle on the kernel's operand precision: silu'd q,k,v rounded to bf16, gate tile rounded to bf16."""
-    D = Hh * hd
-    hp = h.float().clone().requires_grad_(d_out is not None)
-    act = HO.silu(hp)
-    u, v, q, k = torch.split(act, [D, D, D, D], dim=-1)
-
-    def r(t):  # straight-through bf16 rounding
-        return t + (bf(t).float() - t).detach()
-    q, k, v = r(q).view(B, L, D), r(k).view(B, L, D), r(v).view(B, L, D)
-    qh = q.view(B, L, Hh, hd).permute(0, 2, 1, 3)
-    kh = k.view(B, L, Hh, hd).permute(0, 2, 1, 3)
-    vh = v.view(B, L, Hh, hd).permute(0, 2, 1, 3)
-    s = HO.silu(qh @ kh.transpose(-1, -2)) / L
-    m = torch.ones(L, L, dtype=torch.bool).tril()[None, None] & valid[:, None, None, :]
-    pm = r(s * m)
-    out = (pm @ vh).permute(0, 2, 1, 3).reshape(B * L, D)
-    if d_out is None:
-        return out.detach(), None
-    out.backward(d_out.float())
-    return out.detach(), hp.grad
+from kernel_oracles import attn_oracle as _attn_oracle      # the pinned HO.hstu_attention on bf16-rounded operands
 
 
 @pytest.mark.parametrize("B,L,Hh,hd", [(3, 12, 2, 8), (2, 40, 4, 16), (2, 33, 2, 32), (2, 200, 8, 32), (1, 70, 2, 64),
@@ -273,20 +270,7 @@ def test_hstu_attention_golden(ops):
 
 
 # ------------------------------------------------------------------------------------------------
-def _nce_oracle(q, p, negs_n, ls, thres, w=None):
-    """Oracle on the kernel's operand precision: normalised rows rounded to bf16."""
-    def r(t):
-        return t + (bf(t).float() - t).detach()
-    qn, pn = r(HO.l2n(q)), r(HO.l2n(p))
-    scale = torch.clamp(ls, 0.0, math.log(100.0)).exp()
-    pos = (qn * pn).sum(-1, keepdim=True)
-    neg = qn @ negs_n.T
-    fix = pn @ negs_n.T
-    keep = ~(fix > thres)
-    # scale first, mask after: -inf * scale would put NaN into d(scale)
-    logits = torch.cat([pos * scale, torch.where(keep, neg * scale, torch.full_like(neg, float("-inf")))], -1)
-    loss = torch.logsumexp(logits, -1) - logits[:, 0]
-    return loss, logits, keep, neg, pos
+from kernel_oracles import nce_oracle as _nce_oracle        # the pinned HO.nce_logits / HO.token_ce on bf16-rounded operands
 
 
 @pytest.mark.parametrize("D,n_tok,n_neg,dtype", [(16, 37, 30, torch.float32), (64, 200, 96, torch.bfloat16),

@@ -539,6 +539,10 @@ model = get_model("HSTU")(cfg, data).to(dev)
 tr = Trainer(cfg); tr.setup_model(model); tr.train_step = 30
 opt = tr.optimizer
 batch = data.train_batch(8)
+# a HOT item: every other position of every window (72 occurrences per rank, 144 in the exchanged id list = a run over five
+# 32-position chunks of the segment sum): the replicas must still hold the same bits (deterministic chunk-order reduction)
+items = batch[0].clone(); items[:, 1::2] = 7
+batch = (items, batch[1], batch[2], data.item_tags[items].long())
 out = model(batch)
 out["loss"].backward()
 w0 = model.item_embedding.weight.detach().clone()

@@ -1,0 +1,319 @@
+"""Parity at the REAL widths of BASELINE.json configs 2, 3 and 4 (tests/test_gpu_fullsize.py does configs[1]).
+
+  cfg2  HSTU MerRec-shaped, size-4: D = 1024, L = 512, 16 heads x 64, N = 2^20 items, 4096 negatives, 8 event-type heads
+        (reference code/IDNet/hstu-size4.yaml:1-4; hstu.py:137-160, 600-619, 965-1015)
+  cfg3  HLLM with a TinyLlama-1.1B tower: d = 2048, 32 query / 4 KV heads x 64, FFN 5632; 16-head decode over 453 938 items
+        (reference reproduce/HLLM-*.slurm, HLLM/modeling_llama.py:648-795, hllm.py:838-883)
+  cfg4  HLLM with a Baichuan2-7B tower: d = 4096, 32 heads x 128, FFN 11008, packed W_pack projection
+        (reference HLLM/baichuan/modeling_baichuan.py:224-395)
+
+Each test runs the launch at its full width on the GPU and checks (a) the oracle on SAMPLED sequences / tokens / users
+(same tolerances as the small cases: indices bit-exact, losses / logits 1e-4 relative on bf16-rounded operands, bf16-stored
+tensors one rounding, gradients through a second bf16 MFMA operand 2e-2 of max-abs) and (b) size-independent properties
+over everything: sortedness, admissibility, no duplicates, linearity of the backward in its weights, exact zeros.
+"""
+import json
+import math
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+from kernel_oracles import attn_oracle, nce_oracle
+from oracle import decode_oracle as DO
+from oracle import hllm_oracle as LO
+from oracle import hstu_oracle as HO
+from test_gpu_kernels import _check_topk
+
+pytestmark = pytest.mark.gpu
+CODE = os.path.join(ROOT, "multi-head-recommendation-with-human-priors_amd", "code")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    if CODE not in sys.path:
+        sys.path.insert(0, CODE)
+    import mhr_amd  # noqa: F401
+    from mhr_amd import ops as _ops
+    return _ops
+
+
+def _i32(t):
+    t = t & 0xFFFFFFFF
+    return torch.where(t >= (1 << 31), t - (1 << 32), t).int()
+
+
+def _close(got, ref, what, tol=1e-4):
+    """tol relative on the sampled tokens, one bf16-rounding-tie token per sample allowed up to 5 x tol (a component of a
+    normalised operand on a bf16 rounding boundary can round the other way under a different summation order of the norm)."""
+    err = np.abs(got - ref) / (tol + tol * np.abs(ref))
+    assert int((err > 1.0).sum()) <= 1 and float(err.max()) <= 5.0, (what, float(err.max()), int((err > 1.0).sum()))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# cfg2: pointwise-gated attention at L = 512, 16 heads x 64, the full batch of 64 sequences
+# ----------------------------------------------------------------------------------------------------------------------
+def test_cfg2_attention_full_width(ops):
+    B, L, Hh, hd = 64, 512, 16, 64
+    D = Hh * hd
+    g = torch.Generator(device="cuda").manual_seed(31)
+    h = torch.randn(B * L, 4 * D, device="cuda", generator=g).bfloat16()
+    ctx = torch.randint(L // 4, L + 1, (B,), device="cuda", generator=g)
+    valid = torch.arange(L, device="cuda")[None, :] >= (L - ctx)[:, None]            # front padding, as the batches have it
+    valid[5] &= torch.rand(L, device="cuda", generator=g) > 0.2                      # and one ragged mask
+    d_out = (torch.randn(B * L, D, device="cuda", generator=g) * 0.5).bfloat16()
+    kv = valid.to(torch.uint8).contiguous()
+    out, _ = ops.hstu_attn_fwd(h, kv, B, L, Hh, hd, save_act=False)
+    dh = torch.zeros_like(h)
+    ops.hstu_attn_bwd(h, None, kv, d_out, dh, B, L, Hh, hd)
+    dh2 = torch.zeros_like(h)
+    ops.hstu_attn_bwd(h, None, kv, d_out, dh2, B, L, Hh, hd)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(out.float()).all()) and bool(torch.isfinite(dh.float()).all())
+    assert torch.equal(dh, dh2)                                                       # no atomics: bitwise reproducible
+    assert float(dh[:, :D].float().abs().max()) == 0.0                                # u block untouched
+    dead = ~valid.reshape(-1)                                                         # a padded key receives no gradient
+    assert float(dh[dead][:, D:2 * D].float().abs().max()) == 0.0 and float(dh[dead][:, 3 * D:].float().abs().max()) == 0.0
+    for b in (0, 5, 63):                                                              # the oracle, sequence by sequence
+        sl = slice(b * L, (b + 1) * L)
+        ref, gref = attn_oracle(h[sl].cpu(), valid[b:b + 1].cpu(), 1, L, Hh, hd, d_out[sl].cpu())
+        assert float((out[sl].float().cpu() - ref).abs().max()) < 2 ** -7 * float(ref.abs().max()), b
+        got = dh[sl].float().cpu()
+        for name, cs in (("dv", slice(D, 2 * D)), ("dq", slice(2 * D, 3 * D)), ("dk", slice(3 * D, 4 * D))):
+            gs = float(gref[:, cs].abs().max())
+            assert float((got[:, cs] - gref[:, cs]).abs().max()) < 2e-2 * gs, (b, name)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# sampled softmax at D = 1024 (cfg2), 2048 (TinyLlama) and 4096 (Baichuan2-7B)
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("D,G,n_neg,cap,n_live", [(1024, 8, 4096, 32768, 4600),      # cfg2: 8 event heads, B L = 32 768 positions
+                                                    (2048, 8, 8192, 12800, 3100),      # cfg3: B = 64, L = 50, P = 4, 8 categories
+                                                    (4096, 2, 8192, 2048, 1500)])      # cfg4: one launch at the 7B width
+def test_sampled_softmax_full_width(ops, D, G, n_neg, cap, n_live):
+    g = torch.Generator(device="cuda").manual_seed(D)
+    n_src = cap
+    q_rows = torch.randn(n_src, D, device="cuda", generator=g) * 2
+    p_rows = torch.randn(n_src, D, device="cuda", generator=g)
+    n_tok = (torch.randint(-200, 200, (G,), device="cuda", generator=g) + n_live).int()
+    q_idx = torch.stack([torch.randperm(n_src, device="cuda", generator=g) for _ in range(G)]).int().contiguous()   # distinct rows
+    p_idx = torch.stack([torch.randperm(n_src, device="cuda", generator=g) for _ in range(G)]).int().contiguous()
+    negs = torch.nn.functional.normalize(torch.randn(G, n_neg, D, device="cuda", generator=g), dim=-1).bfloat16()
+    for grp in range(G):                                                              # plant false negatives
+        for t in range(0, 64, 4):
+            negs[grp, (t * 131 + grp) % n_neg] = torch.nn.functional.normalize(p_rows[p_idx[grp, t].long()][None], dim=-1)[0].bfloat16()
+    ls = torch.tensor([math.log(20.0)], device="cuda")
+    sv = ops.nce_fwd(q_rows, q_idx, p_rows, p_idx, negs, n_tok, cap, ls, 0.99, want_logs=True)
+    torch.cuda.synchronize()
+    loss = sv.loss.cpu()
+    w = torch.rand(G, cap, device="cuda", generator=g)
+    outs = []
+    for scale in (1.0, 2.5):
+        dq1 = torch.zeros(n_src, D, device="cuda")
+        dp1 = torch.zeros(n_src, D, device="cuda")
+        dn, dls = ops.nce_bwd(sv, (w * scale).contiguous(), ls, q_idx, p_idx, dq1, dp1)
+        outs.append((dq1, dp1, dn.clone(), dls.clone()))
+    torch.cuda.synchronize()
+    for a, b in zip(outs[0], outs[1]):                                                # backward linear in the token weights
+        assert bool(torch.isfinite(a).all())
+        assert float((a * 2.5 - b).abs().max()) <= 2e-2 * float(b.abs().max())
+    dq0, dp0 = torch.zeros(n_src, D, device="cuda"), torch.zeros(n_src, D, device="cuda")
+    dn0, dls0 = ops.nce_bwd(sv, torch.zeros(G, cap, device="cuda"), ls, q_idx, p_idx, dq0, dp0)
+    assert float(dq0.abs().max()) == 0.0 and float(dp0.abs().max()) == 0.0 and float(dn0.abs().max()) == 0.0 and float(dls0.abs().max()) == 0.0
+    for grp in range(G):
+        nt = int(n_tok[grp])
+        assert float(loss[grp, nt:].abs().max()) == 0.0
+        assert bool(torch.isfinite(loss[grp, :nt]).all()) and float(loss[grp, :nt].min()) >= 0.0
+        if grp not in (0, G - 1):
+            continue
+        tok = torch.cat([torch.arange(64), torch.randint(64, nt, (96,), generator=torch.Generator().manual_seed(grp)), torch.tensor([nt - 1])])
+        q = q_rows[q_idx[grp, tok].long()].cpu().requires_grad_(True)
+        p = p_rows[p_idx[grp, tok].long()].cpu().requires_grad_(True)
+        ref, _, keep, neg, pos = nce_oracle(q, p, negs[grp].float().cpu(), ls.cpu()[0], 0.99)
+        _close(loss[grp, tok].numpy(), ref.detach().numpy(), f"D={D} group {grp}")
+        np.testing.assert_array_equal(sv.n_valid.cpu()[grp, tok].numpy(), (keep.sum(-1) + 1).numpy())
+        assert grp > 0 or int((~keep).sum()) >= 16                                    # suppression exercised
+    # gradient rows of sampled tokens of a ONE-group launch (distinct rows: a row's gradient is one token's) vs the oracle
+    sv1 = ops.nce_fwd(q_rows, q_idx[:1].contiguous(), p_rows, p_idx[:1].contiguous(), negs[:1].contiguous(), n_tok[:1].contiguous(),
+                      cap, ls, 0.99)
+    dq1, dp1 = torch.zeros(n_src, D, device="cuda"), torch.zeros(n_src, D, device="cuda")
+    ops.nce_bwd(sv1, w[:1].contiguous(), ls, q_idx[:1].contiguous(), p_idx[:1].contiguous(), dq1, dp1)
+    tok = torch.cat([torch.arange(48), torch.randint(64, int(n_tok[0]), (48,), generator=torch.Generator().manual_seed(9))])
+    q = q_rows[q_idx[0, tok].long()].cpu().requires_grad_(True)
+    p = p_rows[p_idx[0, tok].long()].cpu().requires_grad_(True)
+    ref, *_ = nce_oracle(q, p, negs[0].float().cpu(), ls.cpu()[0], 0.99)
+    (ref * w[0, tok].cpu()).sum().backward()
+    for name, got, want in (("dq", dq1[q_idx[0, tok].long()].cpu(), q.grad), ("dp", dp1[p_idx[0, tok].long()].cpu(), p.grad)):
+        assert float((got - want).abs().max()) <= 2e-2 * float(want.abs().max()), (D, name)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# full-catalog multi-head decode at D = 1024 / N = 2^20 (cfg2), D = 2048 / N = 453 938 x 16 heads (cfg3), D = 4096 (cfg4)
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("D,N,B,H,C", [(1024, 1 << 20, 64, 8, 8), (2048, 453938, 64, 16, 8), (4096, 200003, 32, 8, 8)])
+def test_catalog_topk_full_width(ops, D, N, B, H, C):
+    K = 200
+    g = torch.Generator(device="cuda").manual_seed(D + 1)
+    users = torch.nn.functional.normalize(torch.randn(B * H, D, device="cuda", generator=g), dim=-1).bfloat16()
+    items = torch.nn.functional.normalize(torch.randn(N, D, device="cuda", generator=g), dim=-1).bfloat16()
+    items_p = torch.cat([items, items.new_zeros((32 - N % 32) % 32, D)]).contiguous()
+    tags = torch.rand(N, C, device="cuda", generator=g) < 0.375
+    tags[torch.arange(N, device="cuda"), torch.randint(0, C, (N,), device="cuda", generator=g)] = True
+    tag_bits = _i32((tags.long() * (1 << torch.arange(C, device="cuda"))).sum(1) | (1 << 31))
+    row_bits = _i32(torch.tensor([1 << (r % C) for r in range(B * H)], device="cuda"))
+    row_bits[7] = 0                                                                   # a head switched off (prior_given_at_test)
+    lens = torch.randint(20, 300, (B,), device="cuda", generator=g)
+    hist_ptr = torch.zeros(B + 1, dtype=torch.int32, device="cuda")
+    hist_ptr[1:] = torch.cumsum(lens, 0).int()
+    hu = torch.repeat_interleave(torch.arange(B, device="cuda"), lens)
+    hi = torch.randint(1, N, (int(lens.sum()),), device="cuda", generator=g)
+    # the history filter must matter: put every user's true best items of head 0 into their history
+    best = torch.topk(users.view(B, H, D)[:, 0].float() @ items[:65536].float().T, 5, dim=1).indices.clamp_min(1)    # [B, 5]
+    hu = torch.cat([hu, torch.arange(B, device="cuda").repeat_interleave(5)])
+    hi = torch.cat([hi, best.reshape(-1)])
+    order = torch.argsort(hu * N + hi)
+    hu, hi = hu[order], hi[order]
+    hist_ptr = torch.searchsorted(hu.contiguous(), torch.arange(B + 1, device="cuda")).int()
+    ov, oi = ops.catalog_topk(users, H, items_p, tag_bits, row_bits, hist_ptr, hi.contiguous(), K, n_items=N)
+    ov2, oi2 = ops.catalog_topk(users, H, items_p, tag_bits, row_bits, hist_ptr, hi.contiguous(), K, n_items=N)
+    torch.cuda.synchronize()
+    assert torch.equal(oi, oi2) and torch.equal(ov, ov2)                              # idempotent, bit for bit
+    live = row_bits != 0
+    v, i = ov[live], oi[live]
+    assert bool(torch.isfinite(v).all())
+    assert bool((v[:, 1:] <= v[:, :-1]).all())                                        # sorted, value descending
+    tie = v[:, 1:] == v[:, :-1]
+    assert bool((i[:, 1:][tie] > i[:, :-1][tie]).all())                               # ties: index ascending
+    assert int(i.min()) >= 1 and int(i.max()) < N                                     # pad id never returned
+    assert bool(((tag_bits[i] & row_bits[live][:, None]) != 0).all())                 # category admissible
+    srt, _ = torch.sort(i, dim=1)
+    assert bool((srt[:, 1:] != srt[:, :-1]).all())                                    # no duplicates
+    rows_live = torch.nonzero(live).flatten()
+    key_hist = hu * N + hi
+    key_out = (rows_live // H)[:, None] * N + i
+    pos = torch.searchsorted(key_hist, key_out.reshape(-1)).clamp(max=key_hist.numel() - 1)
+    assert not bool((key_hist[pos] == key_out.reshape(-1)).any())                     # history never returned
+    rec = (items[i].float() * users[live][:, None, :].float()).sum(-1)                # values = fp32 dots of the bf16 operands
+    assert float(((rec - v).abs() / v.abs().clamp_min(1e-3)).max()) <= 1e-4
+    assert bool(torch.isinf(ov[7]).all())
+    sample = [0, B - 1]                                                               # exactness against the numpy oracle
+    uf = users.view(B, H, D)[sample].float().cpu()
+    scores = (uf.reshape(-1, D) @ items.float().cpu().T).view(len(sample), H, N).numpy()
+    tb, rb = tag_bits.cpu(), row_bits.view(B, H).cpu()
+    for si, b in enumerate(sample):
+        for h_ in range(H):
+            scores[si, h_, ((tb & int(rb[b, h_])) == 0).numpy()] = -np.inf
+    hs = torch.cat([torch.full((int(hist_ptr[b + 1] - hist_ptr[b]),), si) for si, b in enumerate(sample)]).numpy()
+    hitems = torch.cat([hi[int(hist_ptr[b]):int(hist_ptr[b + 1])] for b in sample]).cpu().numpy()
+    DO.suppress(scores, hs, hitems)
+    _check_topk(ov.view(B, H, K)[sample].reshape(-1, K), oi.view(B, H, K)[sample].reshape(-1, K), scores, K)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# cfg2 as a model: HSTU size-4 width (D = 1024, L = 512, 16 heads), 8 event-type heads, N = 2^20 - two layers of the 16
+# ----------------------------------------------------------------------------------------------------------------------
+def test_cfg2_model_step_full_width(ops):
+    import mhr_amd.synth as synth
+    from REC.config.configurator import Config, apply_run_fixups
+    from REC.utils import get_model
+    dev = torch.device("cuda", 0)
+    spec = synth.CONFIGS["cfg2"]
+    N = spec["item_num"]
+    cfgd = dict(spec["cfg"], device=dev, n_layers=2, hidden_dropout_prob=0.0, attn_dropout_prob=0.0)
+    cfg = apply_run_fixups(Config(config_dict=cfgd))
+    data = synth.SyntheticData(cfg, N, dev, seed=3)
+    cfg["int_to_category"] = data.int_to_category
+    torch.manual_seed(4)
+    model = get_model("HSTU")(cfg, data).to(dev).train()
+    B = 4
+    batch = data.train_batch(B)                                 # negatives per sample = 4096 / B: the shared pool keeps cfg2's size
+    assert batch[1].shape[1] == 1 and batch[1].numel() == 4096                        # one shared pool of cfg2's size
+    out = model(batch)
+    out["loss"].backward()
+    w = HO.tie_repeated_resblocks({k: v.detach().float().cpu().clone().requires_grad_(v.is_floating_point() and "item_embedding" not in k)
+                                   for k, v in model.state_dict().items()})
+    ocfg = dict(cfg.final_config_dict, category_counts=data.category_counts, category_to_int=data.category_to_int, item_num=N)
+    ref = HO.train_forward(w, ocfg, tuple(t.cpu() for t in batch))
+    ref["loss"].backward()
+    assert abs(float(out["loss"]) - float(ref["loss"])) <= 2e-2 * abs(float(ref["loss"])) + 2e-3
+    for k, v in ref.items():
+        if k.startswith("head_nce_"):
+            assert abs(float(out[k]) - float(v)) <= 2e-2 * abs(float(v)) + 2e-3, k
+    named = dict(model.named_parameters())
+    for k in ("_hstu._attention_layers.0._uvqk", "_hstu._attention_layers.1._o.weight", "medusa_head.2.0.linear.weight", "logit_scale"):
+        gref = w[k].grad
+        assert float((named[k].grad.cpu() - gref).abs().max()) <= 6e-2 * float(gref.abs().max()) + 1e-5, k
+    # predict at the full catalog with the prior given at test time: fused decode == oracle decode of the same operands
+    model.eval()
+    eb = data.eval_batch(4)
+    feat = model.compute_item_all()
+    tags_cn = data.item_tags.long().t().contiguous()
+    fused = model.predict_topk(eb[1], feat, tags_cn, eb[6], eb[3], k=200)
+    heads_n = model._user_heads(eb[1])                                                 # [B, H, D] fp32 normalised
+    ub = heads_n.to(torch.bfloat16).float().cpu()
+    ib = HO.l2n(feat.float()).to(torch.bfloat16).float().cpu()
+    sc = (ub.reshape(-1, ub.shape[-1]) @ ib.T).view(4, -1, N).numpy()
+    given = eb[6][:, :model.given_prior_len].bool().any(dim=1).cpu().numpy()            # [B, C]
+    for h_ in range(sc.shape[1]):
+        sc[:, h_, ~data.item_tags[:, h_ % data.C].cpu().numpy()] = -np.inf
+        sc[~given[:, h_ % data.C], h_] = -np.inf
+    DO.suppress(sc, eb[3][0].cpu().numpy(), eb[3][1].cpu().numpy())
+    _check_topk(fused.values.reshape(-1, 200), fused.indices.reshape(-1, 200), sc, 200)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# cfg3 / cfg4: one decoder layer at the TinyLlama-1.1B and the Baichuan2-7B widths against the pinned decoder oracle
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("arch", ["tinyllama", "baichuan2_7b"])
+def test_decoder_layer_full_width(ops, arch):
+    from REC.model.HLLM.modeling_llama import LlamaConfig, LlamaForCausalLM
+    if arch == "tinyllama":
+        lcfg = dict(hidden_size=2048, intermediate_size=5632, num_hidden_layers=1, num_attention_heads=32, num_key_value_heads=4,
+                    rms_norm_eps=1e-5, rope_theta=10000.0)
+        model = LlamaForCausalLM(LlamaConfig(vocab_size=32, max_position_embeddings=64, **lcfg))
+        oracle = LO.llama_decoder
+    else:
+        from REC.model.HLLM.baichuan.modeling_baichuan import BaichuanConfig, BaichuanForCausalLM
+        lcfg = dict(model_type="baichuan", hidden_size=4096, intermediate_size=11008, num_hidden_layers=1, num_attention_heads=32,
+                    rms_norm_eps=1e-6)
+        model = BaichuanForCausalLM(BaichuanConfig(vocab_size=32, max_position_embeddings=64, **lcfg))
+        oracle = LO.baichuan_decoder
+    torch.manual_seed(21)
+    D = lcfg["hidden_size"]
+    with torch.no_grad():
+        for n_, p_ in model.named_parameters():
+            if "norm" in n_:
+                p_.add_(0.1 * torch.randn_like(p_))
+    model = model.cuda().train()
+    B, L = 3, 50
+    g = torch.Generator().manual_seed(22)
+    x = torch.randn(B, L, D, generator=g)
+    mask = torch.ones(B, L, dtype=torch.int64)
+    mask[0, :13] = 0
+    mask[2, :40] = 0                                                                   # front padding, as the user sequences have it
+    probe = torch.randn(B, L, D, generator=g)
+    xg = x.cuda().requires_grad_(True)
+    hidden = model(inputs_embeds=xg, attention_mask=mask.cuda()).hidden_states[-1]
+    m = mask[..., None].cuda()
+    loss = (hidden.float() * probe.cuda() * m).sum()
+    loss.backward()
+    w = {k: v.detach().float().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items() if v.is_floating_point()}
+    xr = x.clone().requires_grad_(True)
+    ref = oracle(w, lcfg, xr, mask)
+    lref = (ref * probe * mask[..., None]).sum()
+    lref.backward()
+    assert float(((hidden.float().cpu() - ref.detach()) * mask[..., None]).abs().max()) <= 3e-2 * float(ref.abs().max())
+    assert abs(float(loss) - float(lref)) <= 3e-2 * max(1.0, abs(float(lref)))
+    assert float((xg.grad.cpu() - xr.grad).abs().max()) <= 5e-2 * float(xr.grad.abs().max())
+    named = dict(model.named_parameters())
+    for k in w:
+        if w[k].grad is None or k not in named or named[k].grad is None:
+            continue
+        if any(t in k for t in ("q_proj", "W_pack", "down_proj", "input_layernorm", "model.norm", "o_proj")):
+            gref = w[k].grad
+            assert float((named[k].grad.cpu() - gref).abs().max()) <= 5e-2 * float(gref.abs().max()), k
