@@ -139,6 +139,9 @@ class Trainer(object):
         self.optimizer = FusedAdamW(model, lr=self.optim_args['learning_rate'], weight_decay=self.optim_args['weight_decay'],
                                     lazy_table=bool(lazy))
         self._micro_step = 0
+        for st in self.__dict__.pop("_step_graphs", {}).values():      # graphs captured over a previous model / optimizer
+            st.release()
+        self._step_graph = None
         if self.accumulate_grad > 1:                # the item-table gradient rows of all micro-batches are reduced at the step
             model.accumulate_rows = True
 
@@ -175,7 +178,10 @@ class Trainer(object):
             self.train_step += 1
             self.optimizer.step()
             self.optimizer.zero_grad()
-        return model_out
+        # the backward is done: hand back values, not the autograd graph.  (A caller that keeps the loss of the previous step
+        # alive would keep that step's AccumulateGrad nodes - bound to the stream they were created on - alive into the next
+        # one; under a hipGraph capture on its side stream that is a cross-stream dependency and breaks the capture.)
+        return {k: (v.detach() if torch.is_tensor(v) else v) for k, v in model_out.items()}
 
     # ---- hipGraph replay of the step -------------------------------------------------------------
     def _graph_ok(self, data):
@@ -187,12 +193,16 @@ class Trainer(object):
                 and not getattr(m, "dense_embedding_grad", False) and not getattr(self, "_graph_failed", False))
 
     def _graph_step(self, data):
+        # one graph per batch signature (the ragged last batch of an epoch has its own), the four most recent kept
         sig = tuple((tuple(t.shape), t.dtype) for t in data)
-        st = getattr(self, "_step_graph", None)
-        if st is None or st.sig != sig:
-            if st is not None:
-                st.release()
-            st = self._step_graph = _StepGraph(self, sig)
+        graphs = self.__dict__.setdefault("_step_graphs", OrderedDict())
+        st = graphs.get(sig)
+        if st is None:
+            if len(graphs) >= 4:
+                graphs.popitem(last=False)[1].release()
+            st = graphs[sig] = _StepGraph(self, sig)
+        graphs.move_to_end(sig)
+        self._step_graph = st
         return st.step(data)
 
     @property

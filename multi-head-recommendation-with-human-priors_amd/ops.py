@@ -535,8 +535,7 @@ def _nce_fwd_shared(sv, q_rows, p_rows, negs, logit_scale, thres, want_logs, buc
     # (2) the fused streaming forward over the ROWS, suppression off (an all-zero bit table that is never written); its
     #     positive is the target of the row's first token, so the log counters of offset-0 tokens come out of this launch
     zkey = (G, n_tiles, n_p_rows, str(dev))
-    if zkey not in _ZERO_FIX:
-        _ZERO_FIX.clear()
+    if zkey not in _ZERO_FIX:         # grow-only: a captured hipGraph of the step keeps reading the entry of its shape
         _ZERO_FIX[zkey] = (torch.zeros(G, n_tiles, rp_pad, dtype=torch.int32, device=dev),
                            torch.zeros(G, rp_pad, dtype=torch.int32, device=dev), torch.zeros(G, dtype=torch.int32, device=dev),
                            torch.zeros(G, n_p_rows, dtype=torch.int32, device=dev))
