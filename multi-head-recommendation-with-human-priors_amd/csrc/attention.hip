@@ -34,7 +34,7 @@ __device__ unsigned long long g_attn_stamps[16];
     unsigned long long t_;                                                              \
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");          \
     __builtin_amdgcn_sched_barrier(0);                                                  \
-    if (blockIdx.x == 37 && threadIdx.x == 0) g_attn_stamps[k] = t_;                    \
+    if (blockIdx.x == 37 && threadIdx.x == 0 && (k) < 16) g_attn_stamps[k] = t_;        \
   }
 #else
 #define ASTAMP(k)
@@ -162,8 +162,14 @@ __global__ __launch_bounds__(256) void hstu_attn_fwd_kernel(const bf16_t* __rest
 // ------------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------------
-template <int NKS, int ND>
-__global__ __launch_bounds__(256, NKS <= 2 ? ATTN_BWD_WG : 1) void hstu_attn_bwd_kernel(
+// ALL4: the four operand images (Q, dO, K, V) are resident together (short sequences: 4 x 14 KB at cfg1, two workgroups
+// per CU): one staging phase with every load in flight, one barrier, and every fragment of both passes is an LDS read.
+// Otherwise (long sequences) the K / V images replace the Q / dO images between the passes and the per-block fragments
+// come from global memory.  Measured at cfg1 on the two-image form: of 68 k cycles of a workgroup's life only 20 k were
+// tile-pair work - the rest was memory latency in front of dependent work (staging twice, 5-7 k cycles per fragment fetch,
+// 4.5 k per gradient-tile epilogue).
+template <int NKS, int ND, bool ALL4>
+__global__ __launch_bounds__(256, ALL4 ? 2 : (NKS <= 2 ? ATTN_BWD_WG : 1)) void hstu_attn_bwd_kernel(
     const bf16_t* __restrict__ q_pre, const bf16_t* __restrict__ k_pre, const bf16_t* __restrict__ v_pre, int64_t stride,
     const bf16_t* __restrict__ act_q, const bf16_t* __restrict__ act_k, const bf16_t* __restrict__ act_v, int64_t act_stride,
     const uint8_t* __restrict__ key_valid, const bf16_t* __restrict__ d_out, int64_t do_stride, bf16_t* __restrict__ dq,
@@ -172,9 +178,15 @@ __global__ __launch_bounds__(256, NKS <= 2 ? ATTN_BWD_WG : 1) void hstu_attn_bwd
   using T = sg::Tile<NKS>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int Lp = (L + 31) & ~31, nb = Lp >> 5;
-  unsigned char* T0 = smem;                      // Q tiles in pass A, K tiles in pass B
-  unsigned char* T1 = smem + nb * T::BYTES;      // dO tiles in pass A, V tiles in pass B
-  uint32_t* vmask = reinterpret_cast<uint32_t*>(T1 + nb * T::BYTES);
+  const int img = nb * T::BYTES;
+  unsigned char* Tq = smem;                                  // Q tiles
+  unsigned char* Tdo = smem + img;                           // dO tiles
+  unsigned char* Tk = ALL4 ? smem + 2 * img : Tq;            // K tiles (two-image form: over the Q tiles, in pass B)
+  unsigned char* Tv = ALL4 ? smem + 3 * img : Tdo;           // V tiles
+  unsigned char* tail = smem + (ALL4 ? 4 : 2) * img;
+  uint32_t* vmask = reinterpret_cast<uint32_t*>(tail);
+  // gradient tiles leave through a wave-private scratch (store_grad_tile), behind the validity words (16-byte aligned)
+  float* gscratch = reinterpret_cast<float*>(tail + ((nb * 4 + 15) & ~15)) + (threadIdx.x >> 6) * (32 * GS);
 
   int b, head;
   decode_seq_head(n_heads, b, head);
@@ -189,13 +201,16 @@ __global__ __launch_bounds__(256, NKS <= 2 ? ATTN_BWD_WG : 1) void hstu_attn_bwd
   const bf16_t* av = redo ? v_pre + row0 * stride + hoff : act_v + row0 * act_stride + hoff;
   const bf16_t* dop = d_out + row0 * do_stride + hoff;
   const bool chain = apply_silu != 0;
+  const bf16_t* qpre_h = q_pre + (chain ? row0 * stride + hoff : 0);
+  const bf16_t* kpre_h = k_pre + (chain ? row0 * stride + hoff : 0);
+  const bf16_t* vpre_h = v_pre + (chain ? row0 * stride + hoff : 0);
+  bf16_t* dq_h = dq + row0 * d_stride + hoff;
+  bf16_t* dk_h = dk + row0 * d_stride + hoff;
+  bf16_t* dv_h = dv + row0 * d_stride + hoff;
 
-  // Everything the inner loops touch lives in LDS: the per-(query block, key block) work used to fetch its Q / dO (or
-  // K / V) fragments straight from global memory, one dependent L2 round trip per 8 MFMAs (386 MB of traffic per
-  // launch against 65 MB of operands, 176 us per layer at cfg1).
   ASTAMP(0)
-  stage_tiles<NKS>(T0, aq, a_stride, L, Lp, hd, redo, nullptr, 0);
-  stage_tiles<NKS>(T1, dop, do_stride, L, Lp, hd, false, nullptr, 0);
+  if (ALL4) stage_tiles4<NKS>(Tq, aq, a_stride, redo, Tdo, dop, do_stride, false, Tk, ak, a_stride, redo, Tv, av, a_stride, redo, L, Lp, hd);
+  else stage_tiles2<NKS>(Tq, aq, a_stride, redo, Tdo, dop, do_stride, false, L, Lp, hd);
   build_valid_mask(vmask, key_valid + row0, L, nb);
   __syncthreads();
   ASTAMP(1)
@@ -210,14 +225,25 @@ __global__ __launch_bounds__(256, NKS <= 2 ? ATTN_BWD_WG : 1) void hstu_attn_bwd
     if (kb >= nb) continue;
     const int key = kb * 32 + r;
     const bool kvalid = (vmask[kb] >> r) & 1u;
+    GradPre kpre[ND], vpre[ND];                                      // for the SiLU' chain of the epilogue: in flight under the loop
+#pragma unroll
+    for (int dc = 0; dc < ND; ++dc) {
+      kpre[dc] = prefetch_pre(kpre_h, stride, kb * 32, L, dc * 32, hd, chain, lane);
+      vpre[dc] = prefetch_pre(vpre_h, stride, kb * 32, L, dc * 32, hd, chain, lane);
+    }
     bf16x8 kf[NKS], vf[NKS];
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
-      kf[ks] = load_frag(ak, a_stride, key, L, ks * 16 + 8 * half, hd);
-      vf[ks] = load_frag(av, a_stride, key, L, ks * 16 + 8 * half, hd);
-      if (redo) {
-        kf[ks] = silu8(kf[ks]);
-        vf[ks] = silu8(vf[ks]);
+      if (ALL4) {
+        kf[ks] = la.read_a(Tk + kb * T::BYTES, ks);
+        vf[ks] = la.read_a(Tv + kb * T::BYTES, ks);
+      } else {
+        kf[ks] = load_frag(ak, a_stride, key, L, ks * 16 + 8 * half, hd);
+        vf[ks] = load_frag(av, a_stride, key, L, ks * 16 + 8 * half, hd);
+        if (redo) {
+          kf[ks] = silu8(kf[ks]);
+          vf[ks] = silu8(vf[ks]);
+        }
       }
     }
     f32x16 dvacc[ND], dkacc[ND];
@@ -226,10 +252,11 @@ __global__ __launch_bounds__(256, NKS <= 2 ? ATTN_BWD_WG : 1) void hstu_attn_bwd
       dvacc[dc] = zero16();
       dkacc[dc] = zero16();
     }
+    ASTAMP(2 + 3 * it)
     const uint32_t vm_kb = vmask[kb];
     for (int qb = kb; qb < nb && vm_kb != 0; ++qb) {     // a block of padding keys gets zero gradients
-      const unsigned char* qt = T0 + qb * T::BYTES;
-      const unsigned char* dot = T1 + qb * T::BYTES;
+      const unsigned char* qt = Tq + qb * T::BYTES;
+      const unsigned char* dot = Tdo + qb * T::BYTES;
       f32x16 s = zero16(), dp = zero16();
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) {
@@ -268,55 +295,52 @@ __global__ __launch_bounds__(256, NKS <= 2 ? ATTN_BWD_WG : 1) void hstu_attn_bwd
         dkacc[dc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da1, la.read_tr(qt, dc, 1), dkacc[dc], 0, 0, 0);
       }
     }
-    // results: rows (regs) = keys, cols (lanes) = feature
+    ASTAMP(3 + 3 * it)
+    // results: rows (regs) = keys, cols (lanes) = feature -> 16-byte rows through the wave's scratch, SiLU' chain applied
 #pragma unroll
     for (int dc = 0; dc < ND; ++dc) {
-      const int d = dc * 32 + r;
-      if (d < hd) {
-#pragma unroll
-        for (int g = 0; g < 16; ++g) {
-          const int m = kb * 32 + crow(g, half);
-          if (m < L) {
-            float gv = dvacc[dc][g] * inv_n, gk = dkacc[dc][g] * inv_n;
-            if (chain) {
-              gv *= dsilu_f((float)v_pre[(row0 + m) * stride + hoff + d]);
-              gk *= dsilu_f((float)k_pre[(row0 + m) * stride + hoff + d]);
-            }
-            dv[(row0 + m) * d_stride + hoff + d] = (bf16_t)gv;
-            dk[(row0 + m) * d_stride + hoff + d] = (bf16_t)gk;
-          }
-        }
-      }
+      store_grad_tile(gscratch, dvacc[dc], inv_n, dv_h, d_stride, vpre[dc], kb * 32, L, dc * 32, hd, chain, lane);
+      store_grad_tile(gscratch, dkacc[dc], inv_n, dk_h, d_stride, kpre[dc], kb * 32, L, dc * 32, hd, chain, lane);
     }
+    ASTAMP(4 + 3 * it)
   }
 
   // ---- pass B: dQ for query block qb (queries on the lanes) ----------------------------------------
-  ASTAMP(2)
-  __syncthreads();                      // everyone is done reading the Q / dO tiles
-  ASTAMP(3)
-  stage_tiles<NKS>(T0, ak, a_stride, L, Lp, hd, redo, nullptr, 0);
-  stage_tiles<NKS>(T1, av, a_stride, L, Lp, hd, redo, nullptr, 0);
-  __syncthreads();
-  ASTAMP(4)
+  if (!ALL4) {
+    __syncthreads();                      // everyone is done reading the Q / dO tiles
+    ASTAMP(8)
+    stage_tiles2<NKS>(Tk, ak, a_stride, redo, Tv, av, a_stride, redo, L, Lp, hd);
+    __syncthreads();
+  }
+  ASTAMP(9)
   for (int it = 0; it * 4 < nb; ++it) {
     const int qb = nb - 1 - ((it & 1) ? it * 4 + (3 - wave) : it * 4 + wave);     // snake from the heavy end (see the forward)
     if (qb < 0) continue;
     const int qcol = qb * 32 + r;
+    GradPre qpre[ND];
+#pragma unroll
+    for (int dc = 0; dc < ND; ++dc) qpre[dc] = prefetch_pre(qpre_h, stride, qb * 32, L, dc * 32, hd, chain, lane);
     bf16x8 qf[NKS], dof[NKS];
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
-      qf[ks] = load_frag(aq, a_stride, qcol, L, ks * 16 + 8 * half, hd);
-      if (redo) qf[ks] = silu8(qf[ks]);
-      dof[ks] = load_frag(dop, do_stride, qcol, L, ks * 16 + 8 * half, hd);
+      if (ALL4) {
+        qf[ks] = la.read_a(Tq + qb * T::BYTES, ks);
+        dof[ks] = la.read_a(Tdo + qb * T::BYTES, ks);
+      } else {
+        qf[ks] = load_frag(aq, a_stride, qcol, L, ks * 16 + 8 * half, hd);
+        if (redo) qf[ks] = silu8(qf[ks]);
+        dof[ks] = load_frag(dop, do_stride, qcol, L, ks * 16 + 8 * half, hd);
+      }
     }
     f32x16 dqacc[ND];
 #pragma unroll
     for (int dc = 0; dc < ND; ++dc) dqacc[dc] = zero16();
+    ASTAMP(10 + 3 * it)
     for (int kb = 0; kb <= qb; ++kb) {
       const uint32_t vm = vmask[kb];
       if (vm == 0) continue;
-      const unsigned char* kt = T0 + kb * T::BYTES;
-      const unsigned char* vt = T1 + kb * T::BYTES;
+      const unsigned char* kt = Tk + kb * T::BYTES;
+      const unsigned char* vt = Tv + kb * T::BYTES;
       f32x16 s = zero16(), dp = zero16();
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) {
@@ -348,23 +372,12 @@ __global__ __launch_bounds__(256, NKS <= 2 ? ATTN_BWD_WG : 1) void hstu_attn_bwd
         dqacc[dc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, la.read_tr(kt, dc, 1), dqacc[dc], 0, 0, 0);
       }
     }
+    ASTAMP(11 + 3 * it)
 #pragma unroll
-    for (int dc = 0; dc < ND; ++dc) {
-      const int d = dc * 32 + r;
-      if (d < hd) {
-#pragma unroll
-        for (int g = 0; g < 16; ++g) {
-          const int n = qb * 32 + crow(g, half);
-          if (n < L) {
-            float gq = dqacc[dc][g] * inv_n;
-            if (chain) gq *= dsilu_f((float)q_pre[(row0 + n) * stride + hoff + d]);
-            dq[(row0 + n) * d_stride + hoff + d] = (bf16_t)gq;
-          }
-        }
-      }
-    }
+    for (int dc = 0; dc < ND; ++dc)
+      store_grad_tile(gscratch, dqacc[dc], inv_n, dq_h, d_stride, qpre[dc], qb * 32, L, dc * 32, hd, chain, lane);
+    ASTAMP(12 + 3 * it)
   }
-  ASTAMP(5)
 }
 
 }  // namespace
@@ -415,22 +428,30 @@ extern "C" int mhr_hstu_attn_bwd(const void* q_pre, const void* k_pre, const voi
   MHR_REQUIRE((!act_q || act_stride % 8 == 0) && row_stride % 8 == 0 && ((int64_t)n_heads * head_dim) % 8 == 0,
               "hstu_attn_bwd: strides must be multiples of 8");
   const int Lp = (L + 31) & ~31, nb = Lp / 32;
-  size_t lds = (size_t)2 * nb * (32 * sh.nks * 32) + (size_t)nb * 4 + 16;     // two tensors' tile images at a time
+  // operand tile images + validity words + one 32 x 36 float gradient scratch per wave.  Short sequences keep all four
+  // operands resident (ALL4, two workgroups per CU); long ones two at a time (K / V replace Q / dO between the passes)
+  const size_t img = (size_t)nb * (32 * sh.nks * 32), extra = (((size_t)nb * 4 + 15) & ~(size_t)15) + 4 * 32 * 36 * sizeof(float);
+  const bool all4 = 4 * img + extra <= 80 * 1024 && sh.nks <= 4;     // (head_dim 128: the resident form spills)
+  const size_t lds = (all4 ? 4 : 2) * img + extra;
   MHR_REQUIRE(lds <= 160 * 1024 && nb <= 256, "hstu_attn_bwd: L=%d head_dim=%d needs %zu B of LDS (> 160 KiB)", L, head_dim, lds);
   const float inv_n = 1.0f / (float)L;
   const int64_t do_stride = (int64_t)n_heads * head_dim;
   hipStream_t s = (hipStream_t)stream;
-#define L_(NKS, ND)                                                                                                    \
+#define L__(NKS, ND, A4)                                                                                               \
   {                                                                                                                    \
-    auto kern = hstu_attn_bwd_kernel<NKS, ND>;                                                                         \
+    auto kern = hstu_attn_bwd_kernel<NKS, ND, A4>;                                                                     \
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     hipLaunchKernelGGL(kern, dim3(B * n_heads), dim3(256), lds, s, (const bf16_t*)q_pre, (const bf16_t*)k_pre,          \
                        (const bf16_t*)v_pre, row_stride, (const bf16_t*)act_q, (const bf16_t*)act_k, (const bf16_t*)act_v, \
                        act_stride, key_valid, (const bf16_t*)d_out, do_stride, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv,   \
                        d_stride, L, n_heads, head_dim, apply_silu, inv_n);                                             \
   }
+#define L_(NKS, ND)                \
+  if (all4) L__(NKS, ND, true)     \
+  else L__(NKS, ND, false)
   ATTN_DISPATCH(sh, L_);
 #undef L_
+#undef L__
   MHR_CHECK_LAUNCH("hstu_attn_bwd");
   return MHR_OK;
 }

@@ -73,6 +73,134 @@ __device__ __forceinline__ void stage_tiles(unsigned char* dst, const bf16_t* sr
   }
 }
 
+// Two operands staged together: the loads of BOTH are in flight before the first LDS store (one memory round trip for the
+// pair instead of two; a backward workgroup stages two pairs).
+template <int NKS>
+__device__ __forceinline__ void stage_tiles2(unsigned char* dst_a, const bf16_t* src_a, int64_t stride_a, bool silu_a,
+                                             unsigned char* dst_b, const bf16_t* src_b, int64_t stride_b, bool silu_b,
+                                             int L, int Lp, int hd) {
+  using T = sg::Tile<NKS>;
+  constexpr int U = 4;
+  const int total = Lp * T::CH, nt = blockDim.x;
+  for (int c0 = threadIdx.x; c0 < total; c0 += U * nt) {
+    bf16x8 va[U], vb[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int c = c0 + u * nt;
+      const int m = c / T::CH, j = c % T::CH;
+      va[u] = zero8();
+      vb[u] = zero8();
+      if (c < total && m < L && j * 8 < hd) {
+        va[u] = *reinterpret_cast<const bf16x8*>(src_a + (int64_t)m * stride_a + j * 8);
+        vb[u] = *reinterpret_cast<const bf16x8*>(src_b + (int64_t)m * stride_b + j * 8);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int c = c0 + u * nt;
+      if (c >= total) break;
+      const int m = c / T::CH, j = c % T::CH;
+      const bool in = m < L && j * 8 < hd;
+      if (in && silu_a) va[u] = silu8(va[u]);
+      if (in && silu_b) vb[u] = silu8(vb[u]);
+      const int o = (m >> 5) * T::BYTES + T::off(m & 31, j);
+      *reinterpret_cast<bf16x8*>(dst_a + o) = va[u];
+      *reinterpret_cast<bf16x8*>(dst_b + o) = vb[u];
+    }
+  }
+}
+
+// Four operands at once (the backward's resident form): sixteen 16-byte loads per thread in flight before the first store.
+template <int NKS>
+__device__ __forceinline__ void stage_tiles4(unsigned char* d0, const bf16_t* s0, int64_t st0, bool silu0, unsigned char* d1,
+                                             const bf16_t* s1, int64_t st1, bool silu1, unsigned char* d2, const bf16_t* s2,
+                                             int64_t st2, bool silu2, unsigned char* d3, const bf16_t* s3, int64_t st3,
+                                             bool silu3, int L, int Lp, int hd) {
+  using T = sg::Tile<NKS>;
+  constexpr int U = 4;
+  const int total = Lp * T::CH, nt = blockDim.x;
+  unsigned char* dst[4] = {d0, d1, d2, d3};
+  const bf16_t* src[4] = {s0, s1, s2, s3};
+  const int64_t st[4] = {st0, st1, st2, st3};
+  const bool sl[4] = {silu0, silu1, silu2, silu3};
+  for (int c0 = threadIdx.x; c0 < total; c0 += U * nt) {
+    bf16x8 v[4][U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int c = c0 + u * nt;
+      const int m = c / T::CH, j = c % T::CH;
+      const bool in = c < total && m < L && j * 8 < hd;
+#pragma unroll
+      for (int o = 0; o < 4; ++o) v[o][u] = in ? *reinterpret_cast<const bf16x8*>(src[o] + (int64_t)m * st[o] + j * 8) : zero8();
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int c = c0 + u * nt;
+      if (c >= total) break;
+      const int m = c / T::CH, j = c % T::CH;
+      const bool in = m < L && j * 8 < hd;
+      const int off = (m >> 5) * T::BYTES + T::off(m & 31, j);
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        if (in && sl[o]) v[o][u] = silu8(v[o][u]);
+        *reinterpret_cast<bf16x8*>(dst[o] + off) = v[o][u];
+      }
+    }
+  }
+}
+
+// Gradient tile of one wave (32 rows x 32 features: accumulator rows on the registers, features on the lanes) -> global
+// rows, through a wave-private LDS scratch so that memory sees 16-byte accesses: the accumulator layout gives a lane ONE
+// bf16 of 16 different rows - stored directly that is sixteen 2-byte stores and, with the SiLU' chain, sixteen dependent
+// 2-byte loads per tile, each behind its own s_waitcnt (measured: 32 k of the 37 k cycles of the dK / dV pass at cfg1).
+// Here a lane takes 8 consecutive features of one row: one 16-byte load of the pre-activations (fetched before the tile-pair
+// loop, so their latency is hidden), eight SiLU' factors, one 16-byte store.
+// scratch: 32 x GS floats, private to the wave (program order suffices between its writes and reads).
+constexpr int GS = 36;      // row stride in floats: 16-byte aligned rows, and the 8-float reads of a lane group spread over the banks
+
+// Lane -> (row, 8-feature chunk) map of the row-wise pass: lane (r, half) takes row r, chunks half and 2 + half - the same
+// rows and features its MFMA row fragments cover, and conflict-free on the GS-float scratch rows.
+struct GradPre {
+  bf16x8 v[2];
+};
+// pre-activation values of a gradient tile's rows, fetched EARLY (before the tile-pair loop): the loop hides their latency
+__device__ __forceinline__ GradPre prefetch_pre(const bf16_t* pre, int64_t pre_stride, int row_base, int n_rows, int col_base,
+                                                int n_cols, bool chain, int lane) {
+  GradPre p;
+  const int row = row_base + (lane & 31), half = lane >> 5;
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int f0 = col_base + 8 * (2 * u + half);
+    p.v[u] = zero8();
+    if (chain && row < n_rows && f0 < n_cols) p.v[u] = *reinterpret_cast<const bf16x8*>(pre + (int64_t)row * pre_stride + f0);
+  }
+  return p;
+}
+
+__device__ __forceinline__ void store_grad_tile(float* scratch, const f32x16& acc, float scale, bf16_t* out, int64_t out_stride,
+                                                const GradPre& pre, int row_base, int n_rows, int col_base, int n_cols,
+                                                bool chain, int lane) {
+  const int r = lane & 31, half = lane >> 5;
+#pragma unroll
+  for (int g = 0; g < 16; ++g) scratch[crow(g, half) * GS + r] = acc[g] * scale;
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int ch = 2 * u + half, f0 = col_base + 8 * ch;
+    const f32x4 lo = *reinterpret_cast<const f32x4*>(scratch + r * GS + 8 * ch);
+    const f32x4 hi = *reinterpret_cast<const f32x4*>(scratch + r * GS + 8 * ch + 4);
+    bf16x8 w;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float gv = j < 4 ? lo[j] : hi[j - 4];
+      if (chain) gv *= dsilu_f((float)pre.v[u][j]);
+      w[j] = (bf16_t)gv;
+    }
+    if (row_base + r < n_rows && f0 < n_cols) *reinterpret_cast<bf16x8*>(out + (int64_t)(row_base + r) * out_stride + f0) = w;
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
 __device__ __forceinline__ void build_valid_mask(uint32_t* vmask, const uint8_t* kv, int L, int nb) {
   if ((int)threadIdx.x < nb) {
     uint32_t bits = 0;

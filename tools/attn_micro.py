@@ -7,7 +7,7 @@ import mhr_amd.lib as L_
 if os.environ.get("STAMP"):
     L_.LIB_PATH = os.path.join(ROOT, "tools", "_stamp", "libmhr_hip.so")
 from mhr_amd import ops
-B, L, H, hd = 128, 200, 8, 32
+B, L, H, hd = int(os.environ.get("B", 128)), 200, 8, 32
 D = H * hd
 g = torch.Generator(device="cuda").manual_seed(0)
 h = (torch.randn(B * L, 4 * D, device="cuda", generator=g) * 0.5).bfloat16()
@@ -27,5 +27,6 @@ print(f"attn fwd {ev[0].elapsed_time(ev[1])*1e3:.1f} us  bwd {ev[1].elapsed_time
 if os.environ.get("STAMP"):
     dll = ctypes.CDLL(L_.LIB_PATH); buf = (ctypes.c_ulonglong * 16)()
     assert dll.mhr_debug_read_attn_stamps(buf) == 0
-    names = ["stage Q,dO + sync", "pass A (dK,dV) incl. stores", "sync", "restage K,V + sync", "pass B (dQ) incl. stores"]
-    for i, nm in enumerate(names): print(f"  {nm:32s} {buf[i+1]-buf[i]:8d} cycles")
+    names = ["start", "staged Q,dO", "A0 frags", "A0 pairs", "A0 epilogue", "A1 frags", "A1 pairs", "A1 epilogue", "sync", "restaged K,V",
+             "B0 frags", "B0 pairs", "B0 epilogue", "B1 frags", "B1 pairs", "B1 epilogue"]
+    for i in range(1, 16): print(f"  {names[i]:20s} +{buf[i]-buf[i-1]:8d} cycles")
