@@ -118,6 +118,33 @@ class SplitKLinearFn(Function):
         return dx, dw, db, None, None
 
 
+class FusedHeadsLinearFn(Function):
+    """z = x @ [W_0; ...; W_{H-1}]^T + [b_0; ...; b_{H-1}] for H heads whose parameters the fused optimizer laid out back to
+    back (mhr_amd.optim.fused_views / fused_flat): operands are views of the flat bf16 shadow, gradients are reduced straight
+    into the flat fp32 gradient views - no concatenation, no casts, no per-head accumulate kernels (14 small launches per
+    step at cfg1).  The parameters themselves do not pass through autograd."""
+
+    @staticmethod
+    def forward(ctx, x, w16, b16, gw, gb):
+        ctx.save_for_backward(x, w16)
+        ctx.gw, ctx.gb = gw, gb
+        return torch.nn.functional.linear(x, w16, b16)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w16 = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = dy @ w16
+        R = x.shape[0]
+        tiles = -(-w16.shape[0] // 256) * -(-w16.shape[1] // 256)
+        s_max = min(max(1, 256 // tiles), _SPLITK_MAX)
+        S = next((s for s in (64, 32, 16, 8, 4, 2) if s <= s_max and R % s == 0 and R // s >= 256), 1)
+        dw = torch.bmm(dy.view(S, R // S, -1).transpose(1, 2), x.view(S, R // S, -1))          # [S, N, K] bf16 partials
+        ops.sum_rows_into(dw, ctx.gw)
+        ops.sum_rows_into(dy, ctx.gb)
+        return dx, None, None, None, None
+
+
 class HeadsResidualFn(Function):
     """out[b, h, l] = x[b, l] + silu(z[b, l, h]) in the [B, H, L, D] layout the loss reads (reference llm_heads.py:5-40 per
     head + the stack / permute of hstu.py:665-667); x [B*L, D] fp32, z [B*L, H*D] bf16 (the heads' one concatenated GEMM)."""

@@ -149,6 +149,18 @@ class MultiHeadDecoding:
     # ------------------------------------------------------------------------------------------
     # heads and prior switch
     # ------------------------------------------------------------------------------------------
+    def adjacent_parameters(self):
+        """Parameter lists the fused optimizer should lay out back to back (mhr_amd.optim.FusedAdamW): the one-ResBlock
+        decoding heads' weights, and their biases, which `_heads` uses as ONE concatenated GEMM."""
+        heads = getattr(self, 'medusa_head', None)
+        if (heads is None or self.medusa_num_layers != 1 or self.head_interaction == 'hierarchical'
+                or not all(isinstance(h, nn.Sequential) and len(h) == 1 and hasattr(h[0], "linear") for h in heads)):
+            return []
+        ws, bs = [h[0].linear.weight for h in heads], [h[0].linear.bias for h in heads]
+        if len({id(p) for p in ws}) != len(ws):               # heads sharing one module (tied): nothing to lay out
+            return []
+        return [ws, bs]
+
     def _heads(self, x):
         """x [..., D] fp32 -> [..., H, D] fp32 (reference hstu.py:652-667, 915-931 / hllm.py:510-525, 785-801).  bf16
         GEMMs, fp32 residual, like the reference under bf16-mixed autocast."""
@@ -158,11 +170,18 @@ class MultiHeadDecoding:
                 and all(isinstance(h, nn.Sequential) and len(h) == 1 and not h[0].use_norm for h in heads)):
             # one-ResBlock heads: all H projections as ONE GEMM on concatenated weights (x is read once, the weight
             # gradient is one split-K GEMM), SiLU + residual in two elementwise kernels, no stack
-            from REC.model.hstu_functional import SplitKLinearFn
+            from REC.model.hstu_functional import FusedHeadsLinearFn, SplitKLinearFn
+            from mhr_amd import optim as _optim
             H, D = len(heads), x.shape[-1]
-            w = torch.cat([h[0].linear.weight for h in heads], 0)
-            b = torch.cat([h[0].linear.bias for h in heads], 0)
-            z = SplitKLinearFn.apply(x.reshape(-1, D).to(torch.bfloat16), w, b, True, None)
+            ws, bs = [h[0].linear.weight for h in heads], [h[0].linear.bias for h in heads]
+            fw = _optim.fused_views(ws) if torch.is_grad_enabled() else None
+            fb = _optim.fused_flat(bs) if fw is not None else None
+            if fw is not None and fb is not None:     # the fused optimizer laid the heads out back to back: views, no cat / cast
+                z = FusedHeadsLinearFn.apply(x.reshape(-1, D).to(torch.bfloat16), fw[0], fb[0], fw[1], fb[1])
+            else:
+                w = torch.cat(ws, 0)
+                b = torch.cat(bs, 0)
+                z = SplitKLinearFn.apply(x.reshape(-1, D).to(torch.bfloat16), w, b, True, None)
             if x.dim() == 3 and x.dtype == torch.float32 and D % 4 == 0:
                 # bias-added GEMM output -> SiLU + residual written straight in the [B, H, L, D] layout of the loss
                 # (csrc/heads.hip); returned as the [B, L, H, D] view every caller expects
@@ -273,18 +292,12 @@ class MultiHeadDecoding:
                                  float(self.nce_thres), want_logs, logs, o_idx, P,
                                  log_group if want_logs else -1, p_row_mask, share, window, float(ihn_beta))       # [G, P]
         out_logs = None
-        if want_logs:                                   # all counters of the logged group in ONE masked reduction
-            g = log_group
-            first = ((torch.arange(cap, device=dev) < n_tok[g]) & (o_idx[g] == 0)).float()      # tokens of prediction offset 0
+        if want_logs:                                   # all counters of the logged group in ONE launch (mhr_nce_log_counters)
             ks = [k for k in (1, 5, 10, 50, 100) if k <= negs_g.shape[1] + 1]
-            rank = logs["rank"][g]
-            cols = torch.cat([torch.ones_like(first)[None], logs["n_valid"][g].float()[None],
-                              (rank[None, :] < self._const(ks, dev, rank.dtype)[:, None]).float()])
-            sums = cols @ first                                                                  # [2 + len(ks)]
-            n0 = sums[0].clamp_min(1.0)
-            out_logs = {'nce_samples': sums[1] / n0}
+            vals = ops.nce_log_counters(logs["n_valid"], logs["rank"], o_idx, n_tok, log_group, ks)       # [1 + len(ks)]
+            out_logs = {'nce_samples': vals[0]}
             for i, k in enumerate(ks):
-                out_logs[f'nce_top{k}_acc'] = sums[2 + i] / n0
+                out_logs[f'nce_top{k}_acc'] = vals[1 + i]
         return mean_p, out_logs
 
     def _clamp_logit_scale(self):
@@ -311,33 +324,40 @@ class MultiHeadDecoding:
         S, C = self.num_segment_head, self.num_prior_head
         additive = self.head_interaction == 'additive'
         pool_slot = {p: i for i, p in enumerate(pools)}
-        idx = torch.arange(L, device=dev)[:, None] + 1 + torch.arange(P, device=dev)[None, :]      # [L,P]: target of (l, p)
-        base_valid = mask[:, :L, None] & mask[:, idx]                                              # [B,L,P]
-        groups = []                       # (valid [B,L,P], head_for_p [P], pool slot, weight, kind, index)
-        row_masks = []                    # per group: the target rows (b, j) its tokens can point at (a superset is enough)
+        # the window of (l, p) is position l + 1 + p: a strided VIEW of the row (no index kernel, no [L, P] index tensor)
+        base_valid = mask[:, :L, None] & mask[:, 1:].unfold(1, P, 1)                               # [B,L,P]
+        groups = []                       # (head_for_p [P], pool slot, weight, kind, index)
+        valid_parts, row_parts = [], []   # token masks [*,B,L,P] and, per group, the target rows (b, j) its tokens can point at
         if self.loss == 'nce' or (self.loss == 'prior' and additive):
-            groups.append((base_valid, torch.arange(P) // self.seg_len, pool_slot[pools[0]], 1.0, 'nce', 0))
-            row_masks.append(mask)
+            groups.append((torch.arange(P) // self.seg_len, pool_slot[pools[0]], 1.0, 'nce', 0))
+            valid_parts.append(base_valid[None])
+            row_parts.append(mask[None])
         tag_win = None
         if self.loss == 'prior':
             seg_len = P if additive else self.seg_len
             seg_for_p = torch.arange(P) // seg_len
-            tag_win = pos_tags[:, idx].bool()                                                      # [B,L,P,C]
+            tags_b = pos_tags.bool()                                                               # [B,L+P,C]
+            tag_win = tags_b[:, 1:].unfold(1, P, 1).permute(0, 1, 3, 2)                            # [B,L,P,C] (a view)
+            tag_cblp = tag_win.permute(3, 0, 1, 2)                                                 # [C,B,L,P] (a view)
+            if self.pos_sample_mix_ratio > 0.0:
+                tag_cblp = tag_cblp | (torch.rand(tag_cblp.shape, device=dev) < self.pos_sample_mix_ratio)
+                row_parts.append(mask[None].expand(C, -1, -1))
+            else:
+                row_parts.append(mask[None] & tags_b.permute(2, 0, 1))
+            valid_parts.append(base_valid[None] & tag_cblp)                                        # all C categories in one pass
             for c in range(C):
-                valid = base_valid & tag_win[..., c]
-                if self.pos_sample_mix_ratio > 0.0:
-                    valid = base_valid & (tag_win[..., c] | (torch.rand(valid.shape, device=dev) < self.pos_sample_mix_ratio))
                 head_for_p = torch.full((P,), S + c) if additive else seg_for_p * C + c
                 pool = pool_slot[c] if self.neg_sample_by_cat else pool_slot[pools[0]]
-                groups.append((valid, head_for_p, pool, float(self.prior_loss_weight[c]), 'prior', c))
-                row_masks.append(mask if self.pos_sample_mix_ratio > 0.0 else mask & pos_tags[..., c].bool())
-        slots = [g[2] for g in groups]
+                groups.append((head_for_p, pool, float(self.prior_loss_weight[c]), 'prior', c))
+        slots = [g[1] for g in groups]
         negs_g = negs_pools if slots == list(range(len(pools))) else negs_pools[self._const(slots, dev, torch.int64)]
-        return dict(groups=groups, tag_win=tag_win, valid_g=torch.stack([g[0] for g in groups]),
-                    head_for_p_g=torch.stack([g[1] for g in groups]), negs_g=negs_g.contiguous(),
+        valid_g = valid_parts[0] if len(valid_parts) == 1 else torch.cat(valid_parts)
+        rows_g = row_parts[0] if len(row_parts) == 1 else torch.cat(row_parts)
+        return dict(groups=groups, tag_win=tag_win, valid_g=valid_g.contiguous(),
+                    head_for_p_g=torch.stack([g[0] for g in groups]), negs_g=negs_g.contiguous(),
                     # reference: top-k logs come from the nce branch, then are overwritten by prior category 0 (hstu.py:723, 863)
-                    log_group=max(i for i, g in enumerate(groups) if g[4] == 'nce' or g[5] == 0),
-                    p_row_mask=torch.stack(row_masks).reshape(len(groups), -1))
+                    log_group=max(i for i, g in enumerate(groups) if g[3] == 'nce' or g[4] == 0),
+                    p_row_mask=rows_g.reshape(len(groups), -1).contiguous())
 
     def _multihead_loss(self, out, e_rows, negs_pools, pools, mask, pos_tags, plan=None):
         """Everything of the training forward after the sequence encoder (reference hstu.py:648-872 / hllm.py:506-763).
@@ -355,26 +375,25 @@ class MultiHeadDecoding:
         groups, tag_win, valid_g, head_for_p_g = plan["groups"], plan["tag_win"], plan["valid_g"], plan["head_for_p_g"]
         negs_g, log_group, p_row_mask = plan["negs_g"], plan["log_group"], plan["p_row_mask"]
         mean_gp, logs = self._grouped_loss(head_rows, e_rows, negs_g.contiguous(), valid_g, head_for_p_g, log_group, p_row_mask)
-        per_gp = mean_gp * self.horizon_discount.float()[None, :] * self._const([g[3] for g in groups], dev, torch.float32)[:, None]
+        gw = ("gw", tuple(g[2] for g in groups), str(dev))                 # horizon discount x group weight, [G,P], built once
+        if gw not in self._tok_cache:
+            self._tok_cache[gw] = (self.horizon_discount.float()[None, :] * self._const([g[2] for g in groups], dev, torch.float32)[:, None]).contiguous()
+        per_gp = mean_gp * self._tok_cache[gw]
 
         model_out = defaultdict(float)
         total = per_gp.sum()
-        accum = torch.zeros(P, dtype=torch.float32, device=dev)
+        # log values: two small reductions for all groups and segments (the reference's per-head / per-segment sums, hstu.py:
+        # 700-721, 836-858), read out as views
+        seg_all = per_gp.detach().view(len(groups), S, -1).sum(dim=2)                              # [G,S]
+        seg_tot = seg_all[0] if (additive or groups[0][3] == 'nce') else seg_all.sum(dim=0)       # [S]
+        g_tot = seg_all.sum(dim=1)                                                                # [G]
+        for s_ in range(S):
+            model_out[f"seg_{s_}_loss"] = seg_tot[s_]
         for i, g in enumerate(groups):
-            if g[4] == 'nce':
-                seg = per_gp[i].detach().view(S, self.seg_len).sum(dim=1)
-                for s_ in range(S):
-                    model_out[f"seg_{s_}_loss"] = seg[s_]
-            else:
-                model_out[f'head_nce_{self.int_to_category[g[5]]}_loss'] = per_gp[i].sum().detach()
-                accum = accum + per_gp[i].detach()
-        if self.loss == 'prior':
-            if not additive:
-                seg = accum.view(S, self.seg_len).sum(dim=1)
-                for s_ in range(S):
-                    model_out[f"seg_{s_}_loss"] = model_out[f"seg_{s_}_loss"] + seg[s_]
-            else:
-                total = total / 2
+            if g[3] == 'prior':
+                model_out[f'head_nce_{self.int_to_category[g[4]]}_loss'] = g_tot[i]
+        if self.loss == 'prior' and additive:
+            total = total / 2
         if self.prior_switch is not None:
             head_out = head_embs.permute(0, 2, 1, 3)                               # [B,L,H,D]
             for c in range(1 if self.master_switch else C):

@@ -27,10 +27,10 @@ class _StepGraph:
 
     What changes from step to step cannot be a kernel argument of a replayed launch, so it lives in device memory:
       * the batch: static input tensors, refreshed by device-to-device copies in front of the replay;
-      * `ctrl` int64[2] = (dropout step counter, optimizer step): the ln_gate kernels derive their seeds from ctrl[0]
-        (`mhr_ln_gate_*`'s step_seed), the Adam kernels read ctrl[1] (`step_dev`);
-      * the step's Adam constants (lr schedule, bias corrections): row `step % 64` of the optimizer's device-side history,
-        uploaded from a pinned ring in front of the replay (`FusedAdamW.begin_replayed_step`).
+      * `FusedAdamW.ctrl` int64[2] = (dropout step counter, optimizer step): the ln_gate kernels derive their seeds from
+        ctrl[0] (`mhr_ln_gate_*`'s step_seed), the Adam kernels read ctrl[1] (`step_dev`);
+      * the step's Adam constants (lr schedule, bias corrections): row `step % 64` of the optimizer's device-side history;
+        both travel in ONE small upload from a pinned ring in front of the replay (`FusedAdamW.begin_replayed_step`).
     The host may run ahead of the GPU by at most ~48 replays (an event every 16 replays, the third-youngest waited for), so the
     64-row pinned rings are never overwritten while a copy from them is pending."""
     WARM, RING = 3, 64
@@ -46,12 +46,10 @@ class _StepGraph:
     def _capture(self, data):
         tr = self.tr
         model, opt, dev = tr.model, tr.optimizer, data[0].device
-        self.ctrl = torch.zeros(2, dtype=torch.int64, device=dev)
-        self.ctrl_host = torch.zeros(self.RING, 2, dtype=torch.int64).pin_memory()
         self.static = tuple(t.clone() for t in data)
         keep = (model._step_seed, opt.step_count, tr.train_step, tr._micro_step, opt.param_groups[0]["lr"])
         graph = torch.cuda.CUDAGraph()
-        model._seed_dev, opt.step_dev, opt.in_graph = self.ctrl[0:1], self.ctrl[1:2], True
+        model._seed_dev, opt.step_dev, opt.in_graph = opt.ctrl[0:1], opt.ctrl[1:2], True
         try:
             with torch.cuda.graph(graph):
                 out = tr._eager_step(self.static)
@@ -88,10 +86,7 @@ class _StepGraph:
         lr = tr._lr_at(tr.train_step)
         tr.train_step += 1
         tr._micro_step += 1
-        opt.begin_replayed_step(lr)
-        h = self.ctrl_host[self.n % self.RING]
-        h[0], h[1] = model._step_seed, opt.step_count
-        self.ctrl.copy_(h, non_blocking=True)
+        opt.begin_replayed_step(lr, seed_counter=model._step_seed)        # constants + control block: one small upload
         self.n += 1
         self.graph.replay()
         opt.end_replayed_step()

@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void segment_fixup_kernel(const int64_t* __res
     while (head > i0 && sorted_ids[head - 1] == id) --head;
     int64_t last = ch + 1;                                       // chunks ch + 1 .. last hold partials of this run
     while (last + 1 < n_chunks && sorted_ids[(last + 1) * SEG_CHUNK] == id) ++last;
-    constexpr int U = 4;                                         // partial rows in flight
+    constexpr int U = 16;                                        // partial rows in flight (a hot id under Zipf spans ~70 chunks)
     for (int c = lane * 4; c < dim; c += 256) {
       f32x4 acc = *reinterpret_cast<const f32x4*>(out_rows + head * dim + c);
       for (int64_t k0 = ch + 1; k0 <= last; k0 += U) {

@@ -190,8 +190,9 @@ extern "C" int mhr_sum_rows_into(const void* x_bf16, int64_t rows, int64_t cols,
   if (rows == 0) return MHR_OK;
   const int64_t col_blocks = (cols / 8 + 31) / 32;
   MHR_REQUIRE(col_blocks < (1ll << 31), "sum_rows_into: too many columns");
-  // a few row ranges when there are few columns (many would only contend on the same atomics: 512 ranges adding into the
-  // 256 floats of a bias gradient cost far more than they saved); the row loop keeps four loads in flight instead
+  // a few row ranges when there are few columns (many would only contend on the same atomics: 256 ranges adding into the
+  // 256 floats of a bias gradient doubled the launch's time - measured twice, rounds 1 and 2); the row loop keeps four loads
+  // in flight instead
   int64_t splits = 1;
   while (splits < 64 && col_blocks * splits < 512 && rows / (splits * 2) >= 64) splits *= 2;
   const int64_t rpb = (rows + splits - 1) / splits;

@@ -200,7 +200,53 @@ __global__ __launch_bounds__(256) void row_scatter_kernel(const int32_t* __restr
   }
 }
 
+// Training-time log counters of one group (reference hstu.py:621-629: nce_samples and top-k accuracy over the tokens of
+// prediction offset 0): out[0] = mean n_valid, out[1 + i] = mean(rank < ks[i]) over the live tokens with offset 0.
+// One workgroup; replaces about twenty-five small torch kernels (mask, casts, concatenation, GEMV, divisions) per step.
+__global__ __launch_bounds__(256) void nce_log_counters_kernel(const int32_t* __restrict__ n_valid, const int32_t* __restrict__ rank,
+                                                               const int32_t* __restrict__ o_idx, const int32_t* __restrict__ n_tok_dev,
+                                                               int group, int tok_cap, int k0, int k1, int k2, int k3, int k4, int n_k,
+                                                               float* __restrict__ out) {
+  __shared__ float red[4][8];
+  const int64_t base = (int64_t)group * tok_cap;
+  const int nt = min(n_tok_dev[group], tok_cap);
+  const int ks[5] = {k0, k1, k2, k3, k4};
+  float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};        // count, sum n_valid, hits per k
+  for (int t = threadIdx.x; t < nt; t += blockDim.x) {
+    if (o_idx[base + t] != 0) continue;
+    acc[0] += 1.f;
+    acc[1] += (float)n_valid[base + t];
+    const int r = rank[base + t];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) acc[2 + i] += (i < n_k && r < ks[i]) ? 1.f : 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < 7; ++i) acc[i] = wave_sum(acc[i]);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0)
+#pragma unroll
+    for (int i = 0; i < 7; ++i) red[wave][i] = acc[i];
+  __syncthreads();
+  if (threadIdx.x < 1 + n_k) {
+    const int i = threadIdx.x + 1;
+    const float cnt = fmaxf(red[0][0] + red[1][0] + red[2][0] + red[3][0], 1.0f);
+    out[threadIdx.x] = (red[0][i] + red[1][i] + red[2][i] + red[3][i]) / cnt;
+  }
+}
+
 }  // namespace
+
+extern "C" int mhr_nce_log_counters(const int32_t* n_valid, const int32_t* rank, const int32_t* o_idx, const int32_t* n_tok_dev,
+                                    int group, int tok_cap, const int32_t* ks_host, int n_k, float* out, void* stream) {
+  MHR_REQUIRE(n_valid && rank && o_idx && n_tok_dev && out && ks_host, "nce_log_counters: null pointer");
+  MHR_REQUIRE(group >= 0 && tok_cap > 0 && n_k >= 0 && n_k <= 5, "nce_log_counters: bad sizes (n_k=%d)", n_k);
+  int k[5] = {0, 0, 0, 0, 0};
+  for (int i = 0; i < n_k; ++i) k[i] = ks_host[i];
+  hipLaunchKernelGGL(nce_log_counters_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, n_valid, rank, o_idx, n_tok_dev, group,
+                     tok_cap, k[0], k[1], k[2], k[3], k[4], n_k, out);
+  MHR_CHECK_LAUNCH("nce_log_counters");
+  return MHR_OK;
+}
 
 extern "C" int mhr_token_compact(const uint8_t* mask, const int32_t* q_all, const int32_t* p_all, const int32_t* o_all,
                                  int n_groups, int n_slots, int tok_cap, int32_t* q_idx, int32_t* p_idx, int32_t* o_idx,

@@ -61,6 +61,28 @@ def _stream():
 
 
 
+def zeros_many(dev, *specs):
+    """Several zero-initialised 4-byte tensors from ONE allocation and ONE fill launch (each small `torch.zeros` is its own
+    fill kernel: about 4.5 us of device timeline apiece, and a training step used to issue some forty of them).
+    specs: (shape, dtype) with dtype float32 / int32; every tensor starts 16-byte aligned."""
+    sizes = []
+    for shape, dtype in specs:
+        n = 1
+        for d in shape:
+            n *= int(d)
+        sizes.append((n + 3) // 4 * 4)
+    buf = torch.zeros(max(sum(sizes), 4), dtype=torch.int32, device=dev)
+    out, off = [], 0
+    for (shape, dtype), sz in zip(specs, sizes):
+        n = 1
+        for d in shape:
+            n *= int(d)
+        t = buf[off:off + n]
+        out.append((t if dtype == torch.int32 else t.view(dtype)).view(*shape))
+        off += sz
+    return out
+
+
 def _chk(t, name, dtype=None):
     if not t.is_cuda:
         raise RuntimeError(f"{name}: expected a GPU tensor; the MI355X path has no CPU fallback")
@@ -129,10 +151,10 @@ def adam_rows(w, m, v, grad_rows, row_slot, step, lr, grad_scale=1.0, betas=(0.9
 
 
 def adam_flat(w, g, m, v, step, lr, grad_scale=1.0, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, w_bf16=None,
-              hist=None, step_dev=None):
+              hist=None, step_dev=None, hist_len=64):
     """hist [hist_len, 4] f32 + step_dev int64[1] (device): the step's constants come from device memory (hipGraph replay)."""
     lib.call("mhr_adam_flat", w.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), w.numel(), grad_scale, lr,
-             betas[0], betas[1], eps, weight_decay, step, _ptr(w_bf16), _ptr(hist), 0 if hist is None else hist.shape[0],
+             betas[0], betas[1], eps, weight_decay, step, _ptr(w_bf16), _ptr(hist), 0 if hist is None else hist_len,
              _ptr(step_dev), _stream())
 
 
@@ -450,6 +472,21 @@ def token_compact(mask, q_all, p_all, o_all, tok_cap=None, slot_map=False):
     return q_idx, p_idx, o_idx, n_tok
 
 
+def nce_log_counters(n_valid, rank, o_idx, n_tok_dev, group, ks):
+    """-> f32 [1 + len(ks)]: mean n_valid and mean(rank < k) over the live offset-0 tokens of `group` (hstu.py:621-629)."""
+    import ctypes
+    G, cap = o_idx.shape
+    for t in (n_valid, rank, o_idx):
+        _chk(t, "nce_log_counters input", torch.int32) if t.is_contiguous() else None
+        assert t.shape == (G, cap) and t.stride(0) == t.shape[1] * t.stride(1) or t.is_contiguous(), "token tables must share one [G, cap] layout"
+        assert t.stride(0) == cap and t.stride(1) == 1 and t.dtype == torch.int32
+    out = torch.empty(1 + len(ks), dtype=torch.float32, device=o_idx.device)
+    ks_arr = (ctypes.c_int32 * max(1, len(ks)))(*ks)
+    lib.call("mhr_nce_log_counters", n_valid.data_ptr(), rank.data_ptr(), o_idx.data_ptr(), n_tok_dev.data_ptr(), int(group), cap,
+             ctypes.addressof(ks_arr), len(ks), out.data_ptr(), _stream())
+    return out
+
+
 STREAM_DIMS = (16, 32, 64, 128, 256)      # feature dims of the register-stationary streaming kernels
 
 
@@ -480,8 +517,7 @@ def _row_maps(q_idx, n_tok_dev, cap, row_cap):
     row_first [G, row_cap], n_row [G]); all on the device, no host sync (mhr_row_maps: count + scan, like the compaction)."""
     G = q_idx.shape[0]
     dev = q_idx.device
-    r_q = torch.zeros(G, row_cap, dtype=torch.int32, device=dev)
-    r_first = torch.zeros(G, row_cap, dtype=torch.int32, device=dev)
+    r_q, r_first = zeros_many(dev, ((G, row_cap), torch.int32), ((G, row_cap), torch.int32))
     tok2row = torch.empty(G, cap, dtype=torch.int32, device=dev)
     n_row = torch.empty(G, dtype=torch.int32, device=dev)
     scratch = torch.empty(G, (cap + 4095) // 4096, dtype=torch.int32, device=dev)
@@ -496,9 +532,11 @@ def _fix_bits_launch(p_rows, negs, n_neg, D, G, thres, p_row_mask):
     rp_pad = (n_p_rows + 255) // 256 * 256
     n_tiles = (n_neg + 31) // 32
     fix_words = torch.empty(G, n_tiles, rp_pad, dtype=torch.int32, device=dev)
-    fix_any = torch.zeros(G, rp_pad, dtype=torch.int32, device=dev)
-    row_list = n_list = slot_of_row = None
-    if p_row_mask is not None:
+    fix_any, slot_of_row = zeros_many(dev, ((G, rp_pad), torch.int32), ((G, n_p_rows), torch.int32))
+    row_list = n_list = None
+    if p_row_mask is None:
+        slot_of_row = None
+    else:
         assert p_row_mask.shape == (G, n_p_rows)
         key = (G, n_p_rows, str(dev))
         if key not in _ROW_IOTA:
@@ -506,7 +544,6 @@ def _fix_bits_launch(p_rows, negs, n_neg, D, G, thres, p_row_mask):
             _ROW_IOTA[key] = (ar[None].expand(G, -1).contiguous(), ar)
         iota_g, iota = _ROW_IOTA[key]
         row_list, _, _, n_list = token_compact(p_row_mask.contiguous(), iota_g, iota, iota, tok_cap=rp_pad)
-        slot_of_row = torch.zeros(G, n_p_rows, dtype=torch.int32, device=dev)
     lib.call("mhr_nce_fix_bits", p_rows.data_ptr(), _dt(p_rows), n_p_rows, negs.data_ptr(), n_neg, D, G, float(thres),
              fix_words.data_ptr(), _ptr(row_list), _ptr(n_list), _ptr(slot_of_row), fix_any.data_ptr(), _stream())
     return fix_words, fix_any, slot_of_row, (row_list, n_list)
@@ -541,9 +578,10 @@ def _nce_fwd_shared(sv, q_rows, p_rows, negs, logit_scale, thres, want_logs, buc
                            torch.zeros(G, n_p_rows, dtype=torch.int32, device=dev))
     z_words, z_list, z_n, z_slot = _ZERO_FIX[zkey]
     r_p = torch.gather(p_idx, 1, r_first.long().clamp_(max=cap - 1)).contiguous()
-    sum_row = torch.zeros(G, row_cap, dtype=torch.float32, device=dev)
-    nv_row = torch.zeros(G, row_cap, dtype=torch.int32, device=dev) if want_logs else None
-    rk_row = torch.zeros(G, row_cap, dtype=torch.int32, device=dev) if want_logs else None
+    z = zeros_many(dev, ((G, row_cap), torch.float32), ((G, row_cap), torch.int32), ((G, row_cap), torch.int32),
+                   ((G, cap), torch.int32), ((G, cap), torch.int32))
+    sum_row = z[0]
+    nv_row, rk_row = (z[1], z[2]) if want_logs else (None, None)
     qn_row = torch.empty(G, row_cap, D, dtype=torch.bfloat16, device=dev)
     pn_row = torch.empty(G, row_cap, D, dtype=torch.bfloat16, device=dev)
     supp_row = torch.empty(G, n_tiles, row_cap, dtype=torch.int32, device=dev)
@@ -561,8 +599,7 @@ def _nce_fwd_shared(sv, q_rows, p_rows, negs, logit_scale, thres, want_logs, buc
     pn_rows, p_norm = l2norm_rows(p_rows.contiguous(), torch.bfloat16, want_norms=True)
     sv.pn, sv.p_inv = pn_rows, (1.0 / p_norm)
     ssum = torch.empty(G, cap, dtype=torch.float32, device=dev)
-    n_valid = torch.zeros(G, cap, dtype=torch.int32, device=dev) if want_logs else None
-    rank = torch.zeros(G, cap, dtype=torch.int32, device=dev) if want_logs else None
+    n_valid, rank = (z[3], z[4]) if want_logs else (None, None)
     _timed_call("mhr_nce_shared_fwd_tokens", pn_rows.data_ptr(), n_p_rows, p_idx.data_ptr(), tok2row.data_ptr(), G,
                 n_tok_dev.data_ptr(), cap, row_cap, qn_row.data_ptr(), sum_row.data_ptr(), _ptr(nv_row), _ptr(rk_row),
                 negs.data_ptr(), n_neg, D, logit_scale.data_ptr(), fix_words.data_ptr(), _ptr(slot_of_row), fix_any.data_ptr(),
@@ -621,15 +658,18 @@ def nce_fwd(q_rows, q_idx, p_rows, p_idx, negs, n_tok_dev, tok_cap, logit_scale,
     sv.ihn_beta = float(ihn_beta)
     sv.wide = D not in STREAM_DIMS or sv.ihn_beta > 0     # feature dims beyond the register-stationary kernels (and the IHN loss): wide.py
     sv.bucket_idx, sv.n_buckets, sv.bucket_sum, sv.bucket_cnt = bucket_idx, int(n_buckets), None, None
+    shared_path = share_rows and SHARE_ROWS and for_backward and D in STREAM_DIMS and float(ihn_beta) <= 0
+    zf = zeros_many(dev, ((2, G, max(n_buckets, 1)), torch.float32), ((G, cap), torch.float32), ((G, cap), torch.float32),
+                    ((G, cap) if (want_logs and not shared_path) else (1,), torch.int32),
+                    ((G, cap) if (want_logs and not shared_path) else (1,), torch.int32))
     if bucket_idx is not None:       # per-(group, bucket) loss sums and token counts come out of the finalize kernel
         _chk(bucket_idx, "bucket_idx", torch.int32)
         assert bucket_idx.shape == (G, cap)
-        sums = torch.zeros(2, G, n_buckets, dtype=torch.float32, device=dev)
-        sv.bucket_sum, sv.bucket_cnt = sums[0], sums[1]
-    loss = torch.zeros(G, cap, dtype=torch.float32, device=dev)
-    sv.lse = torch.zeros(G, cap, dtype=torch.float32, device=dev)
-    n_valid = torch.zeros(G, cap, dtype=torch.int32, device=dev) if want_logs else None
-    rank = torch.zeros(G, cap, dtype=torch.int32, device=dev) if want_logs else None
+        sv.bucket_sum, sv.bucket_cnt = zf[0][0], zf[0][1]
+    loss = zf[1]
+    sv.lse = zf[2]
+    n_valid = zf[3] if want_logs else None           # (the row-sharing path brings its own per-token counters)
+    rank = zf[4] if want_logs else None
     sv.s_pos = torch.empty(G, cap, dtype=torch.float32, device=dev)
     if sv.ihn_beta > 0:
         sv.ihn_num = torch.zeros(G, cap, dtype=torch.float32, device=dev)

@@ -32,6 +32,23 @@ def fused_views(params):
     return (torch.as_strided(params[0]._mhr_bf16, (rows, k), (k, 1)), torch.as_strided(params[0].grad, (rows, k), (k, 1)))
 
 
+def fused_flat(params):
+    """Like `fused_views` for parameters of any shape (e.g. the H heads' biases): (bf16 shadow, fp32 gradient) as flat views
+    over the adjacent parameters, or None."""
+    n = 0
+    for i, p in enumerate(params):
+        sh = getattr(p, "_mhr_bf16", None)
+        if sh is None or p.grad is None or p._version != p._mhr_ver or not getattr(p, "_mhr_direct_grad", False):
+            return None
+        if i and (p.data_ptr() != params[i - 1].data_ptr() + params[i - 1].numel() * 4
+                  or sh.data_ptr() != params[i - 1]._mhr_bf16.data_ptr() + params[i - 1].numel() * 2
+                  or p.grad.data_ptr() != params[i - 1].grad.data_ptr() + params[i - 1].numel() * 4):
+            return None
+        n += p.numel()
+    return (torch.as_strided(params[0]._mhr_bf16, (n,), (1,)), torch.as_strided(params[0].grad, (n,), (1,)))
+
+
+HOST_RING = 64        # pinned staging slots of the per-step constants upload (the Trainer keeps the host < 48 steps ahead)
 LAZY_HIST = 64        # steps a table row may lag behind before everything is flushed (= length of the constants' history)
 
 
@@ -55,6 +72,20 @@ class FusedAdamW:
                 seen.add(id(p))
                 uniq.append(p)
                 names.append(n)
+        # parameters a model wants back to back in the flat buffers (`adjacent_parameters()` -> lists of parameters): their bf16
+        # shadows / gradients then form ONE GEMM operand / ONE gradient destination (`fused_views`, `fused_flat`) - e.g. the H
+        # decoding heads' weights, which the forward uses as one concatenated [H*D, D] matrix
+        order = list(zip(names, uniq))
+        for group in (getattr(model, "adjacent_parameters", lambda: [])() or []):
+            ids = [id(p) for p in group]
+            pos = [i for i, (_, p) in enumerate(order) if id(p) in ids]
+            if len(pos) != len(ids):
+                continue
+            picked = sorted((order[i] for i in pos), key=lambda np_: ids.index(id(np_[1])))
+            rest = [np_ for i, np_ in enumerate(order) if i not in set(pos)]
+            at = sum(1 for i in range(pos[0]) if i not in set(pos))
+            order = rest[:at] + picked + rest[at:]
+        names, uniq = [n for n, _ in order], [p for _, p in order]
         self.dense = uniq
         self.layout = [[n, p.numel()] for n, p in zip(names, uniq)]     # order of the flat buffers (checked on load)
         sizes = [(p.numel() + 3) // 4 * 4 for p in self.dense]          # keep every view 16-byte aligned
@@ -82,10 +113,16 @@ class FusedAdamW:
         # per-step constants (lr decay, bias corrections) of the last LAZY_HIST steps on the device: the lazy table replay
         # reads them, and so does every Adam kernel of a step replayed from a hipGraph (`step_dev`, set by the Trainer's
         # step graph: the step number in device memory, because a replayed launch cannot take it as an argument)
-        self.hist = torch.zeros(LAZY_HIST, 4, dtype=torch.float32, device=dev)
-        self._hist_host = torch.zeros(LAZY_HIST, 4, dtype=torch.float32)
+        # Row LAZY_HIST of the same buffer carries the replay control block (two int64: dropout step counter, optimizer step),
+        # so ONE small host-to-device copy per step refreshes everything a replayed step reads.  The copy's source is a slot
+        # of a pinned ring: an asynchronous copy reads host memory when the DMA runs, not when it is issued.
+        self.hist = torch.zeros(LAZY_HIST + 1, 4, dtype=torch.float32, device=dev)
+        self.ctrl = self.hist[LAZY_HIST].view(torch.int64)               # device int64[2]
+        self._hist_host = torch.zeros(LAZY_HIST + 1, 4, dtype=torch.float32)
+        self._hist_ring = torch.zeros(HOST_RING, LAZY_HIST + 1, 4, dtype=torch.float32)
         if dev.type == "cuda":
-            self._hist_host = self._hist_host.pin_memory()
+            self._hist_ring = self._hist_ring.pin_memory()
+        self._n_push = 0
         self.step_dev = None
         self.in_graph = False                                            # True while a step is being captured
         if self.lazy:
@@ -106,12 +143,12 @@ class FusedAdamW:
         the lazy table Adam can; the dense table pass (`mhr_adam_rows`) takes its constants as arguments."""
         return self.table is None or self.lazy
 
-    def begin_replayed_step(self, lr):
+    def begin_replayed_step(self, lr, seed_counter=0):
         """Host side of a step that is replayed from a hipGraph: advance the counters the captured Python would have advanced
-        and upload the step's constants (stream-ordered in front of the replay)."""
+        and upload the step's constants and control block (stream-ordered in front of the replay)."""
         self.step_count += 1
         self.param_groups[0]["lr"] = lr
-        self._push_consts(self.step_count, lr)
+        self._push_consts(self.step_count, lr, ctrl=(int(seed_counter), self.step_count))
         if self.lazy:
             self._lagging = True
 
@@ -161,13 +198,20 @@ class FusedAdamW:
                           self.weight_decay)
 
     # ---- lazy table update -------------------------------------------------------------------
-    def _push_consts(self, step, lr):
-        """The step's Adam constants into the device-side history (pinned staging row, asynchronous copy: no host stall)."""
+    def _push_consts(self, step, lr, ctrl=None):
+        """The step's Adam constants (and, for a replayed step, the control block) into the device-side history: one
+        asynchronous copy from a pinned ring slot, no host stall."""
         from . import lib
         row = step % LAZY_HIST
         lib.call("mhr_adam_consts", float(lr), self.betas[0], self.betas[1], self.eps, self.weight_decay, int(step),
                  self._hist_host[row].data_ptr())
-        self.hist[row].copy_(self._hist_host[row], non_blocking=True)
+        if ctrl is not None:
+            c = self._hist_host[LAZY_HIST].view(torch.int64)
+            c[0], c[1] = ctrl
+        slot = self._hist_ring[self._n_push % HOST_RING]
+        self._n_push += 1
+        slot.copy_(self._hist_host)
+        self.hist.copy_(slot, non_blocking=True)
 
     def _lazy_call(self, mode, ids, grad_rows, row_slot, grad_scale, step=None):
         t = self.table
