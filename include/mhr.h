@@ -482,6 +482,33 @@ int mhr_ihn_dense_bwd(const float* neg_logits, const float* fix_logits, int64_t 
                       float beta, const int32_t* n_live_dev, int64_t row_base, int64_t rows, void* g_bf16, int64_t ldg,
                       void* stream);
 
+/* The same scorer at feature dims beyond the register-stationary kernels (dim a multiple of 64, up to 8192: HSTU size-4,
+ * the HLLM twin's TinyLlama / Baichuan2 widths; hstu.py:965-1015 = hllm.py:838-883): an LDS-tiled MFMA GEMM (256 items x
+ * 128 rows per workgroup, 64-feature chunks by LDS-DMA, three stages, loader + consumer waves) with the threshold emit in
+ * its epilogue - the score block never exists in memory.  Operands are PACKED tile images (mhr_pack_tiles): the selected
+ * item rows {item_begin + j * item_stride} with tiles_per_block = 8, the user rows with tiles_per_block = 4; a (256-item
+ * block, 64-feature chunk) is then one contiguous 32 KB run.  Same predicates and list format as
+ * mhr_catalog_score_emit_sliced with FOUR lists per (row, item slice):
+ *   cand_val / cand_idx [n_rows, 4 n_slices, cap_s], cand_cnt [n_rows, 4 n_slices] (written; no zeroing).
+ * A list sees at most 64 items per 256-item block.  n_slices must be mhr_catalog_wide_slices(n_rows) (32 ... 256: the
+ * kernel arranges row blocks x item slices per XCD so that both operands' chunks are shared in that XCD's L2).
+ * item_begin / item_stride only name the items (candidate ids, tag words); the packed image holds them densely. */
+int mhr_catalog_score_emit_wide(const void* users_packed, int n_rows, const void* items_packed, int64_t n_items, int dim,
+                                int64_t item_begin, int64_t item_stride, const uint32_t* tag_bits, const uint32_t* row_bits,
+                                const float* tau, float* cand_val, int32_t* cand_idx, int32_t* cand_cnt, int n_slices,
+                                int cap_s, void* stream);
+int mhr_catalog_wide_slices(int n_rows);
+/* Rows {row_begin + j * row_stride, j < n_sel} of x [n_rows, dim] bf16 (dim % 64 == 0) -> packed tile images
+ * [ceil(n_sel / (32 tiles_per_block))][dim / 64][tiles_per_block][4096 B] (32 rows x 64 features each, XOR-swizzled like
+ * the LDS tiles; rows past n_sel / n_rows are zero).  out: mhr_pack_tiles_bytes(n_sel, dim, tiles_per_block) bytes. */
+int mhr_pack_tiles(const void* x, int64_t n_rows, int dim, int64_t row_begin, int64_t row_stride, int64_t n_sel,
+                   int tiles_per_block, void* out, void* stream);
+int64_t mhr_pack_tiles_bytes(int64_t n_sel, int dim, int tiles_per_block);
+int mhr_catalog_score_emit_wide(const void* users, int n_rows, const void* items, int64_t n_items, int dim,
+                                int64_t item_begin, int64_t item_stride, const uint32_t* tag_bits, const uint32_t* row_bits,
+                                const float* tau, float* cand_val, int32_t* cand_idx, int32_t* cand_cnt, int n_slices,
+                                int cap_s, void* stream);
+
 /* Catalog masks on a dense score chunk (model/IDNet/hstu.py:982-999, trainer.py:724): column j is item
  * item_begin + j * item_stride; scores[r, j] = -inf unless (tag_bits[item] & row_bits[r]) != 0 and item != 0
  * (tag_bits NULL: every item carries bit 31 only).  In place. */

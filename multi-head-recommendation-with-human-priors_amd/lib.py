@@ -19,7 +19,7 @@ def _parse_header():
     with open(HEADER) as f:
         text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
     sigs = {}
-    for m in re.finditer(r"\bint\s+(mhr_[a-z0-9_]+)\s*\(([^;]*?)\)\s*;", text, flags=re.S):
+    for m in re.finditer(r"\b(?:int|int64_t)\s+(mhr_[a-z0-9_]+)\s*\(([^;]*?)\)\s*;", text, flags=re.S):
         name, params = m.group(1), m.group(2).strip()
         args = []
         if params and params != "void":
@@ -42,6 +42,7 @@ def _parse_header():
 
 
 SIGNATURES = _parse_header()
+RETURNS_INT64 = {"mhr_pack_tiles_bytes"}
 
 
 def declared_symbols():
@@ -69,7 +70,7 @@ class _Lib:
                 if fn is None:
                     raise RuntimeError(f"{LIB_PATH} does not export {name} (stale build? run `python __graft_entry__.py`)")
                 fn.argtypes = args
-                fn.restype = ctypes.c_int
+                fn.restype = ctypes.c_int64 if name in RETURNS_INT64 else ctypes.c_int
             self._dll = dll
         return self._dll
 

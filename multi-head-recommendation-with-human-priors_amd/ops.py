@@ -858,6 +858,33 @@ def catalog_emit_sliced(users, items, n_items, tag_bits, row_bits, tau, cap_s, i
     return val, idx, cnt, 2 * n_slices
 
 
+def pack_tiles(x, n_sel=None, row_begin=0, row_stride=1, tiles_per_block=8):
+    """Rows {row_begin + j row_stride} of x [n, D] bf16 -> the wide scorer's packed tile images (uint8 tensor)."""
+    _chk(x, "x", torch.bfloat16)
+    n, D = x.shape
+    if n_sel is None:
+        n_sel = (n - row_begin + row_stride - 1) // row_stride
+    nbytes = lib.load().mhr_pack_tiles_bytes(n_sel, D, tiles_per_block)
+    out = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    lib.call("mhr_pack_tiles", x.data_ptr(), n, D, row_begin, row_stride, n_sel, tiles_per_block, out.data_ptr(), _stream())
+    return out
+
+
+def catalog_emit_wide(users_p, n_rows, D, items_p, n_items, tag_bits, row_bits, tau, cap_s, item_begin=0, item_stride=1):
+    """Feature dims beyond 256 (a multiple of 64): the LDS-tiled MFMA scorer with the fused threshold emit
+    (csrc/catalog_wide.hip) on PACKED operands (pack_tiles: users with 4 tiles per block, the selected items with 8).
+    -> (cand_val, cand_idx [n_rows, n_lists, cap_s], cand_cnt [n_rows, n_lists], n_lists = 4 x slices)."""
+    dev = users_p.device
+    n_slices = lib.load().mhr_catalog_wide_slices(n_rows)        # fixed by the kernel's XCD layout (32 ... 256)
+    val = torch.empty(n_rows, 4 * n_slices, cap_s, dtype=torch.float32, device=dev)
+    idx = torch.empty(n_rows, 4 * n_slices, cap_s, dtype=torch.int32, device=dev)
+    cnt = torch.empty(n_rows, 4 * n_slices, dtype=torch.int32, device=dev)
+    _timed_call("mhr_catalog_score_emit_wide", users_p.data_ptr(), n_rows, items_p.data_ptr(), n_items, D, item_begin, item_stride,
+                _ptr(tag_bits), row_bits.data_ptr(), tau.data_ptr(), val.data_ptr(), idx.data_ptr(), cnt.data_ptr(), n_slices,
+                cap_s, _stream())
+    return val, idx, cnt, 4 * n_slices
+
+
 def topk_select_sliced(cand, H, hist_ptr, hist_items, k):
     """-> (values [n_rows,k], indices [n_rows,k], kth value, valid-candidate count, overflow status)."""
     val, idx, cnt, n_slices = cand
@@ -913,7 +940,7 @@ def catalog_topk(users, H, items, tag_bits, row_bits, hist_ptr, hist_items, k, c
         # row is only re-run, never wrong); every candidate above what is needed costs a divergent slow-path visit.
         target = max(512, int(2.5 * k))
     s1 = max(1, -(-N // 2048))
-    s2 = max(1, -(-N // 32768))
+    s2 = max(1, min(-(-N // 32768), target // 48))       # threshold = the ~50th largest of the second sample (see wide.py)
     t1 = 8
     t2 = max(k // s2 + 1, target // s2)
     # pass 1: every s1-th item, all scores -> the t1-th largest bounds the top ~0.4 %

@@ -21,6 +21,7 @@ import torch
 
 from . import lib
 
+_PACKED = None        # (key, packed catalog, packed threshold samples) of the last catalog the wide scorer saw
 CHUNK = 8192          # tokens per logit block: 8192 x 8192 fp32 = 256 MB (x2: negatives and false-negative logits)
 ITEM_CHUNK = 65536    # items per score block
 
@@ -188,6 +189,68 @@ def _exact_rows(users, H, items, n_items, tag_bits, row_bits, hist_ptr, hist_ite
     return best_v, best_i
 
 
+def _catalog_topk_mfma(users, H, items, N, tag_bits, row_bits, hist_ptr, hist_items, k, chunk, target, stats):
+    """Exact per-row top-k with the hand-written wide scorer (csrc/catalog_wide.hip: LDS-tiled MFMA GEMM, threshold emit in
+    the epilogue - no score block in memory, no library GEMM).  Same scheme as the register-stationary path
+    (ops.catalog_topk): thresholds from two strided sample passes through the SAME kernel, one full pass, the shared exact
+    select; rows that cannot be certified (list overflow, too few candidates) are re-run keeping every score."""
+    from . import lib, ops
+    n_rows, D = users.shape
+    dev = users.device
+    users, items = users.contiguous(), items.contiguous()
+    tb = None if tag_bits is None else tag_bits
+    ninf = torch.full((n_rows,), float("-inf"), dtype=torch.float32, device=dev)
+    users_p = ops.pack_tiles(users, tiles_per_block=4)                              # once per batch (a few MB)
+    SEL = 8192                                                                    # candidates the select kernel holds per row
+    if target is None:
+        target = max(512, int(2.5 * k))
+    s1 = max(1, -(-N // 2048))
+    # second sample: dense enough that the threshold is the ~50th largest of the sample (its rank estimate then scatters by
+    # ~14 %: a row comes up short of k candidates at > 4 sigma; at N = 2^20 a 1 / 32 sample left 2.4 sigma and flagged rows -
+    # each an exact re-run - in most batches)
+    s2 = max(1, min(-(-N // 32768), target // 48))
+    # the catalog's packed images (whole, and the two strided samples of the threshold passes) depend on the table only:
+    # built once per cached catalog (the evaluation normalises and caches it, REC/model/multihead.py:_normalised_items)
+    # (keyed on the tensor OBJECT, which the cache keeps alive: an address alone may be a freed table's, reused)
+    global _PACKED
+    if _PACKED is None or _PACKED[0] is not items or _PACKED[1] != (items._version, N, s1, s2):
+        full = ops.pack_tiles(items, n_sel=N)
+        samp = None if N <= SEL else (ops.pack_tiles(items[:N], row_stride=s1), ops.pack_tiles(items[:N], row_stride=s2))
+        _PACKED = (items, (items._version, N, s1, s2), full, samp)
+    items_p, samples = _PACKED[2], _PACKED[3]
+    if N <= SEL:                                                                   # small catalogs: every score is a candidate
+        cand = ops.catalog_emit_wide(users_p, n_rows, D, items_p, N, tb, row_bits, ninf, 64)     # >= 32 slices: one block per slice at most
+        ov, oi, _, _, _ = ops.topk_select_sliced(cand, H, hist_ptr, hist_items, k)
+        return ov, oi
+    t1 = 8
+    t2 = min(max(k // s2 + 1, target // s2), 1024)                 # (the select kernel picks at most 1024)
+    # pass 1: every s1-th item, all scores (<= 2048 per row, <= 64 per list) -> the t1-th largest bounds the top ~0.4 %
+    c1 = ops.catalog_emit_wide(users_p, n_rows, D, samples[0], N, tb, row_bits, ninf, 64, 0, s1)
+    _, _, kth1, _, st1 = ops.topk_select_sliced(c1, H, hist_ptr, hist_items, t1)
+    # pass 2: every s2-th item above kth1 -> the t2-th largest estimates the score of rank ~target
+    c2 = ops.catalog_emit_wide(users_p, n_rows, D, samples[1], N, tb, row_bits, kth1, 32, 0, s2)
+    _, _, kth2, _, st2 = ops.topk_select_sliced(c2, H, hist_ptr, hist_items, t2)
+    ok2 = (st2 == 0) & (st1 == 0)
+    tau = torch.where(torch.isfinite(kth2) & ok2, kth2, torch.where(ok2, kth1, ninf)).contiguous()
+    n_sl = lib.load().mhr_catalog_wide_slices(n_rows)
+    cap_s = max(32, 4 * -(-target // (4 * n_sl)) + 16)
+    cand = ops.catalog_emit_wide(users_p, n_rows, D, items_p, N, tb, row_bits, tau, cap_s)
+    ov, oi, _, got, stt = ops.topk_select_sliced(cand, H, hist_ptr, hist_items, k)
+    flagged = (stt != 0) | ((got < k) & (row_bits != 0) & torch.isfinite(tau))
+    if stats is not None:
+        stats["mean_candidates"] = float(got.float().mean())
+        stats["flagged_rows"] = int(flagged.sum())
+    if bool(flagged.any()):                               # one host sync per batch; results go to the host anyway
+        users_f = torch.nonzero(flagged.view(-1, H).any(dim=1)).flatten()
+        rows_f = (users_f[:, None] * H + torch.arange(H, device=dev)[None, :]).flatten()
+        sub_ptr, sub_items = ops.sub_history(hist_ptr, hist_items, users_f)
+        fv, fi = _exact_rows(users[rows_f].contiguous(), H, items, N, tag_bits, row_bits[rows_f].contiguous(), sub_ptr, sub_items,
+                             k, chunk)
+        ov[rows_f] = fv
+        oi[rows_f] = fi
+    return ov, oi
+
+
 def catalog_topk_wide(users, H, items, n_items, tag_bits, row_bits, hist_ptr, hist_items, k, chunk=ITEM_CHUNK, target=None,
                       stats=None):
     """Exact per-row top-k over the catalog at any feature dim.  Thresholds from a strided sample of the catalog; the
@@ -198,6 +261,8 @@ def catalog_topk_wide(users, H, items, n_items, tag_bits, row_bits, hist_ptr, hi
     n_rows, D = users.shape
     N = int(n_items)
     dev = users.device
+    if D % 64 == 0 and users.dtype == torch.bfloat16 and items.dtype == torch.bfloat16:
+        return _catalog_topk_mfma(users, H, items, N, tag_bits, row_bits, hist_ptr, hist_items, k, chunk, target, stats)
     if N <= max(4 * k, 2048) or N <= chunk // 8:
         return _exact_rows(users, H, items, N, tag_bits, row_bits, hist_ptr, hist_items, k, chunk)
     st = _stream()

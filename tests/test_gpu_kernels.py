@@ -672,8 +672,8 @@ def test_catalog_topk_sampled_thresholds(ops):
 
 
 def test_catalog_topk_wide_threshold_emit(ops):
-    """Feature dim beyond the streaming kernels (HLLM twin / HSTU size-4): library GEMM by item chunks + the dense
-    threshold-emit epilogue + the shared exact select; exactness must not depend on the sampled threshold."""
+    """Feature dim beyond the register-stationary kernels (HLLM twin / HSTU size-4): the LDS-tiled MFMA scorer with the fused
+    threshold emit (csrc/catalog_wide.hip) + the shared exact select; exactness must not depend on the sampled threshold."""
     from mhr_amd import wide
     B, H, C, N, D, k = 6, 4, 4, 40000, 512, 100
     users, items, tag_bits, row_bits, hp, hi, scores = _catalog_case(B, H, C, N, D, 91, disabled_row=2)
