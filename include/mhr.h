@@ -423,6 +423,14 @@ int mhr_catalog_score_emit(const void* users, int n_rows, int H, const void* ite
                            const int32_t* hist_ptr, const int64_t* hist_items,
                            float* cand_val, int32_t* cand_idx, int32_t* cand_cnt, int cap, void* stream);
 
+/* fp32 re-score of candidate lists: out_val[r, j] = users[r, :] . items[cand_idx[r, j], :] in fp32 for j < cand_cnt[r]
+ * (users [n_rows, dim], items [n_items, dim] fp32, cand_idx [n_rows, k2] int64), out_idx = the indices as int32: the list
+ * format of mhr_topk_select.  The scorers rank bf16 operands; the reference ranks fp32 scores (hstu.py:965-979,
+ * collector.py:245): |s_bf16 - s_fp32| <= 2^-8 for unit vectors, so selecting on the re-scored candidates within 2^-7 of
+ * the k-th bf16 score gives the reference's fp32 top-k (ops.catalog_topk_exact). */
+int mhr_rescore_f32(const float* users, const float* items, int dim, int64_t n_items, const int64_t* cand_idx, int n_rows,
+                    int k2, const int32_t* cand_cnt, float* out_val, int32_t* out_idx, void* stream);
+
 /* Fast path of the same scorer ("sliced lists").  Every (row, item slice, lane half) triple owns a short list
  *   cand_val / cand_idx [n_rows, 2 n_slices, cap_s],  cand_cnt [n_rows, 2 n_slices] (written, no zeroing needed)
  * whose fill count lives in a register of the lane that owns it (mhr_topk_select_sliced then takes 2 n_slices lists): a threshold hit costs two plain stores (no atomic,

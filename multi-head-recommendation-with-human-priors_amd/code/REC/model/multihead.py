@@ -59,6 +59,9 @@ class MultiHeadDecoding:
         else:
             self.logit_scale = nn.Parameter(torch.ones([]) * np.log(temp_init))
         self.nce_thres = config['nce_thres'] if config['nce_thres'] else 0.99
+        # evaluation ranks fp32 scores of fp32 operands like the reference (bit-exact top-k indices wherever the reference's
+        # scores are untied); False: rank the bf16 MFMA scores directly (the candidates' order within 2^-8 may differ)
+        self.exact_fp32_topk = bool(config.get('exact_fp32_topk', True))
         self.seg_len = self.pred_len
         if nl > 0:
             assert self.pred_len % self.num_segment_head == 0, "pred_len must be divisible by the number of segments"
@@ -474,11 +477,14 @@ class MultiHeadDecoding:
         from mhr_amd import ops
         key = (all_item_feature.data_ptr(), all_item_feature._version, None if all_item_tags is None else all_item_tags.data_ptr())
         if self._item_cache is None or self._item_cache[0] != key:
-            items_bf = ops.l2norm_rows(all_item_feature.float().contiguous(), torch.bfloat16)      # hstu.py:974-975
+            feat = all_item_feature.float().contiguous()
+            items_bf = ops.l2norm_rows(feat, torch.bfloat16)                                       # hstu.py:974-975
             if items_bf.shape[0] % 32:      # whole 32-row tiles: the catalog scorer then streams it unclamped
                 items_bf = torch.cat([items_bf, items_bf.new_zeros(32 - items_bf.shape[0] % 32, items_bf.shape[1])]).contiguous()
             tag_bits = self.pack_item_tags(all_item_tags) if (all_item_tags is not None and self.loss == 'prior') else None
-            self._item_cache = (key, items_bf, tag_bits)
+            # fp32 normalised rows for the exact re-score of the final candidates (the reference ranks fp32 scores)
+            items_f32 = ops.l2norm_rows(feat, torch.float32) if self.exact_fp32_topk else None
+            self._item_cache = (key, items_bf, tag_bits, items_f32)
         return self._item_cache[1], self._item_cache[2]
 
     @torch.no_grad()
@@ -510,8 +516,15 @@ class MultiHeadDecoding:
             hist_items = hi[order].contiguous()
             # CSR offsets by binary search on the sorted user column (torch.bincount would sync the host)
             hist_ptr = torch.searchsorted(hu[order].contiguous(), torch.arange(B + 1, device=dev)).int()
-        vals, idx = ops.catalog_topk(users, H, items_bf, tag_bits, row_bits, hist_ptr, hist_items, k, stats=stats,
-                                     n_items=all_item_feature.shape[0])
+        if self.exact_fp32_topk:
+            # ranked on fp32 scores like the reference (hstu.py:965-979 + collector.py:245): bf16 scorer for the candidates
+            # within 2^-7 of the k-th score, fp32 re-score of those, exact select (ops.catalog_topk_exact)
+            vals, idx = ops.catalog_topk_exact(heads_n.reshape(B * H, -1).float().contiguous(), H, items_bf, self._item_cache[3],
+                                               tag_bits, row_bits, hist_ptr, hist_items, k, n_items=all_item_feature.shape[0],
+                                               stats=stats)
+        else:
+            vals, idx = ops.catalog_topk(users, H, items_bf, tag_bits, row_bits, hist_ptr, hist_items, k, stats=stats,
+                                         n_items=all_item_feature.shape[0])
         return FusedTopK(vals.view(B, H, k), idx.view(B, H, k), logs)
 
     @torch.no_grad()

@@ -50,10 +50,19 @@ class _StepGraph:
         keep = (model._step_seed, opt.step_count, tr.train_step, tr._micro_step, opt.param_groups[0]["lr"])
         graph = torch.cuda.CUDAGraph()
         model._seed_dev, opt.step_dev, opt.in_graph = opt.ctrl[0:1], opt.ctrl[1:2], True
+        # no cyclic garbage collection while the stream is capturing: a collected object may own pinned host memory or an
+        # event whose release is a synchronising HIP call - illegal under capture, and it takes the process down (seen with
+        # the pinned staging rings of earlier trainers).  torch.cuda.graph collects once on entry; a step's own Python can
+        # trigger the generational collector again.
+        import gc
+        gc_was = gc.isenabled()
+        gc.disable()
         try:
             with torch.cuda.graph(graph):
                 out = tr._eager_step(self.static)
         finally:
+            if gc_was:
+                gc.enable()
             model._seed_dev, opt.step_dev, opt.in_graph = None, None, False
             # the capture ran the Python of one step (counters moved) and launched nothing: put the counters back
             model._step_seed, opt.step_count, tr.train_step, tr._micro_step, opt.param_groups[0]["lr"] = keep

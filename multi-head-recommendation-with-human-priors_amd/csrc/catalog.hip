@@ -651,6 +651,53 @@ inline int next_pow2(int x) {
 
 }  // namespace
 
+// ------------------------------------------------------------------------------------------
+// fp32 re-score of a row's candidates (exactness against the reference's fp32 score path, hstu.py:965-979)
+// ------------------------------------------------------------------------------------------
+// The scorers rank on bf16 operands: |s_bf16 - s_fp32| <= 2^-8 for unit vectors, so the fp32 top-k is a subset of the
+// candidates within 2^-7 of the k-th bf16 score.  Those few hundred candidates per row are re-scored here from the fp32
+// rows - one wave per (row, candidate), 16 bytes per lane, wave-shuffle sum - and the final select runs on these values.
+__global__ __launch_bounds__(256) void rescore_f32_kernel(const float* __restrict__ users, const float* __restrict__ items, int dim,
+                                                          int64_t n_items, const int64_t* __restrict__ cand_idx, int k2,
+                                                          const int32_t* __restrict__ cand_cnt, int64_t n_pairs,
+                                                          float* __restrict__ out_val, int32_t* __restrict__ out_idx) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  for (int64_t pr = wave; pr < n_pairs; pr += n_waves) {
+    const int64_t row = pr / k2;
+    const int j = (int)(pr - row * k2);
+    if (j >= cand_cnt[row]) continue;
+    const int64_t n = cand_idx[pr];
+    float acc = 0.f;
+    if (n >= 0 && n < n_items) {
+      const float* u = users + row * dim;
+      const float* it = items + n * dim;
+      for (int c = lane * 4; c < dim; c += 256) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(u + c), b = *reinterpret_cast<const f32x4*>(it + c);
+        acc += a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
+      }
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) {
+      out_val[pr] = acc;
+      out_idx[pr] = (int32_t)n;
+    }
+  }
+}
+
+extern "C" int mhr_rescore_f32(const float* users, const float* items, int dim, int64_t n_items, const int64_t* cand_idx,
+                               int n_rows, int k2, const int32_t* cand_cnt, float* out_val, int32_t* out_idx, void* stream) {
+  MHR_REQUIRE(users && items && cand_idx && cand_cnt && out_val && out_idx, "rescore_f32: null pointer");
+  MHR_REQUIRE(dim > 0 && dim % 4 == 0 && n_rows >= 0 && k2 >= 1 && n_items > 0, "rescore_f32: bad sizes (dim=%d)", dim);
+  if (n_rows == 0) return MHR_OK;
+  const int64_t n_pairs = (int64_t)n_rows * k2;
+  hipLaunchKernelGGL(rescore_f32_kernel, dim3(mhr_grid_for(n_pairs, 4)), dim3(256), 0, (hipStream_t)stream, users, items, dim, n_items,
+                     cand_idx, k2, cand_cnt, n_pairs, out_val, out_idx);
+  MHR_CHECK_LAUNCH("rescore_f32");
+  return MHR_OK;
+}
+
 extern "C" int mhr_catalog_score_emit(const void* users, int n_rows, int H, const void* items, int64_t n_items, int dim,
                                       int64_t item_begin, int64_t item_stride, const uint32_t* tag_bits,
                                       const uint32_t* row_bits, const float* tau, const int32_t* hist_ptr,

@@ -941,7 +941,8 @@ def catalog_topk(users, H, items, tag_bits, row_bits, hist_ptr, hist_items, k, c
         target = max(512, int(2.5 * k))
     s1 = max(1, -(-N // 2048))
     s2 = max(1, min(-(-N // 32768), target // 48))       # threshold = the ~50th largest of the second sample (see wide.py)
-    t1 = 8
+    t1 = min(1024, max(8, -(-3 * target // s1)))           # first threshold: about 3x looser than the rank aimed at (a tighter one
+                                                   # starves the second sample and, as the fallback threshold, the candidates)
     t2 = max(k // s2 + 1, target // s2)
     # pass 1: every s1-th item, all scores -> the t1-th largest bounds the top ~0.4 %
     nt1 = -(-(-(-N // s1)) // 32)                                      # tiles of the first sample
@@ -971,6 +972,60 @@ def catalog_topk(users, H, items, tag_bits, row_bits, hist_ptr, hist_items, k, c
         fv, fi, _, _ = topk_select(c3, N, k)
         ov[rows_f] = fv
         oi[rows_f] = fi
+    return ov, oi
+
+
+BF16_SCORE_ERR = 2.0 ** -8       # |u_bf16 . i_bf16 - u . i| for unit vectors u, i (each component rounded to 8 bits)
+
+
+def catalog_topk_exact(users_f32, H, items_bf, items_f32, tag_bits, row_bits, hist_ptr, hist_items, k, n_items=None, stats=None):
+    """Per-row top-k ranked on FP32 scores of fp32 operands - the reference's score path (hstu.py:965-979: fp32 normalise,
+    fp32 matmul; collector.py:245 torch.topk) - without a [B, H, N] tensor.  The bf16 scorer finds every candidate whose bf16
+    score lies within 2^-7 of the k-th bf16 score (a superset of the fp32 top-k: the two scores differ by at most 2^-8),
+    `mhr_rescore_f32` re-scores those few hundred candidates per row from the fp32 rows, and the exact select picks k by
+    (fp32 value desc, index asc).  Rows whose margin set cannot be certified (more than 1024 near-ties) fall back to dense
+    fp32 scoring of that row.  users_f32 [B*H, D] fp32 normalised; items_bf [>= N, D] bf16 / items_f32 [N, D] fp32 normalised."""
+    n_rows, D = users_f32.shape
+    N = items_f32.shape[0] if n_items is None else int(n_items)
+    dev = users_f32.device
+    users_bf = users_f32.to(torch.bfloat16).contiguous()
+    k2 = min(N - 1, 1024, max(2 * k + 64, k + 256))
+    if k2 <= k:
+        k2 = k
+    # top-k2 on bf16 scores, sorted: candidates asked for so that the emit threshold sits well below the margin
+    bv, bi = catalog_topk(users_bf, H, items_bf, tag_bits, row_bits, hist_ptr, hist_items, k2, target=max(512, int(2.5 * k2)),
+                          stats=stats, n_items=N)
+    kk = min(k, k2)
+    kth = bv[:, kk - 1:kk]
+    in_margin = bv >= (kth - 2 * BF16_SCORE_ERR)                      # a prefix of the sorted list (-inf tails: kth = -inf keeps them out via isfinite)
+    in_margin &= torch.isfinite(bv)
+    cnt = in_margin.sum(dim=1).int()
+    rv = torch.empty(n_rows, k2, dtype=torch.float32, device=dev)
+    ri = torch.empty(n_rows, k2, dtype=torch.int32, device=dev)
+    _chk(users_f32, "users_f32", torch.float32)
+    _chk(items_f32, "items_f32", torch.float32)
+    lib.call("mhr_rescore_f32", users_f32.data_ptr(), items_f32.data_ptr(), D, N, bi.data_ptr(), n_rows, k2, cnt.data_ptr(),
+             rv.data_ptr(), ri.data_ptr(), _stream())
+    ov, oi, _, st = topk_select((rv, ri, cnt), k2, k)
+    # uncertified rows: the margin reached the end of the candidate list (the (k2+1)-th bf16 score might be inside it too)
+    full = (cnt >= k2) & (k2 < N - 1)
+    if stats is not None:
+        stats["margin_mean"] = float(cnt.float().mean())
+        stats["uncertified_rows"] = int(full.sum())
+    if bool(full.any()):                                              # one host sync; a handful of rows at most
+        rows = torch.nonzero(full).flatten()
+        sc = users_f32[rows] @ items_f32[:N].t()                      # dense fp32 scores of those rows only
+        if tag_bits is not None:
+            ok = (tag_bits[:N].long()[None, :] & row_bits[rows].long()[:, None]) != 0
+            sc = sc.masked_fill(~ok, float("-inf"))
+        sc[:, 0] = float("-inf")
+        if hist_ptr is not None and hist_items is not None:
+            for j_, r_ in enumerate(rows.tolist()):
+                u_ = r_ // H
+                h_ = hist_items[int(hist_ptr[u_]):int(hist_ptr[u_ + 1])].long()
+                sc[j_, h_[h_ < N]] = float("-inf")
+        v_, p_ = torch.sort(sc, dim=1, descending=True, stable=True)  # stable: ties keep ascending index
+        ov[rows], oi[rows] = v_[:, :k], p_[:, :k]
     return ov, oi
 
 

@@ -222,7 +222,8 @@ def _catalog_topk_mfma(users, H, items, N, tag_bits, row_bits, hist_ptr, hist_it
         cand = ops.catalog_emit_wide(users_p, n_rows, D, items_p, N, tb, row_bits, ninf, 64)     # >= 32 slices: one block per slice at most
         ov, oi, _, _, _ = ops.topk_select_sliced(cand, H, hist_ptr, hist_items, k)
         return ov, oi
-    t1 = 8
+    t1 = min(1024, max(8, -(-3 * target // s1)))           # first threshold: about 3x looser than the rank aimed at (a tighter one
+                                                   # starves the second sample and, as the fallback threshold, the candidates)
     t2 = min(max(k // s2 + 1, target // s2), 1024)                 # (the select kernel picks at most 1024)
     # pass 1: every s1-th item, all scores (<= 2048 per row, <= 64 per list) -> the t1-th largest bounds the top ~0.4 %
     c1 = ops.catalog_emit_wide(users_p, n_rows, D, samples[0], N, tb, row_bits, ninf, 64, 0, s1)

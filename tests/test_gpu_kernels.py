@@ -663,10 +663,11 @@ def test_catalog_topk_sampled_thresholds(ops):
     torch.cuda.synchronize()
     _check_topk(ov, oi, scores, k)
     assert stats["mean_candidates"] < 4096
-    # force the fallback: a tiny capacity flags every row, results must still be exact
+    # force the fallback: a candidate budget of barely k leaves many rows short of k candidates - they are flagged and re-run
+    # exactly, and the results must not change
     stats2 = {}
     ov2, oi2 = ops.catalog_topk(dev(users), H, dev(items), dev(tag_bits), dev(row_bits), dev(hp), dev(hi), k, cap=256,
-                                target=1024, stats=stats2)
+                                target=k + 8, stats=stats2)
     assert stats2["flagged_rows"] > 0
     _check_topk(ov2, oi2, scores, k)
 
@@ -799,3 +800,92 @@ def test_ihn_loss_fwd_bwd(ops, D, n_tok, n_neg, beta):
         gs = float(ref.abs().max())
         assert float((got - ref).abs().max()) < 2e-2 * gs, (name, float((got - ref).abs().max()), gs)
     assert abs(float(dls.cpu()) - float(lsr.grad)) < 2e-2 * abs(float(lsr.grad)) + 1e-4
+
+
+# ------------------------------------------------------------------------------------------------
+# top-k ranked on fp32 scores (ops.catalog_topk_exact): the reference's score path, hstu.py:965-979 + collector.py:245
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["predict_mult", "predict_additive", "predict_switch", "predict_switch_master"])
+def test_exact_topk_matches_reference_scores(ops, name):
+    """The reference's OWN fp32 scores (golden `out/scores_given*`, produced by its predict()) define the expected indices:
+    torch.topk of every (user, head) row.  Fed with the reference's fp32 user heads (the pinned oracle reproduces them) and
+    its fp32 item table, the fused decode must return those indices bit for bit wherever the reference's scores are untied."""
+    from conftest import load_golden
+    from test_oracle_golden import cfg_of, weights_of
+    g = load_golden(name)
+    w, ocfg = weights_of(g), cfg_of(g)
+    seq = torch.from_numpy(g["in/item_seq"])
+    heads = HO.user_head_embeddings(w, ocfg, seq).float()                       # [B, H, D] fp32, L2-normalised (pinned by the goldens)
+    feat = torch.from_numpy(g["out/item_feature"]).float()
+    ref_scores = g["out/scores_given0"] if np.isfinite(g["out/scores_given0"]).any() else g["out/scores_given1"]
+    if not np.isfinite(ref_scores).any():
+        pytest.skip("the fixture's heads are all switched off")
+    B, H, N = ref_scores.shape
+    items_f32 = HO.l2n(feat)
+    assert np.abs((heads.reshape(B * H, -1) @ items_f32.T).numpy().reshape(B, H, N)[np.isfinite(ref_scores)] -
+                  ref_scores[np.isfinite(ref_scores)]).max() < 2e-5            # the oracle's heads ARE the reference's
+    C = ocfg["num_prior_head"]
+    tags = torch.from_numpy(g["in/item_tags"])                                   # [N, C]
+    tag_bits = ((tags.long() * (1 << torch.arange(C))).sum(1) | (1 << 31))
+    tag_bits = torch.where(tag_bits >= (1 << 31), tag_bits - (1 << 32), tag_bits).int()
+    # row bits from the reference's own -inf pattern: a head is constrained to category c iff its row masks exactly the items outside c
+    row_bits = []
+    for b in range(B):
+        for h in range(H):
+            fin = np.isfinite(ref_scores[b, h])
+            bit = -(1 << 31)
+            if not fin.all():
+                cs = [c for c in range(C) if np.array_equal(fin, tags[:, c].numpy().astype(bool))]
+                bit = (1 << cs[0]) if cs else 0
+            row_bits.append(bit)
+    row_bits = torch.tensor(row_bits, dtype=torch.int32)
+    k = 20
+    items_bf = torch.cat([bf(items_f32), torch.zeros((32 - N % 32) % 32, items_f32.shape[1], dtype=torch.bfloat16)])
+    ov, oi = ops.catalog_topk_exact(dev(heads.reshape(B * H, -1)), H, dev(items_bf), dev(items_f32), dev(tag_bits), dev(row_bits),
+                                    None, None, k, n_items=N)
+    torch.cuda.synchronize()
+    sc = ref_scores.copy()
+    sc[:, :, 0] = -np.inf                                                        # pad id (trainer.py:724)
+    for b in range(B):
+        for h in range(H):
+            if row_bits[b * H + h] == 0:
+                continue
+            row = sc[b, h]
+            order = np.lexsort((np.arange(N), -row.astype(np.float64)))
+            got = oi[b * H + h].cpu().numpy()
+            for j in range(k):
+                if not np.isfinite(row[order[j]]):
+                    break
+                untied = (j == 0 or row[order[j - 1]] - row[order[j]] > 1e-6) and (row[order[j]] - row[order[j + 1]] > 1e-6)
+                if untied:
+                    assert got[j] == order[j], (name, b, h, j)
+                assert abs(float(ov[b * H + h, j]) - row[got[j]]) <= 2e-6        # values: the reference's fp32 scores
+
+
+def test_exact_topk_large_catalog_fp32_order(ops):
+    """60 000 items, D = 256: fp32 ranking vs numpy on the fp32 operands - indices exact at untied positions; and the bf16
+    ranking of the same operands differs somewhere (otherwise this test would not test anything)."""
+    g = torch.Generator().manual_seed(123)
+    B, H, N, D, k = 8, 4, 60000, 256, 200
+    users = HO.l2n(torch.randn(B * H, D, generator=g))
+    items = HO.l2n(torch.randn(N, D, generator=g) + 0.3 * torch.randn(1, D, generator=g))        # a common component: crowded top
+    row_bits = torch.full((B * H,), -(1 << 31), dtype=torch.int32)
+    items_bf = bf(items)
+    stats = {}
+    ov, oi = ops.catalog_topk_exact(dev(users), H, dev(items_bf), dev(items), None, dev(row_bits), None, None, k, n_items=N, stats=stats)
+    bv, bi = ops.catalog_topk(dev(bf(users)), H, dev(items_bf), None, dev(row_bits), None, None, k, n_items=N)
+    torch.cuda.synchronize()
+    sc = (users.double() @ items.double().T).numpy()
+    sc[:, 0] = -np.inf
+    n_diff_bf16 = 0
+    for r in range(B * H):
+        order = np.lexsort((np.arange(N), -sc[r]))[:k + 1]
+        got = oi[r].cpu().numpy()
+        for j in range(k):
+            gap_prev = sc[r, order[j - 1]] - sc[r, order[j]] if j else 1.0
+            gap_next = sc[r, order[j]] - sc[r, order[j + 1]]
+            if gap_prev > 2e-6 and gap_next > 2e-6:
+                assert got[j] == order[j], (r, j)
+        n_diff_bf16 += int((bi[r].cpu().numpy() != order[:k]).sum())
+        np.testing.assert_allclose(ov[r].cpu().numpy(), sc[r, got], rtol=0, atol=2e-6)
+    assert n_diff_bf16 > 0 and stats["uncertified_rows"] == 0 and k < stats["margin_mean"] <= 1024

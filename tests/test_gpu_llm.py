@@ -335,8 +335,8 @@ def test_hllm_predict_and_fused_decode(ops):
     fin = np.isfinite(r)
     assert np.abs(s[fin] - r[fin]).max() < 2e-2                                          # cosines, bf16 decoder
     fused = model.predict_topk(seq.cuda(), feat, tags_cn.cuda(), tt.cuda(), None, k=K, suppress_history=False)
-    users = model._heads_at_last(model._last_hidden(seq.cuda(), feat)).to(torch.bfloat16).float().cpu()
-    items = (table / table.norm(dim=-1, keepdim=True)).to(torch.bfloat16).float()
+    users = model._heads_at_last(model._last_hidden(seq.cuda(), feat)).float().cpu()
+    items = (table / table.norm(dim=-1, keepdim=True)).float()
     dense = (users @ items.T).numpy()
     dense[~np.isfinite(s)] = -np.inf
     dense[:, :, 0] = -np.inf

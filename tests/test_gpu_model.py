@@ -121,11 +121,11 @@ def test_predict_vs_reference_golden(rec, name):
         assert np.array_equal(np.isinf(s), np.isinf(ref))                               # identical -inf mask pattern
         fin = np.isfinite(ref)
         assert (not fin.any()) or np.abs(s[fin] - ref[fin]).max() < 2e-2                # cosines, bf16 encoder
-        # fused path == decode of the dense scores it would have produced (indices bit-exact on bf16 operands)
+        # fused path == decode of the fp32 scores of its fp32 user heads and items (the reference's score path; exact indices)
         k = 20
         fused = model.predict_topk(seq, feat, tags, tt, None, k=k, suppress_history=False)
-        users = model._user_heads(seq).to(torch.bfloat16).float().cpu()
-        items = torch.from_numpy(g["out/item_feature"]).to(torch.bfloat16).float()
+        users = model._user_heads(seq).float().cpu()                      # the decode ranks fp32 scores (exact_fp32_topk)
+        items = torch.from_numpy(g["out/item_feature"]).float()
         dense = (users @ items.T).numpy()
         dense[~np.isfinite(scores.cpu().numpy())] = -np.inf       # the dense path's own masks (== the reference's, checked above)
         dense[:, :, 0] = -np.inf
@@ -173,8 +173,8 @@ def test_trainer_eval_metrics_match_oracle_decode(rec):
     sums = {p: {} for p in cfg["metrics_pred_len_list"]}
     n = 0
     for eb in batches:
-        users = model._user_heads(eb[1]).to(torch.bfloat16).float().cpu()
-        items = feat.to(torch.bfloat16).float().cpu()
+        users = model._user_heads(eb[1]).float().cpu()
+        items = feat.float().cpu()
         sc = (users @ items.T).numpy()
         for h in range(sc.shape[1]):
             sc[:, h, ~tags[h % 3].bool().cpu().numpy()] = -np.inf
@@ -245,8 +245,8 @@ def test_wide_model_trains_and_decodes(rec):
     tags = data.item_tags.long().t().contiguous()
     k = 20
     fused = model.predict_topk(item_seq, feat, tags, target_tags, None, k=k, suppress_history=False)
-    users = model._user_heads(item_seq).to(torch.bfloat16).float().cpu()
-    items = feat.to(torch.bfloat16).float().cpu()
+    users = model._user_heads(item_seq).float().cpu()
+    items = feat.float().cpu()
     dense = (users @ items.T).numpy()
     scores, _, _, _ = model.predict(item_seq, None, feat, tags, target_tags)
     dense[~np.isfinite(scores.cpu().numpy())] = -np.inf
@@ -440,8 +440,8 @@ def test_comirec_vs_reference_golden(rec):
     assert np.abs(scores.cpu().numpy() - g["out/scores"]).max() < 2e-2                      # cosines, bf16 encoder
     k = 20
     fused = model.predict_topk(seq, feat, None, None, None, k=k, suppress_history=False)
-    users = model._interest_heads(seq).to(torch.bfloat16).float().cpu()
-    items = torch.from_numpy(g["out/item_feature"]).to(torch.bfloat16).float()
+    users = model._interest_heads(seq).float().cpu()
+    items = torch.from_numpy(g["out/item_feature"]).float()
     dense_s = (users @ items.T).numpy()
     dense_s[:, :, 0] = -np.inf
     rv, ri = DO.per_head_topk(dense_s, k)

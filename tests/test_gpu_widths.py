@@ -255,8 +255,8 @@ def test_cfg2_model_step_full_width(ops):
     tags_cn = data.item_tags.long().t().contiguous()
     fused = model.predict_topk(eb[1], feat, tags_cn, eb[6], eb[3], k=200)
     heads_n = model._user_heads(eb[1])                                                 # [B, H, D] fp32 normalised
-    ub = heads_n.to(torch.bfloat16).float().cpu()
-    ib = HO.l2n(feat.float()).to(torch.bfloat16).float().cpu()
+    ub = heads_n.float().cpu()                                                         # the decode ranks fp32 scores
+    ib = HO.l2n(feat.float()).cpu()
     sc = (ub.reshape(-1, ub.shape[-1]) @ ib.T).view(4, -1, N).numpy()
     given = eb[6][:, :model.given_prior_len].bool().any(dim=1).cpu().numpy()            # [B, C]
     for h_ in range(sc.shape[1]):
