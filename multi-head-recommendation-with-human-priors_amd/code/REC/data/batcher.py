@@ -41,7 +41,7 @@ class SeqStore:
     (row 0 = pad item, all False)."""
 
     def __init__(self, user_seq, train_seq_len, item_tags, device="cpu", user_cluster=None, event_seq=None, item_weights=None,
-                 item_weights_by_cat=None):
+                 item_weights_by_cat=None, item_raw_tag=None):
         """user_cluster [U] ints (category_by = 'user': `dataload.user_cluster_list`); event_seq: per user, the event type of
         every interaction (category_by = 'event': `dataload.event_seq`, parallel to user_seq); item_weights [N] /
         item_weights_by_cat (list of per-category weight vectors parallel to the category's item list): the lists the
@@ -63,6 +63,8 @@ class SeqStore:
             if [len(e) for e in event_seq] != [len(s_) for s_ in user_seq]:
                 raise ValueError("event_seq must be parallel to user_seq")
             self.events = torch.tensor([e for es in event_seq for e in es], dtype=torch.int64).to(device)
+        # item_raw_tag [N] ints, -1 = the item has no tag (`dataload.item_to_info[i]['tag']`; outlier_user_metrics = 'tag')
+        self.item_raw_tag = None if item_raw_tag is None else torch.as_tensor(item_raw_tag, dtype=torch.int64).to(device)
         self.item_weights = None if item_weights is None else torch.as_tensor(item_weights, dtype=torch.float64).to(device)
         self.item_weights_by_cat = None if item_weights_by_cat is None else [torch.as_tensor(w, dtype=torch.float64).to(device)
                                                                              for w in item_weights_by_cat]
@@ -297,6 +299,14 @@ class SeqEvalBatcher:
         if self.outlier == 'event' and self.category_by == 'event':     # a target event type the last L history events never showed
             h_ev = torch.where(pos >= 0, st.events[(base[:, None] + pos).clamp(0, st.events.numel() - 1)], torch.full_like(pos, -1))
             outlier = ~(st.events[tgt_pos][:, :, None] == h_ev[:, None, :]).any(-1).all(-1)
+        if self.outlier == 'tag' and self.category_by == 'item':        # a target tag the whole history never showed (evalset.py:67-79)
+            if st.item_raw_tag is None:
+                raise ValueError("outlier_user_metrics = 'tag' needs SeqStore(item_raw_tag=...)")
+            n_tag = int(st.item_raw_tag.max()) + 2                       # slot 0: "no tag"
+            seen = torch.zeros(B, n_tag, dtype=torch.int32, device=dev)
+            seen.index_put_((hu, st.item_raw_tag[hi] + 1), torch.ones_like(hu, dtype=torch.int32), accumulate=True)
+            t_tag = st.item_raw_tag[item_target] + 1                     # [B, E]
+            outlier = ((t_tag > 0) & (torch.gather(seen, 1, t_tag) == 0)).any(-1)
         if self.outlier == 'category':                        # a target category the whole history never showed (evalset.py:101-109)
             def fixed(t):                                     # items tagged with EVERY category count as untagged
                 return t & ~t.all(-1, keepdim=True)

@@ -371,6 +371,113 @@ def run_llama_cases():
         print("wrote", name, "loss", loss.item())
 
 
+def run_llama_packed_case():
+    """Packed `cu_input_lens` batches of the item tower (flash_self_attn.py:61-130 needs flash-attn, which is not
+    importable here): packing N sequences into one row with per-sequence positions equals N independent passes of the
+    reference's EAGER path (modeling_llama.py:651-682) - which does import.  The fixture holds the packed inputs and the
+    concatenation of the reference's per-sequence outputs and gradients."""
+    import json
+    import numpy as np
+    import torch
+    from REC.model.HLLM.modeling_llama import LlamaConfig, LlamaForCausalLM
+    c = dict(hidden_size=64, intermediate_size=96, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2,
+             rope_theta=10000.0, eps=1e-5)
+    lens = [5, 17, 1, 9, 12]
+    torch.manual_seed(31)
+    cfg = LlamaConfig(hidden_size=c["hidden_size"], intermediate_size=c["intermediate_size"],
+                      num_hidden_layers=c["num_hidden_layers"], num_attention_heads=c["num_attention_heads"],
+                      num_key_value_heads=c["num_key_value_heads"], vocab_size=32, max_position_embeddings=64,
+                      rms_norm_eps=c["eps"], rope_theta=c["rope_theta"], pretraining_tp=1)
+    cfg.use_ft_flash_attn, cfg.use_cache, cfg.output_hidden_states, cfg.return_dict = False, False, True, True
+    model = LlamaForCausalLM(cfg)
+    with torch.no_grad():
+        for n_, p_ in model.named_parameters():
+            if "norm" in n_:
+                p_.add_(0.2 * torch.randn_like(p_))
+    D, T = c["hidden_size"], sum(lens)
+    x = torch.randn(T, D)
+    probe = torch.randn(T, D)
+    hidden, dx, loss, off = [], [], 0.0, 0
+    for n in lens:                                         # one eager pass per sequence: positions 0..n-1, no padding
+        xi = x[off:off + n][None].clone().requires_grad_(True)
+        hi = model(inputs_embeds=xi, attention_mask=torch.ones(1, n, dtype=torch.bool)).hidden_states[-1]
+        li = (hi[0] * probe[off:off + n]).sum()
+        li.backward()                                      # parameter gradients accumulate over the sequences
+        hidden.append(hi[0].detach())
+        dx.append(xi.grad[0])
+        loss += li.item()
+        off += n
+    out = {"w/" + k: v.detach().numpy() for k, v in model.state_dict().items() if not k.startswith("lm_head")}
+    out.update(x=x.numpy(), lens=np.array(lens, np.int64), probe=probe.numpy(), hidden=torch.cat(hidden).numpy(),
+               loss=np.float64(loss), dx=torch.cat(dx).numpy())
+    for k, p_ in model.named_parameters():
+        keep = ("layers.0.self_attn.q_proj", "layers.1.self_attn.k_proj", "layers.0.self_attn.v_proj", "layers.1.mlp.down_proj", "norm")
+        if p_.grad is not None and any(t in k for t in keep):
+            out["g/" + k] = p_.grad.numpy()
+    out["lcfg"] = np.array(json.dumps(dict(hidden_size=D, intermediate_size=c["intermediate_size"],
+                                            num_hidden_layers=c["num_hidden_layers"], num_attention_heads=c["num_attention_heads"],
+                                            num_key_value_heads=c["num_key_value_heads"], rms_norm_eps=c["eps"],
+                                            rope_theta=c["rope_theta"])))
+    np.savez_compressed(os.path.join(OUT, "llama_packed.npz"), **out)
+    print("wrote llama_packed loss", loss)
+
+
+def run_eval_batch_cases():
+    """Eval batches of the host data path: the reference's own `REC/data/dataset/evalset.py`
+    (SeqEvalDataset.__getitem__, 80-150) and `collate_fn.py` (seq_eval_collate, 59-90), loaded BY FILE PATH (the REC.data
+    package pulls polars / torchvision; these two files need only torch and pytz), driven on seeded synthetic users.
+    The fixture holds the raw users / tags / events and every field of every collated batch, for the item-category and the
+    event-category configurations, valid and test phase."""
+    import importlib.util
+    import numpy as np
+    import torch
+
+    def load(path, name):
+        spec = importlib.util.spec_from_file_location(name, path)
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+        return m
+    ev = load(os.path.join(REF, "REC/data/dataset/evalset.py"), "ref_evalset")
+    co = load(os.path.join(REF, "REC/data/dataset/collate_fn.py"), "ref_collate")
+    g = np.random.default_rng(5)
+    n_users, N, C, L, E, B = 23, 90, 3, 8, 4, 7
+    tags = g.random((N, C)) < 0.45
+    tags[np.arange(N), g.integers(0, C, N)] = True
+    tags[:6] = [[False] * C, [True] * C, [True, False, False], [True] * C, [False, True, False], [False, False, True]]
+    user_seq = [[]] + [g.integers(1, N, int(g.integers(10, 30))).tolist() for _ in range(n_users)]
+    train_len = [0] + [len(s_) - 8 for s_ in user_seq[1:]]
+    events = [[]] + [g.integers(0, C, len(s_)).tolist() for s_ in user_seq[1:]]
+    raw_tag = g.integers(0, 6, N).tolist()
+
+    class DL:
+        pass
+    dl = DL()
+    dl.user_num, dl.item_num, dl.user_seq, dl.train_seq_len, dl.event_seq = len(user_seq), N, user_seq, train_len, events
+    dl.item_to_info = [({} if i % 11 == 0 else {"tag_category": tags[i].tolist(), "tag": int(raw_tag[i])}) for i in range(N)]   # (a list: the "tag" outlier mode indexes it with tensors)
+    dl.category_to_int = {f"cat{c}": c for c in range(C)}
+    out = dict(user_flat=np.array([i for s_ in user_seq for i in s_], np.int64), user_len=np.array([len(s_) for s_ in user_seq], np.int64),
+               train_len=np.array(train_len, np.int64), event_flat=np.array([e for es in events for e in es], np.int64),
+               tags=np.array([([False] * C if i % 11 == 0 else tags[i].tolist()) for i in range(N)]), raw_tag=np.array(raw_tag, np.int64),
+               no_info=np.array([i % 11 == 0 for i in range(N)]), L=np.int64(L), E=np.int64(E), B=np.int64(B))
+    cases = {"item_cat": dict(category_by="item", outlier_user_metrics="category"),
+             "item_tag": dict(category_by="item", outlier_user_metrics="tag"),
+             "event": dict(category_by="event", outlier_user_metrics="event")}
+    for cname, kw in cases.items():
+        cfg = Cfg(eval_pred_len=E, MAX_ITEM_LIST_LENGTH=L, eval_num_cats=C, int_to_category={c: f"cat{c}" for c in range(C)},
+                  timestamp_required=False, **kw)
+        for phase in ("valid", "test"):
+            ds = ev.SeqEvalDataset(cfg, dl, phase=phase)
+            n = len(ds)
+            for bi, b0 in enumerate(range(0, n, B)):
+                uid, item_seq, target, (hu, hi), pos_u, _, tt, outl = co.seq_eval_collate([ds[i] for i in range(b0, min(n, b0 + B))])
+                pre = f"{cname}/{phase}/{bi}/"
+                out.update({pre + "uid": uid.numpy(), pre + "item_seq": item_seq.numpy(), pre + "target": target.numpy(),
+                            pre + "hist_u": hu.numpy(), pre + "hist_i": hi.numpy(), pre + "pos_u": pos_u.numpy(),
+                            pre + "target_tags": tt.numpy(), pre + "outlier": outl.numpy()})
+    np.savez_compressed(os.path.join(OUT, "eval_batches.npz"), **out)
+    print("wrote eval_batches", len(out), "arrays")
+
+
 def run_baichuan_cases():
     """Baichuan2-style decoder (REC/model/HLLM/baichuan/modeling_baichuan.py: packed `W_pack` q|k|v projection, rotary base
     10000, full multi-head attention, eager softmax path) on a tiny random-init config, called the way the user decoder
@@ -512,6 +619,13 @@ def main():
         return
     if len(sys.argv) > 1 and sys.argv[1] == "llama":
         run_llama_cases()
+        run_llama_packed_case()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "packed":
+        run_llama_packed_case()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "batches":
+        run_eval_batch_cases()
         return
     if len(sys.argv) > 1 and sys.argv[1] == "comirec":
         run_comirec_cases()
@@ -555,9 +669,11 @@ def main():
     run_schedule_and_adam()
     switch_cases()
     run_llama_cases()
+    run_llama_packed_case()
     run_baichuan_cases()
     run_comirec_cases()
     run_remi_cases()
+    run_eval_batch_cases()
 
 
 if __name__ == "__main__":

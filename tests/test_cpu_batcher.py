@@ -127,6 +127,39 @@ def test_eval_batch_matches_reference_collate():
         assert seen == list(range(1, len(user_seq)))
 
 
+@pytest.mark.parametrize("case", ["item_cat", "item_tag", "event"])
+def test_eval_batches_match_reference_fixture(case):
+    """Every field of every collated eval batch against the reference's OWN `evalset.py` + `collate_fn.py` (loaded by file
+    path in tests/gen_golden.py: fixture eval_batches.npz), valid and test phase: item-category targets with the
+    'category' and 'tag' outlier rules, event-type targets with the 'event' rule; items without info, items tagged with
+    every category, users whose history is shorter / longer than the window."""
+    from conftest import load_golden
+    from REC.data import SeqEvalBatcher, SeqStore
+    g = load_golden("eval_batches")
+    lens = g["user_len"].tolist()
+    flat, ev = g["user_flat"].tolist(), g["event_flat"].tolist()
+    user_seq, events, o = [], [], 0
+    for n in lens:
+        user_seq.append(flat[o:o + n])
+        events.append(ev[o:o + n])
+        o += n
+    raw = np.where(g["no_info"], -1, g["raw_tag"])
+    st = SeqStore(user_seq, g["train_len"].tolist(), g["tags"], event_seq=events, item_raw_tag=raw)
+    kw = dict(item_cat=dict(category_by="item", outlier_user_metrics="category"), item_tag=dict(category_by="item", outlier_user_metrics="tag"),
+              event=dict(category_by="event", outlier_user_metrics="event"))[case]
+    cfg = _cfg(MAX_ITEM_LIST_LENGTH=int(g["L"]), eval_pred_len=int(g["E"]), eval_batch_size=int(g["B"]), eval_num_cats=3, **kw)
+    for phase in ("valid", "test"):
+        n_batches = 0
+        for bi, (uid, item_seq, target, (hu, hi), pos_u, _, tt, outlier) in enumerate(SeqEvalBatcher(cfg, st, phase=phase)):
+            pre = f"{case}/{phase}/{bi}/"
+            for name, got in (("uid", uid), ("item_seq", item_seq), ("target", target), ("hist_u", hu), ("hist_i", hi), ("pos_u", pos_u),
+                              ("target_tags", tt), ("outlier", outlier)):
+                want = g[pre + name]
+                assert np.array_equal(got.cpu().numpy().astype(want.dtype), want), (pre + name)
+            n_batches += 1
+        assert n_batches == sum(1 for k in g if k.startswith(f"{case}/{phase}/") and k.endswith("/uid"))
+
+
 def test_sharding_matches_the_reference_samplers():
     from REC.data import SeqEvalBatcher, SeqStore, SeqTrainBatcher
     user_seq, train_len, tags = _data(seed=7, n_users=33)

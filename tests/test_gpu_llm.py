@@ -200,6 +200,39 @@ def test_llama_decoder_matches_reference_fixture(ops, name):
             assert float((got - gref).abs().max()) <= 5e-2 * float(gref.abs().max()), k
 
 
+def test_llama_decoder_packed_sequences_match_reference_fixture(ops):
+    """The item tower's packed `cu_input_lens` batches (flash_self_attn.py:61-130): the native decoder on ONE packed row
+    reproduces the concatenation of the reference's per-sequence eager passes (tests/golden/llama_packed.npz, generated by
+    the reference's own modeling_llama.py:651-682): last hidden state, loss, input and parameter gradients."""
+    from REC.model.HLLM.modeling_llama import LlamaConfig, LlamaForCausalLM
+    z = np.load(os.path.join(GOLD, "llama_packed.npz"))
+    lcfg = json.loads(str(z["lcfg"]))
+    model = LlamaForCausalLM(LlamaConfig(vocab_size=32, max_position_embeddings=64, **lcfg))
+    missing = model.load_state_dict({k[2:]: torch.tensor(z[k]) for k in z.files if k.startswith("w/")}, strict=False)
+    assert set(missing.missing_keys) <= {"lm_head.weight"} and not missing.unexpected_keys
+    model = model.cuda().train()
+    lens = z["lens"].tolist()
+    x = torch.tensor(z["x"]).cuda().requires_grad_(True)                                  # [T, D] packed
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32).cuda()
+    pos = torch.cat([torch.arange(n) for n in lens]).cuda()
+    hidden = model(inputs_embeds=x[None], cu_input_lens=cu, position_ids=pos[None]).hidden_states[-1].reshape(-1, x.shape[-1])
+    ref = torch.tensor(z["hidden"]).cuda()
+    assert float((hidden.float() - ref).abs().max()) <= 3e-2 * float(ref.abs().max())
+    loss = (hidden.float() * torch.tensor(z["probe"]).cuda()).sum()
+    loss.backward()
+    assert abs(float(loss) - float(z["loss"])) <= 3e-2 * max(1.0, abs(float(z["loss"])))
+    dx_ref = torch.tensor(z["dx"]).cuda()
+    assert float((x.grad - dx_ref).abs().max()) <= 5e-2 * float(dx_ref.abs().max())
+    grads = dict(model.named_parameters())
+    n = 0
+    for k in z.files:
+        if k.startswith("g/"):
+            gref = torch.tensor(z[k]).cuda()
+            assert float((grads[k[2:]].grad - gref).abs().max()) <= 5e-2 * float(gref.abs().max()), k
+            n += 1
+    assert n >= 6
+
+
 # ------------------------------------------------------------------------------------------------
 # HLLM twin (SURVEY a19): user decoder + shared multi-head loss / decode, frozen item tower
 # ------------------------------------------------------------------------------------------------

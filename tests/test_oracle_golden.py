@@ -191,6 +191,34 @@ def test_llama_decoder_oracle_matches_reference(name):
     assert n >= 7
 
 
+def test_llama_packed_sequences_oracle_matches_reference():
+    """Packed `cu_input_lens` batches (flash_self_attn.py:61-130): the oracle's segment-restricted attention on ONE packed
+    row with per-sequence positions reproduces the concatenation of the reference's per-sequence eager passes
+    (tests/golden/llama_packed.npz, generated by the reference's own modeling_llama.py): outputs, loss, gradients."""
+    import json
+    from oracle import hllm_oracle as LO
+    g = load_golden("llama_packed")
+    lcfg = json.loads(str(g["lcfg"]))
+    lens = g["lens"].tolist()
+    w = {k[2:]: torch.tensor(v).requires_grad_(True) for k, v in g.items() if k.startswith("w/")}
+    x = torch.tensor(g["x"])[None].requires_grad_(True)                                   # [1, T, D]: one packed row
+    seg = torch.repeat_interleave(torch.arange(len(lens)), torch.tensor(lens))[None]
+    pos = torch.cat([torch.arange(n) for n in lens])[None]
+    hidden = LO.llama_decoder(w, lcfg, x, None, position_ids=pos, seg_ids=seg)[0]
+    ref = torch.tensor(g["hidden"])
+    assert float((hidden - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    loss = (hidden * torch.tensor(g["probe"])).sum()
+    loss.backward()
+    assert abs(float(loss) - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
+    assert float((x.grad[0] - torch.tensor(g["dx"])).abs().max()) <= 1e-5 * float(np.abs(g["dx"]).max())
+    n = 0
+    for k, v in g.items():
+        if k.startswith("g/"):
+            assert float((w[k[2:]].grad - torch.tensor(v)).abs().max()) <= 2e-5 * float(np.abs(v).max()), k
+            n += 1
+    assert n >= 6
+
+
 # ------------------------------------------------------------------------------------------------
 # ComiRec baseline (SURVEY 8f-4): multi-interest read-out on the HSTU encoder
 # ------------------------------------------------------------------------------------------------
