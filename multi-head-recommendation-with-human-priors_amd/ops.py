@@ -914,8 +914,13 @@ def sub_history(hist_ptr, hist_items, users_f):
     return sub_ptr, hist_items[torch.repeat_interleave(starts, lens) + off].contiguous()
 
 
-def catalog_topk(users, H, items, tag_bits, row_bits, hist_ptr, hist_items, k, cap=4096, target=None, stats=None, n_items=None):
+def catalog_topk(users, H, items, tag_bits, row_bits, hist_ptr, hist_items, k, cap=4096, target=None, stats=None, n_items=None,
+                 k_min=None, tau_out=None):
     """Exact per-row top-k over the whole catalog (value desc, index asc), rows = (user, head) pairs.
+
+    k_min (default k): rows with fewer than k_min candidates are re-run exactly; with k_min < k a row may return fewer than
+    k finite entries (its list then holds EVERY item scoring >= its threshold).  tau_out (dict, optional): receives 'tau'
+    [rows] f32, the emit threshold each row's candidates were collected with (-inf: every admissible item was a candidate).
 
     users [B*H, D] bf16 normalised, items [>= N, D] bf16 normalised (rows beyond n_items = N are padding: give the
     table round_up(N, 32) rows and the item tiles stream unclamped).  Returns (values [B*H,k] f32, indices [B*H,k] i64).
@@ -928,22 +933,26 @@ def catalog_topk(users, H, items, tag_bits, row_bits, hist_ptr, hist_items, k, c
     dev = users.device
     if D not in STREAM_DIMS:
         from . import wide
-        return wide.catalog_topk_wide(users, H, items, N, tag_bits, row_bits, hist_ptr, hist_items, k, target=target, stats=stats)
+        return wide.catalog_topk_wide(users, H, items, N, tag_bits, row_bits, hist_ptr, hist_items, k, target=target, stats=stats,
+                                      k_min=k_min, tau_out=tau_out)
     ninf = torch.full((n_rows,), float("-inf"), dtype=torch.float32, device=dev)
+    k_min = k if k_min is None else min(k, k_min)
     if N <= cap:
         cand = catalog_emit(users, H, items, tag_bits, row_bits, ninf, hist_ptr, hist_items, N, n_items=N)
         ov, oi, _, _ = topk_select(cand, N, k)
+        if tau_out is not None:
+            tau_out["tau"] = ninf
         return ov, oi
     if target is None:
         # candidates aimed at per row.  The threshold is the (target/s2)-th largest of a 1/s2 sample: its rank estimate
         # scatters by about 1/sqrt(target/s2), so 2.5 k leaves > 5 sigma before a row would come up short (and such a
         # row is only re-run, never wrong); every candidate above what is needed costs a divergent slow-path visit.
-        target = max(512, int(2.5 * k))
+        target = max(512, int(2.5 * k_min))
     s1 = max(1, -(-N // 2048))
     s2 = max(1, min(-(-N // 32768), target // 48))       # threshold = the ~50th largest of the second sample (see wide.py)
     t1 = min(1024, max(8, -(-3 * target // s1)))           # first threshold: about 3x looser than the rank aimed at (a tighter one
                                                    # starves the second sample and, as the fallback threshold, the candidates)
-    t2 = max(k // s2 + 1, target // s2)
+    t2 = min(1024, max(k_min // s2 + 1, target // s2))
     # pass 1: every s1-th item, all scores -> the t1-th largest bounds the top ~0.4 %
     nt1 = -(-(-(-N // s1)) // 32)                                      # tiles of the first sample
     c1 = catalog_emit_sliced(users, items, N, tag_bits, row_bits, ninf, 32 * -(-nt1 // _slices_for(n_rows, nt1)), 0, s1)
@@ -957,7 +966,7 @@ def catalog_topk(users, H, items, tag_bits, row_bits, hist_ptr, hist_items, k, c
     cap_s = max(32, 4 * -(-target // n_sl) + 16)
     cand = catalog_emit_sliced(users, items, N, tag_bits, row_bits, tau, cap_s)
     ov, oi, _, cnt, st = topk_select_sliced(cand, H, hist_ptr, hist_items, k)
-    flagged = (st != 0) | ((cnt < k) & (row_bits != 0) & torch.isfinite(tau))
+    flagged = (st != 0) | ((cnt < k_min) & (row_bits != 0) & torch.isfinite(tau))
     if stats is not None:
         stats["mean_candidates"] = float(cnt.float().mean())
         stats["flagged_rows"] = int(flagged.sum())
@@ -972,6 +981,10 @@ def catalog_topk(users, H, items, tag_bits, row_bits, hist_ptr, hist_items, k, c
         fv, fi, _, _ = topk_select(c3, N, k)
         ov[rows_f] = fv
         oi[rows_f] = fi
+        tau = tau.clone()
+        tau[rows_f] = float("-inf")
+    if tau_out is not None:
+        tau_out["tau"] = tau
     return ov, oi
 
 
@@ -992,13 +1005,18 @@ def catalog_topk_exact(users_f32, H, items_bf, items_f32, tag_bits, row_bits, hi
     k2 = min(N - 1, 1024, max(2 * k + 64, k + 256))
     if k2 <= k:
         k2 = k
-    # top-k2 on bf16 scores, sorted: candidates asked for so that the emit threshold sits well below the margin
-    bv, bi = catalog_topk(users_bf, H, items_bf, tag_bits, row_bits, hist_ptr, hist_items, k2, target=max(512, int(2.5 * k2)),
-                          stats=stats, n_items=N)
+    # the bf16 scorer's candidate lists (everything above a per-row threshold tau near the rank-2.5k score), the best k2 of them
+    # sorted; a row is CERTIFIED when its margin [kth - 2^-7, ...) lies above tau (nothing that could enter the fp32 top-k was
+    # left below the threshold) and does not fill all k2 slots
+    tinfo = {}
+    bv, bi = catalog_topk(users_bf, H, items_bf, tag_bits, row_bits, hist_ptr, hist_items, k2, stats=stats, n_items=N, k_min=k,
+                          tau_out=tinfo)
+    tau = tinfo.get("tau")
+    if tau is None:                   # (a scorer that does not report its threshold: nothing can be certified)
+        tau = torch.full((n_rows,), float("inf"), dtype=torch.float32, device=dev)
     kk = min(k, k2)
     kth = bv[:, kk - 1:kk]
-    in_margin = bv >= (kth - 2 * BF16_SCORE_ERR)                      # a prefix of the sorted list (-inf tails: kth = -inf keeps them out via isfinite)
-    in_margin &= torch.isfinite(bv)
+    in_margin = (bv >= (kth - 2 * BF16_SCORE_ERR)) & torch.isfinite(bv)     # a prefix of the sorted list
     cnt = in_margin.sum(dim=1).int()
     rv = torch.empty(n_rows, k2, dtype=torch.float32, device=dev)
     ri = torch.empty(n_rows, k2, dtype=torch.int32, device=dev)
@@ -1007,8 +1025,9 @@ def catalog_topk_exact(users_f32, H, items_bf, items_f32, tag_bits, row_bits, hi
     lib.call("mhr_rescore_f32", users_f32.data_ptr(), items_f32.data_ptr(), D, N, bi.data_ptr(), n_rows, k2, cnt.data_ptr(),
              rv.data_ptr(), ri.data_ptr(), _stream())
     ov, oi, _, st = topk_select((rv, ri, cnt), k2, k)
-    # uncertified rows: the margin reached the end of the candidate list (the (k2+1)-th bf16 score might be inside it too)
-    full = (cnt >= k2) & (k2 < N - 1)
+    # uncertified rows: the margin reaches below the emit threshold, or fills the candidate list (the (k2+1)-th bf16 score
+    # might be inside it too)
+    full = ((cnt >= k2) & (k2 < N - 1)) | (torch.isfinite(kth[:, 0]) & torch.isfinite(tau) & (kth[:, 0] - 2 * BF16_SCORE_ERR < tau))
     if stats is not None:
         stats["margin_mean"] = float(cnt.float().mean())
         stats["uncertified_rows"] = int(full.sum())

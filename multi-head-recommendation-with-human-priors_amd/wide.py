@@ -189,7 +189,7 @@ def _exact_rows(users, H, items, n_items, tag_bits, row_bits, hist_ptr, hist_ite
     return best_v, best_i
 
 
-def _catalog_topk_mfma(users, H, items, N, tag_bits, row_bits, hist_ptr, hist_items, k, chunk, target, stats):
+def _catalog_topk_mfma(users, H, items, N, tag_bits, row_bits, hist_ptr, hist_items, k, chunk, target, stats, k_min=None, tau_out=None):
     """Exact per-row top-k with the hand-written wide scorer (csrc/catalog_wide.hip: LDS-tiled MFMA GEMM, threshold emit in
     the epilogue - no score block in memory, no library GEMM).  Same scheme as the register-stationary path
     (ops.catalog_topk): thresholds from two strided sample passes through the SAME kernel, one full pass, the shared exact
@@ -202,8 +202,9 @@ def _catalog_topk_mfma(users, H, items, N, tag_bits, row_bits, hist_ptr, hist_it
     ninf = torch.full((n_rows,), float("-inf"), dtype=torch.float32, device=dev)
     users_p = ops.pack_tiles(users, tiles_per_block=4)                              # once per batch (a few MB)
     SEL = 8192                                                                    # candidates the select kernel holds per row
+    k_min = k if k_min is None else min(k, k_min)
     if target is None:
-        target = max(512, int(2.5 * k))
+        target = max(512, int(2.5 * k_min))
     s1 = max(1, -(-N // 2048))
     # second sample: dense enough that the threshold is the ~50th largest of the sample (its rank estimate then scatters by
     # ~14 %: a row comes up short of k candidates at > 4 sigma; at N = 2^20 a 1 / 32 sample left 2.4 sigma and flagged rows -
@@ -221,10 +222,12 @@ def _catalog_topk_mfma(users, H, items, N, tag_bits, row_bits, hist_ptr, hist_it
     if N <= SEL:                                                                   # small catalogs: every score is a candidate
         cand = ops.catalog_emit_wide(users_p, n_rows, D, items_p, N, tb, row_bits, ninf, 64)     # >= 32 slices: one block per slice at most
         ov, oi, _, _, _ = ops.topk_select_sliced(cand, H, hist_ptr, hist_items, k)
+        if tau_out is not None:
+            tau_out["tau"] = ninf
         return ov, oi
     t1 = min(1024, max(8, -(-3 * target // s1)))           # first threshold: about 3x looser than the rank aimed at (a tighter one
                                                    # starves the second sample and, as the fallback threshold, the candidates)
-    t2 = min(max(k // s2 + 1, target // s2), 1024)                 # (the select kernel picks at most 1024)
+    t2 = min(max(k_min // s2 + 1, target // s2), 1024)             # (the select kernel picks at most 1024)
     # pass 1: every s1-th item, all scores (<= 2048 per row, <= 64 per list) -> the t1-th largest bounds the top ~0.4 %
     c1 = ops.catalog_emit_wide(users_p, n_rows, D, samples[0], N, tb, row_bits, ninf, 64, 0, s1)
     _, _, kth1, _, st1 = ops.topk_select_sliced(c1, H, hist_ptr, hist_items, t1)
@@ -237,7 +240,7 @@ def _catalog_topk_mfma(users, H, items, N, tag_bits, row_bits, hist_ptr, hist_it
     cap_s = max(32, 4 * -(-target // (4 * n_sl)) + 16)
     cand = ops.catalog_emit_wide(users_p, n_rows, D, items_p, N, tb, row_bits, tau, cap_s)
     ov, oi, _, got, stt = ops.topk_select_sliced(cand, H, hist_ptr, hist_items, k)
-    flagged = (stt != 0) | ((got < k) & (row_bits != 0) & torch.isfinite(tau))
+    flagged = (stt != 0) | ((got < k_min) & (row_bits != 0) & torch.isfinite(tau))
     if stats is not None:
         stats["mean_candidates"] = float(got.float().mean())
         stats["flagged_rows"] = int(flagged.sum())
@@ -249,11 +252,15 @@ def _catalog_topk_mfma(users, H, items, N, tag_bits, row_bits, hist_ptr, hist_it
                              k, chunk)
         ov[rows_f] = fv
         oi[rows_f] = fi
+        tau = tau.clone()
+        tau[rows_f] = float("-inf")
+    if tau_out is not None:
+        tau_out["tau"] = tau
     return ov, oi
 
 
 def catalog_topk_wide(users, H, items, n_items, tag_bits, row_bits, hist_ptr, hist_items, k, chunk=ITEM_CHUNK, target=None,
-                      stats=None):
+                      stats=None, k_min=None, tau_out=None):
     """Exact per-row top-k over the catalog at any feature dim.  Thresholds from a strided sample of the catalog; the
     full pass scores item chunks with the library GEMM and emits the few scores above the threshold (csrc/wide.hip) into
     candidate lists; the exact select of the streaming path (topk_select_sliced) picks the top k with the history filter.
@@ -263,7 +270,7 @@ def catalog_topk_wide(users, H, items, n_items, tag_bits, row_bits, hist_ptr, hi
     N = int(n_items)
     dev = users.device
     if D % 64 == 0 and users.dtype == torch.bfloat16 and items.dtype == torch.bfloat16:
-        return _catalog_topk_mfma(users, H, items, N, tag_bits, row_bits, hist_ptr, hist_items, k, chunk, target, stats)
+        return _catalog_topk_mfma(users, H, items, N, tag_bits, row_bits, hist_ptr, hist_items, k, chunk, target, stats, k_min, tau_out)
     if N <= max(4 * k, 2048) or N <= chunk // 8:
         return _exact_rows(users, H, items, N, tag_bits, row_bits, hist_ptr, hist_items, k, chunk)
     st = _stream()

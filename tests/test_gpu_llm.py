@@ -213,9 +213,9 @@ def test_llama_decoder_packed_sequences_match_reference_fixture(ops):
     model = model.cuda().train()
     lens = z["lens"].tolist()
     x = torch.tensor(z["x"]).cuda().requires_grad_(True)                                  # [T, D] packed
-    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32).cuda()
+    seq_lens = torch.tensor(lens, dtype=torch.int32).cuda()          # `cu_input_lens` carries the LENGTHS (the reference cumsums them, hllm.py:131)
     pos = torch.cat([torch.arange(n) for n in lens]).cuda()
-    hidden = model(inputs_embeds=x[None], cu_input_lens=cu, position_ids=pos[None]).hidden_states[-1].reshape(-1, x.shape[-1])
+    hidden = model(inputs_embeds=x[None], cu_input_lens=seq_lens, position_ids=pos[None]).hidden_states[-1].reshape(-1, x.shape[-1])
     ref = torch.tensor(z["hidden"]).cuda()
     assert float((hidden.float() - ref).abs().max()) <= 3e-2 * float(ref.abs().max())
     loss = (hidden.float() * torch.tensor(z["probe"]).cuda()).sum()

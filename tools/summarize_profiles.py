@@ -85,8 +85,43 @@ def traffic(rnd, mode=""):
         print("wrote", p)
 
 
+def mfma_util(rnd, mode=""):
+    """MFMA utilisation per kernel from `rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE` on bench.py
+    (SURVEY 8d).  SQ_VALU_MFMA_BUSY_CYCLES counts matrix-pipe cycles summed over the chip's 1024 SIMDs (32 per
+    v_mfma_f32_32x32x16_bf16, MI355X_MICROARCH.md); GRBM_GUI_ACTIVE is summed over the 8 XCDs, so GRBM / 8 is the launch's
+    length in shader cycles:  util = MFMA_BUSY / (1024 x GRBM / 8)."""
+    f = newest(os.path.join(ROOT, "gpurun_out", f"pmc_{rnd}_{mode}mfma", "*", "*_counter_collection.csv"))
+    if f is None:
+        return
+    per = {}
+    for r in csv.DictReader(open(f)):
+        k = short(r["Kernel_Name"])
+        per.setdefault((k, r["Dispatch_Id"]), {})[r["Counter_Name"]] = float(r["Counter_Value"])
+    acc = {}
+    for (k, _), c in per.items():
+        if c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) <= 0 or c.get("GRBM_GUI_ACTIVE", 0) <= 0:
+            continue
+        acc.setdefault(k, []).append(c)
+    out = {}
+    for k, lst in acc.items():
+        big = max(lst, key=lambda c: c["SQ_VALU_MFMA_BUSY_CYCLES"])         # the kernel's largest launch (eval: the full-catalog pass)
+        tot_m = sum(c["SQ_VALU_MFMA_BUSY_CYCLES"] for c in lst)
+        tot_g = sum(c["GRBM_GUI_ACTIVE"] for c in lst)
+        out[k] = {"launches_sampled": len(lst), "mfma_busy_cycles_per_launch": round(tot_m / len(lst)),
+                  "shader_cycles_per_launch": round(tot_g / 8 / len(lst)),
+                  "mfma_util": round(tot_m / (1024.0 * tot_g / 8.0), 4),
+                  "mfma_util_largest_launch": round(big["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * big["GRBM_GUI_ACTIVE"] / 8.0), 4),
+                  "sq_busy_cu_cycles_per_launch": round(sum(c.get("SQ_BUSY_CU_CYCLES", 0) for c in lst) / len(lst))}
+    if out:
+        p = os.path.join(ROOT, "profiles", f"{rnd}_mfma_util{'_eval' if mode else ''}.json")
+        json.dump({"how": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE -- python bench.py " +
+                          ("--mode eval " if mode else "") + "(its own pass, no tracing domains); util = MFMA_BUSY / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs)",
+                   "kernels": dict(sorted(out.items(), key=lambda kv: -kv[1]["mfma_busy_cycles_per_launch"]))}, open(p, "w"), indent=1)
+        print("wrote", p)
+
+
 def readme(rnd):
-    """profiles/README.md from the condensed files + the bench lines (gpurun_out/bench_<rnd>_train.json, bench_eval.json)."""
+    """profiles/README.md from the condensed files + the bench lines (gpurun_out/bench_<rnd>_{train,eval}.json)."""
     P = os.path.join(ROOT, "profiles")
 
     def table(f, n, steps):
@@ -94,91 +129,72 @@ def readme(rnd):
         return "\n".join(f"| `{r[0][:70]}` | {int(r[1]) / steps:.0f} | {float(r[3]) / 1e3:.1f} | {float(r[2]) / steps / 1e6:.3f} | {r[4]} |"
                          for r in rows[:n] if r[3])
 
-    bt = be = None
-    for src, dst in ((f"bench_{rnd}_train.json", f"{rnd}_bench_train.json"), ("bench_eval.json", f"{rnd}_bench_eval.json"),
-                     (f"hllm_{rnd}_train.json", f"{rnd}_hllm_train.json"), (f"hllm_{rnd}_eval.json", f"{rnd}_hllm_eval.json")):
+    for src, dst in ((f"bench_{rnd}_train.json", f"{rnd}_bench_train.json"), (f"bench_{rnd}_eval.json", f"{rnd}_bench_eval.json")):
         f = os.path.join(ROOT, "gpurun_out", src)
         if os.path.exists(f):
-            d = json.load(open(f))
-            json.dump(d, open(os.path.join(P, dst), "w"), indent=1)
+            json.dump(json.load(open(f)), open(os.path.join(P, dst), "w"), indent=1)
     bt = json.load(open(os.path.join(P, f"{rnd}_bench_train.json")))
     be = json.load(open(os.path.join(P, f"{rnd}_bench_eval.json")))
     t = json.load(open(os.path.join(P, f"{rnd}_hbm_traffic.json")))["kernels"]
     tr = "\n".join(f"| `{k}` | {v['hbm_read_bytes_per_launch'] / 1e6:.1f} | {v['hbm_write_bytes_per_launch'] / 1e6:.1f} |"
                    for k, v in t.items() if not k.startswith("__amd"))
+    mu = ""
+    for mode in ("", "_eval"):
+        f = os.path.join(P, f"{rnd}_mfma_util{mode}.json")
+        if os.path.exists(f):
+            ks = json.load(open(f))["kernels"]
+            mu += "\n".join(f"| `{k[:70]}` ({'eval' if mode else 'train'}) | {v['launches_sampled']} | {v['mfma_busy_cycles_per_launch']:.3g} | "
+                            f"{v['shader_cycles_per_launch']:.3g} | {100 * v['mfma_util']:.1f} % | {100 * v['mfma_util_largest_launch']:.1f} % |"
+                            for k, v in list(ks.items())[:10]) + "\n"
+    steps = 25
     md = f"""# profiles/ - round {rnd[1:]} (one MI355X, gfx950, ROCm 7.2, cfg1 = HSTU Pixel8M shape)
 
-All files here are condensed by `tools/summarize_profiles.py {rnd}` from rocprofv3 output written under `gpurun_out/` on the GPU box.
+All files here are condensed by `tools/summarize_profiles.py {rnd}` from rocprofv3 output written under `gpurun_out/` on the GPU box
+by `tools/profile_round.sh {rnd}` (round 1's files, `r01_*`, are kept next to them for comparison).
 
 | File | Command it comes from |
 |---|---|
-| `{rnd}_bench_train.json` | `python bench.py` (20 steps, 5 warm-up) - the bench line itself |
-| `{rnd}_bench_eval.json` | `python bench.py --mode eval` |
-| `{rnd}_train_kernel_stats.csv` | `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --no-cpu-baseline` (25 steps incl. warm-up) |
-| `{rnd}_eval_kernel_stats.csv` | `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --mode eval --no-cpu-baseline` |
-| `{rnd}_hbm_traffic.json` | `rocprofv3 --pmc FETCH_SIZE -- python bench.py --no-cpu-baseline --steps 4 --warmup 2` and the same with `--pmc WRITE_SIZE` (separate passes); FETCH_SIZE KB x 2 (gfx950 correction), WRITE_SIZE KB x 1 |
+| `{rnd}_bench_train.json` | `python bench.py --steps 50 --warmup 10` - the bench line itself (train step replayed from a hipGraph; eval / gather / cpu_baseline sub-objects) |
+| `{rnd}_bench_eval.json` | `python bench.py --mode eval --steps 20 --warmup 5` |
+| `{rnd}_train_kernel_stats.csv` | `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --no-cpu-baseline --no-host-probe --no-eval-leg --no-kernel-events --steps 20 --warmup 5` ({steps} steps traced) |
+| `{rnd}_eval_kernel_stats.csv` | the same with `--mode eval` |
+| `{rnd}_hbm_traffic.json`, `{rnd}_hbm_traffic_eval.json` | `rocprofv3 --pmc FETCH_SIZE -- python bench.py ... --steps 4 --warmup 4` and the same with `--pmc WRITE_SIZE` (separate passes); FETCH_SIZE KB x 2 (gfx950 correction), WRITE_SIZE KB x 1 |
+| `{rnd}_mfma_util.json`, `{rnd}_mfma_util_eval.json` | `rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE -- python bench.py ...` (own pass); util = MFMA_BUSY / (1024 SIMDs x GRBM_GUI_ACTIVE / 8) |
 
-## Train step (bench: {bt["value"]} seq/s, {bt["ms_per_step"]} ms/step)
+## Train step (bench: {bt["value"]} seq/s, {bt["ms_per_step"]} ms/step; host issue {bt.get("host_enqueue_ms_per_step")} ms/step)
 
-rocprofv3 kernel stats, per step (25 steps traced):
-
-| kernel | launches/step | avg us | ms/step | % of GPU time |
-|---|---|---|---|---|
-{table(os.path.join(P, f"{rnd}_train_kernel_stats.csv"), 24, 25)}
-
-HIP-event durations measured inside `bench.py` for the library's kernels (ms/step): `{json.dumps(bt["kernel_ms_per_step"])}` -
-they agree with the rocprofv3 averages above to within a few per cent (rocprofv3 serialises a little).
-
-Sampled softmax (bench `sampled_softmax`): `{json.dumps(bt.get("sampled_softmax"))}`.  With query-row sharing
-(`csrc/nce_shared.hip`) the two streaming MFMA kernels (`nce_fwd_d_kernel`, `nce_bwd_n_kernel`) run once per distinct query row
-instead of once per token; *algorithmic* rates are quoted on the reference's per-token formulation (6 N_tok N_neg D flop forward,
-2 N_tok N_neg D for dN), *executed* rates on what the kernels run (two products per row each way).  The same MFMA at full chip
-load sustains about 1.8-2.2 PFLOP/s in a bare loop (`tools/mfma_rate.hip`: the shader clock drops from 2.39 GHz to about 1.85 GHz).
-The roofline object of the bench line is quoted on whichever library kernel takes most of the step (now `hstu_attn_bwd`):
-`{json.dumps(bt.get("roofline"))}`.
-
-## Eval step (bench: {be["value"]} users/s, {be["ms_per_step"]} ms/step of 256 users x 4 heads over 453 938 items)
+rocprofv3 kernel stats, per step ({steps} steps traced):
 
 | kernel | launches/step | avg us | ms/step | % of GPU time |
 |---|---|---|---|---|
-{table(os.path.join(P, f"{rnd}_eval_kernel_stats.csv"), 12, 25)}
+{table(os.path.join(P, f"{rnd}_train_kernel_stats.csv"), 26, steps)}
 
-## HBM traffic per launch (PMC, MB)
+HIP-event durations of the library's kernels from the bench line's evented pass (ms/step): `{json.dumps(bt["kernel_ms_per_step"])}`.
+
+Roofline object of the bench line (dominant kernel of the step): `{json.dumps(bt.get("roofline"))}`.
+
+Embedding gather: `{json.dumps(bt.get("gather"))}`.
+
+Sampled softmax (executed rates: two MFMA products per distinct query row each way): `{json.dumps(bt.get("sampled_softmax"))}`.
+
+## Eval step (bench: {be["value"]} users/s, {be["ms_per_step"]} ms/step of 256 users x 4 heads over 453 938 items, top-k ranked on fp32 scores)
+
+| kernel | launches/step | avg us | ms/step | % of GPU time |
+|---|---|---|---|---|
+{table(os.path.join(P, f"{rnd}_eval_kernel_stats.csv"), 12, steps)}
+
+Catalog scorer roofline (bench line): `{json.dumps(be.get("roofline"))}`.
+
+## MFMA utilisation (PMC)
+
+| kernel | launches | MFMA busy cycles / launch | shader cycles / launch | MFMA util | util of the largest launch |
+|---|---|---|---|---|---|
+{mu}
+## HBM traffic per launch (PMC, MB; train leg)
 
 | kernel | read | written |
 |---|---|---|
 {tr}
-
-Reading: `adam_rows` moves 2.86 GB against 2.79 GB algorithmic (N x D x 24 B) - no wasted re-reads.  `nce_fwd_d` (the fused
-forward; the false-negative bits come from `nce_fix_bits`, once per target row) reads the raw fp32 head / target rows once
-(0.27 GB each) and writes the saved state (two bf16 row matrices, the fp32 U matrix, 0.27 GB of suppression bits); the 4 MB
-negative pools are served from L2/MALL.  `nce_bwd_rows` is float-atomic bound (runs of tokens sharing a head row are combined).
-`hstu_attn_bwd` reads 287 MB against about 65 MB of operands: the activated q/k/v and dO blocks are staged twice (two passes) and
-the pre-activation values are re-read for the SiLU chain rule.
-"""
-    ht, he = os.path.join(P, f"{rnd}_hllm_train.json"), os.path.join(P, f"{rnd}_hllm_eval.json")
-    if os.path.exists(ht) and os.path.exists(he):
-        a, b = json.load(open(ht)), json.load(open(he))
-        md += f"""
-## HLLM twin (`tools/hllm_bench.py`, TinyLlama-1.1B-shaped user decoder, frozen item embeddings, D = 2048)
-
-| leg | workload | ms/step | per second | decoder GEMM TFLOP/s | own kernels, ms/step (HIP events) |
-|---|---|---|---|---|---|
-| train | {a["workload"][12:]} | {a["ms_per_step"]} | {a["seq_per_s"]} seq | {a["decoder_gemm_TFLOPs"]} | `{json.dumps(a["kernel_ms_per_step"])}` |
-| eval | {b["workload"][11:]} | {b["ms_per_step"]} | {b["seq_per_s"]} users | {b["decoder_gemm_TFLOPs"]} | `{json.dumps(b["kernel_ms_per_step"])}` |
-
-The decoder's dense projections are library GEMMs; sampled softmax and catalog decode at D = 2048 run as library GEMMs with the
-fused epilogue kernels of `csrc/wide.hip`.  At this batch (3200 tokens per step) the step is bound by parameter traffic
-(1.1 B weights: cast, gradient write, AdamW), see DESIGN.md section 8.
-"""
-        hs = os.path.join(P, f"{rnd}_hllm_train_kernel_stats.csv")
-        if os.path.exists(hs):
-            md += f"""
-rocprofv3 kernel stats of the HLLM train leg, per step (8 steps traced):
-
-| kernel | launches/step | avg us | ms/step | % of GPU time |
-|---|---|---|---|---|
-{table(hs, 16, 8)}
 """
     open(os.path.join(P, "README.md"), "w").write(md)
     print("wrote", os.path.join(P, "README.md"))
@@ -191,4 +207,6 @@ if __name__ == "__main__":
         kernel_stats(rnd, leg)
     traffic(rnd)
     traffic(rnd, "eval_")
+    mfma_util(rnd)
+    mfma_util(rnd, "eval_")
     readme(rnd)
