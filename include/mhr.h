@@ -154,8 +154,11 @@ int mhr_l2norm_rows_bwd(const float* dy, const float* x, const float* norms, flo
  *   out[b,n,h,:] = sum_{m<=n, key_valid[b,m]} silu(silu(q)[b,n,h].silu(k)[b,m,h]) / L * silu(v)[b,m,h,:]
  * q,k,v are column blocks of the pre-activation uvqk GEMM output ([B*L, row_stride] bf16): the inner
  * SiLU of hstu.py:244-245 is applied on load (apply_silu != 0).  head_dim = dqk = dv, multiple of 8, <= 128.
- * key_valid [B,L] uint8.  out [B*L, n_heads*head_dim] bf16.  L*head_dim is limited by the 160 KiB LDS
- * (K and V^T of one (batch, head) are staged whole): L=512 x head_dim=64 and L=200 x 128 fit.
+ * key_valid [B,L] uint8.  out [B*L, n_heads*head_dim] bf16.  Any L <= 131072: short sequences keep the K / V tile
+ * images of one (batch, head) resident in LDS (one workgroup per (batch, head)); when the images would fill more than
+ * 64 KiB the streamed form runs instead (one workgroup per block of 128 queries, K / V tiles through a two-slot LDS
+ * ring: csrc/attention_stream.hip).  Same arithmetic, same bits.  MHR_ATTN_STREAM=0/1 in the environment forces the form
+ * where both can run.
  * ---------------------------------------------------------------------------------------- */
 int mhr_hstu_attn_fwd(const void* q, const void* k, const void* v, int64_t row_stride,
                       const uint8_t* key_valid, void* out,
@@ -169,7 +172,9 @@ int mhr_hstu_attn_fwd(const void* q, const void* k, const void* v, int64_t row_s
  * stride d_stride (bf16).  act_* are the activated operands saved by the forward (pass q,k,v themselves
  * when apply_silu == 0) - or all NULL with apply_silu != 0: silu(q), silu(k), silu(v) are then recomputed from the
  * pre-activation inputs while they are staged (the forward need not store them: 3 B*L*D bf16 less to write and to read).
- * Two passes per (batch, head) workgroup, no atomics: bitwise reproducible. */
+ * Two passes (dK/dV by key block, dQ by query block), no atomics: bitwise reproducible.  Resident form (all four operand
+ * images in LDS, one workgroup per (batch, head)) while 4 images fit 80 KiB, streamed form (two launches, Q/dO resp.
+ * K/V tiles through the LDS ring) beyond that. */
 int mhr_hstu_attn_bwd(const void* q_pre, const void* k_pre, const void* v_pre, int64_t row_stride,
                       const void* act_q, const void* act_k, const void* act_v, int64_t act_stride,
                       const uint8_t* key_valid, const void* d_out,

@@ -380,8 +380,30 @@ __global__ __launch_bounds__(256, ALL4 ? 2 : (NKS <= 2 ? ATTN_BWD_WG : 1)) void 
   }
 }
 
+// the streamed form (attention_stream.hip): any L; chosen when the resident images do not fit the LDS, or when they fill more
+// than STREAM_ABOVE bytes of it: a resident workgroup that owns a CU alone runs its staging and its tail with nothing to
+// overlap them.  Measured (tools/attn_forms.py, us, resident -> streamed): cfg2 (64 x 512, 16 heads x 64) forward 176 -> 148,
+// backward 456 -> 397; 64 x 300, 8 x 64: 59 -> 59 and 145 -> 134; cfg1 (128 x 200, 8 x 32: 28 KB / 67 KB resident) 27 -> 43
+// and 62 -> 96, so short sequences stay resident.
+// MHR_ATTN_STREAM=0/1 in the environment forces the choice where both forms can run (experiments, tests).
+static bool attn_use_stream(size_t resident_lds, size_t stream_above) {
+  const char* e = getenv("MHR_ATTN_STREAM");
+  const int forced = e ? atoi(e) : -1;
+  if (resident_lds > 160 * 1024) return true;
+  if (forced >= 0) return forced != 0;
+  return resident_lds > stream_above;
+}
+constexpr size_t ATTN_STREAM_ABOVE_FWD = 64 * 1024;
+
 }  // namespace
 
+int mhr_attn_stream_fwd(const void* q, const void* k, const void* v, int64_t row_stride, const uint8_t* key_valid, void* out,
+                        void* act_q, void* act_k, void* act_v, int64_t act_stride, int B, int L, int n_heads, int head_dim,
+                        int apply_silu, hipStream_t s);
+int mhr_attn_stream_bwd(const void* q_pre, const void* k_pre, const void* v_pre, int64_t row_stride, const void* act_q,
+                        const void* act_k, const void* act_v, int64_t act_stride, const uint8_t* key_valid, const void* d_out,
+                        void* dq, void* dk, void* dv, int64_t d_stride, int B, int L, int n_heads, int head_dim, int apply_silu,
+                        hipStream_t s);
 
 extern "C" int mhr_hstu_attn_fwd(const void* q, const void* k, const void* v, int64_t row_stride, const uint8_t* key_valid,
                                  void* out, void* act_q, void* act_k, void* act_v, int64_t act_stride, int B, int L,
@@ -395,10 +417,15 @@ extern "C" int mhr_hstu_attn_fwd(const void* q, const void* k, const void* v, in
               "hstu_attn_fwd: act_q/act_k/act_v must be all set or all null");
   const int Lp = (L + 31) & ~31, nb = Lp / 32;
   size_t lds = (size_t)2 * nb * (32 * sh.nks * 32) + (size_t)nb * 4 + 16;     // K and V tile images + validity words
-  MHR_REQUIRE(lds <= 160 * 1024 && nb <= 256, "hstu_attn_fwd: L=%d head_dim=%d needs %zu B of LDS (> 160 KiB)", L, head_dim, lds);
+  MHR_REQUIRE(nb <= 4096, "hstu_attn_fwd: L=%d too long (<= 131072)", L);
   const float inv_n = 1.0f / (float)L;
   const int64_t out_stride = (int64_t)n_heads * head_dim;
   hipStream_t s = (hipStream_t)stream;
+  if (attn_use_stream(lds, ATTN_STREAM_ABOVE_FWD)) {
+    mhr_attn_stream_fwd(q, k, v, row_stride, key_valid, out, act_q, act_k, act_v, act_stride, B, L, n_heads, head_dim, apply_silu, s);
+    MHR_CHECK_LAUNCH("hstu_attn_fwd(streamed)");
+    return MHR_OK;
+  }
 #define L_(NKS, ND)                                                                                                    \
   {                                                                                                                    \
     auto kern = hstu_attn_fwd_kernel<NKS, ND>;                                                                         \
@@ -433,10 +460,16 @@ extern "C" int mhr_hstu_attn_bwd(const void* q_pre, const void* k_pre, const voi
   const size_t img = (size_t)nb * (32 * sh.nks * 32), extra = (((size_t)nb * 4 + 15) & ~(size_t)15) + 4 * 32 * 36 * sizeof(float);
   const bool all4 = 4 * img + extra <= 80 * 1024 && sh.nks <= 4;     // (head_dim 128: the resident form spills)
   const size_t lds = (all4 ? 4 : 2) * img + extra;
-  MHR_REQUIRE(lds <= 160 * 1024 && nb <= 256, "hstu_attn_bwd: L=%d head_dim=%d needs %zu B of LDS (> 160 KiB)", L, head_dim, lds);
+  MHR_REQUIRE(nb <= 4096, "hstu_attn_bwd: L=%d too long (<= 131072)", L);
   const float inv_n = 1.0f / (float)L;
   const int64_t do_stride = (int64_t)n_heads * head_dim;
   hipStream_t s = (hipStream_t)stream;
+  if (attn_use_stream(lds, all4 ? 160 * 1024 : 0)) {       // streamed whenever the four-image form does not apply
+    mhr_attn_stream_bwd(q_pre, k_pre, v_pre, row_stride, act_q, act_k, act_v, act_stride, key_valid, d_out, dq, dk, dv, d_stride, B, L,
+                        n_heads, head_dim, apply_silu, s);
+    MHR_CHECK_LAUNCH("hstu_attn_bwd(streamed)");
+    return MHR_OK;
+  }
 #define L__(NKS, ND, A4)                                                                                               \
   {                                                                                                                    \
     auto kern = hstu_attn_bwd_kernel<NKS, ND, A4>;                                                                     \
