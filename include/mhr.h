@@ -295,6 +295,9 @@ int mhr_nce_log_counters(const int32_t* n_valid, const int32_t* rank, const int3
  * [n_groups, n_p_rows] int32 scratch (optional, together): the rows of p_rows that tokens of each group can point at
  * (any superset); only those are tested, column j of the bit table = list entry j, and the inverse map is written to
  * fix_slot_of_row.  Rows outside the list must not be referenced by live tokens of that group.
+ * Plain form (u_out set; supp_out, fix_words and the fix_* lists NULL; pn_out optional; n_neg % 32 == 0): the fused
+ * forward with NOTHING suppressed - no bit table, no suppression words loaded or stored, no bit test per logit.  This is
+ * what the query-row-sharing path launches on its row list (the per-token kernels take the false negatives back out).
  * ---------------------------------------------------------------------------------------- */
 int mhr_nce_fwd(const void* q_rows, const int32_t* q_idx, const void* p_rows, const int32_t* p_idx, int io_dtype,
                 const void* negs, int n_neg, int dim, int n_groups, const int32_t* n_tok_dev, int tok_cap,
@@ -334,7 +337,9 @@ int mhr_nce_finalize(const float* sum, const float* s_pos, int n_groups, const i
  *   from `supp`, and accumulates d_negs ([n_neg, dim] f32, float atomics across token splits; caller zeroes) w.r.t.
  *   the normalised negatives.  `lw` is the array mhr_nce_bwd_tokens wrote (launch that first).  Requires
  *   tok_cap % 32 == 0: the forward pads the last live 32-token tile of the saved state (zero qn / pn rows, all-ones
- *   suppression words) so that whole token tiles stream without clamping. */
+ *   suppression words) so that whole token tiles stream without clamping.  supp == NULL: nothing was suppressed (the
+ *   plain form of mhr_nce_fwd); lw of the padding tokens of the last live tile must then be +inf (mhr_nce_row_lw writes
+ *   +inf behind the live rows; callers of mhr_nce_shared_bwd_rows pre-fill lw_row with +inf). */
 int mhr_nce_bwd_tokens(const void* qn, const void* pn, const float* u, int dim, int n_groups,
                        const int32_t* n_tok_dev, int tok_cap, const float* logit_scale_dev,
                        const float* lse, const float* w, const float* q_inv, const float* p_inv, const float* s_pos,
@@ -349,7 +354,7 @@ int mhr_nce_bwd_negs(const void* qn, const void* negs, const uint32_t* supp, int
  * Sampled softmax with QUERY-ROW SHARING (csrc/nce_shared.hip; same reference lines as mhr_nce_fwd, plus the window
  * construction hstu.py:682-690, 808-829 that makes P tokens share one query).  The tokens (b, l, p), p = 0..P-1, of a
  * prior category use the same query row and differ in their target only, so the negative-pool products are evaluated per
- * DISTINCT ROW: the caller runs mhr_nce_fwd and mhr_nce_bwd_negs on the row list (no suppression: an all-zero bit table)
+ * DISTINCT ROW: the caller runs mhr_nce_fwd and mhr_nce_bwd_negs on the row list (plain form: nothing suppressed)
  * and these entry points add what depends on the token.  Token lists must keep the tokens of a row adjacent.
  *   tok2row [n_groups, tok_cap] int32: row of token t;  row arrays are [n_groups, row_cap(, dim)], token arrays
  *   [n_groups, tok_cap(, dim)];  row_first [n_groups, row_cap] int32: first token of row r (entry n_row = n_tok).

@@ -135,6 +135,14 @@ __device__ __forceinline__ float gate_alive(float s, float c1, float c0, uint32_
       : "=&v"(g), "=&v"(m) : "v"(x), "v"(alive_bits), "v"(pos));
   return g;
 }
+// nothing to mask (the plain forms): exp2 only.  The s_nop is the wait state a consumer of a transcendental needs when hipcc
+// cannot see it (the running sum is an inline-asm v_add: without the nop its first lanes read the register too early).
+__device__ __forceinline__ float gate_plain(float s, float c1, float c0) {
+  const float x = s * c1 - c0;
+  float g;
+  asm("v_exp_f32 %0, %1\n\ts_nop 0" : "=v"(g) : "v"(x));
+  return g;
+}
 __device__ __forceinline__ float gate_dead(float s, float c1, float c0, uint32_t dead_bits, int pos) {     // bit = 1: drop
   const float x = s * c1 - c0;
   float g;
@@ -606,7 +614,7 @@ __global__ __launch_bounds__(256, 2) void nce_fix_bits_kernel(const IT* __restri
 // then carries ONE stationary fragment set (the query: 64 VGPRs fewer), 16 instead of 32 MFMAs in the S phase, no compare
 // chain - the tile's 32 suppression bits of a token arrive as one LDS-DMA word per lane, gathered by target row, riding the
 // same ring (one more piece per tile) - and the saved per-token suppression words for nce_bwd_n are that very word.
-template <int NKS, typename IT, bool LOGS>
+template <int NKS, typename IT, bool LOGS, bool SUPP = true>
 __global__ __launch_bounds__(256, 1) void nce_fwd_d_kernel(const IT* __restrict__ q_rows, const int32_t* q_idx,
                                                            const IT* __restrict__ p_rows, const int32_t* p_idx,
                                                            const bf16_t* negs, int n_neg,
@@ -627,11 +635,14 @@ __global__ __launch_bounds__(256, 1) void nce_fwd_d_kernel(const IT* __restrict_
     q_idx += to; p_idx += to; n_tok_dev += grp; negs += grp * (int64_t)((n_neg + 31) & ~31) * T::DIM; sum_out += to;
     if (n_valid) n_valid += to;
     if (rank) rank += to;
-    qn_out += to * T::DIM; pn_out += to * T::DIM; u_out += to * T::DIM;
-    supp_out += grp * (int64_t)((n_neg + 31) >> 5) * tok_cap;
+    qn_out += to * T::DIM; u_out += to * T::DIM;
+    if (pn_out) pn_out += to * T::DIM;
     q_inv += to; p_inv += to; s_pos_out += to;
-    fixw += grp * (int64_t)((n_neg + 31) >> 5) * n_rows_pad;
-    if (slot_of_row) slot_of_row += grp * (int64_t)n_p_rows;
+    if constexpr (SUPP) {
+      supp_out += grp * (int64_t)((n_neg + 31) >> 5) * tok_cap;
+      fixw += grp * (int64_t)((n_neg + 31) >> 5) * n_rows_pad;
+      if (slot_of_row) slot_of_row += grp * (int64_t)n_p_rows;
+    }
   }
   const int n_tok = min(*n_tok_dev, tok_cap);
   const int tok0 = blockIdx.x * 128;
@@ -659,7 +670,7 @@ __global__ __launch_bounds__(256, 1) void nce_fwd_d_kernel(const IT* __restrict_
 #pragma unroll
       for (int i = 0; i < 8; ++i) spos += (float)frag[0][ks][i] * (float)pfrag[ks][i];
     spos += __shfl_xor(spos, 32, 64);
-    if (in_cap) {
+    if (in_cap && pn_out) {
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks)
         *reinterpret_cast<bf16x8*>(pn_out + (int64_t)tok * T::DIM + ks * 16 + 8 * half) = pfrag[ks];
@@ -698,15 +709,16 @@ __global__ __launch_bounds__(256, 1) void nce_fwd_d_kernel(const IT* __restrict_
                                              reinterpret_cast<const char*>(negs) + (int64_t)tn * (32 * T::ROW_BYTES));
   };
   unsigned char* words = smem + 4 * T::BYTES;                  // 4 slots x [4 waves][64 lanes] suppression words of my token's target
-  const uint32_t* my_fix = fixw + (slot_of_row && live ? slot_of_row[p_row] : (slot_of_row ? 0 : p_row));   // + tile * n_rows_pad
+  const uint32_t* my_fix = SUPP ? fixw + (slot_of_row && live ? slot_of_row[p_row] : (slot_of_row ? 0 : p_row)) : nullptr;   // + tile * n_rows_pad
   auto dma_w = [&](auto slot_c, int tn) {
-    sg::dma_words(my_fix + (int64_t)tn * n_rows_pad, words + decltype(slot_c)::value * 1024 + wv * 256);
+    if constexpr (SUPP) sg::dma_words(my_fix + (int64_t)tn * n_rows_pad, words + decltype(slot_c)::value * 1024 + wv * 256);
   };
   auto dma_all = [&](auto slot_c, int tn) {
     auto f = [&](auto k_c) { dma_k(k_c, slot_c, tn); };
     sg::static_for<P::PW>(f);
     dma_w(slot_c, tn);
   };
+  constexpr int NDMA = P::PW + (SUPP ? 1 : 0);               // LDS-DMA instructions per tile and wave
   const uint32_t word_addr = sg::lds_addr(words) + (uint32_t)(wv * 256 + lane * 4);
   sg::LaneAddr<NKS> la;
   la.init(lane);
@@ -734,19 +746,32 @@ __global__ __launch_bounds__(256, 1) void nce_fwd_d_kernel(const IT* __restrict_
     sg::ring_loop<4>(n_tiles + 1, [&](auto slot_c, int i) {
       constexpr int cur = decltype(slot_c)::value, nxt = (cur + 2) % 4, prv = (cur + 3) % 4, par = cur & 1;
       STAMP(2)
-      sg::wait_vmcnt<P::PW + 1>();
+#ifndef EXP_NODMA
+      sg::wait_vmcnt<NDMA>();
+#endif
       STAMP(0)
+#ifndef EXP_NOBAR
       sg::ring_barrier();
+#endif
       STAMP(1)
       const int tn = min(i + 2, t_last);
       sf[par][0] = sg::zero16();
       const f32x16& s_prev = sf[par ^ 1][0];
       // false negatives of THIS tile for my token: bit j = negative 32 i + j suppressed (precomputed per target row)
-      uint32_t word = sg::ds_read_b32_asm<cur * 1024>(word_addr);
-      sg::tile_step<NKS, ND, cur * T::BYTES, prv * T::BYTES, P::PW + 1, 1>(
-          ra, ta, frag, sf[par], u, [&](auto n_c) { sg::wait_lgkm_values<decltype(n_c)::value>(word); },
+      // (SUPP = false: nothing is suppressed - the row-sharing path, whose per-token kernels take the false negatives back
+      //  out - so no words, no bit test; the 'previous tile' of the first iteration is switched off through the exponent)
+      uint32_t word = 0;
+      if constexpr (SUPP) word = sg::ds_read_b32_asm<cur * 1024>(word_addr);
+      const float c0t = (!SUPP && i == 0) ? INFINITY : c1;
+      sg::tile_step<NKS, ND, cur * T::BYTES, prv * T::BYTES, NDMA, 1>(
+          ra, ta, frag, sf[par], u,
+          [&](auto n_c) {
+            if constexpr (SUPP) sg::wait_lgkm_values<decltype(n_c)::value>(word);
+          },
           [&](int g) {                     // gated logit of the previous tile: alive_prev already excludes its false negatives
-            const float ek = gate_alive(s_prev[g], c1, c1, alive_prev, (g & 3) + 8 * (g >> 2));
+            float ek;
+            if constexpr (SUPP) ek = gate_alive(s_prev[g], c1, c1, alive_prev, (g & 3) + 8 * (g >> 2));
+            else ek = gate_plain(s_prev[g], c1, c0t);
             asm volatile("v_add_f32 %0, %0, %1" : "+v"(sum) : "v"(ek));      // volatile: keep the accumulation in this gap
             if constexpr (WITH_LOGS) {
               const int pos = (g & 3) + 8 * (g >> 2);
@@ -758,12 +783,18 @@ __global__ __launch_bounds__(256, 1) void nce_fwd_d_kernel(const IT* __restrict_
           },
           [&](auto k_c) {                  // gaps of the second product: next tile's DMA (tile pieces, then the words)
             constexpr int k = decltype(k_c)::value;
+#ifndef EXP_NODMA
             if constexpr (k < P::PW) dma_k(k_c, std::integral_constant<int, nxt>{}, tn);
-            else if constexpr (k == P::PW) dma_w(std::integral_constant<int, nxt>{}, tn);
+            else if constexpr (k == P::PW && SUPP) dma_w(std::integral_constant<int, nxt>{}, tn);
+#endif
           },
           sg::EpiIdentity{}, [&] { STAMP(3) });
       STAMP(4)
-      if (i < n_tiles && in_cap && half == 0) supp_out[(int64_t)i * tok_cap + tok] = live ? word : 0xFFFFFFFFu;
+#ifndef EXP_NOSUPP
+      if constexpr (SUPP) {
+        if (i < n_tiles && in_cap && half == 0) supp_out[(int64_t)i * tok_cap + tok] = live ? word : 0xFFFFFFFFu;
+      }
+#endif
       const uint32_t sbits = (word >> (4 * half)) & 0x0F0F0F0Fu;
       const int rem = n_neg - i * 32;
       const uint32_t tail = rem >= 32 ? 0xFFFFFFFFu : (rem > 0 ? ~(0xFFFFFFFFu << rem) : 0u);
@@ -976,7 +1007,7 @@ __global__ __launch_bounds__(256) void nce_bwd_rows_kernel(const bf16_t* qn, con
 // ------------------------------------------------------------------------------------------
 // backward, negative-stationary: d_negs
 // ------------------------------------------------------------------------------------------
-template <int NKS>
+template <int NKS, bool SUPP = true>
 __global__ __launch_bounds__(256, 1) void nce_bwd_n_kernel(const bf16_t* qn, const bf16_t* negs,
                                                            const uint32_t* supp, int n_neg,
                                                            const int32_t* n_tok_dev, int tok_cap,
@@ -991,7 +1022,8 @@ __global__ __launch_bounds__(256, 1) void nce_bwd_n_kernel(const bf16_t* qn, con
   using P = sg::DmaPieces<NKS>;
   {
     const int64_t grp = blockIdx.z, to = grp * tok_cap;
-    qn += to * T::DIM; negs += grp * (int64_t)((n_neg + 31) & ~31) * T::DIM; supp += grp * (int64_t)((n_neg + 31) >> 5) * tok_cap;
+    qn += to * T::DIM; negs += grp * (int64_t)((n_neg + 31) & ~31) * T::DIM;
+    if constexpr (SUPP) supp += grp * (int64_t)((n_neg + 31) >> 5) * tok_cap;
     n_tok_dev += grp; lw += to; d_negs += grp * (int64_t)n_neg * T::DIM;
   }
   const int n_tok = min(*n_tok_dev, tok_cap);
@@ -1025,8 +1057,10 @@ __global__ __launch_bounds__(256, 1) void nce_bwd_n_kernel(const bf16_t* qn, con
   dp.init(wv, lane);
   const int my_nt = min((neg0 >> 5) + wv, n_neg_tiles - 1);
   // my word of a token tile: lanes 0-31 the suppression word of (my negative tile, token r), lanes 32-63 lw of token r
-  const char* word_base = half == 0 ? reinterpret_cast<const char*>(supp + (int64_t)my_nt * tok_cap + r)
-                                    : reinterpret_cast<const char*>(lw + r);
+  // (SUPP = false - nothing suppressed, the row-sharing path: both halves fetch lw, and a padded token is switched off by
+  //  lw = +inf, which mhr_nce_row_lw writes behind the live rows)
+  const char* word_base = (SUPP && half == 0) ? reinterpret_cast<const char*>(supp + (int64_t)my_nt * tok_cap + r)
+                                              : reinterpret_cast<const char*>(lw + r);
   const int n_loc = (tt1 - tt0 + tstep - 1) / tstep;
   const int tt_last = tt0 + (n_loc - 1) * tstep;
   auto dma_k = [&](auto k_c, auto slot_c, int tn) {
@@ -1049,7 +1083,7 @@ __global__ __launch_bounds__(256, 1) void nce_bwd_n_kernel(const bf16_t* qn, con
   const uint32_t wd_addr = sg::lds_addr(smem) + T::BYTES + wv * 256 + 16 * half;
   // slot 3 is the "previous tile" of the first iteration: zero rows, all-ones suppression words (G = 0)
   for (int o = threadIdx.x * 16; o < T::BYTES; o += 256 * 16) *reinterpret_cast<f32x4*>(smem + 3 * BUF + o) = f32x4{0.f, 0.f, 0.f, 0.f};
-  reinterpret_cast<uint32_t*>(smem + 3 * BUF + T::BYTES)[threadIdx.x] = 0xFFFFFFFFu;
+  reinterpret_cast<uint32_t*>(smem + 3 * BUF + T::BYTES)[threadIdx.x] = SUPP ? 0xFFFFFFFFu : 0x7F800000u;   // (+inf as lw)
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // published by the first ring barrier
   dma_all(std::integral_constant<int, 0>{}, tt0);
   dma_all(std::integral_constant<int, 1>{}, min(tt0 + tstep, tt_last));
@@ -1062,7 +1096,7 @@ __global__ __launch_bounds__(256, 1) void nce_bwd_n_kernel(const bf16_t* qn, con
     sg::u32x4 s4[4], l4[4];
     auto rd = [&](auto q_c) {
       constexpr int q4 = decltype(q_c)::value;
-      s4[q4] = sg::ds_read_b128_asm<prv * BUF + 32 * q4>(wd_addr);
+      if constexpr (SUPP) s4[q4] = sg::ds_read_b128_asm<prv * BUF + 32 * q4>(wd_addr);
       l4[q4] = sg::ds_read_b128_asm<prv * BUF + 128 + 32 * q4>(wd_addr);
     };
     sg::static_for<4>(rd);
@@ -1070,12 +1104,16 @@ __global__ __launch_bounds__(256, 1) void nce_bwd_n_kernel(const bf16_t* qn, con
     f32x16 acc = sg::zero16();
     sg::bwd_tile<NKS, ND, cur * BUF, prv * BUF, P::PW + 1>(
         ra, ta, frag, acc, dn,
-        [&](auto n_c) { sg::wait_lgkm_values<decltype(n_c)::value>(s4[0], s4[1], s4[2], s4[3], l4[0], l4[1], l4[2], l4[3]); },
+        [&](auto n_c) {
+          if constexpr (SUPP) sg::wait_lgkm_values<decltype(n_c)::value>(s4[0], s4[1], s4[2], s4[3], l4[0], l4[1], l4[2], l4[3]);
+          else sg::wait_lgkm_values<decltype(n_c)::value>(l4[0], l4[1], l4[2], l4[3]);
+        },
         [&](int g) {   // bit r (my negative) of the token's suppression word
           // (whole-vector bit cast, then element: hipcc 7.2 folds element-extract + scalar bit cast of an asm result to
           //  element 0 - the same bug as the ds_read_tr builtin note in stream_gemm.h)
           const f32x4 lf = __builtin_bit_cast(f32x4, l4[g >> 2]);
-          return gate_dead(s_prev[g], c1, lf[g & 3], s4[g >> 2][g & 3], r);
+          if constexpr (SUPP) return gate_dead(s_prev[g], c1, lf[g & 3], s4[g >> 2][g & 3], r);
+          else return gate_plain(s_prev[g], c1, lf[g & 3]);
         },
         [&](auto k_c) {
           if constexpr (decltype(k_c)::value < P::PW + 1) dma_k(k_c, std::integral_constant<int, nxt>{}, tn);
@@ -1141,8 +1179,10 @@ extern "C" int mhr_nce_fwd(const void* q_rows, const int32_t* q_idx, const void*
   MHR_REQUIRE((fix_row_list != nullptr) == (fix_n_rows != nullptr) && (fix_row_list != nullptr) == (fix_slot_of_row != nullptr) &&
                   (!fix_row_list || fix_words),
               "nce_fwd: fix_row_list, fix_n_rows and fix_slot_of_row go together (and need fix_words)");
-  MHR_REQUIRE(!u_out || (qn_out && pn_out && supp_out && q_inv && p_inv && tok_cap % 32 == 0),
+  const bool plain = u_out && !fix_words && !supp_out;     // fused forward with NOTHING suppressed (row-sharing path)
+  MHR_REQUIRE(!u_out || (qn_out && q_inv && p_inv && tok_cap % 32 == 0 && (plain || (pn_out && supp_out))),
               "nce_fwd: u_out (fused training path) needs every saved tensor and tok_cap %% 32 == 0");
+  MHR_REQUIRE(!plain || n_neg % 32 == 0, "nce_fwd: the no-suppression form (supp_out = fix_words = NULL) needs n_neg %% 32 == 0");
   int nks;
   MHR_REQUIRE(nks_for(dim, nks), "nce_fwd: dim=%d unsupported (16/32/64/128/256)", dim);
   MHR_REQUIRE(n_neg > 0 && tok_cap > 0 && n_groups >= 1 && n_groups <= 65535, "nce_fwd: bad sizes");
@@ -1198,6 +1238,24 @@ extern "C" int mhr_nce_fwd(const void* q_rows, const int32_t* q_idx, const void*
     NKS_SWITCH(nks, LF_);
 #undef LF_
     MHR_CHECK_LAUNCH("nce_fwd (fused, hoisted false-negative test)");
+    return MHR_OK;
+  }
+  if (plain) {
+#define LP_(NKS)                                                                                                         \
+  {                                                                                                                      \
+    const size_t ldsd = 4 * sg::Tile<NKS>::BYTES + 4 * 1024;                                                             \
+    const dim3 gu((tok_cap + 127) / 128, 1, n_groups);                                                                   \
+    if (io_dtype == MHR_BF16) {                                                                                          \
+      if (logs) hipLaunchKernelGGL((nce_fwd_d_kernel<NKS, bf16_t, true, false>), gu, dim3(256), ldsd, s, UARGS(bf16_t), (const uint32_t*)nullptr, 0, (const int32_t*)nullptr, 0); \
+      else hipLaunchKernelGGL((nce_fwd_d_kernel<NKS, bf16_t, false, false>), gu, dim3(256), ldsd, s, UARGS(bf16_t), (const uint32_t*)nullptr, 0, (const int32_t*)nullptr, 0);     \
+    } else {                                                                                                             \
+      if (logs) hipLaunchKernelGGL((nce_fwd_d_kernel<NKS, float, true, false>), gu, dim3(256), ldsd, s, UARGS(float), (const uint32_t*)nullptr, 0, (const int32_t*)nullptr, 0); \
+      else hipLaunchKernelGGL((nce_fwd_d_kernel<NKS, float, false, false>), gu, dim3(256), ldsd, s, UARGS(float), (const uint32_t*)nullptr, 0, (const int32_t*)nullptr, 0);     \
+    }                                                                                                                    \
+  }
+    NKS_SWITCH(nks, LP_);
+#undef LP_
+    MHR_CHECK_LAUNCH("nce_fwd (fused, nothing suppressed)");
     return MHR_OK;
   }
   if (u_out) {
@@ -1293,7 +1351,7 @@ extern "C" int mhr_nce_bwd_tokens(const void* qn, const void* pn, const float* u
 extern "C" int mhr_nce_bwd_negs(const void* qn, const void* negs, const uint32_t* supp, int n_neg, int dim, int n_groups,
                                 const int32_t* n_tok_dev, int tok_cap, const float* logit_scale_dev, const float* lw,
                                 float* d_negs, void* stream) {
-  MHR_REQUIRE(qn && negs && supp && n_tok_dev && logit_scale_dev && lw && d_negs, "nce_bwd_negs: null pointer");
+  MHR_REQUIRE(qn && negs && n_tok_dev && logit_scale_dev && lw && d_negs, "nce_bwd_negs: null pointer");
   MHR_REQUIRE(tok_cap % 32 == 0, "nce_bwd_negs: tok_cap=%d must be a multiple of 32", tok_cap);
   int nks;
   MHR_REQUIRE(nks_for(dim, nks), "nce_bwd_negs: dim=%d unsupported (16/32/64/128/256)", dim);
@@ -1307,8 +1365,12 @@ extern "C" int mhr_nce_bwd_negs(const void* qn, const void* negs, const uint32_t
 #define L_(NKS)                                                                                                        \
   {                                                                                                                    \
     size_t lds_n = 4 * (sg::Tile<NKS>::BYTES + 1024);                                                                  \
-    hipLaunchKernelGGL((nce_bwd_n_kernel<NKS>), dim3(neg_groups, splits, n_groups), dim3(256), lds_n, s, (const bf16_t*)qn,      \
-                       (const bf16_t*)negs, supp, n_neg, n_tok_dev, tok_cap, logit_scale_dev, lw, d_negs);          \
+    if (supp)                                                                                                          \
+      hipLaunchKernelGGL((nce_bwd_n_kernel<NKS, true>), dim3(neg_groups, splits, n_groups), dim3(256), lds_n, s,       \
+                         (const bf16_t*)qn, (const bf16_t*)negs, supp, n_neg, n_tok_dev, tok_cap, logit_scale_dev, lw, d_negs); \
+    else                                                                                                               \
+      hipLaunchKernelGGL((nce_bwd_n_kernel<NKS, false>), dim3(neg_groups, splits, n_groups), dim3(256), lds_n, s,      \
+                         (const bf16_t*)qn, (const bf16_t*)negs, supp, n_neg, n_tok_dev, tok_cap, logit_scale_dev, lw, d_negs); \
   }
   NKS_SWITCH(nks, L_);
 #undef L_

@@ -505,7 +505,10 @@ __global__ __launch_bounds__(256) void row_lw_kernel(const float* __restrict__ l
   lw_tok += grp * tok_cap; row_first += grp * row_cap; lw_row += grp * row_cap;
   const int n_row = min(n_row_dev[grp], row_cap - 1);
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= n_row) return;
+  if (r >= n_row) {                  // behind the live rows: +inf switches the row off in mhr_nce_bwd_negs (exp2(. - inf) = 0)
+    if (r < row_cap) lw_row[r] = INFINITY;
+    return;
+  }
   const int t0 = row_first[r], t1 = min(row_first[r + 1], tok_cap);
   float m = INFINITY;
   for (int t = t0; t < t1; ++t) m = fminf(m, lw_tok[t]);

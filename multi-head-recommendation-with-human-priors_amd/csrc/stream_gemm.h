@@ -368,6 +368,12 @@ __device__ __forceinline__ void wait_lgkm(u32x2& a, u32x2& b, u32x2& c, u32x2& d
   asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
 }
 
+template <int N>
+__device__ __forceinline__ void wait_lgkm2(u32x2& a, u32x2& b) {
+  static_assert(N >= 0 && N <= 15, "lgkmcnt is 4 bits");
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
+}
+
 template <int NKS>
 struct TrAddr {           // per-lane LDS byte ADDRESSES (ring base included) of the transposed reads
   uint32_t t[2][4];
@@ -436,6 +442,18 @@ __device__ __forceinline__ void mma_tile_tr_asm(const TrAddr<NKS>& ta, bf16x8 g0
 // overlaps the LDS latency).  `pack(g0, g1)` converts the finished epilogue into the two A fragments of G(t-1).
 // LDS return order is issue order, so `s_waitcnt lgkmcnt(n)` with n = reads issued after the one needed is exact.
 // ---------------------------------------------------------------------------------------------------------
+#ifdef EXP_NOLDS
+__device__ __forceinline__ u32x4 exp_mov4(uint32_t addr) {
+  u32x4 v;
+  asm volatile("v_mov_b32 %0, %4\n\tv_mov_b32 %1, %4\n\tv_mov_b32 %2, %4\n\tv_mov_b32 %3, %4" : "=&v"(v.x), "=&v"(v.y), "=&v"(v.z), "=&v"(v.w) : "v"(addr));
+  return v;
+}
+__device__ __forceinline__ u32x2 exp_mov2(uint32_t addr) {
+  u32x2 v;
+  asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %2" : "=&v"(v.x), "=&v"(v.y) : "v"(addr));
+  return v;
+}
+#endif
 template <int IMM>
 __device__ __forceinline__ u32x4 ds_read_b128_asm(uint32_t addr) {
   static_assert(IMM >= 0 && IMM < 65536, "LDS offset field is 16 bits");
@@ -526,6 +544,102 @@ struct NoMid {
   __device__ __forceinline__ void operator()() const {}
 };
 
+// One stationary fragment set, epilogue spread over BOTH products.  The gated tile G(t-1) enters the second product as two
+// A fragments: g0 = elements 0..7, g1 = elements 8..15.  Sweeping the second product as {all column chunks x g0} then
+// {all column chunks x g1} means g1 is not needed before the second sweep, so only HALF of the per-element epilogue has to
+// finish inside the S gaps; the other half rides the gaps of the first sweep and the next tile's DMA instructions those of
+// the second.  Stamped at D = 256 before the split: S phase 1040 cycles for 16 MFMAs (512 in the matrix pipe) - each gap
+// carried a whole element (fma, quarter-rate exp, bit test, mask, running sum, convert: ~34 issue cycles against a 32-cycle
+// MFMA) - while the gaps of the second product carried two LDS reads and, in 5 of 16, one DMA instruction.
+template <int NKS, int ND, int OFF_CUR, int OFF_PRV, int NDMA, typename Ready, typename Epi, typename DmaFn, typename Mid>
+__device__ __forceinline__ void tile_step_split(const RowAddr<NKS>& ra, const TrAddr<NKS>& ta, const bf16x8 (&frag)[1][NKS],
+                                                f32x16 (&accs)[1], f32x16 (&out)[ND], Ready ready, Epi epi, DmaFn dma, Mid mid) {
+  using T = Tile<NKS>;
+  constexpr int PA = NKS < 4 ? NKS : 4;
+  constexpr int NCH = 2 * ND;                         // transposed chunks (two reads each) in sweep order: c = sweep * ND + dc
+  constexpr int PT = NKS < 2 ? 1 : 2;                 // chunks requested ahead (NCH >= 2 always)
+  constexpr int ES = (8 + NKS - 1) / NKS;             // elements 0..7 per S gap
+  constexpr int EU = (8 + ND - 1) / ND;               // elements 8..15 per gap of the first sweep
+  constexpr int T0 = NKS - PT;                        // S step after which chunk 0 is requested
+  u32x4 a[PA + 1];
+  u32x2 r[PT + 1][2];
+  uint32_t pk[8];
+  float even = 0.f;
+  auto issue_a = [&](auto ks_c) {
+    constexpr int ks = decltype(ks_c)::value;
+#ifdef EXP_NOLDS
+    a[ks % (PA + 1)] = exp_mov4(ra.a[ks & 7]);
+#else
+    a[ks % (PA + 1)] = ds_read_b128_asm<OFF_CUR + 256 * (ks >> 3)>(ra.a[ks & 7]);
+#endif
+  };
+  auto issue_t = [&](auto c_c) {
+    constexpr int c = decltype(c_c)::value, dc = c % ND, sw = c / ND;
+    constexpr int imm = OFF_PRV + 256 * (dc >> 2) + sw * 16 * T::ROW_BYTES;
+    u32x2* q = r[c % (PT + 1)];
+#ifdef EXP_NOLDS
+    q[0] = exp_mov2(ta.t[0][dc & 3]);
+    q[1] = exp_mov2(ta.t[1][dc & 3]);
+#else
+    q[0] = ds_read_tr_asm<imm>(ta.t[0][dc & 3]);
+    q[1] = ds_read_tr_asm<imm>(ta.t[1][dc & 3]);
+#endif
+  };
+  auto element = [&](int e) {
+    const float g = epi(e);
+    if (e & 1) pk[e >> 1] = cvt_pk_bf16(even, g); else even = g;
+  };
+  static_for<PA>(issue_a);
+  ready(std::integral_constant<int, PA>{});
+  auto s_step = [&](auto ks_c) {
+    constexpr int ks = decltype(ks_c)::value;
+    if constexpr (ks + PA < NKS) issue_a(std::integral_constant<int, ks + PA>{});
+    constexpr int a_after = (ks + PA < NKS ? ks + PA : NKS - 1) - ks;
+    constexpr int t_chunks = ks > T0 ? ks - T0 : 0;
+    wait_lgkm1<a_after + 2 * t_chunks>(a[ks % (PA + 1)]);
+    const bf16x8 av = __builtin_bit_cast(bf16x8, a[ks % (PA + 1)]);
+    accs[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, frag[0][ks], accs[0], 0, 0, 0);
+#pragma unroll
+    for (int e = ks * ES; e < ks * ES + ES && e < 8; ++e) element(e);
+    if constexpr (ks >= T0) issue_t(std::integral_constant<int, ks - T0>{});
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  static_for<NKS>(s_step);
+  mid();
+  bf16x8 g0, g1;
+  {
+    const u32x4 g0v = {pk[0], pk[1], pk[2], pk[3]};
+    g0 = __builtin_bit_cast(bf16x8, g0v);
+  }
+  auto t_step = [&](auto c_c) {
+    constexpr int c = decltype(c_c)::value, dc = c % ND, sw = c / ND;
+    if constexpr (c + PT < NCH) issue_t(std::integral_constant<int, c + PT>{});
+    constexpr int ahead = (NCH - 1 - c) < PT ? (NCH - 1 - c) : PT;
+    u32x2* q = r[c % (PT + 1)];
+    wait_lgkm2<2 * ahead>(q[0], q[1]);
+    const u32x4 bv = {q[0].x, q[0].y, q[1].x, q[1].y};
+    if constexpr (sw == 0) {
+      out[dc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g0, __builtin_bit_cast(bf16x8, bv), out[dc], 0, 0, 0);
+#pragma unroll
+      for (int e = 8 + dc * EU; e < 8 + dc * EU + EU && e < 16; ++e) element(e);
+    } else {
+      if constexpr (dc == 0) {
+        const u32x4 g1v = {pk[4], pk[5], pk[6], pk[7]};
+        g1 = __builtin_bit_cast(bf16x8, g1v);
+      }
+      out[dc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g1, __builtin_bit_cast(bf16x8, bv), out[dc], 0, 0, 0);
+      dma(std::integral_constant<int, dc>{});
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  static_for<NCH>(t_step);
+  auto rest = [&](auto k_c) {
+    constexpr int k = decltype(k_c)::value;
+    if constexpr (k >= ND) dma(k_c);
+  };
+  static_for<NDMA>(rest);
+}
+
 // RF = 1: one stationary fragment set (the backward kernels).  RF = 2: two sets sharing every row-fragment read (the
 // fused forward: s = q.n and f = p.n); the per-element epilogue is then split over the two MFMA gaps of a k-step:
 // epi(e) after the first MFMA, epi2(e, value) after the second.
@@ -534,6 +648,10 @@ template <int NKS, int ND, int OFF_CUR, int OFF_PRV, int NDMA, int RF, typename 
 __device__ __forceinline__ void tile_step(const RowAddr<NKS>& ra, const TrAddr<NKS>& ta, const bf16x8 (&frag)[RF][NKS],
                                           f32x16 (&accs)[RF], f32x16 (&out)[ND], Ready ready, Epi epi, DmaFn dma,
                                           Epi2 epi2 = Epi2{}, Mid mid = Mid{}) {
+  if constexpr (RF == 1) {          // one stationary set: the split order (what follows is the RF = 2 order)
+    tile_step_split<NKS, ND, OFF_CUR, OFF_PRV, NDMA>(ra, ta, frag, accs, out, ready, epi, dma, mid);
+    return;
+  }
   using T = Tile<NKS>;
   constexpr int PA = NKS < 4 ? NKS : 4;
   constexpr int PT = ND < 2 ? ND : 2;
@@ -545,16 +663,27 @@ __device__ __forceinline__ void tile_step(const RowAddr<NKS>& ra, const TrAddr<N
   float even = 0.f;
   auto issue_a = [&](auto ks_c) {
     constexpr int ks = decltype(ks_c)::value;
+#ifdef EXP_NOLDS   // experiment: no LDS traffic from the tile step (values are garbage; timing only)
+    a[ks % (PA + 1)] = exp_mov4(ra.a[ks & 7]);
+#else
     a[ks % (PA + 1)] = ds_read_b128_asm<OFF_CUR + 256 * (ks >> 3)>(ra.a[ks & 7]);
+#endif
   };
   auto issue_t = [&](auto dc_c) {
     constexpr int dc = decltype(dc_c)::value;
     constexpr int imm = OFF_PRV + 256 * (dc >> 2), s1 = 16 * T::ROW_BYTES;
     u32x2* q = r[dc % (PT + 1)];
+#ifdef EXP_NOLDS
+    q[0] = exp_mov2(ta.t[0][dc & 3]);
+    q[1] = exp_mov2(ta.t[1][dc & 3]);
+    q[2] = exp_mov2(ta.t[0][dc & 3]);
+    q[3] = exp_mov2(ta.t[1][dc & 3]);
+#else
     q[0] = ds_read_tr_asm<imm>(ta.t[0][dc & 3]);
     q[1] = ds_read_tr_asm<imm>(ta.t[1][dc & 3]);
     q[2] = ds_read_tr_asm<imm + s1>(ta.t[0][dc & 3]);
     q[3] = ds_read_tr_asm<imm + s1>(ta.t[1][dc & 3]);
+#endif
   };
   static_for<PA>(issue_a);
   ready(std::integral_constant<int, PA>{});

@@ -569,31 +569,38 @@ def _nce_fwd_shared(sv, q_rows, p_rows, negs, logit_scale, thres, want_logs, buc
     st = _stream()
     # (1) the real false-negative bit table, per target row
     fix_words, fix_any, slot_of_row = _fix_bits_tables(p_rows, negs, n_neg, D, G, thres, p_row_mask)
-    # (2) the fused streaming forward over the ROWS, suppression off (an all-zero bit table that is never written); its
-    #     positive is the target of the row's first token, so the log counters of offset-0 tokens come out of this launch
-    zkey = (G, n_tiles, n_p_rows, str(dev))
-    if zkey not in _ZERO_FIX:         # grow-only: a captured hipGraph of the step keeps reading the entry of its shape
-        _ZERO_FIX[zkey] = (torch.zeros(G, n_tiles, rp_pad, dtype=torch.int32, device=dev),
-                           torch.zeros(G, rp_pad, dtype=torch.int32, device=dev), torch.zeros(G, dtype=torch.int32, device=dev),
-                           torch.zeros(G, n_p_rows, dtype=torch.int32, device=dev))
-    z_words, z_list, z_n, z_slot = _ZERO_FIX[zkey]
+    # (2) the fused streaming forward over the ROWS with NOTHING suppressed (mhr_nce_fwd's plain form: no bit table, no
+    #     suppression words, no normalised-target rows written); its positive is the target of the row's first token, so the
+    #     log counters of offset-0 tokens come out of this launch.  Pools that are not whole 32-negative tiles take the
+    #     general form with an all-zero bit table that is never written.
+    plain = n_neg % 32 == 0
     r_p = torch.gather(p_idx, 1, r_first.long().clamp_(max=cap - 1)).contiguous()
     z = zeros_many(dev, ((G, row_cap), torch.float32), ((G, row_cap), torch.int32), ((G, row_cap), torch.int32),
                    ((G, cap), torch.int32), ((G, cap), torch.int32))
     sum_row = z[0]
     nv_row, rk_row = (z[1], z[2]) if want_logs else (None, None)
     qn_row = torch.empty(G, row_cap, D, dtype=torch.bfloat16, device=dev)
-    pn_row = torch.empty(G, row_cap, D, dtype=torch.bfloat16, device=dev)
-    supp_row = torch.empty(G, n_tiles, row_cap, dtype=torch.int32, device=dev)
     q_inv_row = torch.empty(G, row_cap, dtype=torch.float32, device=dev)
     p_inv_row = torch.empty(G, row_cap, dtype=torch.float32, device=dev)
     s_pos_row = torch.empty(G, row_cap, dtype=torch.float32, device=dev)
     u_row = torch.empty(G, row_cap, D, dtype=torch.float32, device=dev)
+    if plain:
+        pn_row = supp_row = None
+        fix_args = (0, 0, 0, 0)
+    else:
+        zkey = (G, n_tiles, n_p_rows, str(dev))
+        if zkey not in _ZERO_FIX:         # grow-only: a captured hipGraph of the step keeps reading the entry of its shape
+            _ZERO_FIX[zkey] = (torch.zeros(G, n_tiles, rp_pad, dtype=torch.int32, device=dev),
+                               torch.zeros(G, rp_pad, dtype=torch.int32, device=dev), torch.zeros(G, dtype=torch.int32, device=dev),
+                               torch.zeros(G, n_p_rows, dtype=torch.int32, device=dev))
+        fix_args = tuple(t.data_ptr() for t in _ZERO_FIX[zkey])
+        pn_row = torch.empty(G, row_cap, D, dtype=torch.bfloat16, device=dev)
+        supp_row = torch.empty(G, n_tiles, row_cap, dtype=torch.int32, device=dev)
     _timed_call("mhr_nce_fwd", q_rows.data_ptr(), r_q.data_ptr(), p_rows.data_ptr(), r_p.data_ptr(), _dt(q_rows),
                 negs.data_ptr(), n_neg, D, G, n_row.data_ptr(), row_cap, logit_scale.data_ptr(), float(thres),
-                sum_row.data_ptr(), _ptr(nv_row), _ptr(rk_row), qn_row.data_ptr(), pn_row.data_ptr(), supp_row.data_ptr(),
+                sum_row.data_ptr(), _ptr(nv_row), _ptr(rk_row), qn_row.data_ptr(), _ptr(pn_row), _ptr(supp_row),
                 q_inv_row.data_ptr(), p_inv_row.data_ptr(), s_pos_row.data_ptr(), int(log_group), u_row.data_ptr(), n_p_rows,
-                z_words.data_ptr(), z_list.data_ptr(), z_n.data_ptr(), z_slot.data_ptr(), st)
+                *fix_args, st)
     # (3) per token: s+, sums and counters with the token's own suppressed negatives taken out.  The normalised target is a
     #     property of the TARGET ROW (shared by every token and group that points at it): one l2norm pass over p_rows
     pn_rows, p_norm = l2norm_rows(p_rows.contiguous(), torch.bfloat16, want_norms=True)
@@ -785,7 +792,7 @@ def nce_bwd(sv, w, logit_scale, q_idx, p_idx, dq_rows, dp_rows, d_negs=None, d_l
                 lib.call("mhr_nce_row_lw", lw_tok.data_ptr(), sv.row_first.data_ptr(), sv.n_row_dev.data_ptr(), G, cap, sv.row_cap,
                          lw_row.data_ptr(), st)
         if want_negs:
-            _timed_call("mhr_nce_bwd_negs", sv.qn.data_ptr(), sv.negs.data_ptr(), sv.supp.data_ptr(), sv.n_neg, D, G,
+            _timed_call("mhr_nce_bwd_negs", sv.qn.data_ptr(), sv.negs.data_ptr(), _ptr(sv.supp), sv.n_neg, D, G,
                         sv.n_row_dev.data_ptr(), sv.row_cap, logit_scale.data_ptr(), lw_row.data_ptr(), d_negs.data_ptr(), st)
         return d_negs, d_logit_scale
     lw = torch.empty(G, cap, dtype=torch.float32, device=dev)     # lse log2e - log2 w: written by bwd_tokens, read by bwd_negs

@@ -1,22 +1,23 @@
 """In-kernel phase timing of the sampled-softmax backward (s_memtime stamps, cdna guide section 7).
 
-    python tools/stamp_nce.py build     # here (no GPU): hipcc -DMHR_STAMP csrc/*.hip -> tools/_stamp/libmhr_hip.so
+    python tools/stamp_nce.py build     # here (no GPU): hipcc -DMHR_STAMP csrc/*.hip -> tools/_exp/stamp/libmhr_hip.so
     python tools/stamp_nce.py run       # on the GPU box: runs tools/nce_micro.py against that library, prints cycles/tile
 
 The product library never contains the stamps; this script swaps mhr_amd.lib.LIB_PATH before the first load.
 """
 import ctypes, glob, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-VARIANT = os.environ.get("VARIANT", "")          # e.g. VARIANT="EXP_NOEPI" adds -DEXP_NOEPI and builds into tools/_stamp_EXP_NOEPI
-OUT = os.path.join(ROOT, "tools", "_stamp" + ("_" + VARIANT.replace(" ", "_") if VARIANT else ""))
+VARIANT = os.environ.get("VARIANT", "")          # e.g. VARIANT="EXP_NOEPI" adds -DEXP_NOEPI and builds into tools/_exp/stamp_EXP_NOEPI
+OUT = os.path.join(ROOT, "tools", "_exp", "stamp" + ("_" + VARIANT.replace(" ", "_") if VARIANT else ""))
 LIB = os.path.join(OUT, "libmhr_hip.so")
 NAMES = ["vmcnt wait", "barrier", "loop top / tail", "s,f MFMAs + epilogue", "E.N (tr) MFMAs + DMA issue", "-"]
 
 if sys.argv[1] == "build":
     os.makedirs(OUT, exist_ok=True)
     srcs = sorted(glob.glob(os.path.join(ROOT, "multi-head-recommendation-with-human-priors_amd", "csrc", "*.hip")))
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DMHR_STAMP"] + ["-D" + v for v in VARIANT.split()] + ["-I", os.path.join(ROOT, "include"),
-           "-o", LIB] + srcs
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as ge
+    cmd = [ge.HIPCC] + ge.HIP_FLAGS + ["-shared", "-DMHR_STAMP"] + ["-D" + v for v in VARIANT.split()] + ["-I", os.path.join(ROOT, "include"), "-o", LIB] + srcs
     subprocess.check_call(cmd)
     print("built", LIB)
 else:

@@ -1,0 +1,28 @@
+"""Build / run an experiment variant of the HIP library (extra -D flags), without touching the product library.
+
+    python tools/variant.py build "EXP_NOSREAD EXP_NOTR"          # here: hipcc ... -DEXP_NOSREAD -DEXP_NOTR -> tools/_exp/<name>/libmhr_hip.so
+    python tools/variant.py run   "EXP_NOSREAD EXP_NOTR" tools/nce_micro.py   # on the GPU box: the script runs against that library
+"""
+import glob
+import os
+import runpy
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+defs = sys.argv[2].split()
+OUT = os.path.join(ROOT, "tools", "_exp", "_".join(defs) or "base")
+LIB = os.path.join(OUT, "libmhr_hip.so")
+if sys.argv[1] == "build":
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as ge
+    os.makedirs(OUT, exist_ok=True)
+    srcs = sorted(glob.glob(os.path.join(ROOT, "multi-head-recommendation-with-human-priors_amd", "csrc", "*.hip")))
+    subprocess.check_call([ge.HIPCC] + ge.HIP_FLAGS + ["-shared"] + ["-D" + d for d in defs] + ["-I", os.path.join(ROOT, "include"), "-o", LIB] + srcs)
+    print("built", LIB)
+else:
+    sys.path.insert(0, ROOT)
+    import mhr_amd.lib as L
+    L.LIB_PATH = LIB
+    sys.argv = sys.argv[3:]
+    runpy.run_path(sys.argv[0], run_name="__main__")
