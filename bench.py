@@ -389,21 +389,31 @@ def main():
         batches = leg["batches"]
         for name, (launches, mean_ms, total_ms) in sorted(prof.items(), key=lambda kv: -kv[1][2]):
             if name in ("mhr_nce_fwd", "mhr_nce_bwd_negs"):
-                # algorithmic flops per launch: ONE launch serves all groups (prior categories): sum over groups of live
-                # tokens x negatives x D.  Fused forward: neg logits + false-negative logits + the token-side gradient product
-                # = 3 x 2 N_tok N_neg D (the reference's per-token formulation); negative-side backward: dN only
+                # ONE launch serves all groups (prior categories).  The P prediction offsets of a position share one query
+                # row (reference hstu.py:682-690: head c's embedding at (b, l) is the query of tokens (b, l, 0..P-1)), so the
+                # products against the negative pool are per DISTINCT ROW: algorithmic flop per launch = forward 2 products
+                # (logits s, token-side gradient numerator U) x 2 rows N_neg D, negative-side backward 1 product (dN) - its
+                # recomputation of s is an implementation cost, not algorithmic work.  The reference's own per-token
+                # evaluation (3 x 2 N_tok N_neg D forward) is reported beside it; most of it is repeats.
                 items, _, mask, tags = batches[-1]
                 idx = torch.arange(L, device=dev)[None, :] + 1 + torch.arange(P, device=dev)[:, None]
                 mb = mask.bool()
                 valid = mb[:, None, :L] & mb[:, idx]
                 if cfg["loss"] == "prior":
-                    n_tok = float((valid[..., None] & tags[:, idx].bool()).sum())
+                    live = valid[..., None] & tags[:, idx].bool()                          # [B, P, L, C]
                 else:
-                    n_tok = float(valid.sum())
+                    live = valid[..., None]
+                n_tok, n_row = float(live.sum()), float(live.any(dim=1).sum())
+                shared = os.environ.get("MHR_NCE_SHARE_ROWS", "1") != "0" and P > 1
+                units = n_row if shared else n_tok
                 n_neg = world * B * data.n_neg(B)
-                flops = (6.0 if name == "mhr_nce_fwd" else 2.0) * n_tok * n_neg * D
-                r = _roof(name, flops, None, mean_ms, {"launches_per_step": launches / es, "tokens_per_launch": n_tok,
-                                                      "negatives_per_group": n_neg})
+                fwd = name == "mhr_nce_fwd"
+                flops = (4.0 if fwd else 2.0) * units * n_neg * D
+                r = _roof(name, flops, None, mean_ms,
+                          {"launches_per_step": launches / es, "tokens_per_launch": n_tok, "distinct_query_rows_per_launch": n_row,
+                           "row_sharing": shared, "negatives_per_group": n_neg,
+                           "executed_flops_per_launch": 4.0 * units * n_neg * D,
+                           "reference_per_token_formulation_flops": (6.0 if fwd else 2.0) * n_tok * n_neg * D})
             elif name in ("mhr_hstu_attn_fwd", "mhr_hstu_attn_bwd"):
                 # one launch = one layer over the B sequences.  Algorithmic work: forward 4 L^2 D flop per
                 # (sequence, layer), backward twice that; algorithmic bytes 4 L D 2 B forward (q, k, v in, out),

@@ -265,9 +265,11 @@ int mhr_row_maps(const int32_t* q_idx, const int32_t* n_tok_dev, int n_groups, i
 
 /* Training-time log counters of one group (hstu.py:621-629): over the live tokens of prediction offset 0 (o_idx == 0) of
  * `group`, out[0] = mean n_valid ("nce_samples"), out[1 + i] = mean(rank < ks_host[i]) ("nce_top{k}_acc"), i < n_k <= 5.
- * n_valid / rank / o_idx [n_groups, tok_cap] int32; ks_host is HOST memory (read at launch).  out [1 + n_k] f32. */
+ * n_valid / rank / o_idx [n_groups, tok_cap] int32; ks_host is HOST memory (read at launch).  out [1 + n_k] f32.
+ * scratch8: 8 x uint64 on the device, all zero at the first launch; every launch leaves it zero again (the workgroups'
+ * integer partial sums and a completion ticket live there). */
 int mhr_nce_log_counters(const int32_t* n_valid, const int32_t* rank, const int32_t* o_idx, const int32_t* n_tok_dev,
-                         int group, int tok_cap, const int32_t* ks_host, int n_k, float* out, void* stream);
+                         int group, int tok_cap, const int32_t* ks_host, int n_k, uint64_t* scratch8, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Sampled softmax with false-negative suppression (model/IDNet/hstu.py:600-619 + F.cross_entropy 697/833).

@@ -26,9 +26,9 @@ namespace {
 
 using namespace attn;
 
-#ifdef MHR_STAMP   // in-kernel phase timing, only in the builds tools/stamp_nce.py makes
+#ifdef MHR_STAMP   // in-kernel phase timing, only in the builds tools/stamp_nce.py makes (-DASTAMP_FWD: the forward's stamps)
 __device__ unsigned long long g_attn_stamps[16];
-#define ASTAMP(k)                                                                       \
+#define ASTAMP_BODY(k)                                                                  \
   {                                                                                     \
     __builtin_amdgcn_sched_barrier(0);                                                  \
     unsigned long long t_;                                                              \
@@ -36,8 +36,16 @@ __device__ unsigned long long g_attn_stamps[16];
     __builtin_amdgcn_sched_barrier(0);                                                  \
     if (blockIdx.x == 37 && threadIdx.x == 0 && (k) < 16) g_attn_stamps[k] = t_;        \
   }
+#ifdef ASTAMP_FWD
+#define ASTAMP(k)
+#define FSTAMP(k) ASTAMP_BODY(k)
+#else
+#define ASTAMP(k) ASTAMP_BODY(k)
+#define FSTAMP(k)
+#endif
 #else
 #define ASTAMP(k)
+#define FSTAMP(k)
 #endif
 
 
@@ -87,10 +95,12 @@ __global__ __launch_bounds__(256) void hstu_attn_fwd_kernel(const bf16_t* __rest
   bf16_t* av = act_v ? act_v + row0 * act_stride + head * hd : nullptr;
   const bool do_silu = apply_silu != 0;
 
+  FSTAMP(0)
   stage_tiles<NKS>(Kt, kp, stride, L, Lp, hd, do_silu, ak, act_stride);
   stage_tiles<NKS>(Vt, vp, stride, L, Lp, hd, do_silu, av, act_stride);
   build_valid_mask(vmask, key_valid + row0, L, nb);
   __syncthreads();
+  FSTAMP(1)
 
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, half = lane >> 5;
   sg::LaneAddr<NKS> la;
@@ -112,6 +122,7 @@ __global__ __launch_bounds__(256) void hstu_attn_fwd_kernel(const bf16_t* __rest
     f32x16 o[ND];
 #pragma unroll
     for (int dc = 0; dc < ND; ++dc) o[dc] = zero16();
+    FSTAMP(2 + 3 * it)
 
     for (int kb = 0; kb <= qb; ++kb) {
       const uint32_t vm = vmask[kb];
@@ -142,6 +153,7 @@ __global__ __launch_bounds__(256) void hstu_attn_fwd_kernel(const bf16_t* __rest
         o[dc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(la.read_tr(vt, dc, 1), p1, o[dc], 0, 0, 0);
       }
     }
+    FSTAMP(3 + 3 * it)
     if (qrow < L) {
       bf16_t* orow = out + (row0 + qrow) * out_stride + head * hd;
 #pragma unroll
@@ -156,6 +168,7 @@ __global__ __launch_bounds__(256) void hstu_attn_fwd_kernel(const bf16_t* __rest
           }
         }
     }
+    FSTAMP(4 + 3 * it)
   }
 }
 

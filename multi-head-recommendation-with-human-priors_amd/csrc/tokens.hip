@@ -202,48 +202,65 @@ __global__ __launch_bounds__(256) void row_scatter_kernel(const int32_t* __restr
 
 // Training-time log counters of one group (reference hstu.py:621-629: nce_samples and top-k accuracy over the tokens of
 // prediction offset 0): out[0] = mean n_valid, out[1 + i] = mean(rank < ks[i]) over the live tokens with offset 0.
-// One workgroup; replaces about twenty-five small torch kernels (mask, casts, concatenation, GEMV, divisions) per step.
+// Replaces about twenty-five small torch kernels (mask, casts, concatenation, GEMV, divisions) per step.  The workgroups add
+// their integer partial sums into `scratch` (8 x uint64, all zero between launches); the last one to arrive - a ticket in
+// scratch[7] - divides and zeroes the scratch again.  Integer sums: the result does not depend on the arrival order.
+// (As ONE workgroup striding over the ~67 k tokens of a cfg1 group this was 141 us of dependent-load latency per step.)
 __global__ __launch_bounds__(256) void nce_log_counters_kernel(const int32_t* __restrict__ n_valid, const int32_t* __restrict__ rank,
                                                                const int32_t* __restrict__ o_idx, const int32_t* __restrict__ n_tok_dev,
                                                                int group, int tok_cap, int k0, int k1, int k2, int k3, int k4, int n_k,
-                                                               float* __restrict__ out) {
-  __shared__ float red[4][8];
+                                                               unsigned long long* __restrict__ scratch, float* __restrict__ out) {
+  __shared__ unsigned long long red[4][7];
+  __shared__ bool last;
   const int64_t base = (int64_t)group * tok_cap;
   const int nt = min(n_tok_dev[group], tok_cap);
   const int ks[5] = {k0, k1, k2, k3, k4};
-  float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};        // count, sum n_valid, hits per k
-  for (int t = threadIdx.x; t < nt; t += blockDim.x) {
+  unsigned long long acc[7] = {0, 0, 0, 0, 0, 0, 0};          // count, sum n_valid, hits per k
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < nt; t += gridDim.x * blockDim.x) {
     if (o_idx[base + t] != 0) continue;
-    acc[0] += 1.f;
-    acc[1] += (float)n_valid[base + t];
+    acc[0] += 1;
+    acc[1] += (unsigned long long)max(n_valid[base + t], 0);
     const int r = rank[base + t];
 #pragma unroll
-    for (int i = 0; i < 5; ++i) acc[2 + i] += (i < n_k && r < ks[i]) ? 1.f : 0.f;
+    for (int i = 0; i < 5; ++i) acc[2 + i] += (i < n_k && r < ks[i]) ? 1 : 0;
   }
 #pragma unroll
-  for (int i = 0; i < 7; ++i) acc[i] = wave_sum(acc[i]);
+  for (int i = 0; i < 7; ++i) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc[i] += __shfl_xor(acc[i], o, 64);
+  }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (lane == 0)
 #pragma unroll
     for (int i = 0; i < 7; ++i) red[wave][i] = acc[i];
   __syncthreads();
+  if (threadIdx.x < 7) atomicAdd(scratch + threadIdx.x, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) last = atomicAdd(scratch + 7, 1ull) == (unsigned long long)gridDim.x - 1;
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
   if (threadIdx.x < 1 + n_k) {
-    const int i = threadIdx.x + 1;
-    const float cnt = fmaxf(red[0][0] + red[1][0] + red[2][0] + red[3][0], 1.0f);
-    out[threadIdx.x] = (red[0][i] + red[1][i] + red[2][i] + red[3][i]) / cnt;
+    const unsigned long long cnt = atomicAdd(scratch + 0, 0ull), v = atomicAdd(scratch + 1 + threadIdx.x, 0ull);   // device-scope reads
+    out[threadIdx.x] = (float)((double)v / (double)(cnt > 0 ? cnt : 1));
   }
+  __syncthreads();
+  if (threadIdx.x < 8) scratch[threadIdx.x] = 0;              // ready for the next launch
 }
 
 }  // namespace
 
 extern "C" int mhr_nce_log_counters(const int32_t* n_valid, const int32_t* rank, const int32_t* o_idx, const int32_t* n_tok_dev,
-                                    int group, int tok_cap, const int32_t* ks_host, int n_k, float* out, void* stream) {
-  MHR_REQUIRE(n_valid && rank && o_idx && n_tok_dev && out && ks_host, "nce_log_counters: null pointer");
+                                    int group, int tok_cap, const int32_t* ks_host, int n_k, uint64_t* scratch8, float* out,
+                                    void* stream) {
+  MHR_REQUIRE(n_valid && rank && o_idx && n_tok_dev && out && ks_host && scratch8, "nce_log_counters: null pointer");
   MHR_REQUIRE(group >= 0 && tok_cap > 0 && n_k >= 0 && n_k <= 5, "nce_log_counters: bad sizes (n_k=%d)", n_k);
   int k[5] = {0, 0, 0, 0, 0};
   for (int i = 0; i < n_k; ++i) k[i] = ks_host[i];
-  hipLaunchKernelGGL(nce_log_counters_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, n_valid, rank, o_idx, n_tok_dev, group,
-                     tok_cap, k[0], k[1], k[2], k[3], k[4], n_k, out);
+  const int blocks = (int)((tok_cap + 1023) / 1024 < 128 ? (tok_cap + 1023) / 1024 : 128);
+  hipLaunchKernelGGL(nce_log_counters_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n_valid, rank, o_idx, n_tok_dev, group,
+                     tok_cap, k[0], k[1], k[2], k[3], k[4], n_k, (unsigned long long*)scratch8, out);
   MHR_CHECK_LAUNCH("nce_log_counters");
   return MHR_OK;
 }

@@ -482,9 +482,15 @@ def nce_log_counters(n_valid, rank, o_idx, n_tok_dev, group, ks):
         assert t.stride(0) == cap and t.stride(1) == 1 and t.dtype == torch.int32
     out = torch.empty(1 + len(ks), dtype=torch.float32, device=o_idx.device)
     ks_arr = (ctypes.c_int32 * max(1, len(ks)))(*ks)
+    key = str(o_idx.device)
+    if key not in _COUNTER_SCRATCH:       # self-cleaning (the kernel zeroes it again), one per device, never freed: graph-safe
+        _COUNTER_SCRATCH[key] = torch.zeros(8, dtype=torch.int64, device=o_idx.device)
     lib.call("mhr_nce_log_counters", n_valid.data_ptr(), rank.data_ptr(), o_idx.data_ptr(), n_tok_dev.data_ptr(), int(group), cap,
-             ctypes.addressof(ks_arr), len(ks), out.data_ptr(), _stream())
+             ctypes.addressof(ks_arr), len(ks), _COUNTER_SCRATCH[key].data_ptr(), out.data_ptr(), _stream())
     return out
+
+
+_COUNTER_SCRATCH = {}
 
 
 STREAM_DIMS = (16, 32, 64, 128, 256)      # feature dims of the register-stationary streaming kernels

@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import mhr_amd.lib as L_
 if os.environ.get("STAMP"):
-    L_.LIB_PATH = os.path.join(ROOT, "tools", "_stamp", "libmhr_hip.so")
+    L_.LIB_PATH = os.path.join(ROOT, "tools", "_exp", os.environ["STAMP"], "libmhr_hip.so")      # STAMP = variant dir, e.g. stamp or stamp_ASTAMP_FWD
 from mhr_amd import ops
 B, L, H, hd = int(os.environ.get("B", 128)), 200, 8, 32
 D = H * hd
@@ -29,4 +29,6 @@ if os.environ.get("STAMP"):
     assert dll.mhr_debug_read_attn_stamps(buf) == 0
     names = ["start", "staged Q,dO", "A0 frags", "A0 pairs", "A0 epilogue", "A1 frags", "A1 pairs", "A1 epilogue", "sync", "restaged K,V",
              "B0 frags", "B0 pairs", "B0 epilogue", "B1 frags", "B1 pairs", "B1 epilogue"]
-    for i in range(1, 16): print(f"  {names[i]:20s} +{buf[i]-buf[i-1]:8d} cycles")
+    if "FWD" in os.environ["STAMP"]:
+        names = ["start", "staged K,V", "0 q frags", "0 pairs", "0 store", "1 q frags", "1 pairs", "1 store"]
+    for i in range(1, len(names)): print(f"  {names[i]:20s} +{buf[i]-buf[i-1]:8d} cycles")
