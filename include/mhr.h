@@ -361,7 +361,9 @@ int mhr_nce_bwd_negs(const void* qn, const void* negs, const uint32_t* supp, int
  *   tok2row [n_groups, tok_cap] int32: row of token t;  row arrays are [n_groups, row_cap(, dim)], token arrays
  *   [n_groups, tok_cap(, dim)];  row_first [n_groups, row_cap] int32: first token of row r (entry n_row = n_tok).
  * mhr_nce_fix_bits: the false-negative bit table of mhr_nce_fwd as a launch of its own (same arguments), plus
- *   fix_any [n_groups, round_up(n_p_rows, 256)] int32 (caller zeroes): != 0 where a target row has any suppressed negative.
+ *   fix_any [n_groups, round_up(n_p_rows, 256)] int32 (caller zeroes): != 0 where a target row has any suppressed negative;
+ *   bit k = a suppressed negative in the 32-negative tiles [k << s, (k + 1) << s), s the smallest shift with ceil(n_tiles / 2^s) <= 32
+ *   (the token kernels read only the flagged groups of the row's column of the bit table).
  * The normalised targets are a property of the TARGET ROW: pn_rows [n_p_rows, dim] bf16 = bf16(p_rows / |p_rows|) and p_inv
  *   [n_p_rows] f32 (mhr_l2norm_rows, once per step) are shared by all tokens and groups; `pn` / `p_inv` below are these tables.
  * mhr_nce_shared_fwd_tokens: per token: s_pos = qn_row . pn_rows[p_idx],

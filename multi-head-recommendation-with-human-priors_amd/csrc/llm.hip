@@ -143,7 +143,16 @@ __global__ __launch_bounds__(256) void sum_rows_into_kernel(const bf16_t* __rest
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (c0 < cols) {
     int64_t r = r0 + ty;
-    for (; r + 24 < r1; r += 32) {                       // four independent 16-byte loads in flight per thread
+    for (; r + 56 < r1; r += 64) {                       // eight independent 16-byte loads in flight per thread
+      bf16x8 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const bf16x8*>(x + (r + 8 * u) * cols + c0);
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        acc[e] += (((float)v[0][e] + (float)v[1][e]) + ((float)v[2][e] + (float)v[3][e])) +
+                  (((float)v[4][e] + (float)v[5][e]) + ((float)v[6][e] + (float)v[7][e]));
+    }
+    for (; r + 24 < r1; r += 32) {
       const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(x + r * cols + c0);
       const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(x + (r + 8) * cols + c0);
       const bf16x8 v2 = *reinterpret_cast<const bf16x8*>(x + (r + 16) * cols + c0);

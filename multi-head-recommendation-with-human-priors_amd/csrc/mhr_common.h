@@ -118,3 +118,12 @@ __device__ __forceinline__ float mhr_uniform(uint64_t seed, uint64_t idx) {
   x ^= x >> 15;
   return (float)(x >> 8) * (1.0f / 16777216.0f);
 }
+
+// Any-hit summary of the false-negative bit table (mhr_nce_fix_bits: fix_any[row]): bit k = some negative of the tiles
+// [k << shift, (k + 1) << shift) is suppressed for the row.  shift makes the n_tiles 32-negative tiles fit 32 groups.
+__host__ __device__ inline int fix_group_shift(int n_tiles) {
+  int sh = 0;
+  while (((n_tiles + (1 << sh) - 1) >> sh) > 32) ++sh;
+  return sh;
+}
+

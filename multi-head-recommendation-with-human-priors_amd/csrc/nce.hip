@@ -537,6 +537,7 @@ __global__ __launch_bounds__(256, 2) void nce_fix_bits_kernel(const IT* __restri
   negs += (int64_t)blockIdx.z * ((n_neg + 31) & ~31) * T::DIM;
   fixw += (int64_t)blockIdx.z * n_tiles * n_rows_pad;
   if (any_out) any_out += (int64_t)blockIdx.z * n_rows_pad;
+  const int any_shift = fix_group_shift((n_neg + 31) >> 5);
   const int t0 = blockIdx.y * tiles_per_slice, t1 = min(n_tiles, t0 + tiles_per_slice);
   if (t0 >= t1) return;
   // with a row list only the rows some token of this group points at are tested (slot j of the list = column j of the
@@ -599,7 +600,7 @@ __global__ __launch_bounds__(256, 2) void nce_fix_bits_kernel(const IT* __restri
       uint32_t w = b << (4 * half);
       w |= __shfl_xor(w, 32, 64);
       if (half == 0) fixw[(int64_t)t * n_rows_pad + row[f]] = w;       // rows >= n_rows are zero rows: w = 0, inside the padding
-      if (half == 0 && w != 0u && any_out) atomicOr(any_out + row[f], 1);   // rare: lets token kernels skip rows without hits
+      if (half == 0 && w != 0u && any_out) atomicOr(reinterpret_cast<unsigned int*>(any_out + row[f]), 1u << (t >> any_shift));   // rare: token kernels skip rows without hits, and scan only the flagged tile groups
     }
   });
   sg::wait_vmcnt<0>();

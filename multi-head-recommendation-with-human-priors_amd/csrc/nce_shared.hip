@@ -36,22 +36,30 @@ __device__ __forceinline__ float clamp_scale(const float* logit_scale_dev) {
 
 // Visits the suppressed negatives of one target row (wave-uniform control flow): f(j) for every set bit of the row's
 // column of the bit table.  fixw: [n_tiles, n_rows_pad] words of this group, bit b of word [tile, slot] = negative 32 tile + b.
+// `groups` = fix_any[slot] (wave-uniform): only the flagged tile groups are read - typically 8 words of the 256 a cfg1 row
+// has (its column of the table is strided by the row count: every word is a cache line of its own).
 template <typename F>
 __device__ __forceinline__ void for_each_hit(const uint32_t* __restrict__ fixw, int n_tiles, int n_rows_pad, int slot, int n_neg,
-                                             int lane, F&& f) {
-  for (int w0 = 0; w0 < n_tiles; w0 += 64) {
-    const int tile = w0 + lane;
-    const uint32_t word = tile < n_tiles ? fixw[(int64_t)tile * n_rows_pad + slot] : 0u;
-    uint64_t m = __ballot(word != 0u);
-    while (m) {
-      const int l = __builtin_ctzll(m);
-      m &= m - 1;
-      uint32_t wv = (uint32_t)__builtin_amdgcn_readlane((int)word, l);
-      while (wv) {
-        const int b = __builtin_ctz(wv);
-        wv &= wv - 1;
-        const int j = (w0 + l) * 32 + b;
-        if (j < n_neg) f(j);
+                                             int lane, uint32_t groups, F&& f) {
+  const int sh = fix_group_shift(n_tiles), per = 1 << sh;
+  while (groups) {
+    const int k = __builtin_ctz(groups);
+    groups &= groups - 1;
+    const int g0 = k << sh, g1 = min(g0 + per, n_tiles);
+    for (int w0 = g0; w0 < g1; w0 += 64) {
+      const int tile = w0 + lane;
+      const uint32_t word = tile < g1 ? fixw[(int64_t)tile * n_rows_pad + slot] : 0u;
+      uint64_t m = __ballot(word != 0u);
+      while (m) {
+        const int l = __builtin_ctzll(m);
+        m &= m - 1;
+        uint32_t wv = (uint32_t)__builtin_amdgcn_readlane((int)word, l);
+        while (wv) {
+          const int b = __builtin_ctz(wv);
+          wv &= wv - 1;
+          const int j = (w0 + l) * 32 + b;
+          if (j < n_neg) f(j);
+        }
       }
     }
   }
@@ -85,10 +93,15 @@ __global__ __launch_bounds__(256) void shared_tok_fwd_kernel(
   const int wave_g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), n_waves = gridDim.x * (blockDim.x >> 6);
   const float scale = clamp_scale(logit_scale_dev);
   const float c1 = scale * LOG2E;
-  constexpr int TB = 4;                               // tokens in flight per wave pass (independent row loads)
+  // lane owns the 4 consecutive columns 4 lane .. 4 lane + 3: one 8-byte load per row and lane (a 512-byte row is one
+  // wave-instruction); TB tokens in flight, and the dependent index loads (target row -> table slot -> any-hit flag) of
+  // all of them are issued before the first row is consumed
+  constexpr int TB = 8;
+  const int d0 = lane * 4;
+  const bool in_dim = d0 < dim;
   for (int t0 = wave_g * TB; t0 < n_tok; t0 += n_waves * TB) {
-    int rr[TB], prr[TB];
-    float pv[TB][NC], qv[TB][NC];
+    int rr[TB], prr[TB], slot[TB], any[TB];
+    bf16x4 pv[TB], qv[TB];
 #pragma unroll
     for (int b = 0; b < TB; ++b) {
       const int tk = min(t0 + b, n_tok - 1);
@@ -97,35 +110,34 @@ __global__ __launch_bounds__(256) void shared_tok_fwd_kernel(
     }
 #pragma unroll
     for (int b = 0; b < TB; ++b) {
-      const bf16_t* ps = pn_rows + (int64_t)prr[b] * dim;       // the target's normalised row: a property of the target row, shared by its tokens
-      const bf16_t* qs = qn_row + (int64_t)rr[b] * dim;
-#pragma unroll
-      for (int c = 0; c < NC; ++c) {
-        const int d = c * 64 + lane;
-        pv[b][c] = d < dim ? (float)ps[d] : 0.f;
-        qv[b][c] = d < dim ? (float)qs[d] : 0.f;
-      }
+      const bf16x4 z = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+      pv[b] = in_dim ? *reinterpret_cast<const bf16x4*>(pn_rows + (int64_t)prr[b] * dim + d0) : z;   // the target's normalised row
+      qv[b] = in_dim ? *reinterpret_cast<const bf16x4*>(qn_row + (int64_t)rr[b] * dim + d0) : z;
+      slot[b] = slot_of_row ? slot_of_row[prr[b]] : prr[b];
     }
+#pragma unroll
+    for (int b = 0; b < TB; ++b) any[b] = fix_any[slot[b]];
 #pragma unroll
     for (int b = 0; b < TB; ++b) {
       const int tk = t0 + b;
       if (tk >= n_tok) break;
-      const int r = rr[b], pr = prr[b];
-      float sp = 0.f;
+      const int r = rr[b];
+      float q4[4], sp = 0.f;
 #pragma unroll
-      for (int c = 0; c < NC; ++c) sp += qv[b][c] * pv[b][c];
+      for (int e = 0; e < 4; ++e) {
+        q4[e] = (float)qv[b][e];
+        sp += q4[e] * (float)pv[b][e];
+      }
       sp = wave_sum(sp);
       float corr = 0.f;
       int hits = 0, above = 0;
-      const int slot = slot_of_row ? slot_of_row[pr] : pr;
-      if (fix_any[slot] != 0) {                                     // wave-uniform; a few percent of the tokens
-        for_each_hit(fixw, n_tiles, n_rows_pad, slot, n_neg, lane, [&](int j) {
-          const bf16_t* ns = negs + (int64_t)j * dim;
+      if (any[b] != 0) {                                            // wave-uniform; a few percent of the tokens
+        for_each_hit(fixw, n_tiles, n_rows_pad, slot[b], n_neg, lane, (uint32_t)any[b], [&](int j) {
           float s = 0.f;
+          if (in_dim) {
+            const bf16x4 nv = *reinterpret_cast<const bf16x4*>(negs + (int64_t)j * dim + d0);
 #pragma unroll
-          for (int c = 0; c < NC; ++c) {
-            const int d = c * 64 + lane;
-            s += d < dim ? qv[b][c] * (float)ns[d] : 0.f;
+            for (int e = 0; e < 4; ++e) s += q4[e] * (float)nv[e];
           }
           s = wave_sum(s);
           corr += __builtin_amdgcn_exp2f(s * c1 - c1);
@@ -221,8 +233,9 @@ __global__ __launch_bounds__(256) void shared_tok_bwd_kernel(
       // this token's suppressed negatives: out of U, and out of what the row-level negative-side kernel adds to d_negs
       float uc[NC] = {0.f, 0.f, 0.f, 0.f};
       const int slot = slot_of_row ? slot_of_row[pi] : pi;
-      if (fix_any[slot] != 0) {
-        for_each_hit(fixw, n_tiles, n_rows_pad, slot, n_neg, lane, [&](int j) {
+      const uint32_t hit_groups = (uint32_t)fix_any[slot];
+      if (hit_groups != 0) {
+        for_each_hit(fixw, n_tiles, n_rows_pad, slot, n_neg, lane, hit_groups, [&](int j) {
           const bf16_t* ns = negs + (int64_t)j * dim;
           float nv[NC];
           float s = 0.f;
@@ -332,7 +345,7 @@ __global__ __launch_bounds__(256) void shared_bwd_rows_kernel(
       const int tk = c0 + lane;
       const bool live = tk < t1;
       float wi = 0.f, sp = 0.f, ls = 0.f;
-      int slot = 0, pi = 0;
+      int slot = 0, pi = 0, hit_groups = 0;
       bool hit = false;
       if (live) {
         wi = w_bucket ? w[w_bucket[tk]] : w[tk];
@@ -340,7 +353,8 @@ __global__ __launch_bounds__(256) void shared_bwd_rows_kernel(
         ls = lse[tk];
         pi = p_idx[tk];
         slot = slot_of_row ? slot_of_row[pi] : pi;
-        hit = fix_any[slot] != 0;
+        hit_groups = fix_any[slot];
+        hit = hit_groups != 0;
       }
       const float a = live ? wi * __expf(scale - ls) : 0.f;
       const float coef = live ? wi * (__expf(scale * sp - ls) - 1.0f) : 0.f;
@@ -372,10 +386,11 @@ __global__ __launch_bounds__(256) void shared_bwd_rows_kernel(
         const int i = __builtin_ctzll(hm);
         hm &= hm - 1;
         const int slot_u = __builtin_amdgcn_readlane(slot, i);
+        const uint32_t groups_u = (uint32_t)__builtin_amdgcn_readlane(hit_groups, i);
         const float a_u = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a), i));
         const float wi_u = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wi), i));
         const float ls_u = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ls), i));
-        for_each_hit(fixw, n_tiles, n_rows_pad, slot_u, n_neg, lane, [&](int j) {
+        for_each_hit(fixw, n_tiles, n_rows_pad, slot_u, n_neg, lane, groups_u, [&](int j) {
           const bf16_t* ns = negs + (int64_t)j * dim;
           float nv[NC];
           float s = 0.f;
@@ -535,11 +550,11 @@ extern "C" int mhr_nce_shared_fwd_tokens(const void* pn_rows, int64_t n_p_rows, 
   MHR_REQUIRE(s_pos && sum_tok, "nce_shared_fwd_tokens: null output pointer");
   MHR_REQUIRE((n_valid_row != nullptr) == (n_valid_tok != nullptr) && (rank_row != nullptr) == (rank_tok != nullptr),
               "nce_shared_fwd_tokens: row / token log counters go together");
-  MHR_REQUIRE(dim > 0 && dim <= 256, "nce_shared_fwd_tokens: dim=%d unsupported (<= 256)", dim);
+  MHR_REQUIRE(dim > 0 && dim <= 256 && dim % 4 == 0, "nce_shared_fwd_tokens: dim=%d unsupported (multiple of 4, <= 256)", dim);
   MHR_REQUIRE(tok_cap > 0 && row_cap > 0 && n_neg > 0 && n_p_rows > 0 && n_groups >= 1 && n_groups <= 65535,
               "nce_shared_fwd_tokens: bad sizes");
   const int n_rows_pad = (int)((n_p_rows + 255) / 256 * 256);
-  int blocks = (tok_cap + 15) / 16;                  // 4 waves x 4 tokens
+  int blocks = (tok_cap + 31) / 32;                  // 4 waves x 8 tokens
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(shared_tok_fwd_kernel, dim3(blocks, 1, n_groups), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)pn_rows, (int)n_p_rows, p_idx, tok2row, n_tok_dev, tok_cap, row_cap, (const bf16_t*)qn_row,
