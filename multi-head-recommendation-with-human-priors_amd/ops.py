@@ -928,7 +928,7 @@ def sub_history(hist_ptr, hist_items, users_f):
 
 
 def catalog_topk(users, H, items, tag_bits, row_bits, hist_ptr, hist_items, k, cap=4096, target=None, stats=None, n_items=None,
-                 k_min=None, tau_out=None):
+                 k_min=None, tau_out=None, margin=None):
     """Exact per-row top-k over the whole catalog (value desc, index asc), rows = (user, head) pairs.
 
     k_min (default k): rows with fewer than k_min candidates are re-run exactly; with k_min < k a row may return fewer than
@@ -947,7 +947,7 @@ def catalog_topk(users, H, items, tag_bits, row_bits, hist_ptr, hist_items, k, c
     if D not in STREAM_DIMS:
         from . import wide
         return wide.catalog_topk_wide(users, H, items, N, tag_bits, row_bits, hist_ptr, hist_items, k, target=target, stats=stats,
-                                      k_min=k_min, tau_out=tau_out)
+                                      k_min=k_min, tau_out=tau_out, margin=margin)
     ninf = torch.full((n_rows,), float("-inf"), dtype=torch.float32, device=dev)
     k_min = k if k_min is None else min(k, k_min)
     if N <= cap:
@@ -1015,7 +1015,9 @@ def catalog_topk_exact(users_f32, H, items_bf, items_f32, tag_bits, row_bits, hi
     N = items_f32.shape[0] if n_items is None else int(n_items)
     dev = users_f32.device
     users_bf = users_f32.to(torch.bfloat16).contiguous()
-    k2 = min(N - 1, 1024, max(2 * k + 64, k + 256))
+    # candidates kept per row: the margin set must fit.  Wide feature dims concentrate the cosines of (near-)random embeddings
+    # around 0 (std 1 / sqrt(D)), so a 2^-7 margin below the k-th score holds several hundred items there: keep the maximum
+    k2 = min(N - 1, 1024, max(2 * k + 64, k + 256) if D <= 256 else 1024)
     if k2 <= k:
         k2 = k
     # the bf16 scorer's candidate lists (everything above a per-row threshold tau near the rank-2.5k score), the best k2 of them
@@ -1023,7 +1025,7 @@ def catalog_topk_exact(users_f32, H, items_bf, items_f32, tag_bits, row_bits, hi
     # left below the threshold) and does not fill all k2 slots
     tinfo = {}
     bv, bi = catalog_topk(users_bf, H, items_bf, tag_bits, row_bits, hist_ptr, hist_items, k2, stats=stats, n_items=N, k_min=k,
-                          tau_out=tinfo)
+                          tau_out=tinfo, margin=2 * BF16_SCORE_ERR)      # (margin: used by the wide scorer's threshold, see wide.py)
     tau = tinfo.get("tau")
     if tau is None:                   # (a scorer that does not report its threshold: nothing can be certified)
         tau = torch.full((n_rows,), float("inf"), dtype=torch.float32, device=dev)

@@ -189,7 +189,8 @@ def _exact_rows(users, H, items, n_items, tag_bits, row_bits, hist_ptr, hist_ite
     return best_v, best_i
 
 
-def _catalog_topk_mfma(users, H, items, N, tag_bits, row_bits, hist_ptr, hist_items, k, chunk, target, stats, k_min=None, tau_out=None):
+def _catalog_topk_mfma(users, H, items, N, tag_bits, row_bits, hist_ptr, hist_items, k, chunk, target, stats, k_min=None, tau_out=None,
+                       margin=None):
     """Exact per-row top-k with the hand-written wide scorer (csrc/catalog_wide.hip: LDS-tiled MFMA GEMM, threshold emit in
     the epilogue - no score block in memory, no library GEMM).  Same scheme as the register-stationary path
     (ops.catalog_topk): thresholds from two strided sample passes through the SAME kernel, one full pass, the shared exact
@@ -233,9 +234,20 @@ def _catalog_topk_mfma(users, H, items, N, tag_bits, row_bits, hist_ptr, hist_it
     _, _, kth1, _, st1 = ops.topk_select_sliced(c1, H, hist_ptr, hist_items, t1)
     # pass 2: every s2-th item above kth1 -> the t2-th largest estimates the score of rank ~target
     c2 = ops.catalog_emit_wide(users_p, n_rows, D, samples[1], N, tb, row_bits, kth1, 32, 0, s2)
-    _, _, kth2, _, st2 = ops.topk_select_sliced(c2, H, hist_ptr, hist_items, t2)
+    ov2, _, kth2, _, st2 = ops.topk_select_sliced(c2, H, hist_ptr, hist_items, t2)
     ok2 = (st2 == 0) & (st1 == 0)
     tau = torch.where(torch.isfinite(kth2) & ok2, kth2, torch.where(ok2, kth1, ninf)).contiguous()
+    if margin is not None:
+        # the caller re-ranks everything within `margin` of the k_min-th score (ops.catalog_topk_exact): the threshold must lie
+        # below that band, however many items it holds - with (near-)random embeddings at wide feature dims the cosines
+        # concentrate (std 1 / sqrt(D)) and the band holds several hundred.  The k_min-th score is estimated from the second
+        # sample (rank k_min / s2, taken two standard deviations of its rank noise further down).
+        r_k = k_min // s2 + 1
+        r_lo = min(t2 - 1, r_k + int(2.0 * r_k ** 0.5) + 1)
+        est = ov2[:, r_lo]
+        tau_m = torch.where(torch.isfinite(est) & ok2, est - margin, tau)
+        tau = torch.minimum(tau, tau_m).contiguous()
+        target = max(target, 4096)                   # list capacity for the band (candidates per row the lists can hold)
     n_sl = lib.load().mhr_catalog_wide_slices(n_rows)
     cap_s = max(32, 4 * -(-target // (4 * n_sl)) + 16)
     cand = ops.catalog_emit_wide(users_p, n_rows, D, items_p, N, tb, row_bits, tau, cap_s)
@@ -260,7 +272,7 @@ def _catalog_topk_mfma(users, H, items, N, tag_bits, row_bits, hist_ptr, hist_it
 
 
 def catalog_topk_wide(users, H, items, n_items, tag_bits, row_bits, hist_ptr, hist_items, k, chunk=ITEM_CHUNK, target=None,
-                      stats=None, k_min=None, tau_out=None):
+                      stats=None, k_min=None, tau_out=None, margin=None):
     """Exact per-row top-k over the catalog at any feature dim.  Thresholds from a strided sample of the catalog; the
     full pass scores item chunks with the library GEMM and emits the few scores above the threshold (csrc/wide.hip) into
     candidate lists; the exact select of the streaming path (topk_select_sliced) picks the top k with the history filter.
@@ -270,7 +282,8 @@ def catalog_topk_wide(users, H, items, n_items, tag_bits, row_bits, hist_ptr, hi
     N = int(n_items)
     dev = users.device
     if D % 64 == 0 and users.dtype == torch.bfloat16 and items.dtype == torch.bfloat16:
-        return _catalog_topk_mfma(users, H, items, N, tag_bits, row_bits, hist_ptr, hist_items, k, chunk, target, stats, k_min, tau_out)
+        return _catalog_topk_mfma(users, H, items, N, tag_bits, row_bits, hist_ptr, hist_items, k, chunk, target, stats, k_min, tau_out,
+                                  margin)
     if N <= max(4 * k, 2048) or N <= chunk // 8:
         return _exact_rows(users, H, items, N, tag_bits, row_bits, hist_ptr, hist_items, k, chunk)
     st = _stream()

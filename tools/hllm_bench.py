@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--mode", default="train", choices=["train", "eval"])
+    ap.add_argument("--profile", action="store_true", help="after the timed steps: torch.profiler over 2 steps, top device kernels on stderr")
     args = ap.parse_args()
     import torch
     import REC  # noqa: F401
@@ -99,6 +100,15 @@ def main():
     el = time.perf_counter() - t0
     prof = ops.profile_summary()
     ops.PROFILE = None
+    if args.profile:
+        from torch.profiler import profile, ProfilerActivity
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as tp:
+            for i in range(2):
+                step(i)
+            torch.cuda.synchronize()
+        rows = sorted(((getattr(e, "self_device_time_total", 0) / 2, e.count / 2, e.key) for e in tp.key_averages()), reverse=True)
+        for dt, n, key in rows[:18]:
+            print(f"{dt:10.1f} us/step {n:7.1f} calls  {key[:120]}", file=sys.stderr)
     D, F, nh, nkv = args.hidden, args.ffn, args.heads, args.kv_heads
     hd = D // nh
     per_tok = args.layers * 2 * (D * (nh + 2 * nkv) * hd + D * D + 3 * D * F)          # GEMM flops per token, forward
