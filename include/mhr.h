@@ -42,6 +42,11 @@ int mhr_abi_version(void);
  * Item embedding.
  * ---------------------------------------------------------------------------------------- */
 
+/* Ids outside [0, n_rows) that the gather kernels met since the last reset (they clamp and count where nn.Embedding
+ * raises: a kernel cannot).  SYNCHRONISES (device-to-host copy of one word): call it where the host waits anyway.
+ * host_count: HOST memory.  reset != 0 clears the counter. */
+int mhr_bad_id_count(int64_t* host_count, int reset);
+
 /* out[r,:] = table[ids[r],:]  (nn.Embedding forward, model/IDNet/hstu.py:413,637,670,752,883).
  * Optional fused position add (hstu.py:640-643): when x_out != NULL, ids is viewed as
  * [n_ids/window_len, window_len] and x_out[b,l,:] = table[ids[b,l],:] + pos_table[l,:] for

@@ -159,6 +159,12 @@ class Trainer(object):
     def _check_nan(self, loss):
         if torch.isnan(loss):
             raise ValueError('Training loss is nan')
+        if loss.is_cuda:                       # (the loss was just read: the device is idle, one more word costs nothing)
+            from mhr_amd import ops
+            bad = ops.bad_id_count()
+            if bad:
+                raise IndexError(f"{bad} item ids outside [0, item_num) reached the embedding gather (the reference's nn.Embedding "
+                                 f"raises 'index out of range in self' for them)")
 
     def train_step_fn(self, data, graph=None):
         """One forward / backward; every `accumulate_grad`-th call also exchanges the gradients and runs the fused Adam
@@ -258,20 +264,39 @@ class Trainer(object):
         return self.best_valid_score, self.best_valid_result
 
     def _save_checkpoint(self):
-        """DP replicas are identical: rank 0 writes model + optimizer state (reference trainer.py:319-340)."""
+        """DP replicas are identical: rank 0 writes model + optimizer state, the step counters, the dropout step counter of the
+        model and the RNG states (reference trainer.py:319-340 saves model, optimizer, rng_state / cuda_rng_state and config)."""
         if self.rank == 0:
             os.makedirs(self.checkpoint_dir, exist_ok=True)
-            torch.save({"model": self.model.state_dict(), "optimizer": self.optimizer.state_dict(), "iter_idx": self.train_step,
-                        "best_valid_score": self.best_valid_score}, os.path.join(self.checkpoint_dir, self.saved_model_name))
+            m = self.model.module if hasattr(self.model, "module") else self.model
+            ck = {"model": self.model.state_dict(), "optimizer": self.optimizer.state_dict(), "iter_idx": self.train_step,
+                  "best_valid_score": self.best_valid_score, "micro_step": int(getattr(self, "_micro_step", 0)),
+                  "step_seed": int(getattr(m, "_step_seed", 0)), "rng_state": torch.get_rng_state(),
+                  "config": {k: v for k, v in getattr(self.config, "final_config_dict", {}).items()
+                             if isinstance(v, (int, float, str, bool, list, tuple, type(None)))}}
+            if self.device.type == "cuda":
+                ck["cuda_rng_state"] = torch.cuda.get_rng_state(self.device)
+            torch.save(ck, os.path.join(self.checkpoint_dir, self.saved_model_name))
         if self.world > 1:
             torch.distributed.barrier()
 
     def resume(self, path):
+        """Continue a run: weights, optimizer moments and step count, lr-schedule position, the model's dropout step counter
+        (the masks of step n + 1 follow, they do not restart at step 1) and the RNG streams the batchers draw from."""
         ck = torch.load(path, map_location=self.device, weights_only=True)
         self.model.load_state_dict(ck["model"])
         self.optimizer.load_state_dict(ck["optimizer"])
         self.train_step = int(ck["iter_idx"])
         self.best_valid_score = ck["best_valid_score"]
+        self._micro_step = int(ck.get("micro_step", 0))
+        m = self.model.module if hasattr(self.model, "module") else self.model
+        if hasattr(m, "_step_seed"):
+            m._step_seed = int(ck.get("step_seed", self.train_step))
+        if "rng_state" in ck:
+            torch.set_rng_state(ck["rng_state"].cpu())
+        if "cuda_rng_state" in ck and self.device.type == "cuda":
+            torch.cuda.set_rng_state(ck["cuda_rng_state"].cpu(), self.device)
+        # (captured step graphs stay valid: they read the weights in place and their counters from device memory)
 
     # ------------------------------------------------------------------------------------------
     @torch.no_grad()

@@ -10,6 +10,9 @@
 // ------------------------------------------------------------------------------------------
 // gather
 // ------------------------------------------------------------------------------------------
+// ids outside [0, n_rows) seen by the gather kernels since the last reset (mhr_bad_id_count)
+__device__ unsigned int g_bad_ids = 0;
+
 template <typename OT, typename XT>
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ table, int64_t n_rows, int dim,
                                                           const int64_t* __restrict__ ids, int64_t n_ids,
@@ -25,7 +28,10 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
     for (int u = 0; u < U; ++u) {
       int64_t r = r0 + u;
       int64_t v = r < n_ids ? ids[r] : 0;
-      v = v < 0 ? 0 : (v >= n_rows ? n_rows - 1 : v);
+      if (v < 0 || v >= n_rows) {                          // nn.Embedding raises here; a kernel cannot: count, clamp, and let the
+        if (lane == 0) atomicAdd(&g_bad_ids, 1u);          // host ask (mhr_bad_id_count) where it synchronises anyway
+        v = v < 0 ? 0 : n_rows - 1;
+      }
       id[u] = v;
     }
     for (int c = lane * 4; c < dim; c += 256) {
@@ -49,6 +55,18 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
       }
     }
   }
+}
+
+extern "C" int mhr_bad_id_count(int64_t* host_count, int reset) {
+  MHR_REQUIRE(host_count, "bad_id_count: null pointer");
+  unsigned int c = 0;
+  MHR_REQUIRE(hipMemcpyFromSymbol(&c, HIP_SYMBOL(g_bad_ids), sizeof(c)) == hipSuccess, "bad_id_count: hipMemcpyFromSymbol failed");
+  *host_count = c;
+  if (reset && c) {
+    const unsigned int z = 0;
+    MHR_REQUIRE(hipMemcpyToSymbol(HIP_SYMBOL(g_bad_ids), &z, sizeof(z)) == hipSuccess, "bad_id_count: hipMemcpyToSymbol failed");
+  }
+  return MHR_OK;
 }
 
 extern "C" int mhr_embedding_gather_fwd(const float* table, int64_t n_rows, int dim, const int64_t* ids, int64_t n_ids,

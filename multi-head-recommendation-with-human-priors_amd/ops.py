@@ -178,6 +178,15 @@ def heads_residual_bwd(d_out, z, B, L, H):
     return dz, dx
 
 
+def bad_id_count(reset=True):
+    """Ids outside the table that embedding gathers met since the last reset (they are clamped on the device, where the
+    reference's nn.Embedding raises).  Synchronises: call it where the host reads device results anyway."""
+    import ctypes
+    c = ctypes.c_int64(0)
+    lib.call("mhr_bad_id_count", ctypes.addressof(c), 1 if reset else 0)
+    return int(c.value)
+
+
 def sum_rows_into(x, out):
     """out [cols] fp32 += column sums of x [rows, cols] bf16 (contiguous)."""
     _chk(x, "x", torch.bfloat16)

@@ -138,3 +138,27 @@ def test_host_issued_steps_interleave_with_replays(rec):
         a, b = sd_a[k].float(), sd_b[k].float()
         assert float((a - b).abs().max()) <= 1e-2 * float(a.abs().max()) + 1e-6, k
     assert torch.equal(tr_a.optimizer.last_step, tr_b.optimizer.last_step)
+
+
+def test_resume_continues_the_run(rec, tmp_path):
+    """A checkpoint carries the weights, the optimizer (moments, step, lazy-table bookkeeping), the lr-schedule position and the
+    model's dropout step counter: the resumed trainer's next steps are the original run's next steps (reference
+    trainer.py:319-340 / 350-372)."""
+    dev = torch.device("cuda", 0)
+    tr_a, m_a, data = _trainer(rec, True, dev)
+    batches = [data.train_batch(16) for _ in range(4)]
+    for i in range(7):
+        tr_a.train_step_fn(batches[i % 4])
+    tr_a.checkpoint_dir, tr_a.saved_model_name = str(tmp_path), "ck.pth"
+    tr_a._save_checkpoint()
+    la = [float(tr_a.train_step_fn(batches[(7 + i) % 4])["loss"]) for i in range(4)]
+    tr_b, m_b, _ = _trainer(rec, True, dev)
+    tr_b.resume(os.path.join(str(tmp_path), "ck.pth"))
+    assert tr_b.train_step == 7 and tr_b.optimizer.step_count == 7 and m_b._step_seed == 7
+    lb = [float(tr_b.train_step_fn(batches[(7 + i) % 4])["loss"]) for i in range(4)]
+    np.testing.assert_allclose(lb, la, rtol=2e-3)                   # same dropout masks, same constants; float-atomic noise only
+    tr_c, m_c, _ = _trainer(rec, True, dev)                         # without the step counter the masks restart: a different run
+    tr_c.resume(os.path.join(str(tmp_path), "ck.pth"))
+    m_c._step_seed = 0
+    lc = [float(tr_c.train_step_fn(batches[(7 + i) % 4])["loss"]) for i in range(4)]
+    assert max(abs(a - c) / abs(a) for a, c in zip(la, lc)) > 2e-3

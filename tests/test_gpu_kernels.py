@@ -61,6 +61,19 @@ def test_gather_and_pos(ops):
     assert torch.equal(r2.cpu(), t2[i2])
 
 
+
+def test_gather_counts_ids_outside_the_table(ops):
+    """nn.Embedding raises on an id outside [0, N) (reference hstu.py:413, 637); the gather kernel clamps, counts, and the
+    host asks where it synchronises anyway (Trainer._check_nan raises IndexError)."""
+    g = torch.Generator().manual_seed(3)
+    table = torch.randn(50, 64, generator=g)
+    ops.bad_id_count()                                              # clear
+    ids = torch.tensor([0, 49, 7, 50, -1, 3, 1000], dtype=torch.int64)
+    rows, _ = ops.embedding_gather(dev(table), dev(ids), torch.float32)
+    torch.cuda.synchronize()
+    assert torch.equal(rows.cpu()[[0, 1, 2, 5]], table[[0, 49, 7, 3]])
+    assert ops.bad_id_count() == 3 and ops.bad_id_count() == 0      # counted once each, then reset
+
 def test_scatter_add_dense(ops):
     g = torch.Generator().manual_seed(1)
     N, D, R = 300, 64, 2000
