@@ -94,6 +94,72 @@ def _host_cores():
     return max(1, min(cores, 16))
 
 
+def _oracle_trainer(cfgd, item_num, B, pool_size=None):
+    """-> train_step() -> seconds: one oracle train step (forward, autograd backward, dense AdamW over every parameter, fp32) of
+    B windows at the shape of `cfgd`; pool_size: negatives per pool (default: the config's per-window count x B)."""
+    import torch
+    from oracle import hstu_oracle as HO
+    from oracle import optim_oracle as OO
+    import mhr_amd.synth as synth
+    from REC.config.configurator import Config
+    from REC.utils import get_model
+    cfg = Config(config_dict=dict(cfgd, device="cpu"))
+    data = synth.SyntheticData(cfg, item_num, "cpu")
+    cfg["int_to_category"] = data.int_to_category
+    torch.manual_seed(2020)
+    model = get_model("HSTU")(cfg, data)
+    w = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    params = {k: w[k].requires_grad_(True) for k, _ in model.named_parameters()}
+    w.update(params)
+    w = HO.tie_repeated_resblocks(w)
+    ocfg = dict(cfgd, category_counts=data.category_counts, category_to_int=data.category_to_int,
+                int_to_category=data.int_to_category)
+    if pool_size is not None:
+        data.config = dict(cfgd, num_negatives=-(-pool_size // B) * B)
+    state = {k: (torch.zeros_like(p), torch.zeros_like(p)) for k, p in params.items()}
+    step_no = [0]
+
+    def train_step():
+        batch = data.train_batch(B)
+        t0 = time.perf_counter()
+        out = HO.train_forward(w, ocfg, batch)
+        out["loss"].backward()
+        step_no[0] += 1
+        with torch.no_grad():
+            for k, p in params.items():
+                if p.grad is None:
+                    continue
+                OO.adamw_step(p, p.grad, state[k][0], state[k][1], step_no[0], 1e-4)
+                p.grad = None
+        return time.perf_counter() - t0
+
+    return train_step
+
+
+def cpu_baseline_cfg0(budget_s=4.0):
+    """BASELINE.json configs[0] - the reference's own CPU-runnable case (HSTU-Pixel8M-base: seqlen 50, dim 64, 1 head) - as
+    the oracle's train step on ONE thread (the reference pins one, run.py:20-21) and on all cores."""
+    import torch
+    import mhr_amd.synth as synth
+    spec = synth.CONFIGS["cfg0"]
+    B = int(spec["cfg"].get("train_batch_size", 32))
+    step = _oracle_trainer(dict(spec["cfg"]), spec["item_num"], B)
+    cores = _host_cores()
+    out = {}
+    for name, thr in (("one_thread", 1), ("all_cores", cores)):
+        torch.set_num_threads(thr)
+        step()
+        n, used = 0, 0.0
+        while used < budget_s / 2 and n < 200:
+            used += step()
+            n += 1
+        out[name] = {"value": round(B * n / max(used, 1e-9), 2), "unit": "seq/s", "cores": thr, "steps": n}
+    torch.set_num_threads(cores)
+    out["workload"] = f"cfg0 (reference's CPU case): L={spec['cfg']['MAX_ITEM_LIST_LENGTH']} D={spec['cfg']['item_embedding_size']} " \
+                      f"{spec['cfg']['n_layers']} layers, N={spec['item_num']} items, B={B} windows per step"
+    return out
+
+
 def cpu_baseline(cfgd, item_num, budget_s=14.0):
     """The oracle's fp32 train step (forward + autograd backward + dense AdamW over every parameter) and eval step
     (user heads -> full-catalog scores -> masks -> per-head top-k -> merge) on the host, at the GPU run's shape: same
@@ -178,7 +244,11 @@ def cpu_baseline(cfgd, item_num, budget_s=14.0):
     ev_all, n3 = timed(eval_step, cores, budget_s * 0.2, Be, True)
     ev_one, n4 = timed(eval_step, 1, budget_s * 0.3, Be, False)
     torch.set_num_threads(cores)
-    return {"value": tr_all, "unit": "seq/s", "cores": cores, "kind": "port",
+    try:
+        cfg0 = cpu_baseline_cfg0()
+    except Exception as e:  # noqa: BLE001
+        cfg0 = {"error": repr(e)[:160]}
+    return {"value": tr_all, "unit": "seq/s", "cores": cores, "kind": "port", "cfg0": cfg0,
             "one_thread": {"value": tr_one, "unit": "seq/s", "cores": 1, "steps": n2},
             "eval": {"value": ev_all, "unit": "users/s", "cores": cores, "steps": n3,
                      "one_thread": {"value": ev_one, "unit": "users/s", "cores": 1, "steps": n4}},
