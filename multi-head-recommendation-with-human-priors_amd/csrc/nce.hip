@@ -729,12 +729,21 @@ __global__ __launch_bounds__(256, 1) void nce_fwd_d_kernel(const IT* __restrict_
   ra.init(la, smem);
   // slot 3 is the "previous tile" of the first iteration (E = 0 there): make it finite
   for (int o = threadIdx.x * 16; o < T::BYTES; o += 256 * 16) *reinterpret_cast<f32x4*>(smem + 3 * T::BYTES + o) = f32x4{0.f, 0.f, 0.f, 0.f};
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // published by the first ring barrier
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // published by the prologue's ring barrier
   dma_all(std::integral_constant<int, 0>{}, 0);
   dma_all(std::integral_constant<int, 1>{}, min(1, t_last));
   // scalars first used inside the loop: touch them here, or hipcc places the `s_waitcnt lgkmcnt(0)` that covers their
   // kernel-argument load INSIDE the loop body, where it drains the LDS read pipeline once per tile
   asm volatile("" ::"s"(n_rows_pad), "s"(c1), "s"(tok_cap), "s"(n_neg));
+  // The ring barrier sits in the MIDDLE of a tile step (sg::tile_step_pf): the barrier of step i publishes tile i + 1, whose
+  // first row fragments (and suppression word) are requested from the last gaps of step i.  Prologue: tile 0 the same way.
+  sg::wait_vmcnt<NDMA>();                               // my pieces of tile 0 (tile 1's may still be in flight)
+  sg::ring_barrier();
+  constexpr int PA = NKS < 4 ? NKS : 4;
+  sg::u32x4 a_pf[PA + 1];
+  uint32_t word = 0;                     // false negatives of the CURRENT tile for my token: bit j = negative 32 i + j suppressed
+  if constexpr (SUPP) word = sg::ds_read_b32_asm<0>(word_addr);
+  sg::prefetch_first<NKS, 0>(ra, a_pf);
   // S accumulators ping-pong by tile parity: tile t's epilogue runs one iteration later, straight from the other set
   f32x16 sf[2][1] = {{sg::zero16()}, {sg::zero16()}};
   uint32_t alive_prev = 0;               // live-row bits of the previous tile, pre-shifted by 4*half
@@ -745,27 +754,17 @@ __global__ __launch_bounds__(256, 1) void nce_fwd_d_kernel(const IT* __restrict_
   auto run = [&](auto logs_c) {
     constexpr bool WITH_LOGS = decltype(logs_c)::value;
     sg::ring_loop<4>(n_tiles + 1, [&](auto slot_c, int i) {
-      constexpr int cur = decltype(slot_c)::value, nxt = (cur + 2) % 4, prv = (cur + 3) % 4, par = cur & 1;
+      constexpr int cur = decltype(slot_c)::value, nx1 = (cur + 1) % 4, nxt = (cur + 2) % 4, prv = (cur + 3) % 4, par = cur & 1;
       STAMP(2)
-#ifndef EXP_NODMA
-      sg::wait_vmcnt<NDMA>();
-#endif
-      STAMP(0)
-#ifndef EXP_NOBAR
-      sg::ring_barrier();
-#endif
-      STAMP(1)
       const int tn = min(i + 2, t_last);
       sf[par][0] = sg::zero16();
       const f32x16& s_prev = sf[par ^ 1][0];
-      // false negatives of THIS tile for my token: bit j = negative 32 i + j suppressed (precomputed per target row)
       // (SUPP = false: nothing is suppressed - the row-sharing path, whose per-token kernels take the false negatives back
       //  out - so no words, no bit test; the 'previous tile' of the first iteration is switched off through the exponent)
-      uint32_t word = 0;
-      if constexpr (SUPP) word = sg::ds_read_b32_asm<cur * 1024>(word_addr);
       const float c0t = (!SUPP && i == 0) ? INFINITY : c1;
-      sg::tile_step<NKS, ND, cur * T::BYTES, prv * T::BYTES, NDMA, 1>(
-          ra, ta, frag, sf[par], u,
+      uint32_t word_next = 0;
+      sg::tile_step_pf<NKS, ND, cur * T::BYTES, prv * T::BYTES, nx1 * T::BYTES, NDMA, SUPP ? 1 : 0>(
+          ra, ta, frag, sf[par], u, a_pf,
           [&](auto n_c) {
             if constexpr (SUPP) sg::wait_lgkm_values<decltype(n_c)::value>(word);
           },
@@ -782,24 +781,30 @@ __global__ __launch_bounds__(256, 1) void nce_fwd_d_kernel(const IT* __restrict_
             }
             return ek;
           },
-          [&](auto k_c) {                  // gaps of the second product: next tile's DMA (tile pieces, then the words)
+          [&](auto k_c) {                  // gaps of the second sweep: tile i + 2's DMA (tile pieces, then the words)
             constexpr int k = decltype(k_c)::value;
-#ifndef EXP_NODMA
             if constexpr (k < P::PW) dma_k(k_c, std::integral_constant<int, nxt>{}, tn);
             else if constexpr (k == P::PW && SUPP) dma_w(std::integral_constant<int, nxt>{}, tn);
-#endif
           },
-          sg::EpiIdentity{}, [&] { STAMP(3) });
+          [&] {                            // between the products: tile i + 1 has landed (mine), then everybody's
+            STAMP(3)
+            sg::wait_vmcnt<0>();
+            STAMP(0)
+            sg::ring_barrier();
+            STAMP(1)
+          },
+          [&] {                            // my word of tile i + 1, requested right before its first row fragments
+            if constexpr (SUPP) word_next = sg::ds_read_b32_asm<nx1 * 1024>(word_addr);
+          });
       STAMP(4)
-#ifndef EXP_NOSUPP
       if constexpr (SUPP) {
         if (i < n_tiles && in_cap && half == 0) supp_out[(int64_t)i * tok_cap + tok] = live ? word : 0xFFFFFFFFu;
       }
-#endif
       const uint32_t sbits = (word >> (4 * half)) & 0x0F0F0F0Fu;
       const int rem = n_neg - i * 32;
       const uint32_t tail = rem >= 32 ? 0xFFFFFFFFu : (rem > 0 ? ~(0xFFFFFFFFu << rem) : 0u);
       alive_prev = (live && i < n_tiles) ? ((tail >> (4 * half)) & ~sbits) : 0u;
+      word = word_next;
     });
   };
   if (do_logs) run(std::true_type{});
@@ -1085,26 +1090,35 @@ __global__ __launch_bounds__(256, 1) void nce_bwd_n_kernel(const bf16_t* qn, con
   // slot 3 is the "previous tile" of the first iteration: zero rows, all-ones suppression words (G = 0)
   for (int o = threadIdx.x * 16; o < T::BYTES; o += 256 * 16) *reinterpret_cast<f32x4*>(smem + 3 * BUF + o) = f32x4{0.f, 0.f, 0.f, 0.f};
   reinterpret_cast<uint32_t*>(smem + 3 * BUF + T::BYTES)[threadIdx.x] = SUPP ? 0xFFFFFFFFu : 0x7F800000u;   // (+inf as lw)
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // published by the first ring barrier
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // published by the prologue's ring barrier
   dma_all(std::integral_constant<int, 0>{}, tt0);
   dma_all(std::integral_constant<int, 1>{}, min(tt0 + tstep, tt_last));
-  f32x16 s_prev = sg::zero16();
-  sg::ring_loop<4>(n_loc + 1, [&](auto slot_c, int i) {
-    constexpr int cur = decltype(slot_c)::value, nxt = (cur + 2) % 4, prv = (cur + 3) % 4;
-    sg::wait_vmcnt<P::PW + 1>();
-    sg::ring_barrier();
-    // per-token words of the PREVIOUS tile (requested first: complete before bwd_tile's first counted wait)
-    sg::u32x4 s4[4], l4[4];
+  // ring barrier in the MIDDLE of the tile step (sg::tile_step_pf, see nce_fwd_d_kernel): the barrier of step i publishes tile
+  // i + 1; the per-token words of tile i (the epilogue of step i + 1 needs them) and the first row fragments of tile i + 1 are
+  // requested from the last gaps of step i
+  sg::wait_vmcnt<P::PW + 1>();
+  sg::ring_barrier();
+  constexpr int PA = NKS < 4 ? NKS : 4;
+  sg::u32x4 a_pf[PA + 1];
+  sg::u32x4 s4[4], l4[4];                // per-token words of the PREVIOUS tile: suppression words / lw
+  auto rd_words = [&](auto slot_c) {
+    constexpr int sl = decltype(slot_c)::value;
     auto rd = [&](auto q_c) {
       constexpr int q4 = decltype(q_c)::value;
-      if constexpr (SUPP) s4[q4] = sg::ds_read_b128_asm<prv * BUF + 32 * q4>(wd_addr);
-      l4[q4] = sg::ds_read_b128_asm<prv * BUF + 128 + 32 * q4>(wd_addr);
+      if constexpr (SUPP) s4[q4] = sg::ds_read_b128_asm<sl * BUF + 32 * q4>(wd_addr);
+      l4[q4] = sg::ds_read_b128_asm<sl * BUF + 128 + 32 * q4>(wd_addr);
     };
     sg::static_for<4>(rd);
+  };
+  rd_words(std::integral_constant<int, 3>{});
+  sg::prefetch_first<NKS, 0>(ra, a_pf);
+  f32x16 s_prev = sg::zero16();
+  sg::ring_loop<4>(n_loc + 1, [&](auto slot_c, int i) {
+    constexpr int cur = decltype(slot_c)::value, nx1 = (cur + 1) % 4, nxt = (cur + 2) % 4, prv = (cur + 3) % 4;
     const int tn = min(tt0 + (i + 2) * tstep, tt_last);
-    f32x16 acc = sg::zero16();
-    sg::bwd_tile<NKS, ND, cur * BUF, prv * BUF, P::PW + 1>(
-        ra, ta, frag, acc, dn,
+    f32x16 accs[1] = {sg::zero16()};
+    sg::tile_step_pf<NKS, ND, cur * BUF, prv * BUF, nx1 * BUF, P::PW + 1, SUPP ? 8 : 4>(
+        ra, ta, frag, accs, dn, a_pf,
         [&](auto n_c) {
           if constexpr (SUPP) sg::wait_lgkm_values<decltype(n_c)::value>(s4[0], s4[1], s4[2], s4[3], l4[0], l4[1], l4[2], l4[3]);
           else sg::wait_lgkm_values<decltype(n_c)::value>(l4[0], l4[1], l4[2], l4[3]);
@@ -1118,8 +1132,13 @@ __global__ __launch_bounds__(256, 1) void nce_bwd_n_kernel(const bf16_t* qn, con
         },
         [&](auto k_c) {
           if constexpr (decltype(k_c)::value < P::PW + 1) dma_k(k_c, std::integral_constant<int, nxt>{}, tn);
-        });
-    s_prev = acc;
+        },
+        [&] {                              // between the products: tile i + 1 has landed (mine), then everybody's
+          sg::wait_vmcnt<0>();
+          sg::ring_barrier();
+        },
+        [&] { rd_words(std::integral_constant<int, cur>{}); });     // the words of THIS tile, for the next step's epilogue
+    s_prev = accs[0];
   });
   sg::wait_vmcnt<0>();
   // dn[dc][g]: row (reg) = negative neg0 + wave*32 + crow(g,half), column (lane) = feature dc*32 + r

@@ -640,6 +640,139 @@ __device__ __forceinline__ void tile_step_split(const RowAddr<NKS>& ra, const Tr
   static_for<NDMA>(rest);
 }
 
+// The split tile step with the NEXT tile's first row-fragment reads issued from its last gaps, for loops whose ring barrier sits
+// in the MIDDLE of the step (`mid`, between the two products) instead of at the top.  With the barrier at the top every tile
+// began with an empty matrix pipe: counted DMA wait, barrier, then a full LDS round trip before the first MFMA (stamped: ~410
+// cycles of loop top + ~150 of wait / barrier per ~2250-cycle tile).  Here the barrier that publishes tile t + 1 is crossed
+// while tile t's second product still has its MFMAs to issue, the first PA fragments of tile t + 1 are requested in the last PA
+// gaps of that product, and the next step starts with them in flight.
+//   a      : in/out, the PA prefetched fragments (k-steps 0..PA-1) of the tile at OFF_CUR on entry, of the tile at OFF_NXT on exit
+//   tail() : the caller's own LDS reads for the NEXT step (NW of them), issued right before the prefetch; `ready(PA)` of the next
+//            step waits for them (exactly PA reads are issued after them)
+// Counted waits: the transposed reads of chunk c are issued at the start of step c - PT; the prefetch reads are issued in the
+// steps F .. NCH - 1 of the second sweep after their MFMA (PP per step; the tail reads in step F, before the first), so a
+// wait in step c also lets the prefetch / tail reads of steps c - PT .. c - 1 stay outstanding.
+template <int NKS, int ND, int NW>
+struct PfCount {
+  static constexpr int PA = NKS < 4 ? NKS : 4;
+  static constexpr int NCH = 2 * ND;
+  static constexpr int PT = NKS < 2 ? 1 : 2;        // transposed chunks requested ahead (3 was tried: -2 %, +-0)
+  // first step that carries prefetch reads: inside the SECOND sweep (the caller's tail reads may overwrite registers the
+  // epilogue elements of the first sweep still read), as late as the PA reads allow
+  static constexpr int F = (NCH - PA) > ND ? (NCH - PA) : ND;
+  static constexpr int PP = (PA + (NCH - F) - 1) / (NCH - F);           // prefetch reads per step
+  static constexpr int first(int st) { return (st - F) * PP; }          // index of the first prefetch read of step st
+  static constexpr int count(int st) {                                   // prefetch reads issued in step st
+    if (st < F) return 0;
+    const int left = PA - first(st);
+    return left <= 0 ? 0 : (left < PP ? left : PP);
+  }
+  static constexpr int extra(int c) {        // prefetch / tail reads issued after chunk c's reads and before its wait
+    int lo = c - PT < 0 ? 0 : c - PT, n = 0;
+    for (int st = lo; st < c; ++st) n += count(st) + (st == F ? NW : 0);
+    return n;
+  }
+};
+
+template <int NKS, int ND, int OFF_CUR, int OFF_PRV, int OFF_NXT, int NDMA, int NW, typename Ready, typename Epi, typename DmaFn,
+          typename Mid, typename Tail>
+__device__ __forceinline__ void tile_step_pf(const RowAddr<NKS>& ra, const TrAddr<NKS>& ta, const bf16x8 (&frag)[1][NKS],
+                                             f32x16 (&accs)[1], f32x16 (&out)[ND], u32x4 (&a)[(NKS < 4 ? NKS : 4) + 1], Ready ready,
+                                             Epi epi, DmaFn dma, Mid mid, Tail tail) {
+  using T = Tile<NKS>;
+  using C = PfCount<NKS, ND, NW>;
+  constexpr int PA = C::PA, NCH = C::NCH, PT = C::PT;
+  constexpr int ES = (8 + NKS - 1) / NKS;
+  constexpr int EU = (8 + ND - 1) / ND;
+  constexpr int T0 = NKS - PT;
+  u32x2 r[PT + 1][2];
+  uint32_t pk[8];
+  float even = 0.f;
+  auto issue_a = [&](auto ks_c) {
+    constexpr int ks = decltype(ks_c)::value;
+    a[ks % (PA + 1)] = ds_read_b128_asm<OFF_CUR + 256 * (ks >> 3)>(ra.a[ks & 7]);
+  };
+  auto issue_t = [&](auto c_c) {
+    constexpr int c = decltype(c_c)::value, dc = c % ND, sw = c / ND;
+    constexpr int imm = OFF_PRV + 256 * (dc >> 2) + sw * 16 * T::ROW_BYTES;
+    u32x2* q = r[c % (PT + 1)];
+    q[0] = ds_read_tr_asm<imm>(ta.t[0][dc & 3]);
+    q[1] = ds_read_tr_asm<imm>(ta.t[1][dc & 3]);
+  };
+  auto element = [&](int e) {
+    const float g = epi(e);
+    if (e & 1) pk[e >> 1] = cvt_pk_bf16(even, g); else even = g;
+  };
+  ready(std::integral_constant<int, PA>{});
+  auto s_step = [&](auto ks_c) {
+    constexpr int ks = decltype(ks_c)::value;
+    if constexpr (ks + PA < NKS) issue_a(std::integral_constant<int, ks + PA>{});
+    constexpr int a_after = (ks + PA < NKS ? ks + PA : NKS - 1) - ks;
+    constexpr int t_chunks = ks > T0 ? ks - T0 : 0;
+    wait_lgkm1<a_after + 2 * t_chunks>(a[ks % (PA + 1)]);
+    const bf16x8 av = __builtin_bit_cast(bf16x8, a[ks % (PA + 1)]);
+    accs[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, frag[0][ks], accs[0], 0, 0, 0);
+#pragma unroll
+    for (int e = ks * ES; e < ks * ES + ES && e < 8; ++e) element(e);
+    if constexpr (ks >= T0) issue_t(std::integral_constant<int, ks - T0>{});
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  static_for<NKS>(s_step);
+  mid();
+  __builtin_amdgcn_sched_barrier(0);
+  bf16x8 g0, g1;
+  {
+    const u32x4 g0v = {pk[0], pk[1], pk[2], pk[3]};
+    g0 = __builtin_bit_cast(bf16x8, g0v);
+  }
+  auto t_step = [&](auto c_c) {
+    constexpr int c = decltype(c_c)::value, dc = c % ND, sw = c / ND;
+    if constexpr (c + PT < NCH) issue_t(std::integral_constant<int, c + PT>{});
+    constexpr int ahead = (NCH - 1 - c) < PT ? (NCH - 1 - c) : PT;
+    u32x2* q = r[c % (PT + 1)];
+    wait_lgkm2<2 * ahead + C::extra(c)>(q[0], q[1]);
+    const u32x4 bv = {q[0].x, q[0].y, q[1].x, q[1].y};
+    if constexpr (sw == 0) {
+      out[dc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g0, __builtin_bit_cast(bf16x8, bv), out[dc], 0, 0, 0);
+#pragma unroll
+      for (int e = 8 + dc * EU; e < 8 + dc * EU + EU && e < 16; ++e) element(e);
+    } else {
+      if constexpr (dc == 0) {
+        const u32x4 g1v = {pk[4], pk[5], pk[6], pk[7]};
+        g1 = __builtin_bit_cast(bf16x8, g1v);
+      }
+      out[dc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g1, __builtin_bit_cast(bf16x8, bv), out[dc], 0, 0, 0);
+      dma(std::integral_constant<int, dc>{});
+    }
+    if constexpr (c >= C::F) {
+      if constexpr (c == C::F) tail();
+      auto pf = [&](auto j_c) {
+        constexpr int k = C::first(c) + decltype(j_c)::value;
+        a[k] = ds_read_b128_asm<OFF_NXT + 256 * (k >> 3)>(ra.a[k & 7]);
+      };
+      static_for<C::count(c)>(pf);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  static_for<NCH>(t_step);
+  auto rest = [&](auto k_c) {
+    constexpr int k = decltype(k_c)::value;
+    if constexpr (k >= ND) dma(k_c);
+  };
+  static_for<NDMA>(rest);
+}
+
+// the prologue of such a loop: the PA fragments of the first tile
+template <int NKS, int OFF>
+__device__ __forceinline__ void prefetch_first(const RowAddr<NKS>& ra, u32x4 (&a)[(NKS < 4 ? NKS : 4) + 1]) {
+  constexpr int PA = NKS < 4 ? NKS : 4;
+  auto f = [&](auto k_c) {
+    constexpr int k = decltype(k_c)::value;
+    a[k] = ds_read_b128_asm<OFF + 256 * (k >> 3)>(ra.a[k & 7]);
+  };
+  static_for<PA>(f);
+}
+
 // RF = 1: one stationary fragment set (the backward kernels).  RF = 2: two sets sharing every row-fragment read (the
 // fused forward: s = q.n and f = p.n); the per-element epilogue is then split over the two MFMA gaps of a k-step:
 // epi(e) after the first MFMA, epi2(e, value) after the second.

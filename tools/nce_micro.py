@@ -3,7 +3,7 @@ import math, os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import mhr_amd
 from mhr_amd import ops
-D, n_tok, n_neg, cap, G = 256, int(os.environ.get("NTOK", 68000)), 8192, 204800, int(os.environ.get("GROUPS", 4))
+D, n_tok, n_neg, cap, G = int(os.environ.get("D", 256)), int(os.environ.get("NTOK", 68000)), 8192, 204800, int(os.environ.get("GROUPS", 4))
 reps = int(os.environ.get("REPS", 3))
 g = torch.Generator(device="cuda").manual_seed(0)
 q_rows = torch.randn(cap, D, device="cuda", generator=g)
