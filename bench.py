@@ -263,7 +263,7 @@ def cpu_baseline(cfgd, item_num, budget_s=14.0):
 # ------------------------------------------------------------------------------------------------
 KERNEL_NAMES = {"mhr_nce_bwd_tokens": ["nce_bwd_rows_kernel"], "mhr_nce_bwd_negs": ["nce_bwd_n_kernel"],
                 "mhr_hstu_attn_bwd": ["hstu_attn_bwd_kernel"], "mhr_hstu_attn_fwd": ["hstu_attn_fwd_kernel"],
-                "mhr_nce_fwd": ["nce_fwd_d_kernel", "nce_fix_bits_kernel"],
+                "mhr_nce_fwd": ["nce_fwd_d_kernel"],       # (the plain form launches no bit-table kernel; mhr_nce_fix_bits is its own call)
                 "mhr_catalog_score_emit": ["catalog_emit_kernel"], "mhr_catalog_score_emit_sliced": ["catalog_emit_sliced_kernel"],
                 "mhr_adam_rows": ["adam_rows_kernel"], "mhr_embedding_gather_fwd": ["gather_rows_kernel"]}
 
