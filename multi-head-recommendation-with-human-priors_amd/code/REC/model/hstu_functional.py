@@ -100,11 +100,17 @@ class SplitKLinearFn(Function):
         s_max = min(max(1, 256 // tiles), _SPLITK_MAX)
         S = next((s for s in (64, 32, 16, 8, 4, 2) if s <= s_max and R % s == 0 and R // s >= 256), 1)
         xs, dys = x.view(S, R // S, -1), dy.view(S, R // S, -1)
+        # with the optimizer's partial arena on, the S partials land in the parameter's columns of ONE [S, total] buffer that
+        # the optimizer sums with one launch at the step (optim.FusedAdamW.enable_partial_arena)
+        opt = getattr(ctx.w_leaf, "_mhr_opt", None) if ctx.w_leaf is not None else None
+        slot = opt.partial_view(ctx.w_leaf, S) if (opt is not None and S > 1 and _SUM_KERNEL) else None
         if ctx.w_is_nk:
-            dw = torch.bmm(dys.transpose(1, 2), xs)               # [S, N, K]
+            dw = torch.bmm(dys.transpose(1, 2), xs, out=slot) if slot is not None else torch.bmm(dys.transpose(1, 2), xs)   # [S, N, K]
         else:
-            dw = torch.bmm(xs.transpose(1, 2), dys)               # [S, K, N]
-        if ctx.w_leaf is not None:                                # reduction of the split-K partials straight into p.grad
+            dw = torch.bmm(xs.transpose(1, 2), dys, out=slot) if slot is not None else torch.bmm(xs.transpose(1, 2), dys)   # [S, K, N]
+        if slot is not None:
+            dw = None
+        elif ctx.w_leaf is not None:                              # reduction of the split-K partials straight into p.grad
             SplitKLinearFn._into(ctx.w_leaf, dw)
             dw = None
         else:

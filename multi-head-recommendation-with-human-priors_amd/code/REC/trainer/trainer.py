@@ -143,6 +143,8 @@ class Trainer(object):
         self.optimizer = FusedAdamW(model, lr=self.optim_args['learning_rate'], weight_decay=self.optim_args['weight_decay'],
                                     lazy_table=bool(lazy))
         self._micro_step = 0
+        if self.accumulate_grad == 1 and hasattr(self.optimizer, "enable_partial_arena"):
+            self.optimizer.enable_partial_arena(True)     # one backward per step: all split-K partials summed by one launch
         for st in self.__dict__.pop("_step_graphs", {}).values():      # graphs captured over a previous model / optimizer
             st.release()
         self._step_graph = None

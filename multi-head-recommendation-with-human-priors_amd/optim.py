@@ -89,7 +89,7 @@ class FusedAdamW:
         self.dense = uniq
         self.layout = [[n, p.numel()] for n, p in zip(names, uniq)]     # order of the flat buffers (checked on load)
         sizes = [(p.numel() + 3) // 4 * 4 for p in self.dense]          # keep every view 16-byte aligned
-        total = sum(sizes)
+        total = (sum(sizes) + 7) // 8 * 8                               # (whole 8-column groups for the batched partial sum)
         self.flat_w = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_m = torch.zeros(total, dtype=torch.float32, device=dev)
@@ -107,6 +107,8 @@ class FusedAdamW:
                 p._mhr_bf16 = self.flat_w16[off:off + n].view(p.shape)
                 p._mhr_ver = -1                                          # shadow not valid before the first step
             p._mhr_direct_grad = os.environ.get("MHR_OPT_DIRECT", "1") != "0"   # backward kernels may write p.grad in place
+            p._mhr_flat_off = off
+            p._mhr_opt = None                                            # set by enable_partial_arena()
             off += sz
         self.param_groups = [{"lr": lr}]                                 # scheduler-facing view
         self.lazy = bool(lazy_table) and self.table is not None and os.environ.get("MHR_LAZY_ADAM", "1") != "0"
@@ -129,6 +131,48 @@ class FusedAdamW:
             self.last_step = torch.zeros(self.table.shape[0], dtype=torch.int32, device=dev)
             model._table_optimizer = self                                # the model's forward / eval hooks find us here
             self._lagging = False                                        # rows behind step_count exist (host-side flag)
+
+    # ---- split-K partials of ALL weight gradients in one arena, reduced by ONE launch at the step -------------------------
+    def enable_partial_arena(self, on=True):
+        """The projections' weight gradients are split-K batched GEMMs whose S bf16 partials are summed into the flat fp32
+        gradient (SplitKLinearFn).  With the arena on, every such GEMM writes its partials straight into its parameter's columns
+        of ONE [S, total] buffer and `step()` sums the whole buffer with one launch - 16 small launches per step fewer at cfg1.
+        Only valid with exactly one backward per optimizer step (the Trainer turns it on when accumulate_grad == 1): a second
+        backward would overwrite the first one's partials."""
+        self._arena_on = bool(on) and os.environ.get("MHR_PARTIAL_ARENA", "1") != "0"
+        for p in self.dense:
+            p._mhr_opt = self if self._arena_on else None
+        self._arena = None
+        self._arena_used = set()
+
+    def partial_view(self, p, S):
+        """[S, *p.shape] bf16 view of the arena for parameter p (batch stride = the arena's row pitch), or None when the arena
+        cannot serve this call: a different S than the arena was built for, a parameter already written in this step (tied
+        weights: the second use must ADD), or an arena that would be larger than 2 GB (LLM-sized models)."""
+        if not getattr(self, "_arena_on", False) or p.dim() != 2:
+            return None
+        if getattr(self, "_arena", None) is None:
+            if S * self.flat_g.numel() * 2 > (2 << 30):
+                self._arena_on = False
+                return None
+            self._arena = torch.zeros(S, self.flat_g.numel(), dtype=torch.bfloat16, device=self.flat_g.device)
+            self._arena_used = set()
+        off, n = p._mhr_flat_off, p.numel()
+        if id(p) in self._arena_used:
+            return None
+        if self._arena.shape[0] != S:
+            if getattr(p, "_mhr_in_arena", False):       # its columns hold an earlier step's partials: never add them again
+                self._arena[:, off:off + n].zero_()
+                p._mhr_in_arena = False
+            return None
+        self._arena_used.add(id(p))
+        p._mhr_in_arena = True
+        return self._arena[:, off:off + n].view(S, *p.shape)
+
+    def _reduce_arena(self):
+        if getattr(self, "_arena", None) is not None and self._arena_used:
+            ops.sum_rows_into(self._arena, self.flat_g)
+            self._arena_used = set()
 
     def zero_grad(self):
         global GRAD_EPOCH
@@ -160,6 +204,7 @@ class FusedAdamW:
         self.step_count += 1
         lr = self.param_groups[0]["lr"]
         W = D.world_size()
+        self._reduce_arena()                         # the split-K partials of all weight gradients: one launch
         # data parallel: dense bucket and gradient rows go on the wire back to back (RCCL's stream); the flat Adam waits
         # for the bucket only, so it - and the id sort of the row reduction - run underneath the row all-gather
         dense_work = D.allreduce_sum_begin(self.flat_g)

@@ -114,9 +114,10 @@ def test_replayed_steps_follow_the_host_issued_trajectory(rec, loss):
     np.testing.assert_allclose(lg, le, rtol=3e-2)                   # (atomic-order noise grows along 70 steps of lr 2e-3)
     assert le[-1] < le[0]
     sd_e, sd_g = m_e.state_dict(), m_g.state_dict()                 # state_dict() flushes the lazy table
-    for k in sd_e:
-        a, b = sd_e[k].float(), sd_g[k].float()
-        assert float((a - b).abs().max()) <= 2e-2 * float(a.abs().max()) + 1e-6, k
+    for k in sd_e:                                                  # (Adam turns float-atomic noise into sign flips of tiny updates:
+        a, b = sd_e[k].float(), sd_g[k].float()                     #  single elements may drift, the bulk must not)
+        scale = float(a.abs().max()) + 1e-6
+        assert float((a - b).abs().mean()) <= 5e-3 * scale and float((a - b).abs().max()) <= 0.15 * scale, k
     # a different dropout mask would show: replaying with a frozen step counter must NOT reproduce the trajectory
     assert abs(lg[10] - lg[4]) > 0 or loss == "nce"
 
@@ -162,3 +163,24 @@ def test_resume_continues_the_run(rec, tmp_path):
     m_c._step_seed = 0
     lc = [float(tr_c.train_step_fn(batches[(7 + i) % 4])["loss"]) for i in range(4)]
     assert max(abs(a - c) / abs(a) for a, c in zip(la, lc)) > 2e-3
+
+
+def test_partial_arena_gives_the_per_layer_reduction(rec):
+    """With one backward per step the split-K partials of all weight gradients go through ONE arena and ONE reduction launch
+    (optim.FusedAdamW.enable_partial_arena); per layer they are summed by a launch each.  Same partials, same order of
+    summation per column: the two trainers stay together (up to the float-atomic noise of the loss backward)."""
+    dev = torch.device("cuda", 0)
+    tr_a, m_a, data = _trainer(rec, False, dev, hidden_dropout_prob=0.0)
+    tr_b, m_b, _ = _trainer(rec, False, dev, hidden_dropout_prob=0.0)
+    tr_b.optimizer.enable_partial_arena(False)
+    assert tr_a.optimizer._arena_on and not tr_b.optimizer._arena_on
+    batches = [data.train_batch(64) for _ in range(4)]           # 64 x 24 tokens: the weight gradients split four ways
+    for i in range(6):
+        la = float(tr_a.train_step_fn(batches[i % 4])["loss"])
+        lb = float(tr_b.train_step_fn(batches[i % 4])["loss"])
+        assert abs(la - lb) <= 2e-3 * abs(lb)
+    assert tr_a.optimizer._arena is not None and tr_b.optimizer._arena is None
+    sd_a, sd_b = m_a.state_dict(), m_b.state_dict()
+    for k in sd_a:
+        a, b = sd_a[k].float(), sd_b[k].float()
+        assert float((a - b).abs().max()) <= 1e-2 * float(a.abs().max()) + 1e-6, k
