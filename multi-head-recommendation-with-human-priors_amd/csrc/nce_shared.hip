@@ -330,15 +330,27 @@ __global__ __launch_bounds__(256) void shared_bwd_rows_kernel(
   const float scale = clamp_scale(logit_scale_dev);
   const float c1 = scale * LOG2E;
   float dls = 0.f;
+  // Row vectors live as 4 CONSECUTIVE columns per lane (d0 = 4 lane: one 8-byte load per bf16 row, one 16-byte load per fp32
+  // row - the column-strided form took four 2-byte loads per row and token).  Float atomics want the other shape - a wave
+  // instruction covering 64 consecutive floats - so what is added atomically passes through a wave-private 1 KB LDS transpose.
+  __shared__ float xpose[4][256];
+  float* xp = xpose[threadIdx.x >> 6];
+  const int d0 = lane * 4;
+  const bool in_dim = d0 < dim;
   for (int r = wave_g; r < n_row; r += n_waves) {
     const int t0 = row_first[r], t1 = min(row_first[r + 1], tok_cap);
-    float qv[NC], uv[NC], accp[NC] = {0.f, 0.f, 0.f, 0.f}, accu[NC] = {0.f, 0.f, 0.f, 0.f};
+    float q4[4] = {0.f, 0.f, 0.f, 0.f}, u4[4] = {0.f, 0.f, 0.f, 0.f}, ap[4] = {0.f, 0.f, 0.f, 0.f}, au[4] = {0.f, 0.f, 0.f, 0.f};
+    if (in_dim) {
+      const bf16x4 qb = *reinterpret_cast<const bf16x4*>(qn_row + (int64_t)r * dim + d0);
+      const f32x4 ub = *reinterpret_cast<const f32x4*>(u_row + (int64_t)r * dim + d0);
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      const int d = c * 64 + lane;
-      qv[c] = d < dim ? (float)qn_row[(int64_t)r * dim + d] : 0.f;
-      uv[c] = d < dim ? u_row[(int64_t)r * dim + d] : 0.f;
+      for (int e = 0; e < 4; ++e) {
+        q4[e] = (float)qb[e];
+        u4[e] = ub[e];
+      }
     }
+    bool have_qc = false;                                       // the row's query in column order (d = c 64 + lane): hit path only
+    float qc[NC] = {0.f, 0.f, 0.f, 0.f};
     float a_sum = 0.f, lw_m = INFINITY, lw_s = 0.f;
     for (int c0 = t0; c0 < t1; c0 += 64) {
       // lane = token of the row: every per-token scalar (and the dependent slot / hit-flag look-ups) in ONE round of loads
@@ -375,10 +387,10 @@ __global__ __launch_bounds__(256) void shared_bwd_rows_kernel(
       for (int i = 0; i < cnt; ++i) {                          // independent row loads: the compiler keeps several in flight
         const float cf = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, coef), i));
         const bf16_t* ps = pn + (int64_t)__builtin_amdgcn_readlane(pi, i) * dim;        // the token's target row (L2-resident table)
+        if (in_dim) {
+          const bf16x4 pb = *reinterpret_cast<const bf16x4*>(ps + d0);
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
-          const int d = c * 64 + lane;
-          accp[c] += d < dim ? cf * (float)ps[d] : 0.f;
+          for (int e = 0; e < 4; ++e) ap[e] += cf * (float)pb[e];
         }
       }
       uint64_t hm = __ballot(hit);
@@ -390,46 +402,62 @@ __global__ __launch_bounds__(256) void shared_bwd_rows_kernel(
         const float a_u = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a), i));
         const float wi_u = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wi), i));
         const float ls_u = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ls), i));
-        for_each_hit(fixw, n_tiles, n_rows_pad, slot_u, n_neg, lane, groups_u, [&](int j) {
-          const bf16_t* ns = negs + (int64_t)j * dim;
-          float nv[NC];
-          float s = 0.f;
+        if (!have_qc && d_negs) {                              // (wave-uniform) the query once in the atomics' column order
+          *reinterpret_cast<f32x4*>(xp + d0) = f32x4{q4[0], q4[1], q4[2], q4[3]};
+          __builtin_amdgcn_wave_barrier();
 #pragma unroll
-          for (int c = 0; c < NC; ++c) {
-            const int d = c * 64 + lane;
-            nv[c] = d < dim ? (float)ns[d] : 0.f;
-            s += qv[c] * nv[c];
+          for (int c = 0; c < NC; ++c) qc[c] = xp[c * 64 + lane];
+          __builtin_amdgcn_wave_barrier();
+          have_qc = true;
+        }
+        for_each_hit(fixw, n_tiles, n_rows_pad, slot_u, n_neg, lane, groups_u, [&](int j) {
+          float nv[4] = {0.f, 0.f, 0.f, 0.f};
+          float s = 0.f;
+          if (in_dim) {
+            const bf16x4 nb = *reinterpret_cast<const bf16x4*>(negs + (int64_t)j * dim + d0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              nv[e] = (float)nb[e];
+              s += q4[e] * nv[e];
+            }
           }
           s = wave_sum(s);
           const float eb = (float)(bf16_t)__builtin_amdgcn_exp2f(s * c1 - c1);
           const float gneg = -scale * wi_u * __expf(scale * s - ls_u);
 #pragma unroll
-          for (int c = 0; c < NC; ++c) {
-            const int d = c * 64 + lane;
-            accu[c] += a_u * eb * nv[c];
-            if (d_negs && d < dim && wi_u != 0.f) atomicAdd(d_negs + (int64_t)j * dim + d, gneg * qv[c]);
+          for (int e = 0; e < 4; ++e) au[e] += a_u * eb * nv[e];
+          if (d_negs && wi_u != 0.f) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+              const int d = c * 64 + lane;
+              if (d < dim) atomicAdd(d_negs + (int64_t)j * dim + d, gneg * qc[c]);
+            }
           }
         });
       }
     }
-    float dqn[NC];
+    float dqn[4];
     float dot_q = 0.f, dot_raw = 0.f;
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      const float raw = a_sum * uv[c] - accu[c];
-      dqn[c] = scale * (raw + accp[c]);
-      dot_raw += qv[c] * raw;
-      dot_q += qv[c] * dqn[c];
+    for (int e = 0; e < 4; ++e) {
+      const float raw = a_sum * u4[e] - au[e];
+      dqn[e] = scale * (raw + ap[e]);
+      dot_raw += q4[e] * raw;
+      dot_q += q4[e] * dqn[e];
     }
     dot_q = wave_sum(dot_q);
     dls += wave_sum(dot_raw);
     const float iq = q_inv_row[r];
+    *reinterpret_cast<f32x4*>(xp + d0) = f32x4{(dqn[0] - q4[0] * dot_q) * iq, (dqn[1] - q4[1] * dot_q) * iq, (dqn[2] - q4[2] * dot_q) * iq,
+                                               (dqn[3] - q4[3] * dot_q) * iq};
+    __builtin_amdgcn_wave_barrier();
     float* qdst = dq_rows + (int64_t)row_q[r] * dim;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       const int d = c * 64 + lane;
-      if (d < dim) atomicAdd(qdst + d, (dqn[c] - qv[c] * dot_q) * iq);
+      if (d < dim) atomicAdd(qdst + d, xp[d]);
     }
+    __builtin_amdgcn_wave_barrier();
     if (lane == 0) lw_row[r] = lw_m < INFINITY ? lw_m - __log2f(lw_s) : INFINITY;
   }
   // d(logit_scale): ONE atomic per workgroup (every wave adding to the same address serialises: 61 k adds cost 0.6 ms)
@@ -452,14 +480,17 @@ __global__ __launch_bounds__(256) void shared_bwd_targets_kernel(
   const int wave_g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), n_waves = gridDim.x * (blockDim.x >> 6);
   const float scale = clamp_scale(logit_scale_dev);
   const int W = L + P, n_cand = n_groups * P;
+  const int d0 = lane * 4;                                   // 4 consecutive columns per lane: 8-byte bf16 / 16-byte fp32 accesses
+  const bool in_dim = d0 < dim;
   for (int m = wave_g; m < n_p_rows; m += n_waves) {
     const int b = m / W, pos = m - b * W;
-    float acc[NC] = {0.f, 0.f, 0.f, 0.f};
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
     int t_any = -1;
     for (int c0 = 0; c0 < n_cand; c0 += 64) {
-      // lane = candidate (group, offset): the token (l = pos - 1 - p, p) of that group, if it is live
+      // lane = candidate (group, offset): the token (l = pos - 1 - p, p) of that group, if it is live; its query row index is
+      // fetched here too, so the row loads of the loop below do not wait on a dependent index load each
       const int cand = c0 + lane;
-      int tk = -1, g = 0;
+      int tk = -1, g = 0, row = 0;
       float coef = 0.f;
       if (cand < n_cand) {
         g = cand / P;
@@ -473,41 +504,44 @@ __global__ __launch_bounds__(256) void shared_bwd_targets_kernel(
           const int64_t o = (int64_t)g * tok_cap + tk;
           const float wi = w_bucket ? w[(int64_t)g * n_buckets + w_bucket[o]] : w[o];
           coef = wi * (__expf(scale * s_pos[o] - lse[o]) - 1.0f);
+          row = tok2row[o];
         }
       }
       uint64_t live = __ballot(tk >= 0);
       while (live) {
         const int ln = __builtin_ctzll(live);
         live &= live - 1;
-        const int tk_u = __builtin_amdgcn_readlane(tk, ln), g_u = __builtin_amdgcn_readlane(g, ln);
+        const int g_u = __builtin_amdgcn_readlane(g, ln), r = __builtin_amdgcn_readlane(row, ln);
         const float cf = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, coef), ln));
-        const int r = tok2row[(int64_t)g_u * tok_cap + tk_u];
-        const bf16_t* qs = qn_row + ((int64_t)g_u * row_cap + r) * dim;
+        if (in_dim) {
+          const bf16x4 qb = *reinterpret_cast<const bf16x4*>(qn_row + ((int64_t)g_u * row_cap + r) * dim + d0);
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
-          const int d = c * 64 + lane;
-          acc[c] += d < dim ? cf * (float)qs[d] : 0.f;
+          for (int e = 0; e < 4; ++e) acc[e] += cf * (float)qb[e];
         }
-        t_any = tk_u;
+        t_any = ln;
       }
     }
     if (t_any < 0) continue;                                 // no live token points at this row: its gradient stays as it is
     const float ip = p_inv[m];
-    float pv[NC], dpn[NC];
+    float pv[4] = {0.f, 0.f, 0.f, 0.f}, dpn[4];
     float dot = 0.f;
+    if (in_dim) {
+      const bf16x4 pb = *reinterpret_cast<const bf16x4*>(pn + (int64_t)m * dim + d0);
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      const int d = c * 64 + lane;
-      pv[c] = d < dim ? (float)pn[(int64_t)m * dim + d] : 0.f;
-      dpn[c] = scale * acc[c];
-      dot += pv[c] * dpn[c];
+      for (int e = 0; e < 4; ++e) pv[e] = (float)pb[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      dpn[e] = scale * acc[e];
+      dot += pv[e] * dpn[e];
     }
     dot = wave_sum(dot);
-    float* dst = dp_rows + (int64_t)m * dim;
+    if (in_dim) {
+      f32x4* dst = reinterpret_cast<f32x4*>(dp_rows + (int64_t)m * dim + d0);
+      f32x4 cur = *dst;
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      const int d = c * 64 + lane;
-      if (d < dim) dst[d] += (dpn[c] - pv[c] * dot) * ip;
+      for (int e = 0; e < 4; ++e) cur[e] += (dpn[e] - pv[e] * dot) * ip;
+      *dst = cur;
     }
   }
 }
@@ -601,7 +635,7 @@ extern "C" int mhr_nce_shared_bwd_rows(const void* qn_row, const float* u_row, c
   MHR_REQUIRE(qn_row && u_row && q_inv_row && row_q && row_first && n_row_dev && pn && logit_scale_dev && lse && w && s_pos,
               "nce_shared_bwd_rows: null input pointer");
   MHR_REQUIRE(p_idx && dq_rows && lw_row && negs && fix_words && fix_any, "nce_shared_bwd_rows: null index/output pointer");
-  MHR_REQUIRE(dim > 0 && dim <= 256, "nce_shared_bwd_rows: dim=%d unsupported (<= 256)", dim);
+  MHR_REQUIRE(dim > 0 && dim <= 256 && dim % 4 == 0, "nce_shared_bwd_rows: dim=%d unsupported (<= 256)", dim);
   MHR_REQUIRE(tok_cap > 0 && row_cap > 1 && n_neg > 0 && n_p_rows > 0 && n_groups >= 1 && n_groups <= 65535,
               "nce_shared_bwd_rows: bad sizes");
   const int n_rows_pad = (int)((n_p_rows + 255) / 256 * 256);
@@ -623,7 +657,7 @@ extern "C" int mhr_nce_shared_bwd_targets(const void* qn_row, int row_cap, const
                                           void* stream) {
   MHR_REQUIRE(qn_row && tok2row && tok_of_slot && n_tok_dev && pn && p_inv && logit_scale_dev && lse && w && s_pos && dp_rows,
               "nce_shared_bwd_targets: null pointer");
-  MHR_REQUIRE(dim > 0 && dim <= 256, "nce_shared_bwd_targets: dim=%d unsupported (<= 256)", dim);
+  MHR_REQUIRE(dim > 0 && dim <= 256 && dim % 4 == 0, "nce_shared_bwd_targets: dim=%d unsupported (<= 256)", dim);
   MHR_REQUIRE(seq_len > 0 && pred_len > 0 && n_slots > 0 && n_slots % (seq_len * pred_len) == 0 &&
                   n_p_rows == (int64_t)(n_slots / (seq_len * pred_len)) * (seq_len + pred_len),
               "nce_shared_bwd_targets: slots must be (b, l, p) windows and p_rows the [B, L + P] targets (n_slots=%d L=%d P=%d "
