@@ -58,6 +58,25 @@ def prior_loss_weights(cfg):
 
 
 # --------------------------------------------------------------------------- #
+# bf16-mixed emulation (tests only)
+# --------------------------------------------------------------------------- #
+# The reference's GPU recipe is Fabric bf16-mixed autocast (run.py:3): matrix products take bf16 operands and emit bf16.
+# With MIXED = a rounding function (e.g. tests/kernel_oracles.bf16_round, straight-through for autograd) every dense product
+# of this oracle rounds its operands and its result the way the MI355X path stores them; None (default) is the fp32
+# arithmetic the golden fixtures were generated with.  Set only by tests that want a tolerance tighter than "bf16-sized".
+MIXED = None
+
+
+def _r(t):
+    return t if MIXED is None else MIXED(t)
+
+
+def _mm(a, b):
+    """a @ b with bf16-rounded operands and result under MIXED."""
+    return a @ b if MIXED is None else MIXED(MIXED(a) @ MIXED(b))
+
+
+# --------------------------------------------------------------------------- #
 # encoder
 # --------------------------------------------------------------------------- #
 def layer_norm(x, eps=1e-6):
@@ -105,15 +124,15 @@ def hstu_layer(x, w_uvqk, w_o, b_o, key_valid, n_heads, act="silu", drop_mask=No
     drop_mask: optional [B,L,D] keep-mask already scaled by 1/(1-p).
     """
     D = x.shape[-1]
-    h = layer_norm(x, eps) @ w_uvqk
+    h = _mm(layer_norm(x, eps), w_uvqk)
     if act == "silu":
         h = silu(h)
     u, v, q, k = torch.split(h, [D, D, D, D], dim=-1)
-    a = hstu_attention(q, k, v, key_valid, n_heads)
+    a = _r(hstu_attention(_r(q), _r(k), _r(v), key_valid, n_heads, operand_round=MIXED))
     o_in = u * layer_norm(a, eps)
     if drop_mask is not None:
         o_in = o_in * drop_mask
-    return o_in @ w_o.T + b_o + x
+    return _r(_mm(o_in, w_o.T) + _r(b_o)) + x
 
 
 def hstu_encoder(x, weights, cfg, key_valid):
@@ -152,7 +171,7 @@ def res_block(x, weights, prefix):
     """x + silu(Linear(x)), optional affine LayerNorm first. model/llm_heads.py:5-40"""
     if prefix + "norm.weight" in weights:
         x = _affine_ln(x, weights[prefix + "norm.weight"], weights[prefix + "norm.bias"])
-    return x + silu(x @ weights[prefix + "linear.weight"].T + weights[prefix + "linear.bias"])
+    return x + silu(_r(_mm(x, weights[prefix + "linear.weight"].T) + _r(weights[prefix + "linear.bias"])))
 
 
 def _sequential(x, weights, prefix):
@@ -327,7 +346,7 @@ def prior_switch_loss(weights, cfg, out, heads, tg, c, w_c):
 def gather_negatives(weights, neg_ids):
     """hstu.py:669-673 / 751-755 at world size 1: gather, L2-normalise, flatten."""
     n = item_tower(weights, weights["item_embedding.weight"][neg_ids])
-    return l2n(n).reshape(-1, n.shape[-1])
+    return _r(l2n(n)).reshape(-1, n.shape[-1])            # (the negatives are stored normalised in bf16 under MIXED)
 
 
 def train_forward(weights, cfg, batch, extra_negs=None):
@@ -392,7 +411,7 @@ def multihead_loss(weights, cfg, e, out, mask, tags, negs_for, n_pools):
         head_for_p = torch.arange(P) // seg_len
         cur = heads[:, head_for_p]                                         # [B,P,L,D]
         m = valid
-        logits = nce_logits(cur[m], tgt[m], shared, weights["logit_scale"], thres)
+        logits = nce_logits(cur[m], tgt[m], shared, weights["logit_scale"], thres, operand_round=MIXED)
         tl = token_ce(logits)
         per_p = lam * _per_offset_mean(tl, p_grid[m], P)
         res["loss"] = res["loss"] + per_p.sum()
@@ -425,7 +444,7 @@ def multihead_loss(weights, cfg, e, out, mask, tags, negs_for, n_pools):
             else:
                 head_for_p = seg_for_p * C + c
             cur = heads[:, head_for_p]
-            logits = nce_logits(cur[m], tgt[m], negs, weights["logit_scale"], thres)
+            logits = nce_logits(cur[m], tgt[m], negs, weights["logit_scale"], thres, operand_round=MIXED)
             tl = token_ce(logits)
             per_p = lam * w_c[c] * _per_offset_mean(tl, p_grid[m], P)
             res["loss"] = res["loss"] + per_p.sum()
