@@ -55,7 +55,7 @@ def attention(q, k, v, allowed):
     s = s.masked_fill(~allowed, float("-inf"))
     dead = ~allowed.any(-1, keepdim=True)
     p = torch.softmax(s.masked_fill(dead, 0.0), dim=-1).masked_fill(dead, 0.0)
-    return p @ v
+    return HO._r(p) @ v                         # (under HO.MIXED the probability tile is a bf16 matrix operand)
 
 
 def decoder_layer(x, w, pfx, lcfg, allowed, cos, sin, position_ids):
@@ -65,21 +65,21 @@ def decoder_layer(x, w, pfx, lcfg, allowed, cos, sin, position_ids):
     hd = D // nh
     h = rms_norm(x, w[pfx + "input_layernorm.weight"], lcfg["rms_norm_eps"])
     def proj(name):                # Qwen2 towers carry q/k/v biases (modeling_qwen2.py), Llama / Mistral do not
-        y = h @ w[pfx + f"self_attn.{name}_proj.weight"].T
-        return y + w[pfx + f"self_attn.{name}_proj.bias"] if pfx + f"self_attn.{name}_proj.bias" in w else y
+        y = HO._mm(h, w[pfx + f"self_attn.{name}_proj.weight"].T)
+        return HO._r(y + HO._r(w[pfx + f"self_attn.{name}_proj.bias"])) if pfx + f"self_attn.{name}_proj.bias" in w else y
 
     q = proj("q").view(B, L, nh, hd).transpose(1, 2)
     k = proj("k").view(B, L, nkv, hd).transpose(1, 2)
     v = proj("v").view(B, L, nkv, hd).transpose(1, 2)
-    q, k = apply_rope(q, cos, sin, position_ids), apply_rope(k, cos, sin, position_ids)
+    q, k = HO._r(apply_rope(q, cos, sin, position_ids)), HO._r(apply_rope(k, cos, sin, position_ids))
     k = k.repeat_interleave(nh // nkv, dim=1)                   # repeat_kv, modeling_llama.py:489-500
     v = v.repeat_interleave(nh // nkv, dim=1)
-    a = attention(q, k, v, allowed).transpose(1, 2).reshape(B, L, D)
-    x = x + a @ w[pfx + "self_attn.o_proj.weight"].T
+    a = HO._r(attention(q, k, v, allowed)).transpose(1, 2).reshape(B, L, D)
+    x = x + HO._mm(a, w[pfx + "self_attn.o_proj.weight"].T)
     h = rms_norm(x, w[pfx + "post_attention_layernorm.weight"], lcfg["rms_norm_eps"])
-    g = h @ w[pfx + "mlp.gate_proj.weight"].T
-    u = h @ w[pfx + "mlp.up_proj.weight"].T
-    return x + (HO.silu(g) * u) @ w[pfx + "mlp.down_proj.weight"].T
+    g = HO._mm(h, w[pfx + "mlp.gate_proj.weight"].T)
+    u = HO._mm(h, w[pfx + "mlp.up_proj.weight"].T)
+    return x + HO._mm(HO.silu(g) * u, w[pfx + "mlp.down_proj.weight"].T)
 
 
 def llama_decoder(w, lcfg, inputs_embeds, attention_mask=None, position_ids=None, seg_ids=None, prefix="model."):
