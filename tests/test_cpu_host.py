@@ -265,3 +265,36 @@ def test_kernel_oracles_are_the_pinned_oracle_functions():
     loss_r, *_ = nce_oracle(qq, pp, negs, ls, 0.99)
     assert 0 < float((loss_r - loss).abs().max()) <= 0.25
     assert float((bf16_round(qq) - qq).abs().max()) <= 2 ** -8 * float(qq.abs().max())
+
+
+def test_bench_launches_its_own_ranks_and_checks_the_world_size(monkeypatch):
+    """`python bench.py --gpus N` is the documented contract: with N > 1 and no launcher around it, bench.py starts N ranks
+    under torch.distributed.run on 127.0.0.1 (before anything touches the GPU) and relays their exit code; under a launcher
+    whose WORLD_SIZE disagrees with --gpus it refuses to run (round-1 advice: --gpus used to be ignored)."""
+    import importlib
+    import subprocess
+    import sys as _sys
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    class _R:
+        returncode = 7
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return _R()
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(_sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7                                               # the launcher's exit code is relayed
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert "WORLD_SIZE=2" in str(e.value.code) and "--gpus 4" in str(e.value.code)
