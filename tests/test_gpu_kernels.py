@@ -288,6 +288,7 @@ from kernel_oracles import nce_oracle as _nce_oracle        # the pinned HO.nce_
 
 @pytest.mark.parametrize("D,n_tok,n_neg,dtype", [(16, 37, 30, torch.float32), (64, 200, 96, torch.bfloat16),
                                                  (256, 300, 512, torch.bfloat16), (256, 129, 8192, torch.bfloat16),
+                                                 (32, 90, 128, torch.float32), (128, 140, 320, torch.bfloat16),   # every tile-step shape
                                                  (512, 150, 96, torch.float32)])     # 512: the generic-width (library GEMM) path
 def test_nce_fwd_bwd(ops, D, n_tok, n_neg, dtype):
     g = torch.Generator().manual_seed(8 + D)
@@ -339,7 +340,9 @@ def test_nce_fwd_bwd(ops, D, n_tok, n_neg, dtype):
 
 
 @pytest.mark.parametrize("D,n_pos,P,n_neg,dtype", [(64, 40, 4, 96, torch.float32), (256, 70, 8, 512, torch.bfloat16),
-                                                   (256, 33, 8, 8192, torch.float32), (32, 50, 3, 70, torch.bfloat16)])
+                                                   (256, 33, 8, 8192, torch.float32), (32, 50, 3, 70, torch.bfloat16),
+                                                   (16, 30, 2, 64, torch.float32), (32, 45, 3, 96, torch.bfloat16),      # plain forms (whole
+                                                   (128, 60, 4, 256, torch.bfloat16), (64, 50, 5, 160, torch.float32)])  #  32-negative tiles)
 def test_nce_shared_query_rows_match_per_token_oracle(ops, D, n_pos, P, n_neg, dtype):
     """Query-row sharing (nce_shared.hip): runs of tokens with the same query row (the offsets of one position) through
     the row-level streaming kernels + per-token corrections vs the per-token oracle: loss 1e-4, log counters, gradients.
