@@ -116,6 +116,9 @@ int mhr_adam_rows_lazy(float* w, float* m, float* v, int64_t n_rows, int dim, co
  * partials and of bias gradients straight into the flat gradient buffer (autograd's accumulate semantics: the caller
  * zeroes the buffer once per step).  Many-row inputs are reduced by several workgroups meeting through float atomics. */
 int mhr_sum_rows_into(const void* x_bf16, int64_t rows, int64_t cols, float* out, void* stream);
+/* The same column sums for n equally shaped bf16 matrices in ONE launch: ptrs is a DEVICE int64 array of 2 n addresses - the n
+ * sources [rows, cols] first, then the n fp32 destinations [cols] (accumulated into, float atomics across row ranges). */
+int mhr_sum_rows_many(const int64_t* ptrs, int n, int64_t rows, int64_t cols, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Normalisation / gating (HSTU layer, model/IDNet/hstu.py:213-219, 241, 277-285).

@@ -118,7 +118,9 @@ class SplitKLinearFn(Function):
         db = None
         if ctx.has_bias:
             if ctx.b_leaf is not None:
-                SplitKLinearFn._into(ctx.b_leaf, dy)
+                bopt = getattr(ctx.b_leaf, "_mhr_opt", None)
+                if not (bopt is not None and _SUM_KERNEL and bopt.queue_bias_sum(dy, ctx.b_leaf)):     # all such sums: one launch at the step
+                    SplitKLinearFn._into(ctx.b_leaf, dy)
             else:
                 db = torch.sum(dy, 0, dtype=torch.float32)
         return dx, dw, db, None, None

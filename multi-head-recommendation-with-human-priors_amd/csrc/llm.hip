@@ -134,8 +134,8 @@ extern "C" int mhr_rope_inplace(void* x_bf16, int64_t row_stride, const int32_t*
 // Block = 32 column threads (8 columns each) x 8 row lanes; row ranges are split over blockIdx.y when there are many rows
 // (then the partial sums meet in out[] through float atomics; with one row range the update is a plain read-modify-write).
 namespace {
-__global__ __launch_bounds__(256) void sum_rows_into_kernel(const bf16_t* __restrict__ x, int64_t rows, int64_t cols,
-                                                            float* __restrict__ out, int64_t rows_per_block) {
+__device__ __forceinline__ void sum_rows_body(const bf16_t* __restrict__ x, int64_t rows, int64_t cols, float* __restrict__ out,
+                                              int64_t rows_per_block) {
   __shared__ float red[8][32][8];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int64_t c0 = ((int64_t)blockIdx.x * 32 + tx) * 8;
@@ -190,6 +190,20 @@ __global__ __launch_bounds__(256) void sum_rows_into_kernel(const bf16_t* __rest
     }
   }
 }
+
+__global__ __launch_bounds__(256) void sum_rows_into_kernel(const bf16_t* __restrict__ x, int64_t rows, int64_t cols,
+                                                            float* __restrict__ out, int64_t rows_per_block) {
+  sum_rows_body(x, rows, cols, out, rows_per_block);
+}
+
+// the same reduction for MANY equally shaped matrices in one launch (blockIdx.z picks the matrix): the bias gradients of the
+// encoder's output projections - eight [B L, D] column sums per step at cfg1, each too small to fill the chip on its own
+__global__ __launch_bounds__(256) void sum_rows_many_kernel(const int64_t* __restrict__ ptrs, int n, int64_t rows, int64_t cols,
+                                                            int64_t rows_per_block) {
+  const bf16_t* x = reinterpret_cast<const bf16_t*>(ptrs[blockIdx.z]);
+  float* out = reinterpret_cast<float*>(ptrs[n + blockIdx.z]);
+  sum_rows_body(x, rows, cols, out, rows_per_block);
+}
 }  // namespace
 
 extern "C" int mhr_sum_rows_into(const void* x_bf16, int64_t rows, int64_t cols, float* out, void* stream) {
@@ -208,5 +222,19 @@ extern "C" int mhr_sum_rows_into(const void* x_bf16, int64_t rows, int64_t cols,
   hipLaunchKernelGGL(sum_rows_into_kernel, dim3((unsigned)col_blocks, (unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0,
                      (hipStream_t)stream, (const bf16_t*)x_bf16, rows, cols, out, rpb);
   MHR_CHECK_LAUNCH("sum_rows_into");
+  return MHR_OK;
+}
+
+extern "C" int mhr_sum_rows_many(const int64_t* ptrs, int n, int64_t rows, int64_t cols, void* stream) {
+  MHR_REQUIRE(ptrs && n > 0 && n <= 65535, "sum_rows_many: bad arguments");
+  MHR_REQUIRE(rows > 0 && cols > 0 && cols % 8 == 0, "sum_rows_many: cols=%lld must be a positive multiple of 8", (long long)cols);
+  const int64_t col_blocks = (cols / 8 + 31) / 32;
+  int64_t splits = 1;
+  while (splits < 64 && col_blocks * splits * n < 512 && rows / (splits * 2) >= 64) splits *= 2;
+  if (splits < 2 && rows >= 128) splits = 2;        // (>= 2 row ranges: the atomic path; one range would do a plain read-modify-write)
+  const int64_t rpb = (rows + splits - 1) / splits;
+  hipLaunchKernelGGL(sum_rows_many_kernel, dim3((unsigned)col_blocks, (unsigned)((rows + rpb - 1) / rpb), (unsigned)n), dim3(256), 0,
+                     (hipStream_t)stream, ptrs, n, rows, cols, rpb);
+  MHR_CHECK_LAUNCH("sum_rows_many");
   return MHR_OK;
 }

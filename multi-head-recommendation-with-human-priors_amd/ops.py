@@ -178,6 +178,13 @@ def heads_residual_bwd(d_out, z, B, L, H):
     return dz, dx
 
 
+def sum_rows_many(ptr_table, n, rows, cols, keep=None):
+    """out_i += x_i.sum(0) for n equally shaped bf16 matrices in one launch; ptr_table: device int64 [2 n] (sources, then fp32
+    destinations).  `keep`: the tensors behind the addresses (held by the caller until the launch is enqueued)."""
+    _chk(ptr_table, "ptr_table", torch.int64)
+    _timed_call("mhr_sum_rows_many", ptr_table.data_ptr(), int(n), int(rows), int(cols), _stream())
+
+
 def bad_id_count(reset=True):
     """Ids outside the table that embedding gathers met since the last reset (they are clamped on the device, where the
     reference's nn.Embedding raises).  Synchronises: call it where the host reads device results anyway."""

@@ -169,10 +169,55 @@ class FusedAdamW:
         p._mhr_in_arena = True
         return self._arena[:, off:off + n].view(S, *p.shape)
 
+    def finish_grads(self):
+        """Fold every deferred reduction into `flat_g` (step() does this itself; anything that reads the flat gradient before
+        the step - a test, a norm - calls it first)."""
+        self._reduce_arena()
+
     def _reduce_arena(self):
         if getattr(self, "_arena", None) is not None and self._arena_used:
             ops.sum_rows_into(self._arena, self.flat_g)
             self._arena_used = set()
+        self._reduce_bias_queue()
+
+    # ---- bias gradients of equally shaped projections: ONE column-sum launch for all of them ------------------------------
+    def queue_bias_sum(self, dy, bias_param):
+        """Defer `bias.grad += dy.sum(0)` to the step (same one-backward-per-step condition as the arena): the eight output
+        projections of the cfg1 encoder each reduce a [B L, D] matrix - alone a launch that cannot fill the chip."""
+        if not getattr(self, "_arena_on", False) or dy.dtype != torch.bfloat16 or not dy.is_contiguous() or dy.dim() != 2 \
+                or dy.shape[1] % 8 or bias_param.grad is None or not bias_param.grad.is_contiguous():
+            return False
+        if not hasattr(self, "_bias_q"):
+            self._bias_q = []
+        self._bias_q.append((dy, bias_param.grad))
+        return True
+
+    def _reduce_bias_queue(self):
+        q, self._bias_q = getattr(self, "_bias_q", []), []
+        groups = {}
+        for dy, g in q:
+            groups.setdefault(tuple(dy.shape), []).append((dy, g))
+        for (rows, cols), items in groups.items():
+            if len(items) == 1:
+                ops.sum_rows_into(items[0][0], items[0][1])
+                continue
+            n = len(items)
+            key = (n, rows, cols)
+            if not hasattr(self, "_bias_tabs"):
+                self._bias_tabs = {}
+            if key not in self._bias_tabs:       # pinned ring of pointer tables + their device copy (grow-only: captured graphs read them)
+                host = torch.zeros(HOST_RING, 2 * n, dtype=torch.int64)
+                if self.flat_g.is_cuda:
+                    host = host.pin_memory()
+                self._bias_tabs[key] = [host, torch.zeros(2 * n, dtype=torch.int64, device=self.flat_g.device), 0]
+            host, devt, k = self._bias_tabs[key]
+            slot = host[k % HOST_RING]
+            self._bias_tabs[key][2] = k + 1
+            for i, (dy, g) in enumerate(items):
+                slot[i] = dy.data_ptr()
+                slot[n + i] = g.data_ptr()
+            devt.copy_(slot, non_blocking=True)
+            ops.sum_rows_many(devt, n, rows, cols, keep=items)
 
     def zero_grad(self):
         global GRAD_EPOCH

@@ -489,6 +489,23 @@ def test_sum_rows_into(ops, rows, cols):
     assert float((out.cpu().double() - ref).abs().max()) <= 1e-5 * scale
 
 
+@pytest.mark.parametrize("n,rows,cols", [(8, 25600, 256), (3, 5, 64), (2, 4097, 1032), (16, 1, 8)])
+def test_sum_rows_many(ops, n, rows, cols):
+    """The one-launch form for n equally shaped matrices (the encoder's bias gradients): each destination gets exactly what
+    `sum_rows_into` gives it, on top of what it already held; the matrices do not mix."""
+    g = torch.Generator().manual_seed(n * rows + cols)
+    xs = [dev(bf(torch.randn(rows, cols, generator=g) * (i + 1))) for i in range(n)]
+    bases = [torch.randn(cols, generator=g) for _ in range(n)]
+    outs = [dev(b.clone()) for b in bases]
+    table = torch.tensor([x.data_ptr() for x in xs] + [o.data_ptr() for o in outs], dtype=torch.int64, device="cuda")
+    ops.sum_rows_many(table, n, rows, cols, keep=(xs, outs))
+    torch.cuda.synchronize()
+    for x, b, o in zip(xs, bases, outs):
+        ref = b.double() + x.cpu().double().sum(0)
+        scale = float(x.float().abs().sum(0).max()) + 1.0
+        assert float((o.cpu().double() - ref).abs().max()) <= 1e-5 * scale
+
+
 @pytest.mark.parametrize("rows,D", [(7, 64), (300, 256), (33, 1024)])
 def test_add_layernorm_fwd_bwd(ops, rows, D):
     """Fused residual add + LayerNorm vs torch fp32 on the same bf16-rounded branch: x_out exact (fp32 add), xn and

@@ -595,6 +595,7 @@ out["loss"].backward()
 w0 = model.item_embedding.weight.detach().clone()
 # the exchange exactly as FusedAdamW.step drives it
 from mhr_amd import distributed as D
+opt.finish_grads()
 h = D.allreduce_sum_begin(opt.flat_g); model.begin_sparse_exchange(); h.wait()
 sg = model.finish_sparse_grad()
 slot = sg.row_slot.long()
@@ -667,6 +668,7 @@ def test_data_parallel_train_step_two_ranks_one_card(rec, tmp_path, overlap):
         tg = torch.zeros_like(model.item_embedding.weight)
         tg[slot >= 0] = sg.rows[slot[slot >= 0]]
         sg.row_slot.fill_(-1)
+        opt.finish_grads()
         flat_sum = flat_sum + opt.flat_g.clone()
         table_sum = table_sum + tg
         losses.append(float(out["loss"]))
@@ -725,6 +727,7 @@ def test_gradient_accumulation_matches_separate_micro_batches(rec):
         sg = model1.finish_sparse_grad()
         table = table + sg.to_dense()
         sg.row_slot.fill_(-1)
+        tr1.optimizer.finish_grads()             # accumulate_grad == 1 defers the partial and bias reductions to the step
         flat = flat + tr1.optimizer.flat_g.clone()
     assert float((seen["flat"] - flat).abs().max()) <= 1e-3 * float(flat.abs().max())
     assert float((seen["table"] - table).abs().max()) <= 1e-3 * float(table.abs().max())
