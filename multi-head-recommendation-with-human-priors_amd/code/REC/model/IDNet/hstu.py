@@ -18,6 +18,7 @@ Differences from the reference that are deliberate:
   * `predict_topk` returns per-head top-k without materialising the [B,H,N] score tensor; `predict`
     still returns dense scores for callers written against the reference.
 """
+import os
 from logging import getLogger
 
 import torch
@@ -27,6 +28,8 @@ import torch.nn.functional as F
 from REC.model.basemodel import BaseModel, all_gather_pool_ids
 from REC.model.multihead import FusedTopK, MultiHeadDecoding  # noqa: F401  (FusedTopK re-exported)
 from REC.utils.enum_type import InputType
+
+EARLY_LOSS_PREP = os.environ.get("MHR_EARLY_LOSS_PREP", "1") != "0"      # 0: the loss preparation runs in line, after the encoder
 
 
 def truncated_normal(x, mean, std):
@@ -118,6 +121,8 @@ class HSTU(MultiHeadDecoding, BaseModel):
         self.dense_embedding_grad = False
         self.sparse_grad = None
         self._row_slot = None
+        self._side_stream = None
+        self._presorted = None
         self._pending_rows = None
         self._shared_pending = None
         self._row_exchange = None
@@ -251,8 +256,37 @@ class HSTU(MultiHeadDecoding, BaseModel):
         negs_pools = L2NormFn.apply(rows_negs.contiguous(), self if fused_pos else None).view(len(pools), n_pool, D)
 
         key_valid = mask[:, :L].to(torch.uint8).contiguous()
+        # everything of the loss that waits for nothing the encoder makes (token lists, row maps, the false-negative bit table of
+        # the target rows, the id sort of the embedding backward) goes on a second stream UNDERNEATH the encoder: some fifty
+        # few-microsecond launches that otherwise sit on the step's critical path one after the other
+        plan = early = None
+        side = None
+        if EARLY_LOSS_PREP and torch.is_grad_enabled():
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream(device=items.device)
+            side = self._side_stream
+            side.wait_stream(torch.cuda.current_stream())        # the fork: everything up to here (rows, negatives) is visible
         out = self._encode(x, key_valid)                                 # [B,L,D] fp32
-        return self._multihead_loss(out, e_rows, negs_pools, pools, mask, pos_tags)
+        if side is not None:
+            # issued AFTER the encoder's launches (so they reach the GPU first), ordered only after the fork above
+            with torch.cuda.stream(side), torch.no_grad():
+                plan = self._loss_plan(None, pools, mask, pos_tags)
+                early = self._loss_prepare(plan, e_rows, negs_pools)
+                self._presort_ids(ids_all)
+            torch.cuda.current_stream().wait_stream(side)
+        return self._multihead_loss(out, e_rows, negs_pools, pools, mask, pos_tags, plan=plan, early=early)
+
+    def _presort_ids(self, ids_all):
+        """The id sort and the zeroed row buffer of the sparse embedding backward (EmbeddingGatherFn.backward) depend on the
+        batch's ids only: made early, next to the loss preparation (one-rank, one-backward-per-step training only - data
+        parallel / accumulating steps sort the exchanged ids of all micro-batches at the optimizer step)."""
+        from mhr_amd import distributed as dist_
+        self._presorted = None
+        if dist_.world_size() > 1 or getattr(self, "accumulate_rows", False) or getattr(self, "dense_embedding_grad", False):
+            return
+        sorted_ids, perm = torch.sort(ids_all)
+        rows = torch.zeros(ids_all.numel(), self.item_embedding.weight.shape[1], dtype=torch.float32, device=ids_all.device)
+        self._presorted = (ids_all, sorted_ids, perm, rows)
 
     def begin_sparse_exchange(self):
         """Data parallel: put the cross-rank exchange of the last backward's gradient rows on the wire (asynchronous;

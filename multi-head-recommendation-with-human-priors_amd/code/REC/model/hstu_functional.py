@@ -311,8 +311,12 @@ class EmbeddingGatherFn(Function):
             holder._pending_rows.append((ids_all, d_rows, n_item_ids, shared))
             holder.sparse_grad = None
             return None, d_pos, None, None, None, None, None
-        sorted_ids, perm = torch.sort(ids_all)
-        out_rows = torch.zeros(ids_all.numel(), D, dtype=torch.float32, device=dev)
+        pre, holder._presorted = getattr(holder, "_presorted", None), None
+        if pre is not None and pre[0].data_ptr() == ids_all.data_ptr() and pre[0].numel() == ids_all.numel():        # sorted (and the row buffer zeroed) early, underneath the encoder forward
+            _, sorted_ids, perm, out_rows = pre
+        else:
+            sorted_ids, perm = torch.sort(ids_all)
+            out_rows = torch.zeros(ids_all.numel(), D, dtype=torch.float32, device=dev)
         ops.sparse_rows_segment_sum(sorted_ids, perm, d_items, d_negs if n_neg_ids else None, d_x, L, window, out_rows, holder._row_slot)
         holder.sparse_grad = SparseRowGrad(sorted_ids, out_rows, holder._row_slot, n_rows)
         return None, d_pos, None, None, None, None, None
@@ -405,10 +409,12 @@ class NceLossFn(Function):
 
     @staticmethod
     def forward(ctx, q_rows, p_rows, negs, logit_scale, q_idx, p_idx, n_tok_dev, tok_cap, thres, want_logs, logs_out,
-                bucket_idx=None, n_buckets=0, log_group=-1, p_row_mask=None, share_rows=False, window=None, ihn_beta=0.0):
+                bucket_idx=None, n_buckets=0, log_group=-1, p_row_mask=None, share_rows=False, window=None, ihn_beta=0.0,
+                prep=None):
         sv = ops.nce_fwd(q_rows, q_idx, p_rows, p_idx, negs, n_tok_dev, tok_cap, logit_scale.detach().view(1), thres,
                          want_logs=want_logs, for_backward=True, bucket_idx=bucket_idx, n_buckets=n_buckets,
-                         log_group=log_group, p_row_mask=p_row_mask, share_rows=share_rows, window=window, ihn_beta=ihn_beta)
+                         log_group=log_group, p_row_mask=p_row_mask, share_rows=share_rows, window=window, ihn_beta=ihn_beta,
+                         prep=prep)
         ctx.sv = sv
         ctx.save_for_backward(q_idx, p_idx, logit_scale)
         ctx.shapes = (q_rows.shape, p_rows.shape)
@@ -432,4 +438,4 @@ class NceLossFn(Function):
             w = w / sv.bucket_cnt.clamp_min(1.0)                      # d(mean)/d(loss_t) = 1 / count of the bucket
         d_negs, d_ls = ops.nce_bwd(sv, w, logit_scale.detach().view(1), q_idx, p_idx, dq, dp, want_negs=ctx.needs_input_grad[2])
         ctx.sv = None
-        return dq, dp, d_negs, d_ls.view(logit_scale.shape), None, None, None, None, None, None, None, None, None, None, None, None, None, None
+        return dq, dp, d_negs, d_ls.view(logit_scale.shape), None, None, None, None, None, None, None, None, None, None, None, None, None, None, None

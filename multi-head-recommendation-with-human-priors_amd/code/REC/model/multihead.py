@@ -268,7 +268,34 @@ class MultiHeadDecoding:
             self._tok_cache[key] = (q_all, p_all, o_all)
         return self._tok_cache[key]
 
-    def _grouped_loss(self, head_rows, e_rows, negs_g, valid_g, head_for_p, log_group, p_row_mask=None, q_all=None, ihn_beta=0.0):
+    def _token_lists(self, valid_g, head_for_p, q_all=None):
+        """Ordered compaction of the live (group, slot) pairs of valid_g [G,B,L,P]: (share, q_idx, p_idx, o_idx, n_tok, window)."""
+        from mhr_amd import ops
+        G, B, L, P = valid_g.shape
+        n_slots = B * P * L
+        q_static, p_all, o_all = self._token_tables(B, valid_g.device, head_for_p)
+        q_all = q_static if q_all is None else q_all          # (a model may pick the query row per token itself: ComiRec)
+        share = P > 1 and q_all is q_static      # the P offsets of a position share their query row (csrc/nce_shared.hip)
+        if share:
+            q_idx, p_idx, o_idx, n_tok, tos = ops.token_compact(valid_g.reshape(G, n_slots), q_all, p_all, o_all, slot_map=True)
+            return share, q_idx, p_idx, o_idx, n_tok, (tos, L, P)
+        q_idx, p_idx, o_idx, n_tok = ops.token_compact(valid_g.reshape(G, n_slots), q_all, p_all, o_all)
+        return share, q_idx, p_idx, o_idx, n_tok, None
+
+    def _loss_prepare(self, plan, e_rows, negs_pools):
+        """The batch-only half of the grouped loss, built EARLY (HSTU.forward runs it on a second stream underneath the
+        sequence encoder): the token lists of the plan's groups and `ops.nce_shared_prepare` (row maps, false-negative bit
+        table, normalised targets) - some forty small launches and one MFMA kernel that wait for nothing the encoder makes."""
+        from mhr_amd import ops
+        tokens = self._token_lists(plan["valid_g"], plan["head_for_p_g"])
+        prep = None
+        if tokens[0] and plan["slots"] == list(range(negs_pools.shape[0])):          # negs_g IS negs_pools: same memory on both streams
+            prep = ops.nce_shared_prepare(tokens[1], tokens[2], tokens[4], e_rows.detach(), negs_pools.detach().contiguous(),
+                                          float(self.nce_thres), plan["p_row_mask"], plan["log_group"] is not None)
+        return dict(tokens=tokens, prep=prep)
+
+    def _grouped_loss(self, head_rows, e_rows, negs_g, valid_g, head_for_p, log_group, p_row_mask=None, q_all=None, ihn_beta=0.0,
+                      early=None):
         """Sampled-softmax loss of G (token mask, negative pool) groups in ONE fused launch per kernel.
         valid_g [G,B,L,P] bool (offset fastest), negs_g [G,n_neg,D] bf16, head_for_p [G,P].  Returns (mean loss per (group, offset)
         [G,P] fp32, logs of `log_group` or None).  No host sync: tokens are compacted by scatter at fixed capacity
@@ -276,24 +303,15 @@ class MultiHeadDecoding:
         hstu.py:688-690, 814-829)."""
         from REC.model.hstu_functional import NceLossFn
         G, B, L, P = valid_g.shape
-        dev = valid_g.device
-        n_slots = B * P * L
-        q_static, p_all, o_all = self._token_tables(B, dev, head_for_p)
-        q_all = q_static if q_all is None else q_all          # (a model may pick the query row per token itself: ComiRec)
         from mhr_amd import ops
-        share = P > 1 and q_all is q_static      # the P offsets of a position share their query row (csrc/nce_shared.hip)
-        window = None
-        if share:
-            q_idx, p_idx, o_idx, n_tok, tos = ops.token_compact(valid_g.reshape(G, n_slots), q_all, p_all, o_all, slot_map=True)
-            window = (tos, L, P)
-        else:
-            q_idx, p_idx, o_idx, n_tok = ops.token_compact(valid_g.reshape(G, n_slots), q_all, p_all, o_all)
+        share, q_idx, p_idx, o_idx, n_tok, window = early["tokens"] if early is not None else self._token_lists(valid_g, head_for_p, q_all)
         cap = q_idx.shape[1]
         want_logs = log_group is not None
         logs = {} if want_logs else None
         mean_p = NceLossFn.apply(head_rows, e_rows, negs_g, self.logit_scale, q_idx, p_idx, n_tok, cap,
                                  float(self.nce_thres), want_logs, logs, o_idx, P,
-                                 log_group if want_logs else -1, p_row_mask, share, window, float(ihn_beta))       # [G, P]
+                                 log_group if want_logs else -1, p_row_mask, share, window, float(ihn_beta),
+                                 early["prep"] if early is not None else None)       # [G, P]
         out_logs = None
         if want_logs:                                   # all counters of the logged group in ONE launch (mhr_nce_log_counters)
             ks = [k for k in (1, 5, 10, 50, 100) if k <= negs_g.shape[1] + 1]
@@ -353,19 +371,22 @@ class MultiHeadDecoding:
                 pool = pool_slot[c] if self.neg_sample_by_cat else pool_slot[pools[0]]
                 groups.append((head_for_p, pool, float(self.prior_loss_weight[c]), 'prior', c))
         slots = [g[1] for g in groups]
-        negs_g = negs_pools if slots == list(range(len(pools))) else negs_pools[self._const(slots, dev, torch.int64)]
+        negs_g = None                     # (negs_pools=None: the caller picks the pools itself, `_multihead_loss` does)
+        if negs_pools is not None:
+            negs_g = (negs_pools if slots == list(range(len(pools))) else negs_pools[self._const(slots, dev, torch.int64)]).contiguous()
         valid_g = valid_parts[0] if len(valid_parts) == 1 else torch.cat(valid_parts)
         rows_g = row_parts[0] if len(row_parts) == 1 else torch.cat(row_parts)
         return dict(groups=groups, tag_win=tag_win, valid_g=valid_g.contiguous(),
-                    head_for_p_g=torch.stack([g[0] for g in groups]), negs_g=negs_g.contiguous(),
+                    head_for_p_g=torch.stack([g[0] for g in groups]), negs_g=negs_g, slots=slots,
                     # reference: top-k logs come from the nce branch, then are overwritten by prior category 0 (hstu.py:723, 863)
                     log_group=max(i for i, g in enumerate(groups) if g[3] == 'nce' or g[4] == 0),
                     p_row_mask=rows_g.reshape(len(groups), -1).contiguous())
 
-    def _multihead_loss(self, out, e_rows, negs_pools, pools, mask, pos_tags, plan=None):
+    def _multihead_loss(self, out, e_rows, negs_pools, pools, mask, pos_tags, plan=None, early=None):
         """Everything of the training forward after the sequence encoder (reference hstu.py:648-872 / hllm.py:506-763).
         out [B,L,D] fp32 encoder output; e_rows [B*(L+P), D] fp32 target-item rows; negs_pools [len(pools), n_pool, D]
-        bf16 L2-normalised; mask [B,L+P] bool; pos_tags [B,L+P,C]; plan: `_loss_plan(...)` when the caller built it early."""
+        bf16 L2-normalised; mask [B,L+P] bool; pos_tags [B,L+P,C]; plan / early: `_loss_plan(...)` / `_loss_prepare(...)` when the
+        caller built them before the encoder ran."""
         dev = out.device
         B = out.shape[0]
         L, P, D = self.max_seq_length, self.pred_len, self._head_dim
@@ -377,7 +398,11 @@ class MultiHeadDecoding:
             plan = self._loss_plan(negs_pools, pools, mask, pos_tags)
         groups, tag_win, valid_g, head_for_p_g = plan["groups"], plan["tag_win"], plan["valid_g"], plan["head_for_p_g"]
         negs_g, log_group, p_row_mask = plan["negs_g"], plan["log_group"], plan["p_row_mask"]
-        mean_gp, logs = self._grouped_loss(head_rows, e_rows, negs_g.contiguous(), valid_g, head_for_p_g, log_group, p_row_mask)
+        if negs_g is None:
+            slots = plan["slots"]
+            negs_g = negs_pools if slots == list(range(len(pools))) else negs_pools[self._const(slots, dev, torch.int64)]
+        mean_gp, logs = self._grouped_loss(head_rows, e_rows, negs_g.contiguous(), valid_g, head_for_p_g, log_group, p_row_mask,
+                                           early=early)
         gw = ("gw", tuple(g[2] for g in groups), str(dev))                 # horizon discount x group weight, [G,P], built once
         if gw not in self._tok_cache:
             self._tok_cache[gw] = (self.horizon_discount.float()[None, :] * self._const([g[2] for g in groups], dev, torch.float32)[:, None]).contiguous()

@@ -576,29 +576,62 @@ def _fix_bits_tables(p_rows, negs, n_neg, D, G, thres, p_row_mask):
     return tabs[0], tabs[1], tabs[2]
 
 
+def nce_shared_prepare(q_idx, p_idx, n_tok_dev, p_rows, negs, thres, p_row_mask, want_logs):
+    """Everything the row-sharing forward needs that depends on the BATCH only (token lists, target rows, negatives) and not
+    on the query rows: the row maps of the token lists, the false-negative bit table of the target rows, the first target of
+    every row, the normalised target rows and the zeroed accumulators.  `nce_fwd(share_rows=True)` builds it itself; a model
+    may build it EARLY - on a second stream underneath the sequence encoder - and hand it in (`prep=`).
+    Returns None when the shapes are not the row-sharing path's (ragged capacity / pool sizes, feature dims it does not take)."""
+    G, cap = q_idx.shape
+    n_neg, D = negs.shape[1], negs.shape[2]
+    if not SHARE_ROWS or D not in STREAM_DIMS or cap % 32 or n_neg % 32:
+        return None
+    prep = _shared_prepare_inline(q_idx, p_idx, n_tok_dev, cap, cap + 32, p_rows, negs, n_neg, D, G, thres, p_row_mask)
+    prep["key"] = (q_idx.data_ptr(), p_idx.data_ptr(), p_rows.data_ptr(), negs.data_ptr(), float(thres), bool(want_logs))
+    prep["keep"] = (q_idx, p_idx, p_rows, negs)
+    return prep
+
+
+def _shared_prepare_inline(q_idx, p_idx, n_tok_dev, cap, row_cap, p_rows, negs, n_neg, D, G, thres, p_row_mask):
+    dev = negs.device
+    prep = {"row_maps": _row_maps(q_idx, n_tok_dev, cap, row_cap),
+            # the real false-negative bit table, per target row
+            "fix": _fix_bits_tables(p_rows, negs, n_neg, D, G, thres, p_row_mask)}
+    prep["r_p"] = torch.gather(p_idx, 1, prep["row_maps"][2].long().clamp_(max=cap - 1)).contiguous()
+    prep["z"] = zeros_many(dev, ((G, row_cap), torch.float32), ((G, row_cap), torch.int32), ((G, row_cap), torch.int32),
+                           ((G, cap), torch.int32), ((G, cap), torch.int32))
+    # the normalised target is a property of the TARGET ROW (shared by every token and group that points at it)
+    pn_rows, p_norm = l2norm_rows(p_rows.contiguous(), torch.bfloat16, want_norms=True)
+    prep["pn"] = (pn_rows, 1.0 / p_norm)
+    return prep
+
+
 def _nce_fwd_shared(sv, q_rows, p_rows, negs, logit_scale, thres, want_logs, bucket_idx, n_buckets, log_group, p_row_mask, loss,
-                    window=None):
+                    window=None, prep=None):
     """Query-row sharing (csrc/nce_shared.hip): the streaming kernels see each distinct query row once."""
     dev = negs.device
     G, n_neg, D = sv.groups, sv.n_neg, sv.dim              # negs itself is padded to whole 32-row tiles
     cap, tok_cap, n_tok_dev = sv.cap, sv.tok_cap, sv.n_tok_dev
     q_idx, p_idx = sv.q_idx, sv.p_idx
     row_cap = cap + 32
-    r_q, tok2row, r_first, n_row = _row_maps(q_idx, n_tok_dev, cap, row_cap)
     n_p_rows = p_rows.shape[0]
     rp_pad = (n_p_rows + 255) // 256 * 256
     n_tiles = (n_neg + 31) // 32
     st = _stream()
+    key = (q_idx.data_ptr(), p_idx.data_ptr(), p_rows.data_ptr(), negs.data_ptr(), float(thres), bool(want_logs))
+    if prep is not None and prep["key"] != key:
+        raise ValueError("nce_fwd: prep was built for other token lists / target rows / negatives than this call's")
+    if prep is None:
+        prep = _shared_prepare_inline(q_idx, p_idx, n_tok_dev, cap, row_cap, p_rows, negs, n_neg, D, G, thres, p_row_mask)
+    r_q, tok2row, r_first, n_row = prep["row_maps"]
     # (1) the real false-negative bit table, per target row
-    fix_words, fix_any, slot_of_row = _fix_bits_tables(p_rows, negs, n_neg, D, G, thres, p_row_mask)
+    fix_words, fix_any, slot_of_row = prep["fix"]
     # (2) the fused streaming forward over the ROWS with NOTHING suppressed (mhr_nce_fwd's plain form: no bit table, no
     #     suppression words, no normalised-target rows written); its positive is the target of the row's first token, so the
     #     log counters of offset-0 tokens come out of this launch.  Pools that are not whole 32-negative tiles take the
     #     general form with an all-zero bit table that is never written.
     plain = n_neg % 32 == 0
-    r_p = torch.gather(p_idx, 1, r_first.long().clamp_(max=cap - 1)).contiguous()
-    z = zeros_many(dev, ((G, row_cap), torch.float32), ((G, row_cap), torch.int32), ((G, row_cap), torch.int32),
-                   ((G, cap), torch.int32), ((G, cap), torch.int32))
+    r_p, z = prep["r_p"], prep["z"]
     sum_row = z[0]
     nv_row, rk_row = (z[1], z[2]) if want_logs else (None, None)
     qn_row = torch.empty(G, row_cap, D, dtype=torch.bfloat16, device=dev)
@@ -625,8 +658,8 @@ def _nce_fwd_shared(sv, q_rows, p_rows, negs, logit_scale, thres, want_logs, buc
                 *fix_args, st)
     # (3) per token: s+, sums and counters with the token's own suppressed negatives taken out.  The normalised target is a
     #     property of the TARGET ROW (shared by every token and group that points at it): one l2norm pass over p_rows
-    pn_rows, p_norm = l2norm_rows(p_rows.contiguous(), torch.bfloat16, want_norms=True)
-    sv.pn, sv.p_inv = pn_rows, (1.0 / p_norm)
+    pn_rows, sv.p_inv = prep["pn"]
+    sv.pn = pn_rows
     ssum = torch.empty(G, cap, dtype=torch.float32, device=dev)
     n_valid, rank = (z[3], z[4]) if want_logs else (None, None)
     _timed_call("mhr_nce_shared_fwd_tokens", pn_rows.data_ptr(), n_p_rows, p_idx.data_ptr(), tok2row.data_ptr(), G,
@@ -649,7 +682,7 @@ def _nce_fwd_shared(sv, q_rows, p_rows, negs, logit_scale, thres, want_logs, buc
 
 def nce_fwd(q_rows, q_idx, p_rows, p_idx, negs, n_tok_dev, tok_cap, logit_scale, thres=0.99, want_logs=False,
             for_backward=True, bucket_idx=None, n_buckets=0, log_group=-1, p_row_mask=None, share_rows=False, window=None,
-            ihn_beta=0.0):
+            ihn_beta=0.0, prep=None):
     """Grouped sampled softmax.  q_rows/p_rows [*, D] (bf16 or f32, same dtype, shared by all groups);
     q_idx/p_idx [G, tok_cap] int32; negs [G, n_neg, D] bf16 normalised; n_tok_dev [G] int32.
     (1-D q_idx / 2-D negs are accepted as a single group.)  Saved tensors carry the leading group axis.
@@ -660,7 +693,8 @@ def nce_fwd(q_rows, q_idx, p_rows, p_idx, negs, n_tok_dev, tok_cap, logit_scale,
     window = (tok_of_slot, L, P) (with share_rows): the lists are the compaction of (b, l, p) window slots with
     p_idx = b (L + P) + l + 1 + p (token_compact(slot_map=True)): the backward then needs no per-token atomics.
     ihn_beta > 0: REMI's interest-aware hard-negative loss (remi.py:203-288) instead of the plain sampled softmax; runs on the
-    dense path (library GEMM + the ihn_dense epilogues of csrc/wide.hip) at every feature dim."""
+    dense path (library GEMM + the ihn_dense epilogues of csrc/wide.hip) at every feature dim.
+    prep: `nce_shared_prepare(...)` of exactly these lists / rows / negatives, built earlier (row-sharing path only)."""
     if q_idx.dim() == 1:
         q_idx, p_idx, negs, n_tok_dev = q_idx[None], p_idx[None], negs[None], n_tok_dev.view(1)
     _chk(negs, "negs", torch.bfloat16)
@@ -707,7 +741,7 @@ def nce_fwd(q_rows, q_idx, p_rows, p_idx, negs, n_tok_dev, tok_cap, logit_scale,
         sv.negs = negs
         sv.n_tok_dev, sv.tok_cap, sv.cap, sv.thres, sv.dim, sv.n_neg, sv.groups = n_tok_dev, tok_cap, cap, float(thres), D, n_neg, G
         return _nce_fwd_shared(sv, q_rows, p_rows, negs, logit_scale, thres, want_logs, bucket_idx, n_buckets, log_group,
-                               p_row_mask, loss, window)
+                               p_row_mask, loss, window, prep)
     if for_backward or sv.wide:
         sv.qn = torch.empty(G, cap, D, dtype=torch.bfloat16, device=dev)
         sv.pn = torch.empty(G, cap, D, dtype=torch.bfloat16, device=dev)

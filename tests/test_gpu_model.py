@@ -734,6 +734,53 @@ def test_gradient_accumulation_matches_separate_micro_batches(rec):
     assert int((seen["table"].abs().sum(1) > 0).sum()) == int((table.abs().sum(1) > 0).sum())
 
 
+def test_early_loss_preparation_is_the_inline_path(rec):
+    """HSTU.forward builds the batch-only half of the loss (token lists, row maps, false-negative bit table, normalised targets,
+    the id sort of the embedding backward) on a second stream underneath the encoder (MHR_EARLY_LOSS_PREP, default on).  Same
+    kernels on the same inputs: loss and gradients are the in-line path's up to the order of float atomics."""
+    import mhr_amd.synth as synth
+    from REC.config.configurator import Config, apply_run_fixups
+    from REC.model.IDNet import hstu as hstu_mod
+    from REC.trainer import Trainer
+    from REC.utils import get_model
+    dev = torch.device("cuda", 0)
+    kw = dict(MAX_ITEM_LIST_LENGTH=24, pred_len=4, eval_pred_len=2, n_layers=2, n_heads=2, item_embedding_size=64,
+              hstu_embedding_size=64, num_negatives=256, total_iters=100, eval_interval=0, checkpoint_dir=None, save_model_note="t",
+              hidden_dropout_prob=0.0, attn_dropout_prob=0.0, loss='prior', num_prior_head=3, medusa_num_layers=1, eval_num_cats=3,
+              device=dev)
+    got = {}
+    flag = hstu_mod.EARLY_LOSS_PREP
+    try:
+        for early in (True, False):
+            hstu_mod.EARLY_LOSS_PREP = early
+            cfg = apply_run_fixups(Config(config_dict=synth.base_config(**kw)))
+            data = synth.SyntheticData(cfg, 3000, dev, seed=11)
+            cfg["int_to_category"] = data.int_to_category
+            torch.manual_seed(5)
+            model = get_model("HSTU")(cfg, data).to(dev)
+            tr = Trainer(cfg)
+            tr.setup_model(model)
+            losses = []
+            for i in range(3):                          # three steps: the second stream's buffers are recycled across steps
+                batch = data.train_batch(16)
+                tr.optimizer.zero_grad()
+                out = model(batch)
+                out["loss"].backward()
+                assert (model._side_stream is not None) == early
+                losses.append(float(out["loss"]))
+                sg = model.finish_sparse_grad()
+                table = sg.to_dense()
+                sg.row_slot.fill_(-1)
+                tr.optimizer.finish_grads()
+            got[early] = (losses, tr.optimizer.flat_g.clone(), table)
+    finally:
+        hstu_mod.EARLY_LOSS_PREP = flag
+    assert np.allclose(got[True][0], got[False][0], rtol=1e-6, atol=0)       # (the per-offset loss sums are float atomics)
+    for a, b in ((got[True][1], got[False][1]), (got[True][2], got[False][2])):
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
+    assert torch.equal(got[True][2].abs().sum(1) > 0, got[False][2].abs().sum(1) > 0)
+
+
 def test_lazy_table_adam_is_bitwise_the_dense_update(rec):
     """Lazy table optimizer (rows replayed through their gradient-free steps when next read) against the dense per-step
     update of the whole table, fed the SAME sparse gradients: 150 steps under a varying learning rate with weight decay
