@@ -279,6 +279,16 @@ int mhr_row_maps(const int32_t* q_idx, const int32_t* n_tok_dev, int n_groups, i
 int mhr_nce_log_counters(const int32_t* n_valid, const int32_t* rank, const int32_t* o_idx, const int32_t* n_tok_dev,
                          int group, int tok_cap, const int32_t* ks_host, int n_k, uint64_t* scratch8, float* out, void* stream);
 
+/* Weighted total of the per-(group, offset) mean losses plus the logged partial sums in ONE launch (reference hstu.py:697-723,
+ * 836-870: `loss_p = mean over the offset's tokens`, horizon discount x head weight, per-segment and per-head sums).
+ * bucket_sum / bucket_cnt [G, P] are mhr_nce_finalize's; weight [G, P]; P % n_segments == 0.
+ * total [1]; out [G P + G S + G + S] = per_gp = sum / max(cnt, 1) * weight | seg_all [G, S] | g_tot [G] | seg_sum [S] (over groups).
+ * Sums in index order (deterministic).  _bwd: w_out [G P] = d_total[0] * weight / max(cnt, 1), the per-bucket token weight
+ * mhr_nce_shared_bwd_rows / mhr_nce_bwd_tokens take. */
+int mhr_loss_reduce(const float* bucket_sum, const float* bucket_cnt, const float* weight, int n_groups, int n_buckets,
+                    int n_segments, float* total, float* out, void* stream);
+int mhr_loss_reduce_bwd(const float* d_total, const float* bucket_cnt, const float* weight, int n, float* w_out, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Sampled softmax with false-negative suppression (model/IDNet/hstu.py:600-619 + F.cross_entropy 697/833).
  * Tokens are described by row indices instead of compacted copies: token t uses query row

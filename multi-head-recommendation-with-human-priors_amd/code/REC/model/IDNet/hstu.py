@@ -271,7 +271,7 @@ class HSTU(MultiHeadDecoding, BaseModel):
             # issued AFTER the encoder's launches (so they reach the GPU first), ordered only after the fork above
             with torch.cuda.stream(side), torch.no_grad():
                 plan = self._loss_plan(None, pools, mask, pos_tags)
-                early = self._loss_prepare(plan, e_rows, negs_pools)
+                early = self._loss_prepare(plan, e_rows, negs_pools, n_q_rows=B * self.medusa_num_heads * L)
                 self._presort_ids(ids_all)
             torch.cuda.current_stream().wait_stream(side)
         return self._multihead_loss(out, e_rows, negs_pools, pools, mask, pos_tags, plan=plan, early=early)

@@ -410,7 +410,7 @@ class NceLossFn(Function):
     @staticmethod
     def forward(ctx, q_rows, p_rows, negs, logit_scale, q_idx, p_idx, n_tok_dev, tok_cap, thres, want_logs, logs_out,
                 bucket_idx=None, n_buckets=0, log_group=-1, p_row_mask=None, share_rows=False, window=None, ihn_beta=0.0,
-                prep=None):
+                prep=None, bucket_weight=None, n_segments=1):
         sv = ops.nce_fwd(q_rows, q_idx, p_rows, p_idx, negs, n_tok_dev, tok_cap, logit_scale.detach().view(1), thres,
                          want_logs=want_logs, for_backward=True, bucket_idx=bucket_idx, n_buckets=n_buckets,
                          log_group=log_group, p_row_mask=p_row_mask, share_rows=share_rows, window=window, ihn_beta=ihn_beta,
@@ -424,18 +424,35 @@ class NceLossFn(Function):
             return sv.loss
         if logs_out is not None:
             logs_out["bucket_cnt"] = sv.bucket_cnt
+        ctx.bucket_weight = bucket_weight
+        if bucket_weight is not None:
+            # (total, [per_gp | seg_all | g_tot | seg_sum]): the weighted total and the logged partial sums in ONE launch
+            total, red = ops.loss_reduce(sv.bucket_sum, sv.bucket_cnt, bucket_weight, n_segments)
+            ctx.mark_non_differentiable(red)
+            return total, red
         return sv.bucket_sum / sv.bucket_cnt.clamp_min(1.0)
 
     @staticmethod
-    def backward(ctx, d_out):
+    def backward(ctx, d_out, _d_red=None):
         q_idx, p_idx, logit_scale = ctx.saved_tensors
         sv = ctx.sv
         q_shape, p_shape = ctx.shapes
-        dq = torch.zeros(q_shape, dtype=torch.float32, device=d_out.device)
-        dp = torch.zeros(p_shape, dtype=torch.float32, device=d_out.device)
-        w = d_out.contiguous().float()
-        if sv.bucket_idx is not None:
-            w = w / sv.bucket_cnt.clamp_min(1.0)                      # d(mean)/d(loss_t) = 1 / count of the bucket
-        d_negs, d_ls = ops.nce_bwd(sv, w, logit_scale.detach().view(1), q_idx, p_idx, dq, dp, want_negs=ctx.needs_input_grad[2])
+        bufs, sv.bwd_bufs = getattr(sv, "bwd_bufs", None), None
+        d_negs0 = d_ls0 = lw_row = None
+        if bufs is not None and bufs[0].shape == q_shape and bufs[1].shape == p_shape:     # zeroed early (ops.nce_shared_prepare)
+            dq, dp, d_negs0, d_ls0, lw_row = bufs
+            if not ctx.needs_input_grad[2]:
+                d_negs0 = None
+        else:
+            dq = torch.zeros(q_shape, dtype=torch.float32, device=d_out.device)
+            dp = torch.zeros(p_shape, dtype=torch.float32, device=d_out.device)
+        if ctx.bucket_weight is not None:
+            w = ops.loss_reduce_bwd(d_out, sv.bucket_cnt, ctx.bucket_weight)      # d(total)/d(loss_t) = weight / count of the bucket
+        else:
+            w = d_out.contiguous().float()
+            if sv.bucket_idx is not None:
+                w = w / sv.bucket_cnt.clamp_min(1.0)                      # d(mean)/d(loss_t) = 1 / count of the bucket
+        d_negs, d_ls = ops.nce_bwd(sv, w, logit_scale.detach().view(1), q_idx, p_idx, dq, dp, d_negs=d_negs0, d_logit_scale=d_ls0,
+                                   want_negs=ctx.needs_input_grad[2], lw_row=lw_row)
         ctx.sv = None
-        return dq, dp, d_negs, d_ls.view(logit_scale.shape), None, None, None, None, None, None, None, None, None, None, None, None, None, None, None
+        return (dq, dp, d_negs, d_ls.view(logit_scale.shape)) + (None,) * 17

@@ -282,7 +282,7 @@ class MultiHeadDecoding:
         q_idx, p_idx, o_idx, n_tok = ops.token_compact(valid_g.reshape(G, n_slots), q_all, p_all, o_all)
         return share, q_idx, p_idx, o_idx, n_tok, None
 
-    def _loss_prepare(self, plan, e_rows, negs_pools):
+    def _loss_prepare(self, plan, e_rows, negs_pools, n_q_rows=None):
         """The batch-only half of the grouped loss, built EARLY (HSTU.forward runs it on a second stream underneath the
         sequence encoder): the token lists of the plan's groups and `ops.nce_shared_prepare` (row maps, false-negative bit
         table, normalised targets) - some forty small launches and one MFMA kernel that wait for nothing the encoder makes."""
@@ -291,11 +291,11 @@ class MultiHeadDecoding:
         prep = None
         if tokens[0] and plan["slots"] == list(range(negs_pools.shape[0])):          # negs_g IS negs_pools: same memory on both streams
             prep = ops.nce_shared_prepare(tokens[1], tokens[2], tokens[4], e_rows.detach(), negs_pools.detach().contiguous(),
-                                          float(self.nce_thres), plan["p_row_mask"], plan["log_group"] is not None)
+                                          float(self.nce_thres), plan["p_row_mask"], plan["log_group"] is not None, n_q_rows=n_q_rows)
         return dict(tokens=tokens, prep=prep)
 
     def _grouped_loss(self, head_rows, e_rows, negs_g, valid_g, head_for_p, log_group, p_row_mask=None, q_all=None, ihn_beta=0.0,
-                      early=None):
+                      early=None, bucket_weight=None, n_segments=1):
         """Sampled-softmax loss of G (token mask, negative pool) groups in ONE fused launch per kernel.
         valid_g [G,B,L,P] bool (offset fastest), negs_g [G,n_neg,D] bf16, head_for_p [G,P].  Returns (mean loss per (group, offset)
         [G,P] fp32, logs of `log_group` or None).  No host sync: tokens are compacted by scatter at fixed capacity
@@ -311,7 +311,9 @@ class MultiHeadDecoding:
         mean_p = NceLossFn.apply(head_rows, e_rows, negs_g, self.logit_scale, q_idx, p_idx, n_tok, cap,
                                  float(self.nce_thres), want_logs, logs, o_idx, P,
                                  log_group if want_logs else -1, p_row_mask, share, window, float(ihn_beta),
-                                 early["prep"] if early is not None else None)       # [G, P]
+                                 early["prep"] if early is not None else None, bucket_weight, n_segments)
+        # [G, P] mean loss per (group, offset) - or, with bucket_weight [G, P], the pair (sum of weight x mean, flat log vector
+        # per_gp | seg_all | g_tot | seg_sum) straight from one launch (ops.loss_reduce)
         out_logs = None
         if want_logs:                                   # all counters of the logged group in ONE launch (mhr_nce_log_counters)
             ks = [k for k in (1, 5, 10, 50, 100) if k <= negs_g.shape[1] + 1]
@@ -401,20 +403,18 @@ class MultiHeadDecoding:
         if negs_g is None:
             slots = plan["slots"]
             negs_g = negs_pools if slots == list(range(len(pools))) else negs_pools[self._const(slots, dev, torch.int64)]
-        mean_gp, logs = self._grouped_loss(head_rows, e_rows, negs_g.contiguous(), valid_g, head_for_p_g, log_group, p_row_mask,
-                                           early=early)
         gw = ("gw", tuple(g[2] for g in groups), str(dev))                 # horizon discount x group weight, [G,P], built once
         if gw not in self._tok_cache:
             self._tok_cache[gw] = (self.horizon_discount.float()[None, :] * self._const([g[2] for g in groups], dev, torch.float32)[:, None]).contiguous()
-        per_gp = mean_gp * self._tok_cache[gw]
-
+        G = len(groups)
         model_out = defaultdict(float)
-        total = per_gp.sum()
-        # log values: two small reductions for all groups and segments (the reference's per-head / per-segment sums, hstu.py:
-        # 700-721, 836-858), read out as views
-        seg_all = per_gp.detach().view(len(groups), S, -1).sum(dim=2)                              # [G,S]
-        seg_tot = seg_all[0] if (additive or groups[0][3] == 'nce') else seg_all.sum(dim=0)       # [S]
-        g_tot = seg_all.sum(dim=1)                                                                # [G]
+        # the mean per offset, its weighting, the total and the log values (the reference's per-head / per-segment sums,
+        # hstu.py:700-721, 836-858) come out of ONE launch behind the loss kernels; the log values are views of its output
+        (total, red), logs = self._grouped_loss(head_rows, e_rows, negs_g.contiguous(), valid_g, head_for_p_g, log_group,
+                                                p_row_mask, early=early, bucket_weight=self._tok_cache[gw], n_segments=S)
+        seg_all = red[G * P:G * P + G * S].view(G, S)
+        g_tot = red[G * P + G * S:G * P + G * S + G]
+        seg_tot = seg_all[0] if (additive or groups[0][3] == 'nce') else red[G * P + G * S + G:]
         for s_ in range(S):
             model_out[f"seg_{s_}_loss"] = seg_tot[s_]
         for i, g in enumerate(groups):

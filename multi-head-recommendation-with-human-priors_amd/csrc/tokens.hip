@@ -249,7 +249,71 @@ __global__ __launch_bounds__(256) void nce_log_counters_kernel(const int32_t* __
   if (threadIdx.x < 8) scratch[threadIdx.x] = 0;              // ready for the next launch
 }
 
+// Weighted total of the per-(group, offset) mean losses and the logged partial sums, ONE launch (reference hstu.py:697-723,
+// 836-870: mean per offset, horizon discount x head weight, per-segment / per-head sums).  The sums are taken in index order by
+// one wave: at most a few hundred terms, and the same bits on every run.
+//   total[0];  out = [ per_gp G*P | seg_all G*S | g_tot G | seg_sum S ],  per_gp = sum / max(cnt, 1) * weight
+__global__ __launch_bounds__(64) void loss_reduce_kernel(const float* __restrict__ bsum, const float* __restrict__ bcnt,
+                                                         const float* __restrict__ weight, int G, int P, int S,
+                                                         float* __restrict__ total, float* __restrict__ out) {
+  const int n = G * P, seg_len = P / S;
+  float* per_gp = out;
+  float* seg_all = per_gp + n;
+  float* g_tot = seg_all + G * S;
+  float* seg_sum = g_tot + G;
+  for (int i = threadIdx.x; i < n; i += 64) per_gp[i] = bsum[i] / fmaxf(bcnt[i], 1.0f) * weight[i];
+  __syncthreads();
+  for (int i = threadIdx.x; i < G * S; i += 64) {
+    const int g = i / S, sg = i % S;
+    float a = 0.0f;
+    for (int p = sg * seg_len; p < (sg + 1) * seg_len; ++p) a += per_gp[g * P + p];
+    seg_all[i] = a;
+  }
+  __syncthreads();
+  for (int g = threadIdx.x; g < G; g += 64) {
+    float a = 0.0f;
+    for (int sg = 0; sg < S; ++sg) a += seg_all[g * S + sg];
+    g_tot[g] = a;
+  }
+  for (int sg = threadIdx.x; sg < S; sg += 64) {
+    float a = 0.0f;
+    for (int g = 0; g < G; ++g) a += seg_all[g * S + sg];
+    seg_sum[sg] = a;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float a = 0.0f;
+    for (int g = 0; g < G; ++g) a += g_tot[g];
+    total[0] = a;
+  }
+}
+
+// its backward: the weight of every token of bucket (g, p) = d_total * weight[g, p] / max(cnt[g, p], 1)
+__global__ __launch_bounds__(64) void loss_reduce_bwd_kernel(const float* __restrict__ d_total, const float* __restrict__ bcnt,
+                                                             const float* __restrict__ weight, int n, float* __restrict__ w_out) {
+  const float d = d_total[0];
+  for (int i = threadIdx.x; i < n; i += 64) w_out[i] = d * weight[i] / fmaxf(bcnt[i], 1.0f);
+}
+
 }  // namespace
+
+extern "C" int mhr_loss_reduce(const float* bucket_sum, const float* bucket_cnt, const float* weight, int n_groups, int n_buckets,
+                               int n_segments, float* total, float* out, void* stream) {
+  MHR_REQUIRE(bucket_sum && bucket_cnt && weight && total && out, "loss_reduce: null pointer");
+  MHR_REQUIRE(n_groups >= 1 && n_buckets >= 1 && n_segments >= 1 && n_buckets % n_segments == 0 && (int64_t)n_groups * n_buckets <= 65536,
+              "loss_reduce: bad sizes (groups=%d buckets=%d segments=%d)", n_groups, n_buckets, n_segments);
+  hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, bucket_sum, bucket_cnt, weight, n_groups, n_buckets,
+                     n_segments, total, out);
+  MHR_CHECK_LAUNCH("loss_reduce");
+  return MHR_OK;
+}
+
+extern "C" int mhr_loss_reduce_bwd(const float* d_total, const float* bucket_cnt, const float* weight, int n, float* w_out, void* stream) {
+  MHR_REQUIRE(d_total && bucket_cnt && weight && w_out && n >= 1, "loss_reduce_bwd: null pointer / bad size");
+  hipLaunchKernelGGL(loss_reduce_bwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, d_total, bucket_cnt, weight, n, w_out);
+  MHR_CHECK_LAUNCH("loss_reduce_bwd");
+  return MHR_OK;
+}
 
 extern "C" int mhr_nce_log_counters(const int32_t* n_valid, const int32_t* rank, const int32_t* o_idx, const int32_t* n_tok_dev,
                                     int group, int tok_cap, const int32_t* ks_host, int n_k, uint64_t* scratch8, float* out,

@@ -488,6 +488,28 @@ def token_compact(mask, q_all, p_all, o_all, tok_cap=None, slot_map=False):
     return q_idx, p_idx, o_idx, n_tok
 
 
+def loss_reduce(bucket_sum, bucket_cnt, weight, n_segments):
+    """[G,P] per-offset loss sums / token counts / weights -> (total [], flat [G P + G S + G + S] = per_gp | seg_all | g_tot | seg_sum)
+    (mhr_loss_reduce: one launch for the mean, the weighting and every logged partial sum)."""
+    for t, n in ((bucket_sum, "bucket_sum"), (bucket_cnt, "bucket_cnt"), (weight, "weight")):
+        _chk(t, n, torch.float32)
+    G, P = bucket_sum.shape
+    assert bucket_cnt.shape == (G, P) and weight.shape == (G, P) and P % n_segments == 0
+    total = torch.empty((), dtype=torch.float32, device=bucket_sum.device)
+    out = torch.empty(G * P + G * n_segments + G + n_segments, dtype=torch.float32, device=bucket_sum.device)
+    lib.call("mhr_loss_reduce", bucket_sum.data_ptr(), bucket_cnt.data_ptr(), weight.data_ptr(), G, P, int(n_segments),
+             total.data_ptr(), out.data_ptr(), _stream())
+    return total, out
+
+
+def loss_reduce_bwd(d_total, bucket_cnt, weight):
+    """Token weight per (group, offset) bucket for the backward kernels: d_total * weight / max(cnt, 1)."""
+    d_total = d_total.reshape(1).float().contiguous()
+    w = torch.empty_like(weight)
+    lib.call("mhr_loss_reduce_bwd", d_total.data_ptr(), bucket_cnt.data_ptr(), weight.data_ptr(), weight.numel(), w.data_ptr(), _stream())
+    return w
+
+
 def nce_log_counters(n_valid, rank, o_idx, n_tok_dev, group, ks):
     """-> f32 [1 + len(ks)]: mean n_valid and mean(rank < k) over the live offset-0 tokens of `group` (hstu.py:621-629)."""
     import ctypes
@@ -522,7 +544,7 @@ class NceSaved:
                  "bucket_sum", "bucket_cnt", "u", "wide", "scale_dev", "cap_eff",
                  # query-row sharing (nce_shared.hip): row-level state of the streaming kernels + the maps between rows and tokens
                  "shared", "tok2row", "row_first", "n_row_dev", "row_cap", "fix_words", "fix_slot", "fix_any", "n_p_rows", "row_q",
-                 "window",
+                 "window", "bwd_bufs",
                  # REMI's interest-aware hard-negative loss (dense path): beta and the two saved log-sums per token
                  "ihn_beta", "ihn_num", "ihn_imp")
 
@@ -576,10 +598,11 @@ def _fix_bits_tables(p_rows, negs, n_neg, D, G, thres, p_row_mask):
     return tabs[0], tabs[1], tabs[2]
 
 
-def nce_shared_prepare(q_idx, p_idx, n_tok_dev, p_rows, negs, thres, p_row_mask, want_logs):
+def nce_shared_prepare(q_idx, p_idx, n_tok_dev, p_rows, negs, thres, p_row_mask, want_logs, n_q_rows=None):
     """Everything the row-sharing forward needs that depends on the BATCH only (token lists, target rows, negatives) and not
     on the query rows: the row maps of the token lists, the false-negative bit table of the target rows, the first target of
-    every row, the normalised target rows and the zeroed accumulators.  `nce_fwd(share_rows=True)` builds it itself; a model
+    every row, the normalised target rows and the zeroed accumulators (with n_q_rows, the number of query rows, the backward's
+    accumulators as well).  `nce_fwd(share_rows=True)` builds it itself; a model
     may build it EARLY - on a second stream underneath the sequence encoder - and hand it in (`prep=`).
     Returns None when the shapes are not the row-sharing path's (ragged capacity / pool sizes, feature dims it does not take)."""
     G, cap = q_idx.shape
@@ -589,6 +612,10 @@ def nce_shared_prepare(q_idx, p_idx, n_tok_dev, p_rows, negs, thres, p_row_mask,
     prep = _shared_prepare_inline(q_idx, p_idx, n_tok_dev, cap, cap + 32, p_rows, negs, n_neg, D, G, thres, p_row_mask)
     prep["key"] = (q_idx.data_ptr(), p_idx.data_ptr(), p_rows.data_ptr(), negs.data_ptr(), float(thres), bool(want_logs))
     prep["keep"] = (q_idx, p_idx, p_rows, negs)
+    if n_q_rows is not None:       # the backward's accumulators too (zero / +inf fills that wait for nothing): (dq, dp, d_negs, d_scale, lw_row)
+        dq, dp, dn, dls = zeros_many(negs.device, ((int(n_q_rows), D), torch.float32), ((p_rows.shape[0], D), torch.float32),
+                                     ((G, n_neg, D), torch.float32), ((1,), torch.float32))
+        prep["bwd"] = (dq, dp, dn, dls, torch.full((G, cap + 32), float("inf"), dtype=torch.float32, device=negs.device))
     return prep
 
 
@@ -670,6 +697,7 @@ def _nce_fwd_shared(sv, q_rows, p_rows, negs, logit_scale, thres, want_logs, buc
              logit_scale.data_ptr(), loss.data_ptr(), sv.lse.data_ptr(), _ptr(n_valid), _ptr(bucket_idx), int(n_buckets),
              _ptr(sv.bucket_sum), _ptr(sv.bucket_cnt), st)
     sv.shared = True
+    sv.bwd_bufs = prep.get("bwd")
     sv.qn, sv.u, sv.q_inv, sv.supp = qn_row, u_row, q_inv_row, supp_row
     sv.tok2row, sv.row_first, sv.n_row_dev, sv.row_cap, sv.row_q = tok2row, r_first, n_row, row_cap, r_q
     sv.window = window                      # (tok_of_slot [G, n_slots], L, P) of window-structured lists, or None
@@ -717,6 +745,7 @@ def nce_fwd(q_rows, q_idx, p_rows, p_idx, negs, n_tok_dev, tok_cap, logit_scale,
             bucket_idx = torch.nn.functional.pad(bucket_idx, (0, cap - tok_cap)).contiguous()
     sv = NceSaved()
     sv.shared = False
+    sv.bwd_bufs = None
     sv.q_idx, sv.p_idx = q_idx, p_idx
     sv.ihn_beta = float(ihn_beta)
     sv.wide = D not in STREAM_DIMS or sv.ihn_beta > 0     # feature dims beyond the register-stationary kernels (and the IHN loss): wide.py
@@ -794,7 +823,7 @@ def nce_fwd(q_rows, q_idx, p_rows, p_idx, negs, n_tok_dev, tok_cap, logit_scale,
     return sv
 
 
-def nce_bwd(sv, w, logit_scale, q_idx, p_idx, dq_rows, dp_rows, d_negs=None, d_logit_scale=None, want_negs=True):
+def nce_bwd(sv, w, logit_scale, q_idx, p_idx, dq_rows, dp_rows, d_negs=None, d_logit_scale=None, want_negs=True, lw_row=None):
     """w [G, tok_cap] f32 = dLoss/dloss[g, t] - or [G, n_buckets] when the forward was given bucket_idx (every token
     of a bucket then has the same weight).  Accumulates into dq_rows [Rq, D] / dp_rows [Rp, D] (f32, the
     forward's shared row spaces); returns (d_negs [G, n_neg, D] f32, d_logit_scale [1]).  q_idx / p_idx are the
@@ -824,7 +853,9 @@ def nce_bwd(sv, w, logit_scale, q_idx, p_idx, dq_rows, dp_rows, d_negs=None, d_l
     if sv.shared:
         wb_ptr, nb = (sv.bucket_idx.data_ptr(), sv.n_buckets) if bucketed else (0, 0)
         dn_ptr = d_negs.data_ptr() if want_negs else 0
-        lw_row = torch.full((G, sv.row_cap), float("inf"), dtype=torch.float32, device=dev)
+        if lw_row is None:                   # (+inf: a row the kernels do not visit contributes nothing to the negative-side product)
+            lw_row = torch.full((G, sv.row_cap), float("inf"), dtype=torch.float32, device=dev)
+        assert lw_row.shape == (G, sv.row_cap)
         if sv.window is not None:            # window-structured lists: sums formed where they land, no per-token atomics
             tos, L_, P_ = sv.window
             _timed_call("mhr_nce_shared_bwd_rows", sv.qn.data_ptr(), sv.u.data_ptr(), sv.q_inv.data_ptr(), sv.row_q.data_ptr(),

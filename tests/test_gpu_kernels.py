@@ -489,6 +489,27 @@ def test_sum_rows_into(ops, rows, cols):
     assert float((out.cpu().double() - ref).abs().max()) <= 1e-5 * scale
 
 
+@pytest.mark.parametrize("G,P,S", [(4, 8, 1), (5, 8, 2), (1, 1, 1), (33, 12, 4)])
+def test_loss_reduce(ops, G, P, S):
+    """Mean per (group, offset), horizon / head weighting, total and the logged partial sums in one launch (reference
+    hstu.py:697-723, 836-870) against the same arithmetic in float64; the backward's per-bucket token weight likewise."""
+    g = torch.Generator().manual_seed(G * 100 + P)
+    bsum = torch.rand(G, P, generator=g) * 50
+    bcnt = torch.randint(0, 40, (G, P), generator=g).float()
+    w = torch.rand(G, P, generator=g)
+    total, red = ops.loss_reduce(dev(bsum), dev(bcnt), dev(w), S)
+    d_total = torch.tensor(0.37)
+    wt = ops.loss_reduce_bwd(dev(d_total), dev(bcnt), dev(w))
+    torch.cuda.synchronize()
+    per = bsum.double() / bcnt.double().clamp_min(1.0) * w.double()
+    seg = per.view(G, S, -1).sum(2)
+    want = torch.cat([per.reshape(-1), seg.reshape(-1), seg.sum(1), seg.sum(0)])
+    assert float((red.cpu().double() - want).abs().max()) <= 1e-5 * float(want.abs().max())
+    assert abs(float(total) - float(per.sum())) <= 1e-5 * float(per.sum())
+    want_w = 0.37 * w.double() / bcnt.double().clamp_min(1.0)
+    assert float((wt.cpu().double() - want_w).abs().max()) <= 1e-6 * float(want_w.abs().max())
+
+
 @pytest.mark.parametrize("n,rows,cols", [(8, 25600, 256), (3, 5, 64), (2, 4097, 1032), (16, 1, 8)])
 def test_sum_rows_many(ops, n, rows, cols):
     """The one-launch form for n equally shaped matrices (the encoder's bias gradients): each destination gets exactly what
