@@ -375,6 +375,120 @@ __global__ __launch_bounds__(256) void ln_gate_bwd_kernel(const GT* __restrict__
   }
 }
 
+
+// dim == 256, bf16 in and out (the cfg1 encoder): a HALF-wave per row, 16 bytes per lane and tensor, RPH rows per half-wave with
+// all their loads issued together - four rows per wave in flight instead of one (the one-wave-per-row form above moved 39 MB in
+// 14.4 us, 2.7 TB/s: load latency, not bandwidth).  Same arithmetic per element, same dropout index (row * dim + column).
+__device__ __forceinline__ float half_sum(float v) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <int RPH>
+__global__ __launch_bounds__(256) void ln_gate_fwd_h256_kernel(const bf16_t* __restrict__ u, int64_t u_stride, const bf16_t* __restrict__ a,
+                                                               bf16_t* __restrict__ o, float* __restrict__ mean_o,
+                                                               float* __restrict__ rstd_o, int64_t rows, float eps, float p,
+                                                               float keep_scale, uint64_t seed, const int64_t* __restrict__ step_seed) {
+  constexpr int DIM = 256;
+  seed = mhr_step_seed(seed, step_seed);
+  const int lane = threadIdx.x & 63, hl = lane & 31, hw = lane >> 5;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t row0 = (wave * 2 + hw) * RPH;
+  bf16x8 av[RPH], uv[RPH];
+#pragma unroll
+  for (int j = 0; j < RPH; ++j) {
+    const int64_t rr = min(row0 + j, rows - 1);
+    av[j] = *reinterpret_cast<const bf16x8*>(a + rr * DIM + hl * 8);
+    uv[j] = *reinterpret_cast<const bf16x8*>(u + rr * u_stride + hl * 8);
+  }
+#pragma unroll
+  for (int j = 0; j < RPH; ++j) {
+    const int64_t row = row0 + j;
+    float x[8], s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      x[e] = (float)av[j][e];
+      s += x[e];
+    }
+    const float mean = half_sum(s) / (float)DIM;
+    float q = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) q += (x[e] - mean) * (x[e] - mean);
+    const float rstd = rsqrtf(half_sum(q) / (float)DIM + eps);
+    bf16x8 out;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float val = silu_f((float)uv[j][e]) * ((x[e] - mean) * rstd);
+      if (p > 0.f) {
+        const float r = mhr_uniform(seed, (uint64_t)row * DIM + hl * 8 + e);
+        val = r < p ? 0.f : val * keep_scale;
+      }
+      out[e] = (bf16_t)val;
+    }
+    if (row < rows) {
+      *reinterpret_cast<bf16x8*>(o + row * DIM + hl * 8) = out;
+      if (hl == 0) {
+        mean_o[row] = mean;
+        rstd_o[row] = rstd;
+      }
+    }
+  }
+}
+
+template <int RPH>
+__global__ __launch_bounds__(256) void ln_gate_bwd_h256_kernel(const bf16_t* __restrict__ d_o, const bf16_t* __restrict__ u, int64_t u_stride,
+                                                               const bf16_t* __restrict__ a, const float* __restrict__ mean_i,
+                                                               const float* __restrict__ rstd_i, bf16_t* __restrict__ du, int64_t du_stride,
+                                                               bf16_t* __restrict__ da, int64_t rows, float p, float keep_scale,
+                                                               uint64_t seed, const int64_t* __restrict__ step_seed) {
+  constexpr int DIM = 256;
+  seed = mhr_step_seed(seed, step_seed);
+  const int lane = threadIdx.x & 63, hl = lane & 31, hw = lane >> 5;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t row0 = (wave * 2 + hw) * RPH;
+  bf16x8 gv[RPH], av[RPH], uv[RPH];
+  float mean[RPH], rstd[RPH];
+#pragma unroll
+  for (int j = 0; j < RPH; ++j) {
+    const int64_t rr = min(row0 + j, rows - 1);
+    gv[j] = *reinterpret_cast<const bf16x8*>(d_o + rr * DIM + hl * 8);
+    av[j] = *reinterpret_cast<const bf16x8*>(a + rr * DIM + hl * 8);
+    uv[j] = *reinterpret_cast<const bf16x8*>(u + rr * u_stride + hl * 8);
+    mean[j] = mean_i[rr];
+    rstd[j] = rstd_i[rr];
+  }
+#pragma unroll
+  for (int j = 0; j < RPH; ++j) {
+    const int64_t row = row0 + j;
+    float gy[8], xh[8], s1 = 0.f, s2 = 0.f;
+    bf16x8 du_o, da_o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float gk = (float)gv[j][e];
+      if (p > 0.f) {
+        const float r = mhr_uniform(seed, (uint64_t)row * DIM + hl * 8 + e);
+        gk = r < p ? 0.f : gk * keep_scale;
+      }
+      xh[e] = ((float)av[j][e] - mean[j]) * rstd[j];
+      float su, dsu;
+      silu_both((float)uv[j][e], su, dsu);             // one sigmoid for both
+      gy[e] = gk * su;                                 // grad w.r.t. LN(a)
+      du_o[e] = (bf16_t)(gk * xh[e] * dsu);            // grad w.r.t. pre-activation u
+      s1 += gy[e];
+      s2 += gy[e] * xh[e];
+    }
+    s1 = half_sum(s1) / (float)DIM;
+    s2 = half_sum(s2) / (float)DIM;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) da_o[e] = (bf16_t)(rstd[j] * (gy[e] - s1 - xh[e] * s2));
+    if (row < rows) {
+      *reinterpret_cast<bf16x8*>(du + row * du_stride + hl * 8) = du_o;
+      *reinterpret_cast<bf16x8*>(da + row * DIM + hl * 8) = da_o;
+    }
+  }
+}
+
 extern "C" int mhr_ln_gate_fwd(const void* u_base, int64_t u_stride, const void* a, int dtype, void* o, int o_dtype,
                                float* mean, float* rstd, int64_t rows, int dim, float eps, float dropout_p, uint64_t seed,
                                const int64_t* step_seed, void* stream) {
@@ -386,6 +500,14 @@ extern "C" int mhr_ln_gate_fwd(const void* u_base, int64_t u_stride, const void*
   int grid = mhr_grid_for(rows, 4);
   float ks = 1.0f / (1.0f - dropout_p);
   bool tb = dtype == MHR_BF16, ob = o_dtype == MHR_BF16;
+  if (tb && ob && dim == 256 && u_stride % 8 == 0 && ((uintptr_t)u_base | (uintptr_t)a | (uintptr_t)o) % 16 == 0) {
+    constexpr int RPH = 2;                               // rows per half-wave
+    const int64_t waves = (rows + 2 * RPH - 1) / (2 * RPH);
+    hipLaunchKernelGGL((ln_gate_fwd_h256_kernel<RPH>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, (const bf16_t*)u_base, u_stride,
+                       (const bf16_t*)a, (bf16_t*)o, mean, rstd, rows, eps, dropout_p, ks, seed, step_seed);
+    MHR_CHECK_LAUNCH("ln_gate_fwd");
+    return MHR_OK;
+  }
 #define L(NC)                                                                                                             \
   if (tb && ob) hipLaunchKernelGGL((ln_gate_fwd_kernel<bf16_t, bf16_t, NC>), dim3(grid), dim3(256), 0, s,                 \
                                    (const bf16_t*)u_base, u_stride, (const bf16_t*)a, (bf16_t*)o, mean, rstd, rows, dim,  \
@@ -414,6 +536,16 @@ extern "C" int mhr_ln_gate_bwd(const void* d_o, int do_dtype, const void* u_base
   int grid = mhr_grid_for(rows, 4);
   float ks = 1.0f / (1.0f - dropout_p);
   bool tb = dtype == MHR_BF16, gb = do_dtype == MHR_BF16;
+  if (tb && gb && dim == 256 && u_stride % 8 == 0 && du_stride % 8 == 0 &&
+      ((uintptr_t)u_base | (uintptr_t)a | (uintptr_t)d_o | (uintptr_t)du_base | (uintptr_t)da) % 16 == 0) {
+    constexpr int RPH = 2;
+    const int64_t waves = (rows + 2 * RPH - 1) / (2 * RPH);
+    hipLaunchKernelGGL((ln_gate_bwd_h256_kernel<RPH>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, (const bf16_t*)d_o,
+                       (const bf16_t*)u_base, u_stride, (const bf16_t*)a, mean, rstd, (bf16_t*)du_base, du_stride, (bf16_t*)da, rows,
+                       dropout_p, ks, seed, step_seed);
+    MHR_CHECK_LAUNCH("ln_gate_bwd");
+    return MHR_OK;
+  }
 #define LK(GT, T, NC)                                                                                                  \
   hipLaunchKernelGGL((ln_gate_bwd_kernel<GT, T, NC>), dim3(grid), dim3(256), 0, s, (const GT*)d_o, (const T*)u_base,    \
                      u_stride, (const T*)a, mean, rstd, (T*)du_base, du_stride, (T*)da, rows, dim, dropout_p, ks, seed, step_seed)

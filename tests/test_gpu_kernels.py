@@ -209,6 +209,35 @@ def test_ln_gate(ops, D, p):
     assert float(dh[:, D:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("rows,p", [(29, 0.0), (29, 0.25), (1024, 0.25), (3, 0.5)])
+def test_ln_gate_bf16_rows_of_256(ops, rows, p):
+    """dim 256 with bf16 in and out takes the half-wave-per-row kernels (four rows per wave in flight): same values as the
+    one-wave-per-row form (fp32 output rounded) up to the order of the row sums, the SAME dropout mask, ragged row counts."""
+    D = 256
+    g = torch.Generator().manual_seed(rows)
+    h = bf(torch.randn(rows, 4 * D, generator=g))
+    a = bf(torch.randn(rows, D, generator=g) * 0.1)
+    d_o = bf(torch.randn(rows, D, generator=g))
+    o32, mean32, rstd32 = ops.ln_gate_fwd(dev(h), dev(a), D, torch.float32, dropout_p=p, seed=77)
+    o16, mean, rstd = ops.ln_gate_fwd(dev(h), dev(a), D, torch.bfloat16, dropout_p=p, seed=77)
+    assert o16.dtype == torch.bfloat16
+    assert torch.equal(o16 == 0, o32 == 0)                                   # the same mask
+    assert rel_err(o16.float().cpu(), o32.cpu()) < 2 ** -8
+    np.testing.assert_allclose(mean.cpu().numpy(), mean32.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(rstd.cpu().numpy(), rstd32.cpu().numpy(), rtol=1e-5)
+    u = h[:, :D].float().clone().requires_grad_(True)
+    ar = a.float().clone().requires_grad_(True)
+    ref = HO.silu(u) * HO.layer_norm(ar)
+    if p > 0:
+        ref = torch.where((o32 != 0).cpu(), ref / (1 - p), torch.zeros_like(ref))
+    ref.backward(d_o.float())
+    dh = torch.zeros(rows, 4 * D, dtype=torch.bfloat16).cuda()
+    da = ops.ln_gate_bwd(dev(d_o), dev(h), dev(a), mean, rstd, dh, D, dropout_p=p, seed=77)
+    assert rel_err(dh[:, :D].float().cpu(), u.grad) < 2 ** -7
+    assert rel_err(da.float().cpu(), ar.grad) < 2 ** -7
+    assert float(dh[:, D:].abs().max()) == 0.0
+
+
 def test_l2norm(ops):
     g = torch.Generator().manual_seed(6)
     x = torch.randn(33, 256, generator=g) * 5
