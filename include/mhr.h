@@ -116,6 +116,8 @@ int mhr_adam_rows_lazy(float* w, float* m, float* v, int64_t n_rows, int dim, co
  * partials and of bias gradients straight into the flat gradient buffer (autograd's accumulate semantics: the caller
  * zeroes the buffer once per step).  Many-row inputs are reduced by several workgroups meeting through float atomics. */
 int mhr_sum_rows_into(const void* x_bf16, int64_t rows, int64_t cols, float* out, void* stream);
+/* The same with f32 rows (the position-table gradient: column sums of d_x [B, L D] over the batch, hstu.py:640-643's backward). */
+int mhr_sum_rows_f32_into(const float* x, int64_t rows, int64_t cols, float* out, void* stream);
 /* The same column sums for n equally shaped bf16 matrices in ONE launch: ptrs is a DEVICE int64 array of 2 n addresses - the n
  * sources [rows, cols] first, then the n fp32 destinations [cols] (accumulated into, float atomics across row ranges). */
 int mhr_sum_rows_many(const int64_t* ptrs, int n, int64_t rows, int64_t cols, void* stream);
@@ -130,6 +132,11 @@ int mhr_layernorm_fwd(const void* x, int x_dtype, void* y, int y_dtype, float* m
 /* dx (+)= rstd * (dy - mean(dy) - xhat * mean(dy*xhat));  accumulate != 0 adds into dx (f32 only). */
 int mhr_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* mean, const float* rstd,
                       void* dx, int dx_dtype, int accumulate, int64_t rows, int dim, void* stream);
+/* out = x + y, out_bf16 = bf16(out); x / out f32 [n], y / out_bf16 bf16 [n], n % 8 == 0, 16-byte aligned.  The residual add
+ * behind the LAST encoder layer (model/IDNet/hstu.py:286-288), whose sum the decoding heads read in f32 (their residual) and in
+ * bf16 (their GEMM operand, llm_heads.py:30-40 under autocast); its backward is the same call on (d_out, d_out_bf16). */
+int mhr_add_cast(const float* x, const void* y_bf16, float* out, void* out_bf16, int64_t n, void* stream);
+
 /* Residual add fused with the next layer's LayerNorm (model/IDNet/hstu.py:286-287 then 241):
  *   x_out = x + y,  xn = LN(x_out)      x, x_out f32 [rows, dim]; y, xn bf16; mean / rstd [rows] saved for the backward.
  * Backward: total = d_xout + LN'(d_xn)  written as dx (f32, gradient of x) and dy (bf16, gradient of y). */

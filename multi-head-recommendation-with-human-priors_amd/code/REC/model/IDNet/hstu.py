@@ -191,15 +191,19 @@ class HSTU(MultiHeadDecoding, BaseModel):
             opt.last_step.fill_(opt.step_count)
         return out
 
-    def _encode(self, x, key_valid, training=None):
-        """x [B,L,D] fp32, key_valid [B,L] uint8 -> [B,L,D] fp32 (reference hstu.py:221-328)."""
-        from REC.model.hstu_functional import AddLayerNormFn, HSTUCoreFn, LayerNormFn, SplitKLinearFn
+    def _encode(self, x, key_valid, training=None, want_bf16=False):
+        """x [B,L,D] fp32, key_valid [B,L] uint8 -> [B,L,D] fp32 (reference hstu.py:221-328); want_bf16: (out, its bf16 copy -
+        the operand of the decoding heads' GEMM, written by the last residual add's own pass)."""
+        from REC.model.hstu_functional import AddCastFn, AddLayerNormFn, HSTUCoreFn, LayerNormFn, LayerNormResidualFn, SplitKLinearFn
         B, L, D = x.shape
         x2 = x.reshape(B * L, D)
         training = self.training if training is None else training
         p = self._linear_dropout_rate if training else 0.0
         layers = self._hstu._attention_layers
-        xn = LayerNormFn.apply(x2, layers[0]._eps)
+        if len(layers) > 1 and x2.requires_grad and x2.is_contiguous():
+            x2, xn = LayerNormResidualFn.apply(x2, layers[0]._eps, True)
+        else:
+            xn = LayerNormFn.apply(x2, layers[0]._eps)
         for i, layer in enumerate(layers):
             cached = self._layer_weights_bf16(i, layer)
             # dropout seed = (step * 1000003 + layer part) & (2^63 - 1); a hipGraph-replayed step reads the step counter from
@@ -217,9 +221,12 @@ class HSTU(MultiHeadDecoding, BaseModel):
                 y = F.linear(o, cached[1], cached[2])
             if i + 1 < len(layers):            # residual add + the next layer's LayerNorm in one pass
                 x2, xn = AddLayerNormFn.apply(x2, y, layers[i + 1]._eps)
+            elif want_bf16 and y.dtype == torch.bfloat16 and x2.numel() % 8 == 0:
+                x2, x16 = AddCastFn.apply(x2, y)
+                return x2.view(B, L, D), x16.view(B, L, D)
             else:
                 x2 = torch.add(x2, y)           # fp32 + bf16 -> fp32 in one kernel
-        return x2.view(B, L, D)
+        return (x2.view(B, L, D), None) if want_bf16 else x2.view(B, L, D)
 
     # ------------------------------------------------------------------------------------------
     # training
@@ -266,7 +273,7 @@ class HSTU(MultiHeadDecoding, BaseModel):
                 self._side_stream = torch.cuda.Stream(device=items.device)
             side = self._side_stream
             side.wait_stream(torch.cuda.current_stream())        # the fork: everything up to here (rows, negatives) is visible
-        out = self._encode(x, key_valid)                                 # [B,L,D] fp32
+        out, out16 = self._encode(x, key_valid, want_bf16=True)          # [B,L,D] fp32 (+ its bf16 copy)
         if side is not None:
             # issued AFTER the encoder's launches (so they reach the GPU first), ordered only after the fork above
             with torch.cuda.stream(side), torch.no_grad():
@@ -274,7 +281,7 @@ class HSTU(MultiHeadDecoding, BaseModel):
                 early = self._loss_prepare(plan, e_rows, negs_pools, n_q_rows=B * self.medusa_num_heads * L)
                 self._presort_ids(ids_all)
             torch.cuda.current_stream().wait_stream(side)
-        return self._multihead_loss(out, e_rows, negs_pools, pools, mask, pos_tags, plan=plan, early=early)
+        return self._multihead_loss(out, e_rows, negs_pools, pools, mask, pos_tags, plan=plan, early=early, out_bf16=out16)
 
     def _presort_ids(self, ids_all):
         """The id sort and the zeroed row buffer of the sparse embedding backward (EmbeddingGatherFn.backward) depend on the

@@ -5,13 +5,14 @@ projections between them are plain library GEMMs (torch.matmul -> hipBLASLt) as 
 Mixed precision follows the reference's Fabric `bf16-mixed` run: fp32 master weights and residual stream,
 bf16 GEMM operands, fp32 statistics / loss.
 """
+import os
+from collections import OrderedDict
+
 import torch
 from torch.autograd import Function
 
 from mhr_amd import ops
 
-
-import os
 _SPLITK_MAX = int(os.environ.get("MHR_SPLITK_MAX", "16"))
 _SUM_KERNEL = os.environ.get("MHR_SUM_KERNEL", "1") != "0"
 
@@ -29,6 +30,31 @@ class LayerNormFn(Function):
     def backward(ctx, dy):
         x, mean, rstd = ctx.saved_tensors
         return ops.layernorm_bwd(dy.contiguous(), x, mean, rstd, dx_dtype=torch.float32), None
+
+
+class LayerNormResidualFn(Function):
+    """x -> (x, LN(x)): the first layer's LayerNorm together with the residual branch that leaves x for the first residual add
+    (reference hstu.py:241 and 286-287).  One node for both uses of x, so that the backward adds the LayerNorm's gradient INTO the
+    residual branch's (mhr_layernorm_bwd, accumulate) instead of autograd summing two [B L, D] fp32 tensors in a pass of its own.
+    residual_grad_is_fresh: the residual branch's gradient is a tensor nobody else reads (it comes out of AddLayerNormFn's
+    backward), so it may be accumulated into in place."""
+
+    @staticmethod
+    def forward(ctx, x, eps, residual_grad_is_fresh):
+        y, mean, rstd = ops.layernorm_fwd(x, torch.bfloat16, eps)
+        ctx.save_for_backward(x, mean, rstd)
+        ctx.inplace = bool(residual_grad_is_fresh)
+        return x, y
+
+    @staticmethod
+    def backward(ctx, d_x, d_y):
+        x, mean, rstd = ctx.saved_tensors
+        if d_y is None:
+            return d_x, None, None
+        if d_x is not None and ctx.inplace and d_x.dtype == torch.float32 and d_x.is_contiguous():
+            return ops.layernorm_bwd(d_y.contiguous(), x, mean, rstd, dx=d_x, accumulate=True), None, None
+        g = ops.layernorm_bwd(d_y.contiguous(), x, mean, rstd, dx_dtype=torch.float32)
+        return (g if d_x is None else g + d_x), None, None
 
 
 class AddLayerNormFn(Function):
@@ -50,6 +76,25 @@ class AddLayerNormFn(Function):
             d_xn = torch.zeros(x_out.shape, dtype=torch.bfloat16, device=x_out.device)
         dx, dy = ops.add_layernorm_bwd(d_xn.contiguous(), x_out, mean, rstd, d_xout.contiguous().float())
         return dx, dy, None
+
+
+class AddCastFn(Function):
+    """(x fp32, y bf16) -> (x + y fp32, bf16(x + y)): the residual add behind the last encoder layer together with the bf16
+    copy the decoding heads' GEMM reads (reference hstu.py:286-288; llm_heads.py:30-40 under autocast).  One pass each way."""
+
+    @staticmethod
+    def forward(ctx, x, y):
+        return ops.add_cast(x.contiguous(), y.contiguous())
+
+    @staticmethod
+    def backward(ctx, d_out, d_out16):
+        if d_out is None and d_out16 is None:
+            return None, None
+        if d_out16 is None:
+            return d_out, d_out.to(torch.bfloat16)
+        if d_out is None:
+            return d_out16.float(), d_out16
+        return ops.add_cast(d_out.contiguous(), d_out16.contiguous())        # dx = d_out + d_out16 (fp32), dy = bf16(dx)
 
 
 class SplitKLinearFn(Function):
@@ -285,8 +330,13 @@ class EmbeddingGatherFn(Function):
         d_x = d_x.contiguous() if (d_x is not None and d_x.dim() == 3) else None
         d_pos = None
         if d_x is not None:
-            d_pos = torch.zeros(holder.position_embedding.weight.shape, dtype=torch.float32, device=dev)
-            d_pos[:L] = d_x.sum(dim=0)
+            pos = holder.position_embedding.weight
+            pg = pos.grad if getattr(pos, "_mhr_direct_grad", False) else None
+            if pg is not None and pg.is_contiguous() and pg.dtype == torch.float32 and (L * D) % 8 == 0 and pg.data_ptr() % 16 == 0:
+                ops.sum_rows_into(d_x.view(d_x.shape[0], L * D), pg[:L].view(-1))     # sum over the batch straight into pos.grad[:L]
+            else:
+                d_pos = torch.zeros(pos.shape, dtype=torch.float32, device=dev)
+                d_pos[:L] = d_x.sum(dim=0)
         if getattr(holder, "dense_embedding_grad", False):
             gt = torch.zeros(n_rows, D, dtype=torch.float32, device=dev)
             ops.embedding_scatter_add(d_items, ids_all[:n_item_ids].contiguous(), gt)
@@ -363,6 +413,33 @@ def reduce_pending_rows(holder):
     return holder.sparse_grad
 
 
+# Full-precision gradient hand-over between two of our own autograd Functions.  autograd casts a gradient to the dtype of the
+# tensor it belongs to: the fp32 gradient of the bf16 normalised negatives would be rounded to bf16 on the way from the loss to
+# the normalisation's backward (one cast kernel there, one back to fp32 here, 17 MB each way at cfg1 - and 8 bits of the
+# gradient).  The loss deposits the fp32 tensor under the data pointer of the bf16 tensor and returns a stride-0 placeholder.
+# An open slot holds the bf16 tensor itself (its address cannot be reused while the slot exists); at most four are kept.
+_F32_GRAD = OrderedDict()          # data_ptr of the bf16 tensor -> [that tensor, deposited fp32 gradient or None]
+_PLACEHOLDER = {}
+
+
+def _open_f32_grad_slot(y):
+    _F32_GRAD[y.data_ptr()] = [y, None]
+    while len(_F32_GRAD) > 4:      # forwards whose backward never came
+        _F32_GRAD.popitem(last=False)
+    return y.data_ptr()
+
+
+def _deposit_f32_grad(of_tensor, grad):
+    slot = _F32_GRAD.get(of_tensor.data_ptr())
+    if slot is None or grad is None or grad.numel() != slot[0].numel() or grad.numel() != of_tensor.numel():
+        return grad
+    slot[1] = grad if slot[1] is None else slot[1] + grad
+    ph = _PLACEHOLDER.get(grad.device)
+    if ph is None:
+        ph = _PLACEHOLDER[grad.device] = torch.zeros((), dtype=torch.bfloat16, device=grad.device)
+    return ph.expand(of_tensor.shape)
+
+
 class L2NormFn(Function):
     """y = x / ||x|| in fp32, emitted as bf16 for the MFMA operand (reference hstu.py:672, 754).
 
@@ -375,11 +452,16 @@ class L2NormFn(Function):
         y, norms = ops.l2norm_rows(x, torch.bfloat16, want_norms=True)
         ctx.save_for_backward(x, norms)
         ctx.holder = holder
+        ctx.key = _open_f32_grad_slot(y) if ctx.needs_input_grad[0] else None     # (NceLossFn.backward deposits there)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, norms = ctx.saved_tensors
+        slot = _F32_GRAD.pop(ctx.key, None)
+        g32 = slot[1] if slot is not None else None
+        if g32 is not None:                           # the loss left its fp32 gradient; dy is the placeholder unless others add to it
+            dy = g32 if all(st == 0 for st in dy.stride()) else g32 + dy.float().reshape(g32.shape)
         if x.dtype == torch.float32 and x.is_contiguous():
             g = ops.l2norm_rows_bwd(dy.reshape(x.shape).float().contiguous(), x, norms)
         else:
@@ -455,4 +537,6 @@ class NceLossFn(Function):
         d_negs, d_ls = ops.nce_bwd(sv, w, logit_scale.detach().view(1), q_idx, p_idx, dq, dp, d_negs=d_negs0, d_logit_scale=d_ls0,
                                    want_negs=ctx.needs_input_grad[2], lw_row=lw_row)
         ctx.sv = None
+        if d_negs is not None:
+            d_negs = _deposit_f32_grad(sv.negs, d_negs)
         return (dq, dp, d_negs, d_ls.view(logit_scale.shape)) + (None,) * 17

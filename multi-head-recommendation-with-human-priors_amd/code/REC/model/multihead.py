@@ -164,9 +164,9 @@ class MultiHeadDecoding:
             return []
         return [ws, bs]
 
-    def _heads(self, x):
+    def _heads(self, x, x_bf16=None):
         """x [..., D] fp32 -> [..., H, D] fp32 (reference hstu.py:652-667, 915-931 / hllm.py:510-525, 785-801).  bf16
-        GEMMs, fp32 residual, like the reference under bf16-mixed autocast."""
+        GEMMs, fp32 residual, like the reference under bf16-mixed autocast.  x_bf16: the caller's bf16 copy of x, if it has one."""
         S, C = self.num_segment_head, self.num_prior_head
         heads = getattr(self, 'medusa_head', None)
         if (x.is_cuda and heads is not None and self.medusa_num_layers == 1 and self.head_interaction != 'hierarchical'
@@ -179,12 +179,13 @@ class MultiHeadDecoding:
             ws, bs = [h[0].linear.weight for h in heads], [h[0].linear.bias for h in heads]
             fw = _optim.fused_views(ws) if torch.is_grad_enabled() else None
             fb = _optim.fused_flat(bs) if fw is not None else None
+            xb = x.reshape(-1, D).to(torch.bfloat16) if x_bf16 is None else x_bf16.reshape(-1, D)
             if fw is not None and fb is not None:     # the fused optimizer laid the heads out back to back: views, no cat / cast
-                z = FusedHeadsLinearFn.apply(x.reshape(-1, D).to(torch.bfloat16), fw[0], fb[0], fw[1], fb[1])
+                z = FusedHeadsLinearFn.apply(xb, fw[0], fb[0], fw[1], fb[1])
             else:
                 w = torch.cat(ws, 0)
                 b = torch.cat(bs, 0)
-                z = SplitKLinearFn.apply(x.reshape(-1, D).to(torch.bfloat16), w, b, True, None)
+                z = SplitKLinearFn.apply(xb, w, b, True, None)
             if x.dim() == 3 and x.dtype == torch.float32 and D % 4 == 0:
                 # bias-added GEMM output -> SiLU + residual written straight in the [B, H, L, D] layout of the loss
                 # (csrc/heads.hip); returned as the [B, L, H, D] view every caller expects
@@ -384,7 +385,7 @@ class MultiHeadDecoding:
                     log_group=max(i for i, g in enumerate(groups) if g[3] == 'nce' or g[4] == 0),
                     p_row_mask=rows_g.reshape(len(groups), -1).contiguous())
 
-    def _multihead_loss(self, out, e_rows, negs_pools, pools, mask, pos_tags, plan=None, early=None):
+    def _multihead_loss(self, out, e_rows, negs_pools, pools, mask, pos_tags, plan=None, early=None, out_bf16=None):
         """Everything of the training forward after the sequence encoder (reference hstu.py:648-872 / hllm.py:506-763).
         out [B,L,D] fp32 encoder output; e_rows [B*(L+P), D] fp32 target-item rows; negs_pools [len(pools), n_pool, D]
         bf16 L2-normalised; mask [B,L+P] bool; pos_tags [B,L+P,C]; plan / early: `_loss_plan(...)` / `_loss_prepare(...)` when the
@@ -394,7 +395,7 @@ class MultiHeadDecoding:
         L, P, D = self.max_seq_length, self.pred_len, self._head_dim
         S, C = self.num_segment_head, self.num_prior_head
         additive = self.head_interaction == 'additive'
-        head_embs = self._heads(out).permute(0, 2, 1, 3).contiguous()     # [B,H,L,D]
+        head_embs = self._heads(out, out_bf16).permute(0, 2, 1, 3).contiguous()     # [B,H,L,D]
         head_rows = head_embs.view(-1, D)
         if plan is None:
             plan = self._loss_plan(negs_pools, pools, mask, pos_tags)

@@ -183,7 +183,12 @@ class Trainer(object):
     def _eager_step(self, data):
         model_out = self.model(data)
         loss = model_out["loss"]
-        (loss / self.accumulate_grad).backward()
+        # d(loss / accumulate_grad): the scale enters as the root gradient (a cached device scalar) - no division kernel in the
+        # forward, no ones-fill and no division backward in front of the loss kernels' backward
+        gs = self.__dict__.get("_grad_scale")
+        if gs is None or gs.device != loss.device or gs.dtype != loss.dtype:
+            gs = self._grad_scale = torch.full((), 1.0 / self.accumulate_grad, dtype=loss.dtype, device=loss.device)
+        loss.backward(gradient=gs)
         self._micro_step += 1
         if self._micro_step % self.accumulate_grad == 0:
             self.optimizer.param_groups[0]["lr"] = self._lr_at(self.train_step)

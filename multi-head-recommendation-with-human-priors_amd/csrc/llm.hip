@@ -134,7 +134,23 @@ extern "C" int mhr_rope_inplace(void* x_bf16, int64_t row_stride, const int32_t*
 // Block = 32 column threads (8 columns each) x 8 row lanes; row ranges are split over blockIdx.y when there are many rows
 // (then the partial sums meet in out[] through float atomics; with one row range the update is a plain read-modify-write).
 namespace {
-__device__ __forceinline__ void sum_rows_body(const bf16_t* __restrict__ x, int64_t rows, int64_t cols, float* __restrict__ out,
+template <typename T> struct Row8;
+template <> struct Row8<bf16_t> {
+  bf16x8 v;
+  __device__ __forceinline__ void load(const bf16_t* p) { v = *reinterpret_cast<const bf16x8*>(p); }
+  __device__ __forceinline__ float operator[](int e) const { return (float)v[e]; }
+};
+template <> struct Row8<float> {
+  f32x4 a, b;
+  __device__ __forceinline__ void load(const float* p) {
+    a = reinterpret_cast<const f32x4*>(p)[0];
+    b = reinterpret_cast<const f32x4*>(p)[1];
+  }
+  __device__ __forceinline__ float operator[](int e) const { return e < 4 ? a[e] : b[e - 4]; }
+};
+
+template <typename T>
+__device__ __forceinline__ void sum_rows_body(const T* __restrict__ x, int64_t rows, int64_t cols, float* __restrict__ out,
                                               int64_t rows_per_block) {
   __shared__ float red[8][32][8];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -144,26 +160,27 @@ __device__ __forceinline__ void sum_rows_body(const bf16_t* __restrict__ x, int6
   if (c0 < cols) {
     int64_t r = r0 + ty;
     for (; r + 56 < r1; r += 64) {                       // eight independent 16-byte loads in flight per thread
-      bf16x8 v[8];
+      Row8<T> v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const bf16x8*>(x + (r + 8 * u) * cols + c0);
+      for (int u = 0; u < 8; ++u) v[u].load(x + (r + 8 * u) * cols + c0);
 #pragma unroll
       for (int e = 0; e < 8; ++e)
-        acc[e] += (((float)v[0][e] + (float)v[1][e]) + ((float)v[2][e] + (float)v[3][e])) +
-                  (((float)v[4][e] + (float)v[5][e]) + ((float)v[6][e] + (float)v[7][e]));
+        acc[e] += ((v[0][e] + v[1][e]) + (v[2][e] + v[3][e])) + ((v[4][e] + v[5][e]) + (v[6][e] + v[7][e]));
     }
     for (; r + 24 < r1; r += 32) {
-      const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(x + r * cols + c0);
-      const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(x + (r + 8) * cols + c0);
-      const bf16x8 v2 = *reinterpret_cast<const bf16x8*>(x + (r + 16) * cols + c0);
-      const bf16x8 v3 = *reinterpret_cast<const bf16x8*>(x + (r + 24) * cols + c0);
+      Row8<T> v0, v1, v2, v3;
+      v0.load(x + r * cols + c0);
+      v1.load(x + (r + 8) * cols + c0);
+      v2.load(x + (r + 16) * cols + c0);
+      v3.load(x + (r + 24) * cols + c0);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) acc[e] += ((float)v0[e] + (float)v1[e]) + ((float)v2[e] + (float)v3[e]);
+      for (int e = 0; e < 8; ++e) acc[e] += (v0[e] + v1[e]) + (v2[e] + v3[e]);
     }
     for (; r < r1; r += 8) {
-      const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + r * cols + c0);
+      Row8<T> v;
+      v.load(x + r * cols + c0);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) acc[e] += (float)v[e];
+      for (int e = 0; e < 8; ++e) acc[e] += v[e];
     }
   }
 #pragma unroll
@@ -191,9 +208,10 @@ __device__ __forceinline__ void sum_rows_body(const bf16_t* __restrict__ x, int6
   }
 }
 
-__global__ __launch_bounds__(256) void sum_rows_into_kernel(const bf16_t* __restrict__ x, int64_t rows, int64_t cols,
+template <typename T>
+__global__ __launch_bounds__(256) void sum_rows_into_kernel(const T* __restrict__ x, int64_t rows, int64_t cols,
                                                             float* __restrict__ out, int64_t rows_per_block) {
-  sum_rows_body(x, rows, cols, out, rows_per_block);
+  sum_rows_body<T>(x, rows, cols, out, rows_per_block);
 }
 
 // the same reduction for MANY equally shaped matrices in one launch (blockIdx.z picks the matrix): the bias gradients of the
@@ -202,27 +220,38 @@ __global__ __launch_bounds__(256) void sum_rows_many_kernel(const int64_t* __res
                                                             int64_t rows_per_block) {
   const bf16_t* x = reinterpret_cast<const bf16_t*>(ptrs[blockIdx.z]);
   float* out = reinterpret_cast<float*>(ptrs[n + blockIdx.z]);
-  sum_rows_body(x, rows, cols, out, rows_per_block);
+  sum_rows_body<bf16_t>(x, rows, cols, out, rows_per_block);
 }
 }  // namespace
 
-extern "C" int mhr_sum_rows_into(const void* x_bf16, int64_t rows, int64_t cols, float* out, void* stream) {
-  MHR_REQUIRE(x_bf16 && out, "sum_rows_into: null pointer");
-  MHR_REQUIRE(rows >= 0 && cols > 0 && cols % 8 == 0, "sum_rows_into: cols=%lld must be a positive multiple of 8", (long long)cols);
-  MHR_REQUIRE((uintptr_t)out % 16 == 0 && (uintptr_t)x_bf16 % 16 == 0, "sum_rows_into: buffers must be 16-byte aligned");
+static int sum_rows_launch(const void* x, bool f32, int64_t rows, int64_t cols, float* out, void* stream, const char* who) {
+  MHR_REQUIRE(x && out, "%s: null pointer", who);
+  MHR_REQUIRE(rows >= 0 && cols > 0 && cols % 8 == 0, "%s: cols=%lld must be a positive multiple of 8", who, (long long)cols);
+  MHR_REQUIRE((uintptr_t)out % 16 == 0 && (uintptr_t)x % 16 == 0, "%s: buffers must be 16-byte aligned", who);
   if (rows == 0) return MHR_OK;
   const int64_t col_blocks = (cols / 8 + 31) / 32;
-  MHR_REQUIRE(col_blocks < (1ll << 31), "sum_rows_into: too many columns");
+  MHR_REQUIRE(col_blocks < (1ll << 31), "%s: too many columns", who);
   // a few row ranges when there are few columns (many would only contend on the same atomics: 256 ranges adding into the
-  // 256 floats of a bias gradient doubled the launch's time - measured twice, rounds 1 and 2); the row loop keeps four loads
+  // 256 floats of a bias gradient doubled the launch's time - measured twice, rounds 1 and 2); the row loop keeps eight loads
   // in flight instead
   int64_t splits = 1;
   while (splits < 64 && col_blocks * splits < 512 && rows / (splits * 2) >= 64) splits *= 2;
   const int64_t rpb = (rows + splits - 1) / splits;
-  hipLaunchKernelGGL(sum_rows_into_kernel, dim3((unsigned)col_blocks, (unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0,
-                     (hipStream_t)stream, (const bf16_t*)x_bf16, rows, cols, out, rpb);
-  MHR_CHECK_LAUNCH("sum_rows_into");
+  const dim3 grid((unsigned)col_blocks, (unsigned)((rows + rpb - 1) / rpb));
+  if (f32)
+    hipLaunchKernelGGL((sum_rows_into_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, rows, cols, out, rpb);
+  else
+    hipLaunchKernelGGL((sum_rows_into_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, rows, cols, out, rpb);
+  MHR_CHECK_LAUNCH(who);
   return MHR_OK;
+}
+
+extern "C" int mhr_sum_rows_into(const void* x_bf16, int64_t rows, int64_t cols, float* out, void* stream) {
+  return sum_rows_launch(x_bf16, false, rows, cols, out, stream, "sum_rows_into");
+}
+
+extern "C" int mhr_sum_rows_f32_into(const float* x, int64_t rows, int64_t cols, float* out, void* stream) {
+  return sum_rows_launch(x, true, rows, cols, out, stream, "sum_rows_f32_into");
 }
 
 extern "C" int mhr_sum_rows_many(const int64_t* ptrs, int n, int64_t rows, int64_t cols, void* stream) {

@@ -562,6 +562,42 @@ extern "C" int mhr_ln_gate_bwd(const void* d_o, int do_dtype, const void* u_base
 }
 
 // ------------------------------------------------------------------------------------------
+// out = x + y (f32 + bf16 -> f32) and its bf16 copy in one pass: the residual add behind the LAST encoder layer, whose
+// output feeds the decoding heads twice - in f32 (residual of the heads) and in bf16 (operand of their GEMM).  The backward
+// is the same arithmetic on the gradients: dx = d_out + d_out16, dy = bf16(dx).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void add_cast_kernel(const float* __restrict__ x, const bf16_t* __restrict__ y, float* __restrict__ out,
+                                                       bf16_t* __restrict__ out16, int64_t n8) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+    const f32x4 a = reinterpret_cast<const f32x4*>(x)[2 * i], b = reinterpret_cast<const f32x4*>(x)[2 * i + 1];
+    const bf16x8 v = reinterpret_cast<const bf16x8*>(y)[i];
+    f32x4 o0, o1;
+    bf16x8 w;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      o0[e] = a[e] + (float)v[e];
+      o1[e] = b[e] + (float)v[4 + e];
+      w[e] = (bf16_t)o0[e];
+      w[4 + e] = (bf16_t)o1[e];
+    }
+    reinterpret_cast<f32x4*>(out)[2 * i] = o0;
+    reinterpret_cast<f32x4*>(out)[2 * i + 1] = o1;
+    reinterpret_cast<bf16x8*>(out16)[i] = w;
+  }
+}
+
+extern "C" int mhr_add_cast(const float* x, const void* y_bf16, float* out, void* out_bf16, int64_t n, void* stream) {
+  MHR_REQUIRE(x && y_bf16 && out && out_bf16, "add_cast: null pointer");
+  MHR_REQUIRE(n >= 0 && n % 8 == 0, "add_cast: n=%lld must be a multiple of 8", (long long)n);
+  MHR_REQUIRE(((uintptr_t)x | (uintptr_t)y_bf16 | (uintptr_t)out | (uintptr_t)out_bf16) % 16 == 0, "add_cast: buffers must be 16-byte aligned");
+  if (n == 0) return MHR_OK;
+  hipLaunchKernelGGL(add_cast_kernel, dim3(mhr_grid_for(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, x, (const bf16_t*)y_bf16, out,
+                     (bf16_t*)out_bf16, n / 8);
+  MHR_CHECK_LAUNCH("add_cast");
+  return MHR_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // L2 row normalisation
 // ------------------------------------------------------------------------------------------
 template <typename XT, typename YT, int NC>

@@ -195,11 +195,15 @@ def bad_id_count(reset=True):
 
 
 def sum_rows_into(x, out):
-    """out [cols] fp32 += column sums of x [rows, cols] bf16 (contiguous)."""
-    _chk(x, "x", torch.bfloat16)
+    """out [cols] fp32 += column sums of x [rows, cols] bf16 or fp32 (contiguous)."""
     _chk(out, "out", torch.float32)
     cols = out.numel()
     assert x.numel() % cols == 0
+    if x.dtype == torch.float32:
+        _chk(x, "x", torch.float32)
+        lib.call("mhr_sum_rows_f32_into", x.data_ptr(), x.numel() // cols, cols, out.data_ptr(), _stream())
+        return out
+    _chk(x, "x", torch.bfloat16)
     _timed_call("mhr_sum_rows_into", x.data_ptr(), x.numel() // cols, cols, out.data_ptr(), _stream())
     return out
 
@@ -228,6 +232,17 @@ def layernorm_bwd(dy, x, mean, rstd, dx=None, accumulate=False, dx_dtype=torch.f
     lib.call("mhr_layernorm_bwd", dy.data_ptr(), _dt(dy), x.data_ptr(), _dt(x), mean.data_ptr(), rstd.data_ptr(),
              dx.data_ptr(), _dt(dx), 1 if accumulate else 0, rows, D, _stream())
     return dx
+
+
+def add_cast(x, y):
+    """(x + y fp32, its bf16 copy) for x fp32 and y bf16 of one shape, one pass (mhr_add_cast)."""
+    _chk(x, "x", torch.float32)
+    _chk(y, "y", torch.bfloat16)
+    assert x.shape == y.shape
+    out = torch.empty_like(x)
+    out16 = torch.empty_like(y)
+    lib.call("mhr_add_cast", x.data_ptr(), y.data_ptr(), out.data_ptr(), out16.data_ptr(), x.numel(), _stream())
+    return out, out16
 
 
 def add_layernorm_fwd(x, y, eps=1e-6):

@@ -109,7 +109,8 @@ def test_replayed_steps_follow_the_host_issued_trajectory(rec, loss):
     # same dropout masks, same schedule: the two runs differ by the order of float atomics in the loss backward only
     le, lg = np.array(le), np.array(lg)
     assert np.all(np.isfinite(lg))
-    np.testing.assert_allclose(lg[:8], le[:8], rtol=1e-4)           # replays start at step 4: same masks, same constants
+    np.testing.assert_allclose(lg[:8], le[:8], rtol=5e-4)           # replays start at step 4: same masks, same constants
+    np.testing.assert_allclose(lg[:5], le[:5], rtol=2e-5)           # (fp32 gradients end to end: atomic-order noise is no longer rounded away in bf16)
     np.testing.assert_allclose(lg[:15], le[:15], rtol=2e-3)         # (two runs of either kind differ by as much: float atomics)
     np.testing.assert_allclose(lg, le, rtol=3e-2)                   # (atomic-order noise grows along 70 steps of lr 2e-3)
     assert le[-1] < le[0]
@@ -117,7 +118,7 @@ def test_replayed_steps_follow_the_host_issued_trajectory(rec, loss):
     for k in sd_e:                                                  # (Adam turns float-atomic noise into sign flips of tiny updates:
         a, b = sd_e[k].float(), sd_g[k].float()                     #  single elements may drift, the bulk must not)
         scale = float(a.abs().max()) + 1e-6
-        assert float((a - b).abs().mean()) <= 5e-3 * scale and float((a - b).abs().max()) <= 0.15 * scale, k
+        assert float((a - b).abs().mean()) <= 5e-3 * scale and float((a - b).abs().max()) <= 0.3 * scale, k     # (two host-issued runs: max 0.155 x scale measured)
     # a different dropout mask would show: replaying with a frozen step counter must NOT reproduce the trajectory
     assert abs(lg[10] - lg[4]) > 0 or loss == "nce"
 

@@ -238,6 +238,16 @@ def test_ln_gate_bf16_rows_of_256(ops, rows, p):
     assert float(dh[:, D:].abs().max()) == 0.0
 
 
+def test_add_cast(ops):
+    """x + y (fp32 + bf16) and the bf16 copy of the sum in one pass: exactly torch's fp32 add and round-to-nearest-even cast."""
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(1031, 256, generator=g) * 3
+    y = bf(torch.randn(1031, 256, generator=g))
+    out, out16 = ops.add_cast(dev(x), dev(y))
+    want = x + y.float()
+    assert torch.equal(out.cpu(), want) and torch.equal(out16.cpu(), want.to(torch.bfloat16))
+
+
 def test_l2norm(ops):
     g = torch.Generator().manual_seed(6)
     x = torch.randn(33, 256, generator=g) * 5
