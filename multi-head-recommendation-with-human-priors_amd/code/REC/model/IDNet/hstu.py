@@ -191,7 +191,7 @@ class HSTU(MultiHeadDecoding, BaseModel):
             opt.last_step.fill_(opt.step_count)
         return out
 
-    def _encode(self, x, key_valid, training=None, want_bf16=False):
+    def _encode(self, x, key_valid, training=None, want_bf16=False, after_layer=None):
         """x [B,L,D] fp32, key_valid [B,L] uint8 -> [B,L,D] fp32 (reference hstu.py:221-328); want_bf16: (out, its bf16 copy -
         the operand of the decoding heads' GEMM, written by the last residual add's own pass)."""
         from REC.model.hstu_functional import AddCastFn, AddLayerNormFn, HSTUCoreFn, LayerNormFn, LayerNormResidualFn, SplitKLinearFn
@@ -219,6 +219,8 @@ class HSTU(MultiHeadDecoding, BaseModel):
                 h = xn @ cached[0]
                 o = HSTUCoreFn.apply(h, key_valid, B, L, self._num_heads, self._dqk, layer._eps, p, seed)
                 y = F.linear(o, cached[1], cached[2])
+            if after_layer is not None:
+                after_layer(i)                  # (the caller's side-stream work, interleaved with the layers' launches)
             if i + 1 < len(layers):            # residual add + the next layer's LayerNorm in one pass
                 x2, xn = AddLayerNormFn.apply(x2, y, layers[i + 1]._eps)
             elif want_bf16 and y.dtype == torch.bfloat16 and x2.numel() % 8 == 0:
@@ -266,21 +268,32 @@ class HSTU(MultiHeadDecoding, BaseModel):
         # everything of the loss that waits for nothing the encoder makes (token lists, row maps, the false-negative bit table of
         # the target rows, the id sort of the embedding backward) goes on a second stream UNDERNEATH the encoder: some fifty
         # few-microsecond launches that otherwise sit on the step's critical path one after the other
-        plan = early = None
-        side = None
+        st, stages, side = {}, [], None
         if EARLY_LOSS_PREP and torch.is_grad_enabled():
             if self._side_stream is None:
                 self._side_stream = torch.cuda.Stream(device=items.device)
             side = self._side_stream
             side.wait_stream(torch.cuda.current_stream())        # the fork: everything up to here (rows, negatives) is visible
-        out, out16 = self._encode(x, key_valid, want_bf16=True)          # [B,L,D] fp32 (+ its bf16 copy)
+            stages = self._early_loss_stages(st, pools, mask, pos_tags, e_rows, negs_pools, n_q_rows=B * self.medusa_num_heads * L)
+            stages.append(lambda: self._presort_ids(ids_all))
+
+        # Under capture the stages are issued one behind every encoder layer's launches, host-issued steps keep the encoder's
+        # launches together (the host is the slower side in the forward: 4.9 against 5.4 ms per step) and issue the stages behind
+        # them.  (Measured on replayed graphs, same box: no second stream 4.66 ms, stages interleaved 4.54 ms; extra edges that
+        # make the main branch wait for stage k a few layers later changed nothing - 4.52 to 4.55 ms for every distance tried.)
+        capturing = side is not None and torch.cuda.is_current_stream_capturing()
+
+        def next_stage(_layer=None):
+            if stages:
+                with torch.cuda.stream(side), torch.no_grad():
+                    stages.pop(0)()
+
+        out, out16 = self._encode(x, key_valid, want_bf16=True, after_layer=next_stage if capturing else None)
         if side is not None:
-            # issued AFTER the encoder's launches (so they reach the GPU first), ordered only after the fork above
-            with torch.cuda.stream(side), torch.no_grad():
-                plan = self._loss_plan(None, pools, mask, pos_tags)
-                early = self._loss_prepare(plan, e_rows, negs_pools, n_q_rows=B * self.medusa_num_heads * L)
-                self._presort_ids(ids_all)
+            while stages:
+                next_stage()
             torch.cuda.current_stream().wait_stream(side)
+        plan, early = st.get("plan"), st.get("early")
         return self._multihead_loss(out, e_rows, negs_pools, pools, mask, pos_tags, plan=plan, early=early, out_bf16=out16)
 
     def _presort_ids(self, ids_all):

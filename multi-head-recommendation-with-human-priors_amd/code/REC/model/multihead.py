@@ -283,17 +283,31 @@ class MultiHeadDecoding:
         q_idx, p_idx, o_idx, n_tok = ops.token_compact(valid_g.reshape(G, n_slots), q_all, p_all, o_all)
         return share, q_idx, p_idx, o_idx, n_tok, None
 
-    def _loss_prepare(self, plan, e_rows, negs_pools, n_q_rows=None):
-        """The batch-only half of the grouped loss, built EARLY (HSTU.forward runs it on a second stream underneath the
-        sequence encoder): the token lists of the plan's groups and `ops.nce_shared_prepare` (row maps, false-negative bit
-        table, normalised targets) - some forty small launches and one MFMA kernel that wait for nothing the encoder makes."""
+    def _early_loss_stages(self, st, pools, mask, pos_tags, e_rows, negs_pools, n_q_rows=None):
+        """The batch-only half of the grouped loss as a list of stages (callables, run in order on ONE stream - HSTU.forward
+        runs them on a second stream, one between every two encoder layers): the loss plan, the token lists of its groups and
+        the stages of `ops.nce_shared_prepare_stages` (row maps, false-negative bit table, normalised targets, accumulators) -
+        some forty small launches and one MFMA kernel that wait for nothing the encoder makes.  Results land in `st`:
+        st["plan"], st["early"] = dict(tokens, prep)."""
         from mhr_amd import ops
-        tokens = self._token_lists(plan["valid_g"], plan["head_for_p_g"])
-        prep = None
-        if tokens[0] and plan["slots"] == list(range(negs_pools.shape[0])):          # negs_g IS negs_pools: same memory on both streams
-            prep = ops.nce_shared_prepare(tokens[1], tokens[2], tokens[4], e_rows.detach(), negs_pools.detach().contiguous(),
-                                          float(self.nce_thres), plan["p_row_mask"], plan["log_group"] is not None, n_q_rows=n_q_rows)
-        return dict(tokens=tokens, prep=prep)
+        stages = []
+
+        def plan():
+            st["plan"] = self._loss_plan(None, pools, mask, pos_tags)
+
+        def tokens():
+            pl = st["plan"]
+            tk = self._token_lists(pl["valid_g"], pl["head_for_p_g"])
+            st["early"] = dict(tokens=tk, prep=None)
+            if tk[0] and pl["slots"] == list(range(negs_pools.shape[0])):          # negs_g IS negs_pools: same memory on both streams
+                prep, more = ops.nce_shared_prepare_stages(tk[1], tk[2], tk[4], e_rows.detach(), negs_pools.detach().contiguous(),
+                                                           float(self.nce_thres), pl["p_row_mask"], pl["log_group"] is not None,
+                                                           n_q_rows=n_q_rows)
+                st["early"]["prep"] = prep
+                stages[0:0] = more                # next in line (this stage has been taken off the list)
+
+        stages += [plan, tokens]
+        return stages
 
     def _grouped_loss(self, head_rows, e_rows, negs_g, valid_g, head_for_p, log_group, p_row_mask=None, q_all=None, ihn_beta=0.0,
                       early=None, bucket_weight=None, n_segments=1):
@@ -388,7 +402,7 @@ class MultiHeadDecoding:
     def _multihead_loss(self, out, e_rows, negs_pools, pools, mask, pos_tags, plan=None, early=None, out_bf16=None):
         """Everything of the training forward after the sequence encoder (reference hstu.py:648-872 / hllm.py:506-763).
         out [B,L,D] fp32 encoder output; e_rows [B*(L+P), D] fp32 target-item rows; negs_pools [len(pools), n_pool, D]
-        bf16 L2-normalised; mask [B,L+P] bool; pos_tags [B,L+P,C]; plan / early: `_loss_plan(...)` / `_loss_prepare(...)` when the
+        bf16 L2-normalised; mask [B,L+P] bool; pos_tags [B,L+P,C]; plan / early: the results of `_early_loss_stages(...)` when the
         caller built them before the encoder ran."""
         dev = out.device
         B = out.shape[0]

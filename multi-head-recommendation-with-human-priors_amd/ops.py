@@ -613,38 +613,57 @@ def _fix_bits_tables(p_rows, negs, n_neg, D, G, thres, p_row_mask):
     return tabs[0], tabs[1], tabs[2]
 
 
-def nce_shared_prepare(q_idx, p_idx, n_tok_dev, p_rows, negs, thres, p_row_mask, want_logs, n_q_rows=None):
+def nce_shared_prepare_stages(q_idx, p_idx, n_tok_dev, p_rows, negs, thres, p_row_mask, want_logs, n_q_rows=None):
     """Everything the row-sharing forward needs that depends on the BATCH only (token lists, target rows, negatives) and not
     on the query rows: the row maps of the token lists, the false-negative bit table of the target rows, the first target of
     every row, the normalised target rows and the zeroed accumulators (with n_q_rows, the number of query rows, the backward's
-    accumulators as well).  `nce_fwd(share_rows=True)` builds it itself; a model
-    may build it EARLY - on a second stream underneath the sequence encoder - and hand it in (`prep=`).
-    Returns None when the shapes are not the row-sharing path's (ragged capacity / pool sizes, feature dims it does not take)."""
+    accumulators as well).  `nce_fwd(share_rows=True)` builds it itself; a model may build it EARLY - on a second stream
+    underneath the sequence encoder, a stage at a time between the encoder's layers - and hand it in (`prep=`).
+    Returns (prep, stages): the dict the stages fill, and the stages (callables, to be run in order on one stream); (None, [])
+    when the shapes are not the row-sharing path's (ragged capacity / pool sizes, feature dims it does not take)."""
     G, cap = q_idx.shape
     n_neg, D = negs.shape[1], negs.shape[2]
     if not SHARE_ROWS or D not in STREAM_DIMS or cap % 32 or n_neg % 32:
-        return None
-    prep = _shared_prepare_inline(q_idx, p_idx, n_tok_dev, cap, cap + 32, p_rows, negs, n_neg, D, G, thres, p_row_mask)
-    prep["key"] = (q_idx.data_ptr(), p_idx.data_ptr(), p_rows.data_ptr(), negs.data_ptr(), float(thres), bool(want_logs))
-    prep["keep"] = (q_idx, p_idx, p_rows, negs)
-    if n_q_rows is not None:       # the backward's accumulators too (zero / +inf fills that wait for nothing): (dq, dp, d_negs, d_scale, lw_row)
-        dq, dp, dn, dls = zeros_many(negs.device, ((int(n_q_rows), D), torch.float32), ((p_rows.shape[0], D), torch.float32),
-                                     ((G, n_neg, D), torch.float32), ((1,), torch.float32))
-        prep["bwd"] = (dq, dp, dn, dls, torch.full((G, cap + 32), float("inf"), dtype=torch.float32, device=negs.device))
-    return prep
+        return None, []
+    return _shared_prepare_stages(q_idx, p_idx, n_tok_dev, p_rows, negs, n_neg, thres, p_row_mask, want_logs, n_q_rows)
 
 
-def _shared_prepare_inline(q_idx, p_idx, n_tok_dev, cap, row_cap, p_rows, negs, n_neg, D, G, thres, p_row_mask):
+def _shared_prepare_stages(q_idx, p_idx, n_tok_dev, p_rows, negs, n_neg, thres, p_row_mask, want_logs, n_q_rows=None):
+    """(n_neg: the pool's own size; `negs` may be padded to whole 32-row tiles behind it)"""
+    G, cap = q_idx.shape
+    D = negs.shape[2]
     dev = negs.device
-    prep = {"row_maps": _row_maps(q_idx, n_tok_dev, cap, row_cap),
-            # the real false-negative bit table, per target row
-            "fix": _fix_bits_tables(p_rows, negs, n_neg, D, G, thres, p_row_mask)}
-    prep["r_p"] = torch.gather(p_idx, 1, prep["row_maps"][2].long().clamp_(max=cap - 1)).contiguous()
-    prep["z"] = zeros_many(dev, ((G, row_cap), torch.float32), ((G, row_cap), torch.int32), ((G, row_cap), torch.int32),
-                           ((G, cap), torch.int32), ((G, cap), torch.int32))
-    # the normalised target is a property of the TARGET ROW (shared by every token and group that points at it)
-    pn_rows, p_norm = l2norm_rows(p_rows.contiguous(), torch.bfloat16, want_norms=True)
-    prep["pn"] = (pn_rows, 1.0 / p_norm)
+    row_cap = cap + 32
+    prep = {"key": (q_idx.data_ptr(), p_idx.data_ptr(), p_rows.data_ptr(), negs.data_ptr(), float(thres), bool(want_logs)),
+            "keep": (q_idx, p_idx, p_rows, negs)}
+
+    def row_maps():
+        prep["row_maps"] = _row_maps(q_idx, n_tok_dev, cap, row_cap)
+
+    def fix_bits():                 # the real false-negative bit table, per target row
+        prep["fix"] = _fix_bits_tables(p_rows, negs, n_neg, D, G, thres, p_row_mask)
+
+    def rows_and_zeros():
+        prep["r_p"] = torch.gather(p_idx, 1, prep["row_maps"][2].long().clamp_(max=cap - 1)).contiguous()
+        prep["z"] = zeros_many(dev, ((G, row_cap), torch.float32), ((G, row_cap), torch.int32), ((G, row_cap), torch.int32),
+                               ((G, cap), torch.int32), ((G, cap), torch.int32))
+        # the normalised target is a property of the TARGET ROW (shared by every token and group that points at it)
+        pn_rows, p_norm = l2norm_rows(p_rows.contiguous(), torch.bfloat16, want_norms=True)
+        prep["pn"] = (pn_rows, 1.0 / p_norm)
+
+    def backward_buffers():         # zero / +inf fills that wait for nothing: (dq, dp, d_negs, d_scale, lw_row)
+        dq, dp, dn, dls = zeros_many(dev, ((int(n_q_rows), D), torch.float32), ((p_rows.shape[0], D), torch.float32),
+                                     ((G, n_neg, D), torch.float32), ((1,), torch.float32))
+        prep["bwd"] = (dq, dp, dn, dls, torch.full((G, row_cap), float("inf"), dtype=torch.float32, device=dev))
+
+    return prep, [row_maps, fix_bits, rows_and_zeros] + ([backward_buffers] if n_q_rows is not None else [])
+
+
+def nce_shared_prepare(q_idx, p_idx, n_tok_dev, p_rows, negs, thres, p_row_mask, want_logs, n_q_rows=None):
+    """`nce_shared_prepare_stages` run in one go on the current stream: the finished prep (or None)."""
+    prep, stages = nce_shared_prepare_stages(q_idx, p_idx, n_tok_dev, p_rows, negs, thres, p_row_mask, want_logs, n_q_rows)
+    for f in stages:
+        f()
     return prep
 
 
@@ -664,7 +683,9 @@ def _nce_fwd_shared(sv, q_rows, p_rows, negs, logit_scale, thres, want_logs, buc
     if prep is not None and prep["key"] != key:
         raise ValueError("nce_fwd: prep was built for other token lists / target rows / negatives than this call's")
     if prep is None:
-        prep = _shared_prepare_inline(q_idx, p_idx, n_tok_dev, cap, row_cap, p_rows, negs, n_neg, D, G, thres, p_row_mask)
+        prep, stages = _shared_prepare_stages(q_idx, p_idx, n_tok_dev, p_rows, negs, n_neg, thres, p_row_mask, want_logs)
+        for f in stages:
+            f()
     r_q, tok2row, r_first, n_row = prep["row_maps"]
     # (1) the real false-negative bit table, per target row
     fix_words, fix_any, slot_of_row = prep["fix"]
