@@ -191,7 +191,7 @@ class HSTU(MultiHeadDecoding, BaseModel):
             opt.last_step.fill_(opt.step_count)
         return out
 
-    def _encode(self, x, key_valid, training=None, want_bf16=False, after_layer=None):
+    def _encode(self, x, key_valid, training=None, want_bf16=False):
         """x [B,L,D] fp32, key_valid [B,L] uint8 -> [B,L,D] fp32 (reference hstu.py:221-328); want_bf16: (out, its bf16 copy -
         the operand of the decoding heads' GEMM, written by the last residual add's own pass)."""
         from REC.model.hstu_functional import AddCastFn, AddLayerNormFn, HSTUCoreFn, LayerNormFn, LayerNormResidualFn, SplitKLinearFn
@@ -219,8 +219,6 @@ class HSTU(MultiHeadDecoding, BaseModel):
                 h = xn @ cached[0]
                 o = HSTUCoreFn.apply(h, key_valid, B, L, self._num_heads, self._dqk, layer._eps, p, seed)
                 y = F.linear(o, cached[1], cached[2])
-            if after_layer is not None:
-                after_layer(i)                  # (the caller's side-stream work, interleaved with the layers' launches)
             if i + 1 < len(layers):            # residual add + the next layer's LayerNorm in one pass
                 x2, xn = AddLayerNormFn.apply(x2, y, layers[i + 1]._eps)
             elif want_bf16 and y.dtype == torch.bfloat16 and x2.numel() % 8 == 0:
@@ -242,7 +240,9 @@ class HSTU(MultiHeadDecoding, BaseModel):
         L, P, D = self.max_seq_length, self.pred_len, self._hstu_embedding_dim
         mask = user_mask.bool()
         self._step_seed += 1
-        self._clamp_logit_scale()
+        early_prep = EARLY_LOSS_PREP and torch.is_grad_enabled()
+        if not early_prep:
+            self._clamp_logit_scale()
 
         # which negative pools the loss reads (reference hstu.py:669-670, 751-752); ids are shared across ranks
         pools = self._negative_pools(neg_items.shape[1])
@@ -266,33 +266,44 @@ class HSTU(MultiHeadDecoding, BaseModel):
 
         key_valid = mask[:, :L].to(torch.uint8).contiguous()
         # everything of the loss that waits for nothing the encoder makes (token lists, row maps, the false-negative bit table of
-        # the target rows, the id sort of the embedding backward) goes on a second stream UNDERNEATH the encoder: some fifty
-        # few-microsecond launches that otherwise sit on the step's critical path one after the other
+        # the target rows, the accumulators of the loss backward, the id sort of the embedding backward) runs UNDERNEATH the
+        # encoder on a second stream: some fifty few-microsecond launches and one 0.2 ms MFMA kernel on 104 workgroups that
+        # otherwise sit on the step's critical path one after the other
         st, stages, side = {}, [], None
-        if EARLY_LOSS_PREP and torch.is_grad_enabled():
+        capturing = torch.cuda.is_current_stream_capturing()
+        segs = getattr(self, "_graph_segments", None) if capturing else None
+        if early_prep:
+            stages = self._early_loss_stages(st, pools, mask, pos_tags, e_rows, negs_pools, n_q_rows=B * self.medusa_num_heads * L)
+            stages.insert(0, self._clamp_logit_scale)            # (read by the loss kernels only: behind the join)
+            stages.append(lambda: self._presort_ids(ids_all))
+
+        def run_stages():
+            with torch.no_grad():
+                while stages:
+                    stages.pop(0)()
+
+        if segs is not None and stages:
+            # under the Trainer's capture: the stages become a hipGraph of their own on the capture's side stream, replayed
+            # concurrently with the segment that holds the encoder (REC/trainer/trainer.py:_GraphSegments - every launch stays a
+            # single-stream graph, which ROCm enqueues with one cheap host call; a graph with a forked branch costs 2.4 ms of
+            # host time per replay and reaches the GPU at the host's pace)
+            segs.side_branch(run_stages)
+            out, out16 = self._encode(x, key_valid, want_bf16=True)
+            segs.join()
+        elif stages and not capturing:
+            # host-issued steps: a second stream forked here and joined in front of the heads; the encoder's launches go first
+            # (the host is the slower side of the forward), the stages behind them
             if self._side_stream is None:
                 self._side_stream = torch.cuda.Stream(device=items.device)
             side = self._side_stream
             side.wait_stream(torch.cuda.current_stream())        # the fork: everything up to here (rows, negatives) is visible
-            stages = self._early_loss_stages(st, pools, mask, pos_tags, e_rows, negs_pools, n_q_rows=B * self.medusa_num_heads * L)
-            stages.append(lambda: self._presort_ids(ids_all))
-
-        # Under capture the stages are issued one behind every encoder layer's launches, host-issued steps keep the encoder's
-        # launches together (the host is the slower side in the forward: 4.9 against 5.4 ms per step) and issue the stages behind
-        # them.  (Measured on replayed graphs, same box: no second stream 4.66 ms, stages interleaved 4.54 ms; extra edges that
-        # make the main branch wait for stage k a few layers later changed nothing - 4.52 to 4.55 ms for every distance tried.)
-        capturing = side is not None and torch.cuda.is_current_stream_capturing()
-
-        def next_stage(_layer=None):
-            if stages:
-                with torch.cuda.stream(side), torch.no_grad():
-                    stages.pop(0)()
-
-        out, out16 = self._encode(x, key_valid, want_bf16=True, after_layer=next_stage if capturing else None)
-        if side is not None:
-            while stages:
-                next_stage()
+            out, out16 = self._encode(x, key_valid, want_bf16=True)
+            with torch.cuda.stream(side):
+                run_stages()
             torch.cuda.current_stream().wait_stream(side)
+        else:                                                    # (somebody else's capture: one stream, the stages in line)
+            run_stages()
+            out, out16 = self._encode(x, key_valid, want_bf16=True)
         plan, early = st.get("plan"), st.get("early")
         return self._multihead_loss(out, e_rows, negs_pools, pools, mask, pos_tags, plan=plan, early=early, out_bf16=out16)
 

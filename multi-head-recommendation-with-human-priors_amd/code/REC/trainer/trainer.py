@@ -21,6 +21,88 @@ from REC.utils import early_stopping
 from REC.utils.lr_scheduler import cosine_warmup_factor
 
 
+class _GraphSegments:
+    """The captured step as a SEQUENCE of single-stream hipGraphs instead of one graph with branches.
+
+    A graph whose nodes sit on one stream is launched by ROCm with one cheap host call (0.1 ms for the ~175 nodes of a cfg1
+    step); a graph with a forked branch is enqueued node by node (2.4 ms of host time per replay, measured) and its branches
+    reach the GPU at the host's pace.  The model's second-stream work (`HSTU.forward`: the batch-only half of the loss) is
+    therefore captured as a graph of its own: `side_branch(fn)` closes the running main segment, captures fn() on the side
+    stream into its own graph and memory pool, and opens the next main segment; `join()` closes a segment where the main
+    stream must have the side graph's results.  Replay: segments in order on the caller's stream, the side graph on the side
+    stream behind an event, the join as an event wait - every launch a linear graph.
+
+    Memory: the main segments share one pool (they replay one after the other, in capture order); the side graph has its own,
+    because it runs CONCURRENTLY with the main segment behind it - what it reads from the main pool (gathered rows, ids,
+    normalised negatives) is alive until the backward of the same step, what the main segments read from its pool (token
+    lists, bit table, accumulators) is written before the join and not touched by it again."""
+
+    def __init__(self, device):
+        self.main = torch.cuda.Stream(device=device)
+        self.side = torch.cuda.Stream(device=device)
+        self.plan, self.cur, self.pool = [], None, None
+        self.ev_fork, self.ev_side = torch.cuda.Event(), torch.cuda.Event()
+
+    def begin(self):
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        self._ctx = torch.cuda.stream(self.main)
+        self._ctx.__enter__()
+        self._open()
+
+    def _open(self):
+        g = torch.cuda.CUDAGraph()
+        if self.pool is None:
+            self.pool = torch.cuda.graph_pool_handle()
+        g.capture_begin(pool=self.pool)
+        self.cur = g
+
+    def _close(self):
+        self.cur.capture_end()
+        self.plan.append(("main", self.cur))
+        self.cur = None
+
+    def side_branch(self, fn):
+        self._close()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(self.side):
+            g.capture_begin(pool=torch.cuda.graph_pool_handle())
+            try:
+                fn()
+            finally:
+                g.capture_end()
+        self.plan.append(("side", g))
+        self._open()
+
+    def join(self):
+        self._close()
+        self.plan.append(("join", None))
+        self._open()
+
+    def end(self):
+        try:
+            if self.cur is not None:
+                self._close()
+        finally:
+            ctx, self._ctx = getattr(self, "_ctx", None), None
+            if ctx is not None:
+                ctx.__exit__(None, None, None)
+
+    def replay(self):
+        cur = torch.cuda.current_stream()
+        for kind, g in self.plan:
+            if kind == "main":
+                g.replay()
+            elif kind == "side":
+                self.ev_fork.record(cur)
+                self.side.wait_event(self.ev_fork)
+                with torch.cuda.stream(self.side):
+                    g.replay()
+                self.ev_side.record(self.side)
+            else:
+                cur.wait_event(self.ev_side)
+
+
 class _StepGraph:
     """One optimisation step captured as a hipGraph (torch.cuda.CUDAGraph over the C-ABI launches, the library GEMMs and the
     torch glue of the step) and replayed with ONE host call per step.
@@ -48,7 +130,7 @@ class _StepGraph:
         model, opt, dev = tr.model, tr.optimizer, data[0].device
         self.static = tuple(t.clone() for t in data)
         keep = (model._step_seed, opt.step_count, tr.train_step, tr._micro_step, opt.param_groups[0]["lr"])
-        graph = torch.cuda.CUDAGraph()
+        graph = _GraphSegments(dev)
         model._seed_dev, opt.step_dev, opt.in_graph = opt.ctrl[0:1], opt.ctrl[1:2], True
         # no cyclic garbage collection while the stream is capturing: a collected object may own pinned host memory or an
         # event whose release is a synchronising HIP call - illegal under capture, and it takes the process down (seen with
@@ -58,9 +140,14 @@ class _StepGraph:
         gc_was = gc.isenabled()
         gc.disable()
         try:
-            with torch.cuda.graph(graph):
+            model._graph_segments = graph
+            graph.begin()
+            try:
                 out = tr._eager_step(self.static)
+            finally:
+                graph.end()
         finally:
+            model._graph_segments = None
             if gc_was:
                 gc.enable()
             model._seed_dev, opt.step_dev, opt.in_graph = None, None, False
@@ -82,9 +169,9 @@ class _StepGraph:
                 self.release()
                 return tr._eager_step(data)
         model, opt = tr.model, tr.optimizer
-        for s_, t in zip(self.static, data):
-            if s_ is not t:
-                s_.copy_(t, non_blocking=True)
+        pairs = [(s_, t) for s_, t in zip(self.static, data) if s_ is not t]
+        if pairs:                                  # the batch into the static inputs: one multi-tensor copy launch per dtype
+            torch._foreach_copy_([p[0] for p in pairs], [p[1] for p in pairs], non_blocking=True)
         if self.n % 16 == 0:
             ev = torch.cuda.Event()
             ev.record()
