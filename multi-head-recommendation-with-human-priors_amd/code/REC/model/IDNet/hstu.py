@@ -29,7 +29,8 @@ from REC.model.basemodel import BaseModel, all_gather_pool_ids
 from REC.model.multihead import FusedTopK, MultiHeadDecoding  # noqa: F401  (FusedTopK re-exported)
 from REC.utils.enum_type import InputType
 
-EARLY_LOSS_PREP = os.environ.get("MHR_EARLY_LOSS_PREP", "1") != "0"      # 0: the loss preparation runs in line, after the encoder
+EARLY_LOSS_PREP = os.environ.get("MHR_EARLY_LOSS_PREP", "1") != "0"
+WEIGHT_GRAD_STACK = os.environ.get("MHR_WEIGHT_GRAD_STACK", "1") != "0"   # 0: every layer's weight gradients inside its own backward      # 0: the loss preparation runs in line, after the encoder
 
 
 def truncated_normal(x, mean, std):
@@ -194,16 +195,28 @@ class HSTU(MultiHeadDecoding, BaseModel):
     def _encode(self, x, key_valid, training=None, want_bf16=False):
         """x [B,L,D] fp32, key_valid [B,L] uint8 -> [B,L,D] fp32 (reference hstu.py:221-328); want_bf16: (out, its bf16 copy -
         the operand of the decoding heads' GEMM, written by the last residual add's own pass)."""
-        from REC.model.hstu_functional import AddCastFn, AddLayerNormFn, HSTUCoreFn, LayerNormFn, LayerNormResidualFn, SplitKLinearFn
+        from REC.model.hstu_functional import (AddCastFn, AddLayerNormFn, HSTUCoreFn, LayerNormFn, LayerNormResidualFn, SplitKLinearFn,
+                                               WeightGradStack)
         B, L, D = x.shape
         x2 = x.reshape(B * L, D)
         training = self.training if training is None else training
         p = self._linear_dropout_rate if training else 0.0
         layers = self._hstu._attention_layers
-        if len(layers) > 1 and x2.requires_grad and x2.is_contiguous():
-            x2, xn = LayerNormResidualFn.apply(x2, layers[0]._eps, True)
+        n = len(layers)
+        # training with the fused optimizer in its one-backward-per-step mode: the layers' weight-gradient products are formed
+        # for all layers at once at the step (WeightGradStack); the kernels below write their operands straight into its slices
+        stack = None
+        opt = getattr(layers[0]._uvqk, "_mhr_opt", None) if n else None
+        if (WEIGHT_GRAD_STACK and opt is not None and torch.is_grad_enabled() and x2.requires_grad and self._layer_weights_bf16(0, layers[0]) is None
+                and all(getattr(q, "_mhr_direct_grad", False) and q.grad is not None and getattr(q, "_mhr_opt", None) is opt
+                        for ly in layers for q in (ly._uvqk, ly._o.weight))
+                and all(tuple(ly._uvqk.shape) == (D, 4 * D) and tuple(ly._o.weight.shape) == (D, D) for ly in layers)):
+            stack = WeightGradStack(opt, [ly._uvqk for ly in layers], [ly._o.weight for ly in layers], B * L, D, x.device)
+        sl = (lambda buf, i: buf[i]) if stack is not None else (lambda buf, i: None)
+        if n > 1 and x2.requires_grad and x2.is_contiguous():
+            x2, xn = LayerNormResidualFn.apply(x2, layers[0]._eps, True, sl(stack and stack.xn, 0))
         else:
-            xn = LayerNormFn.apply(x2, layers[0]._eps)
+            xn = LayerNormFn.apply(x2, layers[0]._eps, sl(stack and stack.xn, 0))
         for i, layer in enumerate(layers):
             cached = self._layer_weights_bf16(i, layer)
             # dropout seed = (step * 1000003 + layer part) & (2^63 - 1); a hipGraph-replayed step reads the step counter from
@@ -212,17 +225,18 @@ class HSTU(MultiHeadDecoding, BaseModel):
             layer_part = i * 7919 + self.rank * 104729
             seed = layer_part if seed_dev is not None else (self._step_seed * 1000003 + layer_part) & 0x7FFFFFFFFFFFFFFF
             if cached is None:
-                h = SplitKLinearFn.apply(xn, layer._uvqk, None, False, None)
-                o = HSTUCoreFn.apply(h, key_valid, B, L, self._num_heads, self._dqk, layer._eps, p, seed, seed_dev)
-                y = SplitKLinearFn.apply(o, layer._o.weight, layer._o.bias, True, None)
+                h = SplitKLinearFn.apply(xn, layer._uvqk, None, False, None, (stack, "uvqk", i) if stack is not None else None)
+                o = HSTUCoreFn.apply(h, key_valid, B, L, self._num_heads, self._dqk, layer._eps, p, seed, seed_dev,
+                                     sl(stack and stack.o, i), sl(stack and stack.dh, i))
+                y = SplitKLinearFn.apply(o, layer._o.weight, layer._o.bias, True, None, (stack, "o", i) if stack is not None else None)
             else:
                 h = xn @ cached[0]
                 o = HSTUCoreFn.apply(h, key_valid, B, L, self._num_heads, self._dqk, layer._eps, p, seed)
                 y = F.linear(o, cached[1], cached[2])
-            if i + 1 < len(layers):            # residual add + the next layer's LayerNorm in one pass
-                x2, xn = AddLayerNormFn.apply(x2, y, layers[i + 1]._eps)
+            if i + 1 < n:                      # residual add + the next layer's LayerNorm in one pass
+                x2, xn = AddLayerNormFn.apply(x2, y, layers[i + 1]._eps, sl(stack and stack.xn, i + 1), sl(stack and stack.dy, i))
             elif want_bf16 and y.dtype == torch.bfloat16 and x2.numel() % 8 == 0:
-                x2, x16 = AddCastFn.apply(x2, y)
+                x2, x16 = AddCastFn.apply(x2, y, sl(stack and stack.dy, i))
                 return x2.view(B, L, D), x16.view(B, L, D)
             else:
                 x2 = torch.add(x2, y)           # fp32 + bf16 -> fp32 in one kernel

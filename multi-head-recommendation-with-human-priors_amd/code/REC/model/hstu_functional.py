@@ -21,15 +21,15 @@ class LayerNormFn(Function):
     """Affine-free LayerNorm, fp32 in -> bf16 out (reference model/IDNet/hstu.py:213-214, 241)."""
 
     @staticmethod
-    def forward(ctx, x, eps):
-        y, mean, rstd = ops.layernorm_fwd(x, torch.bfloat16, eps)
+    def forward(ctx, x, eps, out=None):
+        y, mean, rstd = ops.layernorm_fwd(x, torch.bfloat16, eps, out=out)
         ctx.save_for_backward(x, mean, rstd)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, mean, rstd = ctx.saved_tensors
-        return ops.layernorm_bwd(dy.contiguous(), x, mean, rstd, dx_dtype=torch.float32), None
+        return ops.layernorm_bwd(dy.contiguous(), x, mean, rstd, dx_dtype=torch.float32), None, None
 
 
 class LayerNormResidualFn(Function):
@@ -40,8 +40,8 @@ class LayerNormResidualFn(Function):
     backward), so it may be accumulated into in place."""
 
     @staticmethod
-    def forward(ctx, x, eps, residual_grad_is_fresh):
-        y, mean, rstd = ops.layernorm_fwd(x, torch.bfloat16, eps)
+    def forward(ctx, x, eps, residual_grad_is_fresh, out=None):
+        y, mean, rstd = ops.layernorm_fwd(x, torch.bfloat16, eps, out=out)
         ctx.save_for_backward(x, mean, rstd)
         ctx.inplace = bool(residual_grad_is_fresh)
         return x, y
@@ -50,11 +50,11 @@ class LayerNormResidualFn(Function):
     def backward(ctx, d_x, d_y):
         x, mean, rstd = ctx.saved_tensors
         if d_y is None:
-            return d_x, None, None
+            return d_x, None, None, None
         if d_x is not None and ctx.inplace and d_x.dtype == torch.float32 and d_x.is_contiguous():
-            return ops.layernorm_bwd(d_y.contiguous(), x, mean, rstd, dx=d_x, accumulate=True), None, None
+            return ops.layernorm_bwd(d_y.contiguous(), x, mean, rstd, dx=d_x, accumulate=True), None, None, None
         g = ops.layernorm_bwd(d_y.contiguous(), x, mean, rstd, dx_dtype=torch.float32)
-        return (g if d_x is None else g + d_x), None, None
+        return (g if d_x is None else g + d_x), None, None, None
 
 
 class AddLayerNormFn(Function):
@@ -62,9 +62,10 @@ class AddLayerNormFn(Function):
     (reference hstu.py:286-287, 241).  x fp32, y bf16 -> x_out fp32, xn bf16."""
 
     @staticmethod
-    def forward(ctx, x, y, eps):
-        x_out, xn, mean, rstd = ops.add_layernorm_fwd(x.contiguous(), y.contiguous(), eps)
+    def forward(ctx, x, y, eps, xn_out=None, dy_out=None):
+        x_out, xn, mean, rstd = ops.add_layernorm_fwd(x.contiguous(), y.contiguous(), eps, xn_out=xn_out)
         ctx.save_for_backward(x_out, mean, rstd)
+        ctx.dy_out = dy_out                      # (the caller's buffer for the gradient of y: WeightGradStack)
         return x_out, xn
 
     @staticmethod
@@ -74,8 +75,8 @@ class AddLayerNormFn(Function):
             d_xout = torch.zeros_like(x_out)
         if d_xn is None:
             d_xn = torch.zeros(x_out.shape, dtype=torch.bfloat16, device=x_out.device)
-        dx, dy = ops.add_layernorm_bwd(d_xn.contiguous(), x_out, mean, rstd, d_xout.contiguous().float())
-        return dx, dy, None
+        dx, dy = ops.add_layernorm_bwd(d_xn.contiguous(), x_out, mean, rstd, d_xout.contiguous().float(), dy_out=ctx.dy_out)
+        return dx, dy, None, None, None
 
 
 class AddCastFn(Function):
@@ -83,18 +84,74 @@ class AddCastFn(Function):
     copy the decoding heads' GEMM reads (reference hstu.py:286-288; llm_heads.py:30-40 under autocast).  One pass each way."""
 
     @staticmethod
-    def forward(ctx, x, y):
+    def forward(ctx, x, y, dy_out=None):
+        ctx.dy_out = dy_out                      # (the caller's buffer for the gradient of y: WeightGradStack)
         return ops.add_cast(x.contiguous(), y.contiguous())
 
     @staticmethod
     def backward(ctx, d_out, d_out16):
         if d_out is None and d_out16 is None:
-            return None, None
+            return None, None, None
         if d_out16 is None:
-            return d_out, d_out.to(torch.bfloat16)
+            return d_out, d_out.to(torch.bfloat16), None
         if d_out is None:
-            return d_out16.float(), d_out16
-        return ops.add_cast(d_out.contiguous(), d_out16.contiguous())        # dx = d_out + d_out16 (fp32), dy = bf16(dx)
+            return d_out16.float(), d_out16, None
+        # dx = d_out + d_out16 (fp32), dy = bf16(dx)
+        return ops.add_cast(d_out.contiguous(), d_out16.contiguous(), out16=ctx.dy_out) + (None,)
+
+
+class WeightGradStack:
+    """The operands of the encoder layers' weight-gradient products side by side, so that the L layers' products run as ONE
+    batched split-K GEMM per projection at the optimizer step instead of L small ones inside the backward.
+
+    Nothing in the backward reads a weight gradient, and each of these products is too small for the chip on its own:
+    [B L, D]^T [B L, 4 D] as 16 slices is 256 workgroups, 27 us per layer at cfg1; [B L, D]^T [B L, D] 64 workgroups, 19 us.
+    Stacked over the 8 layers they take 124 us instead of 220 and 40 us instead of 158 (hipBLASLt, measured in isolation).
+    The producers write straight into the stack: xn[l] (LayerNorm in front of the uvqk projection), dh[l] (gradient of its
+    output, HSTUCoreFn.backward), o[l] (gate output = input of the output projection), dy[l] (gradient of that projection's
+    output: AddLayerNormFn / AddCastFn backward).  `flush()` - queued with the fused optimizer, run first thing in its step -
+    forms [L S, ., .] bf16 partials with two batched GEMMs and queues their per-layer sums into the parameters' fp32 gradients
+    (one `mhr_sum_rows_many` launch per projection).  Needs the optimizer's one-backward-per-step mode (its partial arena)."""
+
+    def __init__(self, opt, uvqk_params, o_params, R, D, device):
+        L = len(uvqk_params)
+        self.opt, self.L, self.R, self.D = opt, L, R, D
+        self.params = {"uvqk": list(uvqk_params), "o": list(o_params)}
+        bf = dict(dtype=torch.bfloat16, device=device)
+        self.xn, self.dh = torch.empty(L, R, D, **bf), torch.empty(L, R, 4 * D, **bf)
+        self.o, self.dy = torch.empty(L, R, D, **bf), torch.empty(L, R, D, **bf)
+        self.seen = {"uvqk": set(), "o": set()}
+        opt.defer(self.flush)
+
+    def operands(self, kind, layer, x, dy):
+        """The backward of layer `layer`'s projection hands over its operands; they are the stack's own slices unless somebody
+        re-materialised them on the way (then they are copied in)."""
+        xs, ds = (self.xn, self.dh) if kind == "uvqk" else (self.o, self.dy)
+        if x.data_ptr() != xs[layer].data_ptr():
+            xs[layer].copy_(x.reshape(xs[layer].shape))
+        if dy.data_ptr() != ds[layer].data_ptr():
+            ds[layer].copy_(dy.reshape(ds[layer].shape))
+        self.seen[kind].add(layer)
+
+    @staticmethod
+    def _splits(R, prefer):
+        return next((s for s in prefer if R % s == 0 and R // s >= 256), 1)
+
+    def flush(self):
+        n = {k: len(v) for k, v in self.seen.items()}
+        if n["uvqk"] == 0 and n["o"] == 0:
+            return                                # a forward whose backward never ran
+        if n["uvqk"] != self.L or n["o"] != self.L:
+            raise RuntimeError(f"WeightGradStack: {n} of {self.L} layers handed their operands over")
+        L, R, D = self.L, self.R, self.D
+        S1 = self._splits(R, (8, 4, 2))           # (slices per layer: measured best at cfg1 - 8 for the wide product, 16 for the square)
+        w1 = torch.bmm(self.xn.view(L * S1, R // S1, D).transpose(1, 2), self.dh.view(L * S1, R // S1, 4 * D))      # [L S1, D, 4D]
+        S2 = self._splits(R, (16, 8, 4, 2))
+        w2 = torch.bmm(self.dy.view(L * S2, R // S2, D).transpose(1, 2), self.o.view(L * S2, R // S2, D))           # [L S2, D(out), D(in)]
+        for l in range(L):
+            self.opt.queue_rows_sum(w1[l * S1:(l + 1) * S1].view(S1, -1), self.params["uvqk"][l].grad)
+            self.opt.queue_rows_sum(w2[l * S2:(l + 1) * S2].view(S2, -1), self.params["o"][l].grad)
+        self.seen = {"uvqk": set(), "o": set()}
 
 
 class SplitKLinearFn(Function):
@@ -106,7 +163,8 @@ class SplitKLinearFn(Function):
     split-K batched GEMM instead - S slices of the token axis, S x more tiles - and the S partials are summed in fp32."""
 
     @staticmethod
-    def forward(ctx, x, w, b, w_is_nk, w_bf16):
+    def forward(ctx, x, w, b, w_is_nk, w_bf16, defer=None):
+        ctx.defer = defer                        # (WeightGradStack, kind, layer): the weight gradient is formed for all layers at once
         if w_bf16 is None:
             sh = getattr(w, "_mhr_bf16", None)       # shadow kept by the fused optimizer, valid while nobody edited w
             w_bf16 = sh if (sh is not None and w._version == w._mhr_ver) else None
@@ -139,6 +197,15 @@ class SplitKLinearFn(Function):
         dy = dy.contiguous()
         dx = dy @ wb if ctx.w_is_nk else dy @ wb.t()
         R = x.shape[0]
+        if ctx.defer is not None and ctx.w_leaf is not None:
+            stack, kind, layer = ctx.defer
+            stack.operands(kind, layer, x, dy)    # (both are slices of the stack already; copied in if somebody re-made them)
+            if ctx.has_bias and ctx.b_leaf is not None:
+                bopt = getattr(ctx.b_leaf, "_mhr_opt", None)
+                if not (bopt is not None and bopt.queue_bias_sum(dy, ctx.b_leaf)):
+                    SplitKLinearFn._into(ctx.b_leaf, dy)
+                return dx, None, None, None, None, None
+            return dx, None, (torch.sum(dy, 0, dtype=torch.float32) if ctx.has_bias else None), None, None, None
         # split the token axis only as far as the output needs it: a [1024, 256] gradient is 4 macro-tiles on a 256-CU part,
         # a [11264, 2048] one (LLM decoder) already has 352 and splitting it would only add partials to write and sum
         tiles = -(-wb.shape[0] // 256) * -(-wb.shape[1] // 256)
@@ -168,7 +235,7 @@ class SplitKLinearFn(Function):
                     SplitKLinearFn._into(ctx.b_leaf, dy)
             else:
                 db = torch.sum(dy, 0, dtype=torch.float32)
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None
 
 
 class FusedHeadsLinearFn(Function):
@@ -252,11 +319,12 @@ class HSTUCoreFn(Function):
     """
 
     @staticmethod
-    def forward(ctx, h, key_valid, B, L, n_heads, head_dim, eps, dropout_p, seed, seed_dev=None):
+    def forward(ctx, h, key_valid, B, L, n_heads, head_dim, eps, dropout_p, seed, seed_dev=None, o_out=None, dh_out=None):
         D = n_heads * head_dim
         # the activated q / k / v are NOT saved: the backward recomputes silu() while it stages them (h is kept anyway)
         a, _ = ops.hstu_attn_fwd(h, key_valid, B, L, n_heads, head_dim, apply_silu=True, save_act=False)
-        o, mean, rstd = ops.ln_gate_fwd(h, a, D, torch.bfloat16, eps, dropout_p, seed, seed_dev)
+        o, mean, rstd = ops.ln_gate_fwd(h, a, D, torch.bfloat16, eps, dropout_p, seed, seed_dev, out=o_out)
+        ctx.dh_out = dh_out                      # (the caller's buffer for the gradient of h: WeightGradStack)
         ctx.save_for_backward(h, key_valid, a, mean, rstd)
         ctx.cfg = (B, L, n_heads, head_dim, dropout_p, seed, seed_dev)
         return o
@@ -266,10 +334,10 @@ class HSTUCoreFn(Function):
         h, key_valid, a, mean, rstd = ctx.saved_tensors
         B, L, n_heads, head_dim, dropout_p, seed, seed_dev = ctx.cfg
         D = n_heads * head_dim
-        dh = torch.empty_like(h)
+        dh = torch.empty_like(h) if ctx.dh_out is None else ctx.dh_out.view(h.shape)
         da = ops.ln_gate_bwd(d_o.contiguous(), h, a, mean, rstd, dh, D, dropout_p, seed, seed_dev)
         ops.hstu_attn_bwd(h, None, key_valid, da, dh, B, L, n_heads, head_dim, apply_silu=True)
-        return dh, None, None, None, None, None, None, None, None, None
+        return (dh,) + (None,) * 11
 
 
 class SparseRowGrad:

@@ -211,11 +211,23 @@ def sum_rows_into(x, out):
 # ------------------------------------------------------------------------------------------------
 # normalisation / gate
 # ------------------------------------------------------------------------------------------------
-def layernorm_fwd(x, out_dtype=torch.bfloat16, eps=1e-6):
+def _out_like(out, shape, dtype, device, name):
+    """`out` (a caller's buffer: same element count and dtype, contiguous) or a fresh tensor."""
+    if out is None:
+        return torch.empty(shape, dtype=dtype, device=device)
+    n = 1
+    for d in shape:
+        n *= int(d)
+    if out.dtype != dtype or out.numel() != n or not out.is_contiguous() or out.device != device:
+        raise ValueError(f"{name}: expected a contiguous {dtype} buffer of {n} elements on {device}")
+    return out
+
+
+def layernorm_fwd(x, out_dtype=torch.bfloat16, eps=1e-6, out=None):
     _chk(x, "x")
     D = x.shape[-1]
     rows = x.numel() // D
-    y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    y = _out_like(out, x.shape, out_dtype, x.device, "layernorm_fwd out")
     mean = torch.empty(rows, dtype=torch.float32, device=x.device)
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
     lib.call("mhr_layernorm_fwd", x.data_ptr(), _dt(x), y.data_ptr(), _dt(y), mean.data_ptr(), rstd.data_ptr(), rows, D,
@@ -234,25 +246,25 @@ def layernorm_bwd(dy, x, mean, rstd, dx=None, accumulate=False, dx_dtype=torch.f
     return dx
 
 
-def add_cast(x, y):
+def add_cast(x, y, out16=None):
     """(x + y fp32, its bf16 copy) for x fp32 and y bf16 of one shape, one pass (mhr_add_cast)."""
     _chk(x, "x", torch.float32)
     _chk(y, "y", torch.bfloat16)
     assert x.shape == y.shape
     out = torch.empty_like(x)
-    out16 = torch.empty_like(y)
+    out16 = _out_like(out16, y.shape, torch.bfloat16, y.device, "add_cast out16")
     lib.call("mhr_add_cast", x.data_ptr(), y.data_ptr(), out.data_ptr(), out16.data_ptr(), x.numel(), _stream())
     return out, out16
 
 
-def add_layernorm_fwd(x, y, eps=1e-6):
+def add_layernorm_fwd(x, y, eps=1e-6, xn_out=None):
     """x_out = x + y (fp32 + bf16), xn = LN(x_out) bf16.  Returns (x_out, xn, mean, rstd)."""
     _chk(x, "x", torch.float32)
     _chk(y, "y", torch.bfloat16)
     D = x.shape[-1]
     rows = x.numel() // D
     x_out = torch.empty_like(x)
-    xn = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    xn = _out_like(xn_out, x.shape, torch.bfloat16, x.device, "add_layernorm_fwd xn_out")
     mean = torch.empty(rows, dtype=torch.float32, device=x.device)
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
     lib.call("mhr_add_layernorm_fwd", x.data_ptr(), y.data_ptr(), x_out.data_ptr(), xn.data_ptr(), mean.data_ptr(),
@@ -260,24 +272,24 @@ def add_layernorm_fwd(x, y, eps=1e-6):
     return x_out, xn, mean, rstd
 
 
-def add_layernorm_bwd(d_xn, x_out, mean, rstd, d_xout):
+def add_layernorm_bwd(d_xn, x_out, mean, rstd, d_xout, dy_out=None):
     """-> (dx f32, dy bf16), both = d_xout + LN'(d_xn)."""
     _chk(d_xn, "d_xn", torch.bfloat16)
     _chk(d_xout, "d_xout", torch.float32)
     D = x_out.shape[-1]
     rows = x_out.numel() // D
     dx = torch.empty_like(x_out)
-    dy = torch.empty(x_out.shape, dtype=torch.bfloat16, device=x_out.device)
+    dy = _out_like(dy_out, x_out.shape, torch.bfloat16, x_out.device, "add_layernorm_bwd dy_out")
     lib.call("mhr_add_layernorm_bwd", d_xn.data_ptr(), x_out.data_ptr(), mean.data_ptr(), rstd.data_ptr(), d_xout.data_ptr(),
              dx.data_ptr(), dy.data_ptr(), rows, D, _stream())
     return dx, dy
 
 
-def ln_gate_fwd(h, a, dim, out_dtype=None, eps=1e-6, dropout_p=0.0, seed=0, seed_dev=None):
+def ln_gate_fwd(h, a, dim, out_dtype=None, eps=1e-6, dropout_p=0.0, seed=0, seed_dev=None, out=None):
     """o = silu(h[:, :dim]) * LN(a) * dropmask.  h [rows, stride] pre-activation, a [rows, dim].
     seed_dev (device int64[1], optional): step counter of a hipGraph-replayed step; `seed` is then the per-layer part."""
     rows = a.numel() // dim
-    o = torch.empty(rows, dim, dtype=out_dtype or a.dtype, device=a.device)
+    o = _out_like(out, (rows, dim), out_dtype or a.dtype, a.device, "ln_gate_fwd out").view(rows, dim)
     mean = torch.empty(rows, dtype=torch.float32, device=a.device)
     rstd = torch.empty(rows, dtype=torch.float32, device=a.device)
     assert h.dtype == a.dtype

@@ -174,13 +174,38 @@ class FusedAdamW:
         the step - a test, a norm - calls it first)."""
         self._reduce_arena()
 
+    def defer(self, fn):
+        """Run fn() first thing at the step (before the deferred reductions are folded into the flat gradient): work of the
+        backward that nothing in the backward waits for (WeightGradStack.flush)."""
+        if not hasattr(self, "_deferred"):
+            self._deferred = []
+        self._deferred.append(fn)
+        if len(self._deferred) > 8:               # forwards whose backward never came: their closures do nothing, drop the oldest
+            self._deferred.pop(0)
+
     def _reduce_arena(self):
+        todo, self._deferred = getattr(self, "_deferred", []), []
+        for fn in todo:
+            fn()
         if getattr(self, "_arena", None) is not None and self._arena_used:
             ops.sum_rows_into(self._arena, self.flat_g)
             self._arena_used = set()
         self._reduce_bias_queue()
 
     # ---- bias gradients of equally shaped projections: ONE column-sum launch for all of them ------------------------------
+    def queue_rows_sum(self, src, grad):
+        """grad (fp32, contiguous, a parameter's view of the flat gradient) += src.sum(0) for src [rows, grad.numel()] bf16,
+        deferred to the step and batched with every other sum of the same shape into one launch."""
+        g = grad.view(-1)
+        ok = (src.dtype == torch.bfloat16 and src.is_contiguous() and src.dim() == 2 and src.shape[1] == g.numel() and src.shape[1] % 8 == 0
+              and g.dtype == torch.float32 and g.is_contiguous() and g.data_ptr() % 16 == 0 and src.data_ptr() % 16 == 0)
+        if not ok:
+            g.add_(torch.sum(src, 0, dtype=torch.float32).view(-1))
+            return
+        if not hasattr(self, "_bias_q"):
+            self._bias_q = []
+        self._bias_q.append((src, g))
+
     def queue_bias_sum(self, dy, bias_param):
         """Defer `bias.grad += dy.sum(0)` to the step (same one-backward-per-step condition as the arena): the eight output
         projections of the cfg1 encoder each reduce a [B L, D] matrix - alone a launch that cannot fill the chip."""

@@ -166,21 +166,31 @@ def test_resume_continues_the_run(rec, tmp_path):
     assert max(abs(a - c) / abs(a) for a, c in zip(la, lc)) > 2e-3
 
 
-def test_partial_arena_gives_the_per_layer_reduction(rec):
-    """With one backward per step the split-K partials of all weight gradients go through ONE arena and ONE reduction launch
-    (optim.FusedAdamW.enable_partial_arena); per layer they are summed by a launch each.  Same partials, same order of
-    summation per column: the two trainers stay together (up to the float-atomic noise of the loss backward)."""
+@pytest.mark.parametrize("stacked", [True, False])
+def test_deferred_weight_gradients_give_the_per_layer_reduction(rec, stacked):
+    """With one backward per step the encoder's weight gradients are deferred to the optimizer step: as ONE batched split-K
+    GEMM per projection over all layers (hstu_functional.WeightGradStack, stacked=True) or, without it, as per-layer split-K
+    GEMMs whose partials go through ONE arena and ONE reduction launch (optim.FusedAdamW.enable_partial_arena).  A trainer with
+    neither forms and sums them inside each layer's backward.  Same products, fp32 sums of bf16 partials: the trainers stay
+    together (up to the partials' rounding and the float-atomic noise of the loss backward)."""
+    from REC.model.IDNet import hstu as hstu_mod
     dev = torch.device("cuda", 0)
-    tr_a, m_a, data = _trainer(rec, False, dev, hidden_dropout_prob=0.0)
-    tr_b, m_b, _ = _trainer(rec, False, dev, hidden_dropout_prob=0.0)
-    tr_b.optimizer.enable_partial_arena(False)
-    assert tr_a.optimizer._arena_on and not tr_b.optimizer._arena_on
-    batches = [data.train_batch(64) for _ in range(4)]           # 64 x 24 tokens: the weight gradients split four ways
-    for i in range(6):
-        la = float(tr_a.train_step_fn(batches[i % 4])["loss"])
-        lb = float(tr_b.train_step_fn(batches[i % 4])["loss"])
-        assert abs(la - lb) <= 2e-3 * abs(lb)
-    assert tr_a.optimizer._arena is not None and tr_b.optimizer._arena is None
+    flag = hstu_mod.WEIGHT_GRAD_STACK
+    try:
+        hstu_mod.WEIGHT_GRAD_STACK = stacked
+        tr_a, m_a, data = _trainer(rec, False, dev, hidden_dropout_prob=0.0)
+        tr_b, m_b, _ = _trainer(rec, False, dev, hidden_dropout_prob=0.0)
+        tr_b.optimizer.enable_partial_arena(False)
+        assert tr_a.optimizer._arena_on and not tr_b.optimizer._arena_on
+        batches = [data.train_batch(64) for _ in range(4)]           # 64 x 24 tokens: the weight gradients split four ways
+        for i in range(6):
+            la = float(tr_a.train_step_fn(batches[i % 4])["loss"])
+            lb = float(tr_b.train_step_fn(batches[i % 4])["loss"])
+            assert abs(la - lb) <= 2e-3 * abs(lb)
+    finally:
+        hstu_mod.WEIGHT_GRAD_STACK = flag
+    assert (tr_a.optimizer._arena is None) == stacked and tr_b.optimizer._arena is None
+    assert not getattr(tr_a.optimizer, "_deferred", []) and not getattr(tr_a.optimizer, "_bias_q", [])
     sd_a, sd_b = m_a.state_dict(), m_b.state_dict()
     for k in sd_a:
         a, b = sd_a[k].float(), sd_b[k].float()
