@@ -470,6 +470,20 @@ int mhr_catalog_score_emit(const void* users, int n_rows, int H, const void* ite
 int mhr_rescore_f32(const float* users, const float* items, int dim, int64_t n_items, const int64_t* cand_idx, int n_rows,
                     int k2, const int32_t* cand_cnt, float* out_val, int32_t* out_idx, void* stream);
 
+/* The decode's exactness bookkeeping (ops.catalog_topk / catalog_topk_exact; replaces the masks the reference needs none of because
+ * it ranks a dense [B, H, N] score tensor, hstu.py:965-1015 + collector.py:245) - one launch per decision:
+ *  pick_tau:     tau[r] = kth2[r] if both sample selects were clean (status 0) and kth2 is finite, else kth1[r] if clean, else -inf.
+ *  flag:         flagged[r] = status != 0 || (count < k_min && row_bits != 0 && isfinite(tau)); any_out[0] = 1 if any row is (written).
+ *  margin_count: count[r] = finite entries of the sorted list sorted_vals[r, 0..k2) that are >= sorted_vals[r, kk - 1] - margin.
+ *  uncertified:  full[r] = (count >= k2 && list_can_fill) || (kth and tau finite && kth - margin < tau), kth = sorted_vals[r, kk - 1];
+ *                any_out[0] = 1 if any row is (written).  flag / uncertified run as ONE workgroup (n_rows = users x heads). */
+int mhr_topk_pick_tau(const float* kth1, const float* kth2, const int32_t* st1, const int32_t* st2, int n_rows, float* tau, void* stream);
+int mhr_topk_flag(const int32_t* status, const int32_t* count, const int32_t* row_bits, const float* tau, int k_min, int n_rows,
+                  uint8_t* flagged, int32_t* any_out, void* stream);
+int mhr_topk_margin_count(const float* sorted_vals, int n_rows, int k2, int kk, float margin, int32_t* count, void* stream);
+int mhr_topk_uncertified(const int32_t* count, const float* sorted_vals, int k2, int kk, const float* tau, int list_can_fill,
+                         float margin, int n_rows, uint8_t* full, int32_t* any_out, void* stream);
+
 /* Fast path of the same scorer ("sliced lists").  Every (row, item slice, lane half) triple owns a short list
  *   cand_val / cand_idx [n_rows, 2 n_slices, cap_s],  cand_cnt [n_rows, 2 n_slices] (written, no zeroing needed)
  * whose fill count lives in a register of the lane that owns it (mhr_topk_select_sliced then takes 2 n_slices lists): a threshold hit costs two plain stores (no atomic,

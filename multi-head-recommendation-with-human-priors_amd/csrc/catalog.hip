@@ -837,3 +837,110 @@ extern "C" int mhr_hit_matrix(const int64_t* topk_idx, int B, int k, const int64
   MHR_CHECK_LAUNCH("hit_matrix");
   return MHR_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// The decode's exactness bookkeeping, one launch per decision instead of 7-12 elementwise launches each (the eval step is a
+// chain of few-microsecond launches around its three big ones, and every host read of a flag drains the queue):
+//   pick_tau:      emit threshold per row from the two sample passes (kth2 if both selects were clean and kth2 is finite, else
+//                  kth1 if clean, else -inf)
+//   flag:          rows whose candidate lists cannot be trusted (list overflow, or fewer than k_min candidates above a finite
+//                  threshold for an admissible row); any[slot] = 1 if there is one (written, not or-ed: one workgroup)
+//   margin_count:  cnt[r] = finite entries of the sorted list bv[r, :] that are >= bv[r, kk - 1] - margin (a prefix)
+//   uncertified:   rows whose margin set reaches below the emit threshold or fills all k2 slots; any[slot] likewise
+// ------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void topk_pick_tau_kernel(const float* __restrict__ kth1, const float* __restrict__ kth2,
+                                                            const int32_t* __restrict__ st1, const int32_t* __restrict__ st2, int n,
+                                                            float* __restrict__ tau) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= n) return;
+  const bool ok = st1[r] == 0 && st2[r] == 0;
+  const float k2 = kth2[r];
+  tau[r] = (ok && isfinite(k2)) ? k2 : (ok ? kth1[r] : -INFINITY);
+}
+
+__device__ __forceinline__ void block_any_write(bool mine, int32_t* __restrict__ any_out) {
+  __shared__ int hit;
+  if (threadIdx.x == 0) hit = 0;
+  __syncthreads();
+  if (mine) atomicOr(&hit, 1);
+  __syncthreads();
+  if (threadIdx.x == 0) any_out[0] = hit;
+}
+
+__global__ __launch_bounds__(1024) void topk_flag_kernel(const int32_t* __restrict__ st, const int32_t* __restrict__ cnt,
+                                                         const int32_t* __restrict__ row_bits, const float* __restrict__ tau, int k_min,
+                                                         int n, uint8_t* __restrict__ flagged, int32_t* __restrict__ any_out) {
+  bool mine = false;
+  for (int r = threadIdx.x; r < n; r += blockDim.x) {
+    const bool f = st[r] != 0 || (cnt[r] < k_min && row_bits[r] != 0 && isfinite(tau[r]));
+    flagged[r] = f ? 1 : 0;
+    mine |= f;
+  }
+  block_any_write(mine, any_out);
+}
+
+__global__ __launch_bounds__(256) void topk_margin_count_kernel(const float* __restrict__ bv, int n, int k2, int kk, float margin,
+                                                                int32_t* __restrict__ cnt) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= n) return;
+  const float* row = bv + (int64_t)r * k2;
+  const float lo = row[kk - 1] - margin;
+  int c = 0;
+  for (int j = lane; j < k2; j += 64) {
+    const float v = row[j];
+    c += (v >= lo && isfinite(v)) ? 1 : 0;
+  }
+  c = wave_sum_i(c);
+  if (lane == 0) cnt[r] = c;
+}
+
+__global__ __launch_bounds__(1024) void topk_uncertified_kernel(const int32_t* __restrict__ cnt, const float* __restrict__ bv, int k2, int kk,
+                                                                const float* __restrict__ tau, int list_can_fill, float margin, int n,
+                                                                uint8_t* __restrict__ full, int32_t* __restrict__ any_out) {
+  bool mine = false;
+  for (int r = threadIdx.x; r < n; r += blockDim.x) {
+    const float kth = bv[(int64_t)r * k2 + kk - 1], t = tau[r];
+    const bool f = (cnt[r] >= k2 && list_can_fill) || (isfinite(kth) && isfinite(t) && kth - margin < t);
+    full[r] = f ? 1 : 0;
+    mine |= f;
+  }
+  block_any_write(mine, any_out);
+}
+}  // namespace
+
+extern "C" int mhr_topk_pick_tau(const float* kth1, const float* kth2, const int32_t* st1, const int32_t* st2, int n_rows, float* tau,
+                                 void* stream) {
+  MHR_REQUIRE(kth1 && kth2 && st1 && st2 && tau && n_rows > 0, "topk_pick_tau: null pointer / bad size");
+  hipLaunchKernelGGL(topk_pick_tau_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, kth1, kth2, st1, st2, n_rows, tau);
+  MHR_CHECK_LAUNCH("topk_pick_tau");
+  return MHR_OK;
+}
+
+extern "C" int mhr_topk_flag(const int32_t* status, const int32_t* count, const int32_t* row_bits, const float* tau, int k_min, int n_rows,
+                             uint8_t* flagged, int32_t* any_out, void* stream) {
+  MHR_REQUIRE(status && count && row_bits && tau && flagged && any_out && n_rows > 0, "topk_flag: null pointer / bad size");
+  hipLaunchKernelGGL(topk_flag_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, status, count, row_bits, tau, k_min, n_rows, flagged,
+                     any_out);
+  MHR_CHECK_LAUNCH("topk_flag");
+  return MHR_OK;
+}
+
+extern "C" int mhr_topk_margin_count(const float* sorted_vals, int n_rows, int k2, int kk, float margin, int32_t* count, void* stream) {
+  MHR_REQUIRE(sorted_vals && count && n_rows > 0 && k2 > 0 && kk >= 1 && kk <= k2, "topk_margin_count: null pointer / bad sizes");
+  hipLaunchKernelGGL(topk_margin_count_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, sorted_vals, n_rows, k2, kk, margin,
+                     count);
+  MHR_CHECK_LAUNCH("topk_margin_count");
+  return MHR_OK;
+}
+
+extern "C" int mhr_topk_uncertified(const int32_t* count, const float* sorted_vals, int k2, int kk, const float* tau, int list_can_fill,
+                                    float margin, int n_rows, uint8_t* full, int32_t* any_out, void* stream) {
+  MHR_REQUIRE(count && sorted_vals && tau && full && any_out && n_rows > 0 && k2 > 0 && kk >= 1 && kk <= k2,
+              "topk_uncertified: null pointer / bad sizes");
+  hipLaunchKernelGGL(topk_uncertified_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, count, sorted_vals, k2, kk, tau, list_can_fill,
+                     margin, n_rows, full, any_out);
+  MHR_CHECK_LAUNCH("topk_uncertified");
+  return MHR_OK;
+}

@@ -1057,7 +1057,7 @@ def sub_history(hist_ptr, hist_items, users_f):
 
 
 def catalog_topk(users, H, items, tag_bits, row_bits, hist_ptr, hist_items, k, cap=4096, target=None, stats=None, n_items=None,
-                 k_min=None, tau_out=None, margin=None):
+                 k_min=None, tau_out=None, margin=None, defer_check=None):
     """Exact per-row top-k over the whole catalog (value desc, index asc), rows = (user, head) pairs.
 
     k_min (default k): rows with fewer than k_min candidates are re-run exactly; with k_min < k a row may return fewer than
@@ -1069,6 +1069,9 @@ def catalog_topk(users, H, items, tag_bits, row_bits, hist_ptr, hist_items, k, c
     Thresholds come from two strided sample passes; the full pass emits the few scores above them into per-(row, item
     slice) lists and an exact select picks the top k.  Exactness is verified (enough candidates, no list overflow, per
     row) and rows that fail are re-run with tau = -inf, so the sampling only affects speed.
+    defer_check (int32 device tensor [>= 1], optional): instead of reading the verification flag here (a host sync) and repairing,
+    write "some row failed" into defer_check[0] and return; the caller reads it together with its own flags and, when set,
+    calls again without defer_check (catalog_topk_exact does).
     """
     n_rows, D = users.shape
     N = items.shape[0] if n_items is None else int(n_items)
@@ -1102,17 +1105,24 @@ def catalog_topk(users, H, items, tag_bits, row_bits, hist_ptr, hist_items, k, c
     # pass 2: every s2-th item above kth1 -> the t2-th largest estimates the score of rank ~target
     c2 = catalog_emit_sliced(users, items, N, tag_bits, row_bits, kth1, 32, 0, s2)
     _, _, kth2, _, st2 = topk_select_sliced(c2, H, hist_ptr, hist_items, t2)
-    ok2 = (st2 == 0) & (st1 == 0)
-    tau = torch.where(torch.isfinite(kth2) & ok2, kth2, torch.where(ok2, kth1, ninf))
+    tau = torch.empty(n_rows, dtype=torch.float32, device=dev)
+    lib.call("mhr_topk_pick_tau", kth1.data_ptr(), kth2.data_ptr(), st1.data_ptr(), st2.data_ptr(), n_rows, tau.data_ptr(), _stream())
     n_sl = _slices_for(n_rows, -(-N // 32))
     cap_s = max(32, 4 * -(-target // n_sl) + 16)
     cand = catalog_emit_sliced(users, items, N, tag_bits, row_bits, tau, cap_s)
     ov, oi, _, cnt, st = topk_select_sliced(cand, H, hist_ptr, hist_items, k)
-    flagged = (st != 0) | ((cnt < k_min) & (row_bits != 0) & torch.isfinite(tau))
+    flagged = torch.empty(n_rows, dtype=torch.bool, device=dev)
+    any_flag = defer_check if defer_check is not None else torch.empty(1, dtype=torch.int32, device=dev)
+    lib.call("mhr_topk_flag", st.data_ptr(), cnt.data_ptr(), row_bits.data_ptr(), tau.data_ptr(), int(k_min), n_rows,
+             flagged.data_ptr(), any_flag.data_ptr(), _stream())
     if stats is not None:
         stats["mean_candidates"] = float(cnt.float().mean())
         stats["flagged_rows"] = int(flagged.sum())
-    if bool(flagged.any()):                               # one host sync per batch; results go to the host anyway
+    if defer_check is not None:                           # the caller reads the flag (with its own) and comes back if it is set
+        if tau_out is not None:
+            tau_out["tau"] = tau
+        return ov, oi
+    if bool(any_flag.item()):                             # one host sync per batch; results go to the host anyway
         users_f = torch.nonzero(flagged.view(-1, H).any(dim=1)).flatten()
         rows_f = (users_f[:, None] * H + torch.arange(H, device=dev)[None, :]).flatten()
         sub_ptr, sub_items = sub_history(hist_ptr, hist_items, users_f)
@@ -1152,30 +1162,47 @@ def catalog_topk_exact(users_f32, H, items_bf, items_f32, tag_bits, row_bits, hi
     # the bf16 scorer's candidate lists (everything above a per-row threshold tau near the rank-2.5k score), the best k2 of them
     # sorted; a row is CERTIFIED when its margin [kth - 2^-7, ...) lies above tau (nothing that could enter the fp32 top-k was
     # left below the threshold) and does not fill all k2 slots
-    tinfo = {}
-    bv, bi = catalog_topk(users_bf, H, items_bf, tag_bits, row_bits, hist_ptr, hist_items, k2, stats=stats, n_items=N, k_min=k,
-                          tau_out=tinfo, margin=2 * BF16_SCORE_ERR)      # (margin: used by the wide scorer's threshold, see wide.py)
-    tau = tinfo.get("tau")
-    if tau is None:                   # (a scorer that does not report its threshold: nothing can be certified)
-        tau = torch.full((n_rows,), float("inf"), dtype=torch.float32, device=dev)
+    # ONE host read per call: the bf16 pass leaves its "some row failed" flag on the device (defer_check) next to this function's
+    # "some row is uncertified" flag; only when the first is set - thresholds that came up short, never seen on trained or random
+    # embeddings - the pass is repeated with its own check-and-repair
+    deferred = D in STREAM_DIMS and N > 4096 and stats is None
+    flags = torch.empty(2, dtype=torch.int32, device=dev)
     kk = min(k, k2)
-    kth = bv[:, kk - 1:kk]
-    in_margin = (bv >= (kth - 2 * BF16_SCORE_ERR)) & torch.isfinite(bv)     # a prefix of the sorted list
-    cnt = in_margin.sum(dim=1).int()
-    rv = torch.empty(n_rows, k2, dtype=torch.float32, device=dev)
-    ri = torch.empty(n_rows, k2, dtype=torch.int32, device=dev)
     _chk(users_f32, "users_f32", torch.float32)
     _chk(items_f32, "items_f32", torch.float32)
-    lib.call("mhr_rescore_f32", users_f32.data_ptr(), items_f32.data_ptr(), D, N, bi.data_ptr(), n_rows, k2, cnt.data_ptr(),
-             rv.data_ptr(), ri.data_ptr(), _stream())
-    ov, oi, _, st = topk_select((rv, ri, cnt), k2, k)
-    # uncertified rows: the margin reaches below the emit threshold, or fills the candidate list (the (k2+1)-th bf16 score
-    # might be inside it too)
-    full = ((cnt >= k2) & (k2 < N - 1)) | (torch.isfinite(kth[:, 0]) & torch.isfinite(tau) & (kth[:, 0] - 2 * BF16_SCORE_ERR < tau))
+
+    def attempt(defer):
+        tinfo = {}
+        bv, bi = catalog_topk(users_bf, H, items_bf, tag_bits, row_bits, hist_ptr, hist_items, k2, stats=stats, n_items=N, k_min=k,
+                              tau_out=tinfo, margin=2 * BF16_SCORE_ERR,      # (margin: used by the wide scorer's threshold, see wide.py)
+                              defer_check=flags[0:1] if defer else None)
+        tau = tinfo.get("tau")
+        if tau is None:               # (a scorer that does not report its threshold: nothing can be certified)
+            tau = torch.full((n_rows,), float("inf"), dtype=torch.float32, device=dev)
+        bv = bv.contiguous()
+        cnt = torch.empty(n_rows, dtype=torch.int32, device=dev)          # the margin set: a prefix of the sorted list
+        lib.call("mhr_topk_margin_count", bv.data_ptr(), n_rows, k2, kk, 2 * BF16_SCORE_ERR, cnt.data_ptr(), _stream())
+        rv = torch.empty(n_rows, k2, dtype=torch.float32, device=dev)
+        ri = torch.empty(n_rows, k2, dtype=torch.int32, device=dev)
+        lib.call("mhr_rescore_f32", users_f32.data_ptr(), items_f32.data_ptr(), D, N, bi.data_ptr(), n_rows, k2, cnt.data_ptr(),
+                 rv.data_ptr(), ri.data_ptr(), _stream())
+        ov, oi, _, st = topk_select((rv, ri, cnt), k2, k)
+        # uncertified rows: the margin reaches below the emit threshold, or fills the candidate list (the (k2+1)-th bf16 score
+        # might be inside it too)
+        full = torch.empty(n_rows, dtype=torch.bool, device=dev)
+        lib.call("mhr_topk_uncertified", cnt.data_ptr(), bv.data_ptr(), k2, kk, tau.contiguous().data_ptr(), 1 if k2 < N - 1 else 0,
+                 2 * BF16_SCORE_ERR, n_rows, full.data_ptr(), flags[1:2].data_ptr(), _stream())
+        return ov, oi, cnt, full
+
+    ov, oi, cnt, full = attempt(deferred)
+    got = flags.tolist()                                                  # the one host sync
+    if deferred and got[0]:
+        ov, oi, cnt, full = attempt(False)
+        got = flags.tolist()
     if stats is not None:
         stats["margin_mean"] = float(cnt.float().mean())
         stats["uncertified_rows"] = int(full.sum())
-    if bool(full.any()):                                              # one host sync; a handful of rows at most
+    if got[1]:                                                            # a handful of rows at most
         rows = torch.nonzero(full).flatten()
         sc = users_f32[rows] @ items_f32[:N].t()                      # dense fp32 scores of those rows only
         if tag_bits is not None:

@@ -238,9 +238,7 @@ class FusedAdamW:
             host, devt, k = self._bias_tabs[key]
             slot = host[k % HOST_RING]
             self._bias_tabs[key][2] = k + 1
-            for i, (dy, g) in enumerate(items):
-                slot[i] = dy.data_ptr()
-                slot[n + i] = g.data_ptr()
+            slot.numpy()[:] = [dy.data_ptr() for dy, _ in items] + [g.data_ptr() for _, g in items]     # (one host write, not 2 n)
             devt.copy_(slot, non_blocking=True)
             ops.sum_rows_many(devt, n, rows, cols, keep=items)
 
