@@ -1143,13 +1143,15 @@ def catalog_topk(users, H, items, tag_bits, row_bits, hist_ptr, hist_items, k, c
 BF16_SCORE_ERR = 2.0 ** -8       # |u_bf16 . i_bf16 - u . i| for unit vectors u, i (each component rounded to 8 bits)
 
 
-def catalog_topk_exact(users_f32, H, items_bf, items_f32, tag_bits, row_bits, hist_ptr, hist_items, k, n_items=None, stats=None):
+def catalog_topk_exact(users_f32, H, items_bf, items_f32, tag_bits, row_bits, hist_ptr, hist_items, k, n_items=None, stats=None,
+                       target=None):
     """Per-row top-k ranked on FP32 scores of fp32 operands - the reference's score path (hstu.py:965-979: fp32 normalise,
     fp32 matmul; collector.py:245 torch.topk) - without a [B, H, N] tensor.  The bf16 scorer finds every candidate whose bf16
     score lies within 2^-7 of the k-th bf16 score (a superset of the fp32 top-k: the two scores differ by at most 2^-8),
     `mhr_rescore_f32` re-scores those few hundred candidates per row from the fp32 rows, and the exact select picks k by
     (fp32 value desc, index asc).  Rows whose margin set cannot be certified (more than 1024 near-ties) fall back to dense
-    fp32 scoring of that row.  users_f32 [B*H, D] fp32 normalised; items_bf [>= N, D] bf16 / items_f32 [N, D] fp32 normalised."""
+    fp32 scoring of that row.  users_f32 [B*H, D] fp32 normalised; items_bf [>= N, D] bf16 / items_f32 [N, D] fp32 normalised.
+    target: the bf16 pass's candidate budget per row (catalog_topk; tests shrink it to force its repair path)."""
     n_rows, D = users_f32.shape
     N = items_f32.shape[0] if n_items is None else int(n_items)
     dev = users_f32.device
@@ -1175,7 +1177,7 @@ def catalog_topk_exact(users_f32, H, items_bf, items_f32, tag_bits, row_bits, hi
         tinfo = {}
         bv, bi = catalog_topk(users_bf, H, items_bf, tag_bits, row_bits, hist_ptr, hist_items, k2, stats=stats, n_items=N, k_min=k,
                               tau_out=tinfo, margin=2 * BF16_SCORE_ERR,      # (margin: used by the wide scorer's threshold, see wide.py)
-                              defer_check=flags[0:1] if defer else None)
+                              defer_check=flags[0:1] if defer else None, target=target)
         tau = tinfo.get("tau")
         if tau is None:               # (a scorer that does not report its threshold: nothing can be certified)
             tau = torch.full((n_rows,), float("inf"), dtype=torch.float32, device=dev)

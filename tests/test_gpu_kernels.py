@@ -982,3 +982,65 @@ def test_exact_topk_large_catalog_fp32_order(ops):
         n_diff_bf16 += int((bi[r].cpu().numpy() != order[:k]).sum())
         np.testing.assert_allclose(ov[r].cpu().numpy(), sc[r, got], rtol=0, atol=2e-6)
     assert n_diff_bf16 > 0 and stats["uncertified_rows"] == 0 and k < stats["margin_mean"] <= 1024
+
+
+def test_exact_topk_one_host_read_and_its_repair_path(ops):
+    """Without `stats` the exact top-k reads its two verification flags in ONE host read (the bf16 pass leaves its flag on the
+    device).  With a starved candidate budget the bf16 pass fails rows; the deferred attempt then notices the flag and repeats the
+    pass with its own check-and-repair: same result as the path that checks at every stage."""
+    g = torch.Generator().manual_seed(321)
+    B, H, N, D, k = 8, 4, 60000, 256, 200
+    users = HO.l2n(torch.randn(B * H, D, generator=g))
+    items = HO.l2n(torch.randn(N, D, generator=g) + 0.3 * torch.randn(1, D, generator=g))
+    row_bits = torch.full((B * H,), -(1 << 31), dtype=torch.int32)
+    items_bf = bf(items)
+    args = (dev(users), H, dev(items_bf), dev(items), None, dev(row_bits), None, None, k)
+    stats = {}
+    ov_s, oi_s = ops.catalog_topk_exact(*args, n_items=N, stats=stats)                 # checks at every stage
+    ov_d, oi_d = ops.catalog_topk_exact(*args, n_items=N)                              # one deferred read
+    assert torch.equal(oi_s, oi_d) and torch.equal(ov_s, ov_d)                       # same kernels on the same candidates
+    stats2 = {}
+    ops.catalog_topk_exact(*args, n_items=N, stats=stats2, target=k + 8)               # starved: the bf16 pass flags rows ...
+    assert stats2["flagged_rows"] > 0
+    ov_r, oi_r = ops.catalog_topk_exact(*args, n_items=N, target=k + 8)                # ... and the deferred attempt comes back for them
+    assert torch.equal(oi_s, oi_r) and float((ov_s - ov_r).abs().max()) <= 2e-6     # (repaired rows: candidates in another order)
+
+
+def test_topk_bookkeeping_kernels(ops):
+    """pick_tau / flag / margin_count / uncertified against the elementwise expressions they replaced."""
+    from mhr_amd import lib
+    g = torch.Generator().manual_seed(5)
+    n, k2, kk, margin = 1000, 64, 20, 2.0 ** -7
+    kth1, kth2 = torch.randn(n, generator=g), torch.randn(n, generator=g)
+    kth2[::7] = float("-inf")
+    st1, st2 = (torch.rand(n, generator=g) < 0.05).int(), (torch.rand(n, generator=g) < 0.05).int()
+    tau = torch.empty(n, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    d = {k_: dev(v) for k_, v in dict(kth1=kth1, kth2=kth2, st1=st1, st2=st2).items()}
+    lib.call("mhr_topk_pick_tau", d["kth1"].data_ptr(), d["kth2"].data_ptr(), d["st1"].data_ptr(), d["st2"].data_ptr(), n, tau.data_ptr(), st)
+    ok = (st1 == 0) & (st2 == 0)
+    want = torch.where(torch.isfinite(kth2) & ok, kth2, torch.where(ok, kth1, torch.full((n,), float("-inf"))))
+    assert torch.equal(tau.cpu(), want)
+    cnt = torch.randint(0, 40, (n,), generator=g).int()
+    bits = torch.where(torch.rand(n, generator=g) < 0.1, torch.zeros(n, dtype=torch.int32), torch.ones(n, dtype=torch.int32))
+    stt = (torch.rand(n, generator=g) < 0.02).int()
+    flagged, anyf = torch.empty(n, dtype=torch.bool, device="cuda"), torch.empty(2, dtype=torch.int32, device="cuda")
+    dc, db, ds = dev(cnt), dev(bits), dev(stt)
+    lib.call("mhr_topk_flag", ds.data_ptr(), dc.data_ptr(), db.data_ptr(), tau.data_ptr(), 20, n, flagged.data_ptr(), anyf.data_ptr(), st)
+    want_f = (stt != 0) | ((cnt < 20) & (bits != 0) & torch.isfinite(want))
+    assert torch.equal(flagged.cpu(), want_f) and int(anyf[0]) == int(want_f.any())
+    zeros = torch.zeros(n, dtype=torch.int32, device="cuda")
+    lib.call("mhr_topk_flag", zeros.data_ptr(), (dc + 100).data_ptr(), db.data_ptr(), tau.data_ptr(), 20, n, flagged.data_ptr(),
+             anyf.data_ptr(), st)
+    assert not bool(flagged.any()) and int(anyf[0]) == 0                              # written, not or-ed
+    bv = torch.sort(torch.randn(n, k2, generator=g) * 0.01, dim=1, descending=True).values
+    bv[::9, 40:] = float("-inf")
+    dbv, mc = dev(bv), torch.empty(n, dtype=torch.int32, device="cuda")
+    lib.call("mhr_topk_margin_count", dbv.data_ptr(), n, k2, kk, margin, mc.data_ptr(), st)
+    want_c = ((bv >= bv[:, kk - 1:kk] - margin) & torch.isfinite(bv)).sum(1).int()
+    assert torch.equal(mc.cpu(), want_c)
+    full = torch.empty(n, dtype=torch.bool, device="cuda")
+    lib.call("mhr_topk_uncertified", mc.data_ptr(), dbv.data_ptr(), k2, kk, tau.data_ptr(), 1, margin, n, full.data_ptr(), anyf[1:2].data_ptr(), st)
+    kth = bv[:, kk - 1]
+    want_u = (want_c >= k2) | (torch.isfinite(kth) & torch.isfinite(want) & (kth - margin < want))
+    assert torch.equal(full.cpu(), want_u) and int(anyf[1]) == int(want_u.any())
