@@ -93,59 +93,87 @@ __global__ __launch_bounds__(256) void shared_tok_fwd_kernel(
   const int wave_g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), n_waves = gridDim.x * (blockDim.x >> 6);
   const float scale = clamp_scale(logit_scale_dev);
   const float c1 = scale * LOG2E;
-  // lane owns the 4 consecutive columns 4 lane .. 4 lane + 3: one 8-byte load per row and lane (a 512-byte row is one
-  // wave-instruction); TB tokens in flight, and the dependent index loads (target row -> table slot -> any-hit flag) of
-  // all of them are issued before the first row is consumed
-  constexpr int TB = 8;
-  const int d0 = lane * 4;
+  // A HALF-wave per token: lane owns the 8 consecutive columns 8 hl .. 8 hl + 7 of its half's token (one 16-byte load per row
+  // and lane; a 512-byte row is one half-wave-instruction), TB token PAIRS in flight per wave, and the dependent index loads
+  // (target row -> table slot -> any-hit flag) of all of them are issued before the first row is consumed.  (One wave per token
+  // with 8-byte loads: 99 us for the 273 k tokens of a cfg1 step - shuffle reductions and load latency, not bandwidth.)
+  // Tokens with suppressed negatives - a few per cent - are then visited by the WHOLE wave, one after the other.
+  constexpr int TB = 4;
+  const int hl = lane & 31, hw = lane >> 5;
+  const int d0 = hl * 8;
   const bool in_dim = d0 < dim;
-  for (int t0 = wave_g * TB; t0 < n_tok; t0 += n_waves * TB) {
+  const int d0w = lane * 4;                                          // (whole-wave layout of the hit path: 4 columns per lane)
+  const bool in_dim_w = d0w < dim;
+  auto half_sum = [](float v) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+  };
+  for (int t0 = wave_g * 2 * TB; t0 < n_tok; t0 += n_waves * 2 * TB) {
     int rr[TB], prr[TB], slot[TB], any[TB];
-    bf16x4 pv[TB], qv[TB];
+    bf16x8 pv[TB], qv[TB];
 #pragma unroll
     for (int b = 0; b < TB; ++b) {
-      const int tk = min(t0 + b, n_tok - 1);
+      const int tk = min(t0 + 2 * b + hw, n_tok - 1);
       rr[b] = tok2row[tk];
       prr[b] = p_idx[tk];
     }
 #pragma unroll
     for (int b = 0; b < TB; ++b) {
-      const bf16x4 z = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
-      pv[b] = in_dim ? *reinterpret_cast<const bf16x4*>(pn_rows + (int64_t)prr[b] * dim + d0) : z;   // the target's normalised row
-      qv[b] = in_dim ? *reinterpret_cast<const bf16x4*>(qn_row + (int64_t)rr[b] * dim + d0) : z;
+      bf16x8 z;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) z[e] = (bf16_t)0.f;
+      pv[b] = in_dim ? *reinterpret_cast<const bf16x8*>(pn_rows + (int64_t)prr[b] * dim + d0) : z;   // the target's normalised row
+      qv[b] = in_dim ? *reinterpret_cast<const bf16x8*>(qn_row + (int64_t)rr[b] * dim + d0) : z;
       slot[b] = slot_of_row ? slot_of_row[prr[b]] : prr[b];
     }
 #pragma unroll
     for (int b = 0; b < TB; ++b) any[b] = fix_any[slot[b]];
 #pragma unroll
     for (int b = 0; b < TB; ++b) {
-      const int tk = t0 + b;
-      if (tk >= n_tok) break;
-      const int r = rr[b];
-      float q4[4], sp = 0.f;
+      if (t0 + 2 * b >= n_tok) break;                                // (wave-uniform)
+      const int tk = t0 + 2 * b + hw;
+      float sp = 0.f;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        q4[e] = (float)qv[b][e];
-        sp += q4[e] * (float)pv[b][e];
-      }
-      sp = wave_sum(sp);
+      for (int e = 0; e < 8; ++e) sp += (float)qv[b][e] * (float)pv[b][e];
+      sp = half_sum(sp);
       float corr = 0.f;
       int hits = 0, above = 0;
-      if (any[b] != 0) {                                            // wave-uniform; a few percent of the tokens
-        for_each_hit(fixw, n_tiles, n_rows_pad, slot[b], n_neg, lane, (uint32_t)any[b], [&](int j) {
-          float s = 0.f;
-          if (in_dim) {
-            const bf16x4 nv = *reinterpret_cast<const bf16x4*>(negs + (int64_t)j * dim + d0);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) s += q4[e] * (float)nv[e];
+      for (int h = 0; h < 2; ++h) {
+        const int any_h = __shfl(any[b], h * 32, 64);
+        if (any_h != 0 && t0 + 2 * b + h < n_tok) {                  // wave-uniform; a few per cent of the tokens
+          const int slot_h = __shfl(slot[b], h * 32, 64), r_h = __shfl(rr[b], h * 32, 64);
+          const float sp_h = __shfl(sp, h * 32, 64);
+          float q4[4] = {0.f, 0.f, 0.f, 0.f};
+          if (in_dim_w) {
+            const bf16x4 qw = *reinterpret_cast<const bf16x4*>(qn_row + (int64_t)r_h * dim + d0w);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) q4[e] = (float)qw[e];
           }
-          s = wave_sum(s);
-          corr += __builtin_amdgcn_exp2f(s * c1 - c1);
-          hits += 1;
-          above += s > sp ? 1 : 0;
-        });
+          float corr_h = 0.f;
+          int hits_h = 0, above_h = 0;
+          for_each_hit(fixw, n_tiles, n_rows_pad, slot_h, n_neg, lane, (uint32_t)any_h, [&](int j) {
+            float sj = 0.f;
+            if (in_dim_w) {
+              const bf16x4 nv = *reinterpret_cast<const bf16x4*>(negs + (int64_t)j * dim + d0w);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) sj += q4[e] * (float)nv[e];
+            }
+            sj = wave_sum(sj);
+            corr_h += __builtin_amdgcn_exp2f(sj * c1 - c1);
+            hits_h += 1;
+            above_h += sj > sp_h ? 1 : 0;
+          });
+          if (hw == h) {
+            corr = corr_h;
+            hits = hits_h;
+            above = above_h;
+          }
+        }
       }
-      if (lane == 0) {
+      if (hl == 0 && tk < n_tok) {
+        const int r = rr[b];
         s_pos[tk] = sp;
         sum_tok[tk] = fmaxf(sum_row[r] - corr, 0.f);
         if (n_valid_row) n_valid_tok[tk] = n_valid_row[r] - hits;
@@ -584,7 +612,7 @@ extern "C" int mhr_nce_shared_fwd_tokens(const void* pn_rows, int64_t n_p_rows, 
   MHR_REQUIRE(s_pos && sum_tok, "nce_shared_fwd_tokens: null output pointer");
   MHR_REQUIRE((n_valid_row != nullptr) == (n_valid_tok != nullptr) && (rank_row != nullptr) == (rank_tok != nullptr),
               "nce_shared_fwd_tokens: row / token log counters go together");
-  MHR_REQUIRE(dim > 0 && dim <= 256 && dim % 4 == 0, "nce_shared_fwd_tokens: dim=%d unsupported (multiple of 4, <= 256)", dim);
+  MHR_REQUIRE(dim > 0 && dim <= 256 && dim % 8 == 0, "nce_shared_fwd_tokens: dim=%d unsupported (multiple of 8, <= 256)", dim);
   MHR_REQUIRE(tok_cap > 0 && row_cap > 0 && n_neg > 0 && n_p_rows > 0 && n_groups >= 1 && n_groups <= 65535,
               "nce_shared_fwd_tokens: bad sizes");
   const int n_rows_pad = (int)((n_p_rows + 255) / 256 * 256);
