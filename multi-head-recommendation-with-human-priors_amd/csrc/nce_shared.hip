@@ -504,23 +504,33 @@ __global__ __launch_bounds__(256) void shared_bwd_targets_kernel(
     const float* __restrict__ p_inv, int dim, const float* __restrict__ logit_scale_dev, const float* __restrict__ lse,
     const float* __restrict__ w, const float* __restrict__ s_pos, const int32_t* __restrict__ w_bucket, int n_buckets,
     int n_p_rows, float* __restrict__ dp_rows) {
-  const int lane = threadIdx.x & 63;
+  // A HALF-wave per target row (two rows per wave): lane hl of a half = candidate (group, offset) hl, hl + 32, ... of ITS row in
+  // the scan, and the 8 consecutive columns 8 hl .. 8 hl + 7 (16-byte bf16 / two 16-byte fp32 accesses) in the accumulation.
+  const int lane = threadIdx.x & 63, hl = lane & 31, hw = lane >> 5;
   const int wave_g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), n_waves = gridDim.x * (blockDim.x >> 6);
   const float scale = clamp_scale(logit_scale_dev);
   const int W = L + P, n_cand = n_groups * P;
-  const int d0 = lane * 4;                                   // 4 consecutive columns per lane: 8-byte bf16 / 16-byte fp32 accesses
+  const int d0 = hl * 8;
   const bool in_dim = d0 < dim;
-  for (int m = wave_g; m < n_p_rows; m += n_waves) {
-    const int b = m / W, pos = m - b * W;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    int t_any = -1;
-    for (int c0 = 0; c0 < n_cand; c0 += 64) {
+  auto half_sum = [](float v) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+  };
+  for (int m0 = wave_g * 2; m0 < n_p_rows; m0 += n_waves * 2) {
+    const int m = m0 + hw;
+    const bool row_ok = m < n_p_rows;
+    const int mm = row_ok ? m : n_p_rows - 1;
+    const int b = mm / W, pos = mm - b * W;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    bool t_any = false;
+    for (int c0 = 0; c0 < n_cand; c0 += 32) {
       // lane = candidate (group, offset): the token (l = pos - 1 - p, p) of that group, if it is live; its query row index is
       // fetched here too, so the row loads of the loop below do not wait on a dependent index load each
-      const int cand = c0 + lane;
+      const int cand = c0 + hl;
       int tk = -1, g = 0, row = 0;
       float coef = 0.f;
-      if (cand < n_cand) {
+      if (row_ok && cand < n_cand) {
         g = cand / P;
         const int p = cand - g * P, l = pos - 1 - p;
         if (l >= 0 && l < L) {
@@ -535,41 +545,61 @@ __global__ __launch_bounds__(256) void shared_bwd_targets_kernel(
           row = tok2row[o];
         }
       }
-      uint64_t live = __ballot(tk >= 0);
-      while (live) {
-        const int ln = __builtin_ctzll(live);
-        live &= live - 1;
-        const int g_u = __builtin_amdgcn_readlane(g, ln), r = __builtin_amdgcn_readlane(row, ln);
-        const float cf = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, coef), ln));
-        if (in_dim) {
-          const bf16x4 qb = *reinterpret_cast<const bf16x4*>(qn_row + ((int64_t)g_u * row_cap + r) * dim + d0);
+      // each half walks ITS live candidates (in candidate order: the sum has one fixed order per row); two row loads in flight
+      const uint64_t both = __ballot(tk >= 0);
+      uint32_t live = (uint32_t)(both >> (32 * hw));
+      const int rounds = max(__popc((uint32_t)both), __popc((uint32_t)(both >> 32)));
+      t_any |= live != 0u;
+      for (int it = 0; it < rounds; it += 2) {
+        int src[2];
+        bool on[2];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc[e] += cf * (float)qb[e];
+        for (int u = 0; u < 2; ++u) {
+          on[u] = live != 0u;
+          src[u] = on[u] ? __builtin_ctz(live) : 0;
+          live &= live - 1;                                          // (0 stays 0)
         }
-        t_any = ln;
+        bf16x8 qb[2];
+        float cf[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int from = hw * 32 + src[u];
+          const int g_u = __shfl(g, from, 64), r = __shfl(row, from, 64);
+          cf[u] = __shfl(coef, from, 64);
+          if (on[u] && in_dim) qb[u] = *reinterpret_cast<const bf16x8*>(qn_row + ((int64_t)g_u * row_cap + r) * dim + d0);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+          if (on[u] && in_dim) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += cf[u] * (float)qb[u][e];
+          }
       }
     }
-    if (t_any < 0) continue;                                 // no live token points at this row: its gradient stays as it is
-    const float ip = p_inv[m];
-    float pv[4] = {0.f, 0.f, 0.f, 0.f}, dpn[4];
+    const float ip = row_ok ? p_inv[mm] : 0.f;
+    float pv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, dpn[8];
     float dot = 0.f;
     if (in_dim) {
-      const bf16x4 pb = *reinterpret_cast<const bf16x4*>(pn + (int64_t)m * dim + d0);
+      const bf16x8 pb = *reinterpret_cast<const bf16x8*>(pn + (int64_t)mm * dim + d0);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) pv[e] = (float)pb[e];
+      for (int e = 0; e < 8; ++e) pv[e] = (float)pb[e];
     }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < 8; ++e) {
       dpn[e] = scale * acc[e];
       dot += pv[e] * dpn[e];
     }
-    dot = wave_sum(dot);
-    if (in_dim) {
+    dot = half_sum(dot);
+    if (t_any && row_ok && in_dim) {                         // (no live token points at a row: its gradient stays as it is)
       f32x4* dst = reinterpret_cast<f32x4*>(dp_rows + (int64_t)m * dim + d0);
-      f32x4 cur = *dst;
+      f32x4 c0v = dst[0], c1v = dst[1];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) cur[e] += (dpn[e] - pv[e] * dot) * ip;
-      *dst = cur;
+      for (int e = 0; e < 4; ++e) {
+        c0v[e] += (dpn[e] - pv[e] * dot) * ip;
+        c1v[e] += (dpn[4 + e] - pv[4 + e] * dot) * ip;
+      }
+      dst[0] = c0v;
+      dst[1] = c1v;
     }
   }
 }
@@ -685,13 +715,13 @@ extern "C" int mhr_nce_shared_bwd_targets(const void* qn_row, int row_cap, const
                                           void* stream) {
   MHR_REQUIRE(qn_row && tok2row && tok_of_slot && n_tok_dev && pn && p_inv && logit_scale_dev && lse && w && s_pos && dp_rows,
               "nce_shared_bwd_targets: null pointer");
-  MHR_REQUIRE(dim > 0 && dim <= 256 && dim % 4 == 0, "nce_shared_bwd_targets: dim=%d unsupported (<= 256)", dim);
+  MHR_REQUIRE(dim > 0 && dim <= 256 && dim % 8 == 0, "nce_shared_bwd_targets: dim=%d unsupported (multiple of 8, <= 256)", dim);
   MHR_REQUIRE(seq_len > 0 && pred_len > 0 && n_slots > 0 && n_slots % (seq_len * pred_len) == 0 &&
                   n_p_rows == (int64_t)(n_slots / (seq_len * pred_len)) * (seq_len + pred_len),
               "nce_shared_bwd_targets: slots must be (b, l, p) windows and p_rows the [B, L + P] targets (n_slots=%d L=%d P=%d "
               "n_p_rows=%lld)", n_slots, seq_len, pred_len, (long long)n_p_rows);
   MHR_REQUIRE(tok_cap > 0 && row_cap > 0 && n_groups >= 1 && n_groups <= 65535, "nce_shared_bwd_targets: bad sizes");
-  int blocks = (int)((n_p_rows + 3) / 4);
+  int blocks = (int)((n_p_rows + 7) / 8);             // 4 waves x 2 rows
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(shared_bwd_targets_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qn_row, row_cap,
                      tok2row, tok_of_slot, n_tok_dev, n_groups, n_slots, tok_cap, seq_len, pred_len, (const bf16_t*)pn, p_inv, dim,
