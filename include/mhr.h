@@ -422,8 +422,10 @@ int mhr_nce_shared_bwd_tokens(const void* qn_row, const float* u_row, const floa
                               const int32_t* fix_slot_of_row, const int32_t* fix_any, float* d_negs, void* stream);
 /* Window-structured lists (slots (b, l, p), p fastest; target row of a slot = b (seq_len + pred_len) + l + 1 + p; tok_of_slot
  * from mhr_token_compact): the backward without per-token atomics.
- * mhr_nce_shared_bwd_rows: one wave per (group, row): dq_rows[row_q[r]] += the row's gradient (chain rule once per row, one
- *   float-atomic set per row), lw_row[r] written, d(logit_scale) added, suppressed pairs taken out of u and of d_negs.
+ * mhr_nce_shared_bwd_rows: a half-wave per (group, row): dq_rows[row_q[r]] += the row's gradient (chain rule once per row),
+ *   lw_row[r] written, d(logit_scale) added, suppressed pairs taken out of u and of d_negs.  exclusive_rows != 0: the caller
+ *   guarantees that no two (group, row) pairs name the same query row (the groups read disjoint decoding heads) - the add is
+ *   then a plain read-modify-write; otherwise one float-atomic set per row.
  * mhr_nce_shared_bwd_targets: one wave per row of p_rows: dp_rows[m] += the gradient of every token of every group that
  *   points at it, gathered through tok_of_slot (plain read-modify-write, no atomics, bitwise reproducible). */
 int mhr_nce_shared_bwd_rows(const void* qn_row, const float* u_row, const float* q_inv_row, const int32_t* row_q,
@@ -432,7 +434,7 @@ int mhr_nce_shared_bwd_rows(const void* qn_row, const float* u_row, const float*
                             const float* w, const float* s_pos, const int32_t* p_idx, float* dq_rows,
                             float* d_logit_scale, float* lw_row, const int32_t* w_bucket, int n_buckets,
                             const void* negs, int n_neg, const uint32_t* fix_words, int64_t n_p_rows,
-                            const int32_t* fix_slot_of_row, const int32_t* fix_any, float* d_negs, void* stream);
+                            const int32_t* fix_slot_of_row, const int32_t* fix_any, float* d_negs, int exclusive_rows, void* stream);
 int mhr_nce_shared_bwd_targets(const void* qn_row, int row_cap, const int32_t* tok2row, const int32_t* tok_of_slot,
                                const int32_t* n_tok_dev, int n_groups, int n_slots, int tok_cap, int seq_len,
                                int pred_len, const void* pn, const float* p_inv, int dim,

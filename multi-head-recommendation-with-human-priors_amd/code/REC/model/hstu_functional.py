@@ -560,12 +560,13 @@ class NceLossFn(Function):
     @staticmethod
     def forward(ctx, q_rows, p_rows, negs, logit_scale, q_idx, p_idx, n_tok_dev, tok_cap, thres, want_logs, logs_out,
                 bucket_idx=None, n_buckets=0, log_group=-1, p_row_mask=None, share_rows=False, window=None, ihn_beta=0.0,
-                prep=None, bucket_weight=None, n_segments=1):
+                prep=None, bucket_weight=None, n_segments=1, exclusive_q_rows=False):
         sv = ops.nce_fwd(q_rows, q_idx, p_rows, p_idx, negs, n_tok_dev, tok_cap, logit_scale.detach().view(1), thres,
                          want_logs=want_logs, for_backward=True, bucket_idx=bucket_idx, n_buckets=n_buckets,
                          log_group=log_group, p_row_mask=p_row_mask, share_rows=share_rows, window=window, ihn_beta=ihn_beta,
                          prep=prep)
         ctx.sv = sv
+        ctx.exclusive_q_rows = bool(exclusive_q_rows)
         ctx.save_for_backward(q_idx, p_idx, logit_scale)
         ctx.shapes = (q_rows.shape, p_rows.shape)
         if want_logs and logs_out is not None:
@@ -603,8 +604,8 @@ class NceLossFn(Function):
             if sv.bucket_idx is not None:
                 w = w / sv.bucket_cnt.clamp_min(1.0)                      # d(mean)/d(loss_t) = 1 / count of the bucket
         d_negs, d_ls = ops.nce_bwd(sv, w, logit_scale.detach().view(1), q_idx, p_idx, dq, dp, d_negs=d_negs0, d_logit_scale=d_ls0,
-                                   want_negs=ctx.needs_input_grad[2], lw_row=lw_row)
+                                   want_negs=ctx.needs_input_grad[2], lw_row=lw_row, exclusive_q_rows=ctx.exclusive_q_rows)
         ctx.sv = None
         if d_negs is not None:
             d_negs = _deposit_f32_grad(sv.negs, d_negs)
-        return (dq, dp, d_negs, d_ls.view(logit_scale.shape)) + (None,) * 17
+        return (dq, dp, d_negs, d_ls.view(logit_scale.shape)) + (None,) * 18

@@ -269,6 +269,15 @@ class MultiHeadDecoding:
             self._tok_cache[key] = (q_all, p_all, o_all)
         return self._tok_cache[key]
 
+    def _groups_read_disjoint_heads(self, head_for_p):
+        """head_for_p [G, P] (host): True when no decoding head is read by two groups - then every query row (b, head, l) belongs
+        to exactly one (group, row) pair of the row-shared loss and its gradient needs no atomics."""
+        key = ("disjoint", tuple(head_for_p.reshape(-1).tolist()), tuple(head_for_p.shape))
+        if key not in self._tok_cache:
+            sets = [set(row.tolist()) for row in head_for_p]
+            self._tok_cache[key] = all(a.isdisjoint(b) for i, a in enumerate(sets) for b in sets[i + 1:])
+        return self._tok_cache[key]
+
     def _token_lists(self, valid_g, head_for_p, q_all=None):
         """Ordered compaction of the live (group, slot) pairs of valid_g [G,B,L,P]: (share, q_idx, p_idx, o_idx, n_tok, window)."""
         from mhr_amd import ops
@@ -326,7 +335,8 @@ class MultiHeadDecoding:
         mean_p = NceLossFn.apply(head_rows, e_rows, negs_g, self.logit_scale, q_idx, p_idx, n_tok, cap,
                                  float(self.nce_thres), want_logs, logs, o_idx, P,
                                  log_group if want_logs else -1, p_row_mask, share, window, float(ihn_beta),
-                                 early["prep"] if early is not None else None, bucket_weight, n_segments)
+                                 early["prep"] if early is not None else None, bucket_weight, n_segments,
+                                 share and self._groups_read_disjoint_heads(head_for_p))
         # [G, P] mean loss per (group, offset) - or, with bucket_weight [G, P], the pair (sum of weight x mean, flat log vector
         # per_gp | seg_all | g_tot | seg_sum) straight from one launch (ops.loss_reduce)
         out_logs = None

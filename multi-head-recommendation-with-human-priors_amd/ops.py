@@ -871,12 +871,15 @@ def nce_fwd(q_rows, q_idx, p_rows, p_idx, negs, n_tok_dev, tok_cap, logit_scale,
     return sv
 
 
-def nce_bwd(sv, w, logit_scale, q_idx, p_idx, dq_rows, dp_rows, d_negs=None, d_logit_scale=None, want_negs=True, lw_row=None):
+def nce_bwd(sv, w, logit_scale, q_idx, p_idx, dq_rows, dp_rows, d_negs=None, d_logit_scale=None, want_negs=True, lw_row=None,
+            exclusive_q_rows=False):
     """w [G, tok_cap] f32 = dLoss/dloss[g, t] - or [G, n_buckets] when the forward was given bucket_idx (every token
     of a bucket then has the same weight).  Accumulates into dq_rows [Rq, D] / dp_rows [Rp, D] (f32, the
     forward's shared row spaces); returns (d_negs [G, n_neg, D] f32, d_logit_scale [1]).  q_idx / p_idx are the
     forward's index lists (the padded copies saved by nce_fwd are what the kernels read).  want_negs=False skips the
-    negative-side product (frozen negatives, e.g. the HLLM twin's cached item tower) and returns d_negs = None."""
+    negative-side product (frozen negatives, e.g. the HLLM twin's cached item tower) and returns d_negs = None.
+    exclusive_q_rows: no two (group, query-row) pairs of the forward name the same row of dq_rows (the groups read disjoint
+    decoding heads): the row-wise backward then adds with plain read-modify-writes instead of float atomics."""
     dev = sv.negs.device
     D, cap, G = sv.dim, sv.cap, sv.groups
     if w.dim() == 1:
@@ -910,7 +913,8 @@ def nce_bwd(sv, w, logit_scale, q_idx, p_idx, dq_rows, dp_rows, d_negs=None, d_l
                         sv.row_first.data_ptr(), sv.n_row_dev.data_ptr(), sv.row_cap, sv.pn.data_ptr(), D, G, cap,
                         logit_scale.data_ptr(), sv.lse.data_ptr(), w.data_ptr(), sv.s_pos.data_ptr(), sv.p_idx.data_ptr(),
                         dq_rows.data_ptr(), d_logit_scale.data_ptr(), lw_row.data_ptr(), wb_ptr, nb, sv.negs.data_ptr(), sv.n_neg,
-                        sv.fix_words.data_ptr(), sv.n_p_rows, _ptr(sv.fix_slot), sv.fix_any.data_ptr(), dn_ptr, st)
+                        sv.fix_words.data_ptr(), sv.n_p_rows, _ptr(sv.fix_slot), sv.fix_any.data_ptr(), dn_ptr,
+                        1 if exclusive_q_rows else 0, st)
             _timed_call("mhr_nce_shared_bwd_targets", sv.qn.data_ptr(), sv.row_cap, sv.tok2row.data_ptr(), tos.data_ptr(),
                         sv.n_tok_dev.data_ptr(), G, tos.shape[1], cap, int(L_), int(P_), sv.pn.data_ptr(), sv.p_inv.data_ptr(), D,
                         logit_scale.data_ptr(), sv.lse.data_ptr(), w.data_ptr(), sv.s_pos.data_ptr(), wb_ptr, nb, sv.n_p_rows,
