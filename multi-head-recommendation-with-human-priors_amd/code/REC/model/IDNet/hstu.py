@@ -207,7 +207,8 @@ class HSTU(MultiHeadDecoding, BaseModel):
         # for all layers at once at the step (WeightGradStack); the kernels below write their operands straight into its slices
         stack = None
         opt = getattr(layers[0]._uvqk, "_mhr_opt", None) if n else None
-        if (WEIGHT_GRAD_STACK and D <= 512 and opt is not None and torch.is_grad_enabled()       # (wider layers: their own products fill the chip) and x2.requires_grad and self._layer_weights_bf16(0, layers[0]) is None
+        if (WEIGHT_GRAD_STACK and D <= 512 and opt is not None and torch.is_grad_enabled()       # (wider layers: their own products fill the chip)
+                and self._layer_weights_bf16(0, layers[0]) is None
                 and all(getattr(q, "_mhr_direct_grad", False) and q.grad is not None and getattr(q, "_mhr_opt", None) is opt
                         for ly in layers for q in (ly._uvqk, ly._o.weight))
                 and all(tuple(ly._uvqk.shape) == (D, 4 * D) and tuple(ly._o.weight.shape) == (D, D) for ly in layers)):
