@@ -300,8 +300,8 @@ class HSTU(MultiHeadDecoding, BaseModel):
         if segs is not None and stages:
             # under the Trainer's capture: the stages become a hipGraph of their own on the capture's side stream, replayed
             # concurrently with the segment that holds the encoder (REC/trainer/trainer.py:_GraphSegments - every launch stays a
-            # single-stream graph, which ROCm enqueues with one cheap host call; a graph with a forked branch costs 2.4 ms of
-            # host time per replay and reaches the GPU at the host's pace)
+            # single-stream graph, which ROCm launches with one cheap host call; a graph with a forked branch cost 2.4 ms of
+            # host time per replay, measured)
             segs.side_branch(run_stages)
             out, out16 = self._encode(x, key_valid, want_bf16=True)
             segs.join()

@@ -25,9 +25,8 @@ class _GraphSegments:
     """The captured step as a SEQUENCE of single-stream hipGraphs instead of one graph with branches.
 
     A graph whose nodes sit on one stream is launched by ROCm with one cheap host call (0.1 ms for the ~175 nodes of a cfg1
-    step); a graph with a forked branch is enqueued node by node (2.4 ms of host time per replay, measured) and its branches
-    reach the GPU at the host's pace.  The model's second-stream work (`HSTU.forward`: the batch-only half of the loss) is
-    therefore captured as a graph of its own: `side_branch(fn)` closes the running main segment, captures fn() on the side
+    step); a graph with a forked branch cost 2.4 ms of host time per replay (measured: `host_enqueue_ms_per_step` of bench.py).
+    The model's second-stream work (`HSTU.forward`: the batch-only half of the loss) is therefore captured as a graph of its own: `side_branch(fn)` closes the running main segment, captures fn() on the side
     stream into its own graph and memory pool, and opens the next main segment; `join()` closes a segment where the main
     stream must have the side graph's results.  Replay: segments in order on the caller's stream, the side graph on the side
     stream behind an event, the join as an event wait - every launch a linear graph.
