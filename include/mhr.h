@@ -472,12 +472,26 @@ int mhr_catalog_score_emit(const void* users, int n_rows, int H, const void* ite
 int mhr_rescore_f32(const float* users, const float* items, int dim, int64_t n_items, const int64_t* cand_idx, int n_rows,
                     int k2, const int32_t* cand_cnt, float* out_val, int32_t* out_idx, void* stream);
 
+/* Dense scores of a FEW rows, every score kept (model/IDNet/hstu.py:965-1015 fp32 score matmul + tag masks,
+ * trainer/trainer.py:724-726 pad / history suppression - what the reference does for every row on its [B,H,N] tensor):
+ * for the n_list rows r = row_list[j] of users [*, dim]: out_val[j, n] = users[r, :] . items[n, :] accumulated in fp32
+ * (operands of `dtype`: MHR_F32 or MHR_BF16, users and items alike), or -inf where item n is the pad id 0, fails
+ * (tag_bits[n] & row_bits[r]) != 0 (tag_bits NULL: bit 31 for every item) or is in the history of user r / H (CSR hist_ptr
+ * int32 / hist_items int64 sorted per user; both NULL: no filter); out_idx[j, n] = n, out_cnt[j] = n_items: the list format
+ * of mhr_topk_select with cap = n_items, which ranks the row exactly (value desc, index asc).  The exact re-run of rows the
+ * threshold scorers cannot certify (ops.catalog_topk_exact, wide.py).  dim % 4 == 0, dim <= 4096; out_* [n_list, n_items]. */
+int mhr_catalog_score_rows_dense(const void* users, const void* items, int dtype, int dim, int64_t n_items,
+                                 const int32_t* row_list, int n_list, int H, const uint32_t* tag_bits,
+                                 const uint32_t* row_bits, const int32_t* hist_ptr, const int64_t* hist_items,
+                                 float* out_val, int32_t* out_idx, int32_t* out_cnt, void* stream);
+
 /* The decode's exactness bookkeeping (ops.catalog_topk / catalog_topk_exact; replaces the masks the reference needs none of because
  * it ranks a dense [B, H, N] score tensor, hstu.py:965-1015 + collector.py:245) - one launch per decision:
  *  pick_tau:     tau[r] = kth2[r] if both sample selects were clean (status 0) and kth2 is finite, else kth1[r] if clean, else -inf.
  *  flag:         flagged[r] = status != 0 || (count < k_min && row_bits != 0 && isfinite(tau)); any_out[0] = 1 if any row is (written).
  *  margin_count: count[r] = finite entries of the sorted list sorted_vals[r, 0..k2) that are >= sorted_vals[r, kk - 1] - margin.
- *  uncertified:  full[r] = (count >= k2 && list_can_fill) || (kth and tau finite && kth - margin < tau), kth = sorted_vals[r, kk - 1];
+ *  uncertified:  full[r] = (count >= k2 && list_can_fill) || (kth finite && tau != -inf && !(kth - margin >= tau)), kth = sorted_vals[r, kk - 1]
+ *                (tau = -inf: an exact list, nothing was left below it; a NaN or +inf tau certifies nothing);
  *                any_out[0] = 1 if any row is (written).  flag / uncertified run as ONE workgroup (n_rows = users x heads). */
 int mhr_topk_pick_tau(const float* kth1, const float* kth2, const int32_t* st1, const int32_t* st2, int n_rows, float* tau, void* stream);
 int mhr_topk_flag(const int32_t* status, const int32_t* count, const int32_t* row_bits, const float* tau, int k_min, int n_rows,

@@ -334,6 +334,15 @@ class HSTU(MultiHeadDecoding, BaseModel):
         rows = torch.zeros(ids_all.numel(), self.item_embedding.weight.shape[1], dtype=torch.float32, device=ids_all.device)
         self._presorted = (ids_all, sorted_ids, perm, rows)
 
+    def reset_step_state(self):
+        """Forget what a half-finished step left for its backward / optimizer step (the Trainer calls this when a hipGraph
+        capture raised partway through a step: the queued tensors belong to a capture that never ran)."""
+        self._presorted = None
+        self._pending_rows = None
+        self._shared_pending = None
+        self._row_exchange = None
+        self.sparse_grad = None
+
     def begin_sparse_exchange(self):
         """Data parallel: put the cross-rank exchange of the last backward's gradient rows on the wire (asynchronous;
         `finish_sparse_grad` completes it).  Called by the fused optimizer before its flat Adam."""

@@ -112,14 +112,15 @@ class _StepGraph:
         ctrl[0] (`mhr_ln_gate_*`'s step_seed), the Adam kernels read ctrl[1] (`step_dev`);
       * the step's Adam constants (lr schedule, bias corrections): row `step % 64` of the optimizer's device-side history;
         both travel in ONE small upload from a pinned ring in front of the replay (`FusedAdamW.begin_replayed_step`).
-    The host may run ahead of the GPU by at most ~48 replays (an event every 16 replays, the third-youngest waited for), so the
-    64-row pinned rings are never overwritten while a copy from them is pending."""
+    The host may run ahead of the GPU by at most ~48 uploads (`FusedAdamW._throttle`: an event every 16 uploads, counted over all
+    step graphs and host-issued steps, the third-youngest waited for), so the 64-slot pinned rings are never overwritten while a
+    copy from them is pending."""
     WARM, RING = 3, 64
 
     def __init__(self, trainer, sig):
         self.tr, self.sig = trainer, sig
         self.warm, self.graph, self.static, self.out = 0, None, None, None
-        self.n, self.events = 0, []
+        self.n = 0
 
     def release(self):
         self.graph = self.static = self.out = None
@@ -164,19 +165,24 @@ class _StepGraph:
                 self._capture(data)
             except Exception as e:  # noqa: BLE001 - a step that cannot be captured still trains, launch by launch
                 tr._graph_failed = True
-                tr.logger.warning(f"hipGraph capture of the train step failed ({type(e).__name__}: {e}); continuing with host-issued launches")
+                tr.graph_failure = f"{type(e).__name__}: {e}"
+                tr.logger.warning(f"hipGraph capture of the train step failed ({tr.graph_failure}); continuing with host-issued launches")
                 self.release()
+                # the capture ran part of a step's Python and launched nothing: whatever it queued for the optimizer step
+                # (deferred weight-gradient products, arena partials, bias sums, pending table rows, the pre-sorted ids) points
+                # at capture-pool tensors that never ran - drop it before the host-issued step
+                tr.optimizer.reset_step_state()
+                if hasattr(tr.model, "reset_step_state"):
+                    tr.model.reset_step_state()
+                if tr.config.get("hip_graph_required", False) or os.environ.get("MHR_HIP_GRAPH_REQUIRED", "0") == "1":
+                    raise RuntimeError(f"hipGraph capture of the train step failed and hip_graph_required is set: {tr.graph_failure}") from e
                 return tr._eager_step(data)
         model, opt = tr.model, tr.optimizer
+        if opt.shadows_stale():                     # weights edited in place since the last step (load_state_dict, resume):
+            opt.refresh_shadows()                   # the graph reads the bf16 shadows through baked pointers
         pairs = [(s_, t) for s_, t in zip(self.static, data) if s_ is not t]
         if pairs:                                  # the batch into the static inputs: one multi-tensor copy launch per dtype
             torch._foreach_copy_([p[0] for p in pairs], [p[1] for p in pairs], non_blocking=True)
-        if self.n % 16 == 0:
-            ev = torch.cuda.Event()
-            ev.record()
-            self.events.append(ev)
-            if len(self.events) > 3:
-                self.events.pop(0).synchronize()
         model._step_seed += 1
         lr = tr._lr_at(tr.train_step)
         tr.train_step += 1
@@ -389,7 +395,11 @@ class Trainer(object):
             torch.set_rng_state(ck["rng_state"].cpu())
         if "cuda_rng_state" in ck and self.device.type == "cuda":
             torch.cuda.set_rng_state(ck["cuda_rng_state"].cpu(), self.device)
-        # (captured step graphs stay valid: they read the weights in place and their counters from device memory)
+        # captured step graphs read the fp32 masters in place and their counters from device memory, but the GEMM operands are
+        # the optimizer's bf16 shadows of the weights: re-cast them from the loaded masters (a replay runs no Python that could
+        # notice a stale shadow)
+        if hasattr(self.optimizer, "refresh_shadows"):
+            self.optimizer.refresh_shadows()
 
     # ------------------------------------------------------------------------------------------
     @torch.no_grad()

@@ -846,7 +846,8 @@ extern "C" int mhr_hit_matrix(const int64_t* topk_idx, int B, int k, const int64
 //   flag:          rows whose candidate lists cannot be trusted (list overflow, or fewer than k_min candidates above a finite
 //                  threshold for an admissible row); any[slot] = 1 if there is one (written, not or-ed: one workgroup)
 //   margin_count:  cnt[r] = finite entries of the sorted list bv[r, :] that are >= bv[r, kk - 1] - margin (a prefix)
-//   uncertified:   rows whose margin set reaches below the emit threshold or fills all k2 slots; any[slot] likewise
+//   uncertified:   rows whose margin set reaches below the emit threshold (tau = -inf: exact list, nothing below; NaN / +inf: no
+//                  threshold known, uncertified) or fills all k2 slots; any[slot] likewise
 // ------------------------------------------------------------------------------------------
 namespace {
 __global__ __launch_bounds__(256) void topk_pick_tau_kernel(const float* __restrict__ kth1, const float* __restrict__ kth2,
@@ -902,7 +903,9 @@ __global__ __launch_bounds__(1024) void topk_uncertified_kernel(const int32_t* _
   bool mine = false;
   for (int r = threadIdx.x; r < n; r += blockDim.x) {
     const float kth = bv[(int64_t)r * k2 + kk - 1], t = tau[r];
-    const bool f = (cnt[r] >= k2 && list_can_fill) || (isfinite(kth) && isfinite(t) && kth - margin < t);
+    // t = -inf: every admissible item was a candidate (exact list); anything else must lie BELOW the margin band - a NaN or
+    // +inf threshold (a scorer that reports none) certifies nothing
+    const bool f = (cnt[r] >= k2 && list_can_fill) || (isfinite(kth) && t != -INFINITY && !(kth - margin >= t));
     full[r] = f ? 1 : 0;
     mine |= f;
   }

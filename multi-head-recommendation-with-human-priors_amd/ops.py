@@ -1144,6 +1144,39 @@ def catalog_topk(users, H, items, tag_bits, row_bits, hist_ptr, hist_items, k, c
     return ov, oi
 
 
+DENSE_ROWS_CHUNK = 128     # rows scored densely per launch (128 x 454 k x 8 B = 465 MB of scratch at cfg1)
+
+
+def dense_rows_topk(users, H, items, n_items, tag_bits, row_bits, hist_ptr, hist_items, rows, k):
+    """Exact top-k (value desc, index asc) of the rows `rows` (int32 [F], indices into users [B*H, D]) with EVERY score
+    kept: `mhr_catalog_score_rows_dense` (fp32 accumulation of fp32 or bf16 operands, tag / pad / history masks in place)
+    + the exact select over the whole row.  hist_ptr / hist_items: the CSR history of ALL users (row // H picks the user).
+    The rare path of the decode (rows the threshold scorers cannot certify); reference hstu.py:965-1015, trainer.py:724-726,
+    collector.py:245.  -> (values [F, k] f32, indices [F, k] i64)."""
+    N = int(n_items)
+    dev = users.device
+    if users.dtype != items.dtype or users.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError(f"dense_rows_topk: users / items must both be fp32 or both bf16 (got {users.dtype}, {items.dtype})")
+    if not (users.is_cuda and users.is_contiguous() and items.is_contiguous()):
+        raise ValueError("dense_rows_topk: contiguous GPU tensors only (no CPU path)")
+    dt = lib.F32 if users.dtype == torch.float32 else lib.BF16
+    rows = rows.to(torch.int32).contiguous()
+    F_ = rows.numel()
+    ov = torch.empty(F_, k, dtype=torch.float32, device=dev)
+    oi = torch.empty(F_, k, dtype=torch.int64, device=dev)
+    for r0 in range(0, F_, DENSE_ROWS_CHUNK):
+        r1 = min(F_, r0 + DENSE_ROWS_CHUNK)
+        val = torch.empty(r1 - r0, N, dtype=torch.float32, device=dev)
+        idx = torch.empty(r1 - r0, N, dtype=torch.int32, device=dev)
+        cnt = torch.empty(r1 - r0, dtype=torch.int32, device=dev)
+        _timed_call("mhr_catalog_score_rows_dense", users.data_ptr(), items.data_ptr(), dt, users.shape[1], N, rows[r0:r1].data_ptr(),
+                    r1 - r0, H, _ptr(tag_bits), row_bits.data_ptr(), _ptr(hist_ptr), _ptr(hist_items), val.data_ptr(),
+                    idx.data_ptr(), cnt.data_ptr(), _stream())
+        fv, fi, _, _ = topk_select((val, idx, cnt), N, k)
+        ov[r0:r1], oi[r0:r1] = fv, fi
+    return ov, oi
+
+
 BF16_SCORE_ERR = 2.0 ** -8       # |u_bf16 . i_bf16 - u . i| for unit vectors u, i (each component rounded to 8 bits)
 
 
@@ -1183,8 +1216,8 @@ def catalog_topk_exact(users_f32, H, items_bf, items_f32, tag_bits, row_bits, hi
                               tau_out=tinfo, margin=2 * BF16_SCORE_ERR,      # (margin: used by the wide scorer's threshold, see wide.py)
                               defer_check=flags[0:1] if defer else None, target=target)
         tau = tinfo.get("tau")
-        if tau is None:               # (a scorer that does not report its threshold: nothing can be certified)
-            tau = torch.full((n_rows,), float("inf"), dtype=torch.float32, device=dev)
+        if tau is None:               # a scorer that does not report its threshold certifies nothing: +inf flags every row
+            tau = torch.full((n_rows,), float("inf"), dtype=torch.float32, device=dev)   # (exact scorers report tau = -inf)
         bv = bv.contiguous()
         cnt = torch.empty(n_rows, dtype=torch.int32, device=dev)          # the margin set: a prefix of the sorted list
         lib.call("mhr_topk_margin_count", bv.data_ptr(), n_rows, k2, kk, 2 * BF16_SCORE_ERR, cnt.data_ptr(), _stream())
@@ -1208,20 +1241,10 @@ def catalog_topk_exact(users_f32, H, items_bf, items_f32, tag_bits, row_bits, hi
     if stats is not None:
         stats["margin_mean"] = float(cnt.float().mean())
         stats["uncertified_rows"] = int(full.sum())
-    if got[1]:                                                            # a handful of rows at most
-        rows = torch.nonzero(full).flatten()
-        sc = users_f32[rows] @ items_f32[:N].t()                      # dense fp32 scores of those rows only
-        if tag_bits is not None:
-            ok = (tag_bits[:N].long()[None, :] & row_bits[rows].long()[:, None]) != 0
-            sc = sc.masked_fill(~ok, float("-inf"))
-        sc[:, 0] = float("-inf")
-        if hist_ptr is not None and hist_items is not None:
-            for j_, r_ in enumerate(rows.tolist()):
-                u_ = r_ // H
-                h_ = hist_items[int(hist_ptr[u_]):int(hist_ptr[u_ + 1])].long()
-                sc[j_, h_[h_ < N]] = float("-inf")
-        v_, p_ = torch.sort(sc, dim=1, descending=True, stable=True)  # stable: ties keep ascending index
-        ov[rows], oi[rows] = v_[:, :k], p_[:, :k]
+    if got[1]:                                                            # a handful of rows at most: every fp32 score kept
+        rows = torch.nonzero(full).flatten().int()
+        fv, fi = dense_rows_topk(users_f32, H, items_f32, N, tag_bits, row_bits, hist_ptr, hist_items, rows, k)
+        ov[rows.long()], oi[rows.long()] = fv, fi
     return ov, oi
 
 

@@ -48,6 +48,7 @@ def fused_flat(params):
     return (torch.as_strided(params[0]._mhr_bf16, (n,), (1,)), torch.as_strided(params[0].grad, (n,), (1,)))
 
 
+GRAPH_SLOTS = 16      # pinned pointer-table slots owned by captured step graphs, per table shape (never recycled)
 HOST_RING = 64        # pinned staging slots of the per-step constants upload (the Trainer keeps the host < 48 steps ahead)
 LAZY_HIST = 64        # steps a table row may lag behind before everything is flushed (= length of the constants' history)
 
@@ -231,16 +232,59 @@ class FusedAdamW:
             if not hasattr(self, "_bias_tabs"):
                 self._bias_tabs = {}
             if key not in self._bias_tabs:       # pinned ring of pointer tables + their device copy (grow-only: captured graphs read them)
-                host = torch.zeros(HOST_RING, 2 * n, dtype=torch.int64)
+                # rows [0, HOST_RING): the ring of host-issued steps; rows [HOST_RING, HOST_RING + GRAPH_SLOTS): one per captured
+                # graph, handed out once and never recycled (allocated here, in a host-issued warm-up step: no pinned allocation
+                # under capture)
+                host = torch.zeros(HOST_RING + GRAPH_SLOTS, 2 * n, dtype=torch.int64)
                 if self.flat_g.is_cuda:
                     host = host.pin_memory()
-                self._bias_tabs[key] = [host, torch.zeros(2 * n, dtype=torch.int64, device=self.flat_g.device), 0]
-            host, devt, k = self._bias_tabs[key]
-            slot = host[k % HOST_RING]
-            self._bias_tabs[key][2] = k + 1
+                self._bias_tabs[key] = [host, torch.zeros(2 * n, dtype=torch.int64, device=self.flat_g.device), 0, 0]
+            host, devt, k, n_graph = self._bias_tabs[key]
+            if self.in_graph:
+                # a captured step bakes a copy node whose SOURCE is this pinned slot and re-reads it at every replay: the slot
+                # belongs to the graph for good (never a ring slot that host-issued steps of the same shape would recycle)
+                if n_graph >= GRAPH_SLOTS:
+                    raise RuntimeError(f"more than {GRAPH_SLOTS} captured step graphs share the bias-sum table {key}")
+                slot = host[HOST_RING + n_graph]
+                self._bias_tabs[key][3] = n_graph + 1
+            else:
+                slot = host[k % HOST_RING]
+                self._bias_tabs[key][2] = k + 1
+                self._throttle()
             slot.numpy()[:] = [dy.data_ptr() for dy, _ in items] + [g.data_ptr() for _, g in items]     # (one host write, not 2 n)
             devt.copy_(slot, non_blocking=True)
             ops.sum_rows_many(devt, n, rows, cols, keep=items)
+
+    def shadows_stale(self):
+        """Somebody edited a parameter in place since the last optimizer step (load_state_dict, a manual copy_): its bf16 shadow
+        - the GEMM operand of the forward, and what a captured step graph reads through baked pointers - no longer matches."""
+        return any(hasattr(p, "_mhr_bf16") and p._version != p._mhr_ver for p in self.dense)
+
+    def refresh_shadows(self):
+        """Re-cast every bf16 shadow from its fp32 master (one pass over the flat buffer) and mark them valid.  Host-issued
+        forwards fall back to casting a stale parameter themselves (SplitKLinearFn checks the version); a REPLAYED step cannot -
+        the check is Python and is not replayed - so the Trainer calls this after resume() and in front of a replay whenever
+        `shadows_stale()`."""
+        if os.environ.get("MHR_OPT_SHADOW", "1") == "0":
+            return
+        self.flat_w16.copy_(self.flat_w)
+        for p in self.dense:
+            if hasattr(p, "_mhr_bf16"):
+                p._mhr_ver = p._version
+
+    def reset_step_state(self):
+        """Drop everything a half-finished step left queued for the optimizer step: deferred closures, split-K partials in the
+        arena, queued bias sums, the flat gradient.  (A hipGraph capture that raises partway through the step has run the
+        step's Python: its queues reference capture-pool tensors that were never executed.)"""
+        self._deferred = []
+        self._bias_q = []
+        if getattr(self, "_arena", None) is not None:
+            for p in self.dense:
+                if getattr(p, "_mhr_in_arena", False):
+                    p._mhr_in_arena = False
+            self._arena.zero_()
+        self._arena_used = set()
+        self.zero_grad()
 
     def zero_grad(self):
         global GRAD_EPOCH
@@ -325,6 +369,22 @@ class FusedAdamW:
         self._n_push += 1
         slot.copy_(self._hist_host)
         self.hist.copy_(slot, non_blocking=True)
+        self._throttle()
+
+    def _throttle(self):
+        """The pinned staging rings have HOST_RING slots and an asynchronous copy reads its slot when the DMA runs: keep the host
+        fewer than ~48 uploads ahead of the GPU, whoever pushes (replayed steps of any batch signature, host-issued steps): an
+        event every 16 uploads, the third-youngest waited for."""
+        if not self.flat_g.is_cuda:
+            return
+        self._n_upload = getattr(self, "_n_upload", 0) + 1
+        if self._n_upload % 16 == 0:
+            ev = torch.cuda.Event()
+            ev.record()
+            evs = self.__dict__.setdefault("_upload_events", [])
+            evs.append(ev)
+            if len(evs) > 3:
+                evs.pop(0).synchronize()
 
     def _lazy_call(self, mode, ids, grad_rows, row_slot, grad_scale, step=None):
         t = self.table
@@ -354,7 +414,19 @@ class FusedAdamW:
 
     def load_state_dict(self, sd):
         lay = sd.get("layout")
-        if lay is not None and [list(x) for x in lay] != self.layout:
+        if lay is None:
+            # a checkpoint from before the layout was recorded: its flat moments follow plain named_parameters() order.  If
+            # this optimizer reordered anything (`adjacent_parameters()`), they would land on the wrong parameters - silently.
+            plain, seen = [], set()
+            for n, p in self.model.named_parameters():
+                if p.requires_grad and p is not self.table and id(p) not in seen:
+                    seen.add(id(p))
+                    plain.append([n, p.numel()])
+            if plain != self.layout:
+                raise RuntimeError("optimizer state without a 'layout' record (an older checkpoint) and this optimizer's flat "
+                                   "buffers are not in plain named_parameters() order: refusing to load the moments onto the "
+                                   "wrong parameters")
+        elif [list(x) for x in lay] != self.layout:
             raise RuntimeError("optimizer state was saved for a different parameter layout (names / sizes / order of the flat "
                                "moment buffers differ): refusing to load it onto the wrong parameters")
         self.step_count = int(sd["step"])

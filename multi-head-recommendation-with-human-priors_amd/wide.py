@@ -146,47 +146,13 @@ def nce_bwd_wide(sv, w_tok, logit_scale, dq_rows, dp_rows, d_negs, d_logit_scale
 # catalog decode
 # ------------------------------------------------------------------------------------------------
 def _exact_rows(users, H, items, n_items, tag_bits, row_bits, hist_ptr, hist_items, k, chunk):
-    """Exact per-row top-k (value desc, index asc) with every score kept: GEMM by item chunks, masks, running merge.
-    Small catalogs and the rows the threshold pass could not certify."""
-    n_rows = users.shape[0]
-    dev = users.device
-    st = _stream()
-    best_v = torch.full((n_rows, 0), float("-inf"), device=dev)
-    best_i = torch.zeros((n_rows, 0), dtype=torch.int64, device=dev)
-    hist_mask = None
-    if hist_ptr is not None and hist_items is not None and hist_items.numel() > 0:
-        lens = (hist_ptr[1:] - hist_ptr[:-1]).long()
-        hu = torch.repeat_interleave(torch.arange(lens.numel(), device=dev), lens)
-        hist_mask = (hu, hist_items.long())
-    for i0 in range(0, n_items, chunk):
-        i1 = min(n_items, i0 + chunk)
-        sc = _mm(users, items[i0:i1].t())                                                         # [n_rows, chunk] fp32
-        lib.call("mhr_catalog_mask_dense", sc.data_ptr(), sc.shape[1], i1 - i0, i0, 1, 0 if tag_bits is None else tag_bits.data_ptr(),
-                 row_bits.data_ptr(), n_rows, st)
-        if hist_mask is not None:
-            hu, hi = hist_mask
-            sel = (hi >= i0) & (hi < i1)
-            rows = (hu[sel][:, None] * H + torch.arange(H, device=dev)[None, :]).reshape(-1)
-            cols = (hi[sel] - i0)[:, None].expand(-1, H).reshape(-1)
-            sc[rows, cols] = float("-inf")
-        ids = torch.arange(i0, i1, device=dev)[None, :].expand(n_rows, -1)
-        cv = torch.cat([best_v, sc], dim=1)
-        ci = torch.cat([best_i, ids], dim=1)
-        # value desc, index asc: stable sort by index first, then by value
-        order = torch.argsort(ci, dim=1, stable=True)
-        cv, ci = torch.gather(cv, 1, order), torch.gather(ci, 1, order)
-        order = torch.argsort(cv, dim=1, descending=True, stable=True)[:, :k]
-        best_v, best_i = torch.gather(cv, 1, order), torch.gather(ci, 1, order)
-    # rows with fewer than k admissible items: complete with (-inf, lowest free ids) like topk_select
-    short = ~torch.isfinite(best_v)
-    if bool(short.any()):
-        for r in torch.nonzero(short.any(dim=1)).flatten().tolist():
-            nsel = int(torch.isfinite(best_v[r]).sum())
-            taken = set(best_i[r, :nsel].tolist())
-            free = [i for i in range(k) if i not in taken][: k - nsel]
-            best_i[r, nsel:] = torch.tensor(free, dtype=torch.int64, device=dev)
-            best_v[r, nsel:] = float("-inf")
-    return best_v, best_i
+    """Exact per-row top-k (value desc, index asc) with every score kept: the dense row scorer (csrc/catalog_dense.hip: fp32
+    accumulation of the operands as given, masks in place) + the exact select over the whole row.  Small catalogs and the
+    rows the threshold pass could not certify.  hist_ptr / hist_items: the CSR history of THESE users (rows // H)."""
+    from . import ops
+    rows = torch.arange(users.shape[0], dtype=torch.int32, device=users.device)
+    return ops.dense_rows_topk(users.contiguous(), H, items if items.is_contiguous() else items.contiguous(), n_items, tag_bits,
+                               row_bits, hist_ptr, hist_items, rows, k)
 
 
 def _catalog_topk_mfma(users, H, items, N, tag_bits, row_bits, hist_ptr, hist_items, k, chunk, target, stats, k_min=None, tau_out=None,

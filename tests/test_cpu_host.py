@@ -88,6 +88,35 @@ def test_registry_and_state_dict_names_match_reference(name):
         model(tuple(torch.from_numpy(g["in/" + k]) for k in ("items", "neg_items", "mask", "tags"))) if "in/items" in g else (_ for _ in ()).throw(RuntimeError("MI355X"))
 
 
+def test_optimizer_state_without_layout_record_is_refused_when_the_order_differs():
+    """FusedAdamW lays the decoding heads' weights (and biases) back to back (`adjacent_parameters()`), so its flat moment
+    buffers are NOT in named_parameters() order for multi-head models.  A checkpoint from before the layout was recorded has
+    no 'layout' key: loading it must fail loudly instead of shifting the moments onto the wrong parameters; for a model whose
+    order is the plain one it loads."""
+    import REC  # noqa: F401
+    import mhr_amd  # noqa: F401
+    from mhr_amd.optim import FusedAdamW
+    from REC.config.configurator import Config
+    from REC.utils import get_model
+    for name, reordered in (("hstu_prior_mult", True), ("hstu_nce_tiny", False)):
+        g, c = _cfg(name)
+        model = get_model("HSTU")(Config(config_dict=c), FakeData(c))
+        opt = FusedAdamW(model)
+        plain = [n for n, p in model.named_parameters() if p is not model.item_embedding.weight]
+        assert ([n for n, _ in opt.layout] != plain) == reordered, name
+        sd = opt.state_dict()
+        opt.load_state_dict(sd)                                       # with its layout record: fine
+        old = {k: v for k, v in sd.items() if k != "layout"}
+        if reordered:
+            with pytest.raises(RuntimeError, match="layout"):
+                opt.load_state_dict(old)
+        else:
+            opt.load_state_dict(old)
+        bad = dict(sd, layout=[[n + "_x", k] for n, k in sd["layout"]])
+        with pytest.raises(RuntimeError, match="layout"):
+            opt.load_state_dict(bad)
+
+
 def test_unknown_head_interaction_raises():
     from REC.config.configurator import Config
     from REC.utils import get_model

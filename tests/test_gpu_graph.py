@@ -166,6 +166,81 @@ def test_resume_continues_the_run(rec, tmp_path):
     assert max(abs(a - c) / abs(a) for a, c in zip(la, lc)) > 2e-3
 
 
+def test_resume_into_a_trainer_with_a_captured_graph_reads_the_loaded_weights(rec, tmp_path):
+    """A captured step reads the GEMM operands from the optimizer's bf16 shadows through baked pointers; load_state_dict()
+    writes the fp32 masters only.  resume() (and any in-place weight load in front of a replay) must re-cast the shadows, or the
+    first replayed step runs forward and backward on the OLD weights and applies that gradient to the loaded ones."""
+    dev = torch.device("cuda", 0)
+    tr, m, data = _trainer(rec, True, dev, hidden_dropout_prob=0.0)
+    batches = [data.train_batch(16) for _ in range(4)]
+    for i in range(7):
+        tr.train_step_fn(batches[i % 4])
+    assert tr.graph_active
+    tr.checkpoint_dir, tr.saved_model_name = str(tmp_path), "ck.pth"
+    tr._save_checkpoint()
+    ck = os.path.join(str(tmp_path), "ck.pth")
+    want = float(tr.train_step_fn(batches[3])["loss"])                # step 8 of the run, from the checkpointed state
+    for i in range(40):                                               # move the weights well away from the checkpoint
+        tr.train_step_fn(batches[i % 4])
+    far = float(tr.train_step_fn(batches[3], graph=False)["loss"])
+    assert abs(far - want) > 2e-2 * abs(want)                         # (otherwise a stale replay could not be told apart)
+    tr.resume(ck)
+    opt = tr.optimizer
+    assert not opt.shadows_stale() and torch.equal(opt.flat_w16, opt.flat_w.to(torch.bfloat16))
+    n_before = tr._step_graph.n
+    got = float(tr.train_step_fn(batches[3])["loss"])
+    assert tr._step_graph.n == n_before + 1                           # a replay, not a host-issued step
+    assert abs(got - want) <= 2e-3 * abs(want), (got, want, far)
+    # an in-place weight load WITHOUT resume(): the replay notices the stale shadows itself
+    sd = torch.load(ck, map_location=dev, weights_only=True)
+    for i in range(20):
+        tr.train_step_fn(batches[i % 4])
+    m.load_state_dict(sd["model"])
+    tr.optimizer.load_state_dict(sd["optimizer"])
+    tr.train_step, m._step_seed, tr._micro_step = int(sd["iter_idx"]), int(sd["step_seed"]), int(sd["micro_step"])
+    assert opt.shadows_stale()
+    got2 = float(tr.train_step_fn(batches[3])["loss"])
+    assert abs(got2 - want) <= 2e-3 * abs(want), (got2, want)
+    # and the same through a fresh trainer issuing every launch from the host: the reference point of both
+    tr_e, m_e, _ = _trainer(rec, False, dev, hidden_dropout_prob=0.0)
+    tr_e.resume(ck)
+    ref = float(tr_e.train_step_fn(batches[3])["loss"])
+    assert abs(ref - want) <= 2e-3 * abs(want)
+
+
+def test_a_failed_capture_leaves_no_half_step_behind(rec, monkeypatch):
+    """A capture that raises partway through the step has run part of a step's Python and launched nothing: the optimizer's
+    deferred queues and the model's pending rows point at capture-pool tensors.  The Trainer drops them and trains on with
+    host-issued launches - the same run as a trainer that never tried to capture."""
+    from REC.model import multihead
+    dev = torch.device("cuda", 0)
+    tr_g, m_g, data = _trainer(rec, True, dev, hidden_dropout_prob=0.0)
+    tr_e, m_e, _ = _trainer(rec, False, dev, hidden_dropout_prob=0.0)
+    batches = [data.train_batch(16) for _ in range(4)]
+    orig = multihead.MultiHeadDecoding._multihead_loss
+    calls = {"n": 0}
+
+    def flaky(self, *a, **kw):
+        if torch.cuda.is_current_stream_capturing():
+            calls["n"] += 1
+            raise RuntimeError("injected failure inside the captured step (after the encoder queued its weight gradients)")
+        return orig(self, *a, **kw)
+    monkeypatch.setattr(multihead.MultiHeadDecoding, "_multihead_loss", flaky)
+    lg, le = [], []
+    for i in range(8):
+        lg.append(float(tr_g.train_step_fn(batches[i % 4])["loss"]))
+        le.append(float(tr_e.train_step_fn(batches[i % 4])["loss"]))
+    assert calls["n"] == 1 and tr_g._graph_failed and not tr_g.graph_active and "injected" in tr_g.graph_failure
+    assert not getattr(tr_g.optimizer, "_deferred", []) and not getattr(tr_g.optimizer, "_bias_q", [])
+    np.testing.assert_allclose(lg, le, rtol=2e-3)
+    assert np.all(np.isfinite(lg))
+    # with hip_graph_required the failure is an error, not a silent change of mode
+    tr_r, _, _ = _trainer(rec, True, dev, hidden_dropout_prob=0.0, hip_graph_required=True)
+    with pytest.raises(RuntimeError, match="hip_graph_required"):
+        for i in range(5):
+            tr_r.train_step_fn(batches[i % 4])
+
+
 @pytest.mark.parametrize("stacked", [True, False])
 def test_deferred_weight_gradients_give_the_per_layer_reduction(rec, stacked):
     """With one backward per step the encoder's weight gradients are deferred to the optimizer step: as ONE batched split-K
