@@ -136,9 +136,21 @@ def _oracle_trainer(cfgd, item_num, B, pool_size=None):
     return train_step
 
 
-def cpu_baseline_cfg0(budget_s=4.0):
+def _median_rate(fn, threads, warm, timed, units):
+    """warm untimed + timed calls of fn() -> seconds on `threads` threads; rate = units / MEDIAN step time."""
+    import statistics
+    import torch
+    torch.set_num_threads(threads)
+    for _ in range(warm):
+        fn()
+    ts = [fn() for _ in range(timed)]
+    return round(units / max(statistics.median(ts), 1e-9), 3), len(ts)
+
+
+def cpu_baseline_cfg0(warm=3, timed=10):
     """BASELINE.json configs[0] - the reference's own CPU-runnable case (HSTU-Pixel8M-base: seqlen 50, dim 64, 1 head) - as
-    the oracle's train step on ONE thread (the reference pins one, run.py:20-21) and on all cores."""
+    the oracle's train step on ONE thread (the reference pins one, run.py:20-21) and on all cores: `warm` warm-up steps, then
+    the MEDIAN of `timed` steps (>= 3 + >= 10)."""
     import torch
     import mhr_amd.synth as synth
     spec = synth.CONFIGS["cfg0"]
@@ -146,21 +158,34 @@ def cpu_baseline_cfg0(budget_s=4.0):
     step = _oracle_trainer(dict(spec["cfg"]), spec["item_num"], B)
     cores = _host_cores()
     out = {}
-    for name, thr in (("one_thread", 1), ("all_cores", cores)):
-        torch.set_num_threads(thr)
-        step()
-        n, used = 0, 0.0
-        while used < budget_s / 2 and n < 200:
-            used += step()
-            n += 1
-        out[name] = {"value": round(B * n / max(used, 1e-9), 2), "unit": "seq/s", "cores": thr, "steps": n}
+    for name, thr in (("all_cores", cores), ("one_thread", 1)):
+        v, n = _median_rate(step, thr, warm, timed, B)
+        out[name] = {"value": v, "unit": "seq/s", "cores": thr, "steps": n, "warmup": warm, "statistic": "median"}
     torch.set_num_threads(cores)
     out["workload"] = f"cfg0 (reference's CPU case): L={spec['cfg']['MAX_ITEM_LIST_LENGTH']} D={spec['cfg']['item_embedding_size']} " \
                       f"{spec['cfg']['n_layers']} layers, N={spec['item_num']} items, B={B} windows per step"
     return out
 
 
-def cpu_baseline(cfgd, item_num, budget_s=14.0):
+def _reference_speed_ratio():
+    """Container-side measurement (tools/ref_vs_oracle_cpu.py, committed under profiles/): how fast the reference's own
+    hstu.py + collector.py run next to this oracle on identical weights and batches.  The reference cannot travel to the GPU
+    box; this ties the port's numbers to it."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_ref_vs_oracle_cpu.json")))
+    if not files:
+        return None
+    d = json.load(open(files[-1]))
+    out = {"source": os.path.relpath(files[-1], ROOT), "host_cores_of_that_run": d.get("host_cores")}
+    for case in ("cfg0", "cfg1_reduced"):
+        for leg in ("train", "eval"):
+            for thr, rec in (d.get(case, {}).get(leg, {}) or {}).items():
+                if isinstance(rec, dict) and "oracle_over_reference_speed" in rec:
+                    out[f"{case}_{leg}_{thr}_oracle_over_reference_speed"] = rec["oracle_over_reference_speed"]
+    return out
+
+
+def cpu_baseline(cfgd, item_num):
     """The oracle's fp32 train step (forward + autograd backward + dense AdamW over every parameter) and eval step
     (user heads -> full-catalog scores -> masks -> per-head top-k -> merge) on the host, at the GPU run's shape: same
     L, P, D, layers, heads, catalog and the SAME negatives per pool (8192); the sample is B = 4 windows per train step
@@ -229,33 +254,30 @@ def cpu_baseline(cfgd, item_num, budget_s=14.0):
         DO.merge_dedup(v_, i_, K)                                           # collector.py:249-275
         return time.perf_counter() - t0
 
-    def timed(fn, threads, budget, units, warm):
-        torch.set_num_threads(threads)
-        if warm:
-            fn()
-        n, used = 0, 0.0
-        while used < budget and n < 40:
-            used += fn()
-            n += 1
-        return round(units * n / max(used, 1e-9), 3), n
-
-    tr_all, n1 = timed(train_step, cores, budget_s * 0.3, B, True)
-    tr_one, n2 = timed(train_step, 1, budget_s * 0.7, B, False)
-    ev_all, n3 = timed(eval_step, cores, budget_s * 0.2, Be, True)
-    ev_one, n4 = timed(eval_step, 1, budget_s * 0.3, Be, False)
+    # the metric's shape (cfg1) is a bounded sample - one step costs ~1.6 s on 16 threads, ~3.5 s on one: 2 warm-up + 5 timed
+    # (median) on all cores, 1 + 2 on one thread; the eval step 2 + 6 / 1 + 3.  The reference's own CPU case (cfg0) gets the
+    # full 3 + 10 protocol of BASELINE.md section 3.2 on both thread counts.
+    tr_all, n1 = _median_rate(train_step, cores, 2, 5, B)
+    tr_one, n2 = _median_rate(train_step, 1, 1, 2, B)
+    ev_all, n3 = _median_rate(eval_step, cores, 2, 6, Be)
+    ev_one, n4 = _median_rate(eval_step, 1, 1, 3, Be)
     torch.set_num_threads(cores)
     try:
         cfg0 = cpu_baseline_cfg0()
     except Exception as e:  # noqa: BLE001
         cfg0 = {"error": repr(e)[:160]}
-    return {"value": tr_all, "unit": "seq/s", "cores": cores, "kind": "port", "cfg0": cfg0,
-            "one_thread": {"value": tr_one, "unit": "seq/s", "cores": 1, "steps": n2},
-            "eval": {"value": ev_all, "unit": "users/s", "cores": cores, "steps": n3,
-                     "one_thread": {"value": ev_one, "unit": "users/s", "cores": 1, "steps": n4}},
-            "sample": f"{n1} oracle train steps (fwd + autograd bwd + dense AdamW over all parameters, fp32) of {B} windows at the "
-                      f"cfg shape with {per_sample * B} negatives per pool (= the GPU run's pool size; GPU batch is "
-                      f"{cfgd['train_batch_size']} windows); eval: {n3} oracle eval steps of {Be} users over the full "
-                      f"{item_num}-item catalog (scores, masks, per-head top-{K}, merge)"}
+    out = {"value": tr_all, "unit": "seq/s", "cores": cores, "kind": "port", "statistic": "median step time", "cfg0": cfg0,
+           "one_thread": {"value": tr_one, "unit": "seq/s", "cores": 1, "steps": n2, "warmup": 1},
+           "eval": {"value": ev_all, "unit": "users/s", "cores": cores, "steps": n3, "warmup": 2,
+                    "one_thread": {"value": ev_one, "unit": "users/s", "cores": 1, "steps": n4, "warmup": 1}},
+           "sample": f"2 warm-up + {n1} timed oracle train steps (fwd + autograd bwd + dense AdamW over all parameters, fp32) of {B} "
+                     f"windows at the cfg shape with {per_sample * B} negatives per pool (= the GPU run's pool size; GPU batch is "
+                     f"{cfgd['train_batch_size']} windows); eval: 2 + {n3} oracle eval steps of {Be} users over the full "
+                     f"{item_num}-item catalog (scores, masks, per-head top-{K}, merge); cfg0: 3 + 10 steps of 64 windows"}
+    ratio = _reference_speed_ratio()
+    if ratio:
+        out["reference_vs_port"] = ratio
+    return out
 
 
 # ------------------------------------------------------------------------------------------------
@@ -265,7 +287,7 @@ KERNEL_NAMES = {"mhr_nce_bwd_tokens": ["nce_bwd_rows_kernel"], "mhr_nce_bwd_negs
                 "mhr_hstu_attn_bwd": ["hstu_attn_bwd_kernel"], "mhr_hstu_attn_fwd": ["hstu_attn_fwd_kernel"],
                 "mhr_nce_fwd": ["nce_fwd_d_kernel"],       # (the plain form launches no bit-table kernel; mhr_nce_fix_bits is its own call)
                 "mhr_catalog_score_emit": ["catalog_emit_kernel"], "mhr_catalog_score_emit_sliced": ["catalog_emit_sliced_kernel"],
-                "mhr_adam_rows": ["adam_rows_kernel"], "mhr_embedding_gather_fwd": ["gather_rows_kernel"]}
+                "mhr_adam_rows": ["adam_rows_kernel"], "mhr_embedding_gather_fwd": ["gather_rows_kernel"], "mhr_embedding_gather_step": ["gather_step_kernel"]}
 
 
 def _roof(kernel, flops, nbytes, ms, extra=None):
@@ -347,6 +369,8 @@ def main():
         cfgd["train_batch_size"] = cfgd["eval_batch_size"] = args.batch
     if args.no_graph:
         cfgd["hip_graph"] = False
+    elif args.mode == "train":
+        cfgd["hip_graph_required"] = True      # a capture that fails is an error here, not a silent host-issued run
     cfg = apply_run_fixups(Config(config_dict=cfgd))
     N = spec["item_num"]
     data = synth.SyntheticData(cfg, N, dev, seed=2020, rank=rank, world=world)
@@ -375,7 +399,7 @@ def main():
     EVENTED = ["mhr_nce_fwd", "mhr_nce_bwd_tokens", "mhr_nce_bwd_negs", "mhr_nce_shared_fwd_tokens", "mhr_nce_shared_bwd_rows",
                "mhr_nce_shared_bwd_targets", "mhr_nce_shared_bwd_tokens", "mhr_catalog_score_emit", "mhr_catalog_score_emit_sliced",
                "mhr_hstu_attn_fwd", "mhr_hstu_attn_bwd", "mhr_adam_rows", "mhr_adam_rows_lazy", "mhr_embedding_gather_fwd",
-               "mhr_sparse_rows_segment_sum", "mhr_topk_select", "mhr_topk_select_sliced", "mhr_sum_rows_into"]
+               "mhr_sparse_rows_segment_sum", "mhr_topk_select", "mhr_topk_select_sliced", "mhr_sum_rows_into", "mhr_embedding_gather_step"]
 
     def run_leg(mode, warmup, steps, event_steps):
         """-> dict(elapsed, host_enqueue, host_alone, prof, prof_max, last, batches, B).  Wall-clock pass first (nothing but
@@ -500,8 +524,11 @@ def main():
             return r
         return None
 
+    rc_fail = None
     legs = {}
     main_leg = legs[args.mode] = run_leg(args.mode, args.warmup, args.steps, args.event_steps)
+    graph_expected = bool(args.mode == "train" and not args.no_graph and (trainer._graph_ok(main_leg["batches"][0]) or getattr(trainer, "_graph_failed", False)))
+    graph_on = bool(getattr(trainer, "graph_active", False))
     if args.mode == "train" and not args.no_eval_leg:
         legs["eval"] = run_leg("eval", 3, 10, min(args.event_steps, 5))
 
@@ -509,7 +536,6 @@ def main():
         B = main_leg["B"]
         elapsed = main_leg["elapsed"]
         value = world * B * args.steps / elapsed
-        graph_on = bool(getattr(trainer, "graph_active", False))
         out = {
             "metric": "user-sequences/sec/node (HSTU Pixel8M, seqlen 200)" if args.mode == "train" else "eval users/sec/node (HSTU Pixel8M full-catalog multi-head decode)",
             "value": round(value, 2), "unit": "seq/s" if args.mode == "train" else "users/s", "n_gpus": world, "steps": args.steps,
@@ -524,6 +550,10 @@ def main():
                        "global_batch": world * B, "seq_len": L, "parallelism": f"dp{world}"},
         }
         assert out["n_gpus"] == args.gpus
+        out["graph_active"] = graph_on
+        out["graph_expected"] = bool(graph_expected)
+        if getattr(trainer, "graph_failure", None):
+            out["graph_failure"] = trainer.graph_failure
         out["host_enqueue_ms_per_step"] = round(1000 * main_leg["host_enqueue"] / args.steps, 3)
         if main_leg["host_alone"] == main_leg["host_alone"]:
             out["host_issue_ms_idle_queue"] = round(1000 * main_leg["host_alone"], 3)
@@ -558,12 +588,23 @@ def main():
                     "bwd_negs_executed_TFLOPs": round(be, 1), "bwd_negs_executed_frac_of_mfma_peak": round(be / MFMA_PEAK_TFLOPS, 4),
                     "reference_formulation_TFLOPs_equiv": round(6.0 * n_tok_ * n_neg_ * D / (prof["mhr_nce_fwd"][1] * 1e-3) / 1e12, 1),
                     "mfma_peak_TFLOPs": MFMA_PEAK_TFLOPS}
-            if "mhr_embedding_gather_fwd" in prof and args.mode == "train":
+            if ("mhr_embedding_gather_fwd" in prof or "mhr_embedding_gather_step" in prof) and args.mode == "train":
                 # item ids + negative-pool ids: table rows read and written as fp32, plus the position-added encoder input
                 n_pools = C if (cfg["loss"] == "prior" and cfg.get("neg_sample_by_cat")) else 1
-                n_ids = B * (L + P) + data.n_neg(B) * B * n_pools * world
-                gbytes = (n_ids * 2 + B * L) * D * 4.0
-                g = _roof("mhr_embedding_gather_fwd", None, gbytes, prof["mhr_embedding_gather_fwd"][1], {"rows_per_launch": n_ids})
+                n_item, n_negs = B * (L + P), data.n_neg(B) * B * n_pools * world
+                fused = "mhr_embedding_gather_step" in prof        # one launch: item windows + negative pools normalised to bf16
+                ms = prof["mhr_embedding_gather_step" if fused else "mhr_embedding_gather_fwd"][1]
+                # bytes the launch moves: item windows read fp32, written fp32 (targets) + fp32 position-added encoder input;
+                # negative pools read fp32, written normalised bf16 (+ 4 B norm per row) - or fp32 rows without the fusion
+                own = (n_item * 2 + B * L) * D * 4.0 + ((n_negs * D * 6.0 + n_negs * 4.0) if fused else n_negs * D * 8.0)
+                # SURVEY 8d / BASELINE.md contract: rows x D x (4 B table read + 2 B bf16 out) over ALL gathered rows
+                contract = (n_item + n_negs) * D * 6.0
+                g = _roof("mhr_embedding_gather_step" if fused else "mhr_embedding_gather_fwd", None, own, ms,
+                          {"rows_per_launch": n_item + n_negs, "item_rows": n_item, "negative_rows": n_negs,
+                           "contract_bytes_per_launch": contract, "contract_GBps": round(contract / (ms * 1e-3) / 1e9, 1),
+                           "frac_on_contract_bytes": round(contract / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                           "note": "frac = the bytes this launch moves (fp32 residual stream: item rows leave as fp32 twice, negatives as "
+                                   "normalised bf16) / time / 8 TB/s; frac_on_contract_bytes prices the same time on SURVEY 8d's rows x D x 6 B"})
                 _attach_traffic(g, "train", standard and args.config == "cfg1")
                 out["gather"] = g
             if "mhr_adam_rows" in prof:
@@ -585,9 +626,13 @@ def main():
             except Exception as e:  # noqa: BLE001 - the baseline must not kill the bench line
                 out["cpu_baseline"] = {"value": None, "error": repr(e)[:200]}
         print(json.dumps(out), flush=True)
+        if out.get("graph_expected") and not out["graph_active"]:
+            rc_fail = "bench.py: the train step was expected to replay from a hipGraph and did not"
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if rc_fail:
+        raise SystemExit(rc_fail)
 
 
 if __name__ == "__main__":

@@ -59,6 +59,17 @@ int mhr_embedding_gather_fwd(const float* table, int64_t n_rows, int dim,
                              const float* pos_table, int seq_len, int window_len,
                              void* x_out, int x_dtype, int64_t n_x_ids, void* stream);
 
+/* Everything a TRAINING step reads from the item table in one launch (hstu.py:637-643, 670-672, 752-754):
+ *   ids[0, n_item_ids) viewed as [n_item_ids / window_len, window_len] item windows:
+ *       rows_out[r,:] = table[ids[r],:] (f32: the targets) and x_out[b,l,:] = table[ids[b,l],:] + pos_table[l,:] for l < seq_len;
+ *   ids[n_item_ids, n_ids) - the negative pools:
+ *       neg_out[j,:] = table[id,:] / |table[id,:]| as bf16 and neg_norms[j] = |table[id,:]| (f32) - gather + L2 normalisation
+ *       without an fp32 copy of the rows; bitwise mhr_embedding_gather_fwd + mhr_l2norm_rows.
+ * dim % 4 == 0, dim <= 2048; ids outside [0, n_rows) are clamped and counted (mhr_bad_id_count). */
+int mhr_embedding_gather_step(const float* table, int64_t n_rows, int dim, const int64_t* ids, int64_t n_ids,
+                              int64_t n_item_ids, float* rows_out, const float* pos_table, int seq_len, int window_len,
+                              float* x_out, void* neg_out, float* neg_norms, void* stream);
+
 /* Dense embedding backward (ATen embedding_dense_backward): grad_table[ids[r],:] += grad_rows[r,:]
  * with float atomics.  grad_table [n_rows, dim] f32 must be zeroed by the caller. */
 int mhr_embedding_scatter_add_bwd(const void* grad_rows, int grad_dtype, const int64_t* ids, int64_t n_ids,
@@ -163,6 +174,11 @@ int mhr_ln_gate_bwd(const void* d_o, int do_dtype, const void* u_base, int64_t u
 int mhr_l2norm_rows(const void* x, int x_dtype, void* y, int y_dtype, float* norms, int64_t rows, int dim, void* stream);
 /* backward of y = x / |x| (autograd of hstu.py:672, 754): dx = (dy - n (n . dy)) / |x| with n = x / |x|; all f32, norms from the forward */
 int mhr_l2norm_rows_bwd(const float* dy, const float* x, const float* norms, float* dx, int64_t rows, int dim, void* stream);
+/* Backward of y = table[ids] / |table[ids]| w.r.t. the gathered rows, reading them THROUGH the id list (the forward is the
+ * negative-pool half of mhr_embedding_gather_step: no fp32 copy of the gathered rows exists; the table is unchanged between a
+ * step's forward and backward).  dx = (dy - n (n . dy)) / |x|, all f32; ids outside [0, n_src_rows) are clamped. */
+int mhr_l2norm_rows_indexed_bwd(const float* dy, const float* table, int64_t n_src_rows, const int64_t* ids, const float* norms,
+                                float* dx, int64_t rows, int dim, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * HSTU pointwise-gated attention (model/IDNet/hstu.py:137-160), fused, never materialises [L,L].

@@ -29,8 +29,9 @@ from REC.model.basemodel import BaseModel, all_gather_pool_ids
 from REC.model.multihead import FusedTopK, MultiHeadDecoding  # noqa: F401  (FusedTopK re-exported)
 from REC.utils.enum_type import InputType
 
-EARLY_LOSS_PREP = os.environ.get("MHR_EARLY_LOSS_PREP", "1") != "0"
-WEIGHT_GRAD_STACK = os.environ.get("MHR_WEIGHT_GRAD_STACK", "1") != "0"   # 0: every layer's weight gradients inside its own backward      # 0: the loss preparation runs in line, after the encoder
+EARLY_LOSS_PREP = os.environ.get("MHR_EARLY_LOSS_PREP", "1") != "0"       # 0: the loss preparation runs in line, after the encoder
+FUSED_NEG_GATHER = os.environ.get("MHR_FUSED_NEG_GATHER", "1") != "0"     # 0: gather the negative pools as fp32 rows, normalise after
+WEIGHT_GRAD_STACK = os.environ.get("MHR_WEIGHT_GRAD_STACK", "1") != "0"   # 0: every layer's weight gradients inside its own backward
 
 
 def truncated_normal(x, mean, std):
@@ -247,7 +248,7 @@ class HSTU(MultiHeadDecoding, BaseModel):
     # training
     # ------------------------------------------------------------------------------------------
     def forward(self, interaction):
-        from REC.model.hstu_functional import EmbeddingGatherFn, L2NormFn
+        from REC.model.hstu_functional import EmbeddingGatherFn, GatherL2NormFn, L2NormFn
         items, neg_items, user_mask, pos_tags = interaction
         if not items.is_cuda:
             raise RuntimeError("HSTU.forward runs on the MI355X only (no CPU path); move the batch to the GPU")
@@ -267,9 +268,11 @@ class HSTU(MultiHeadDecoding, BaseModel):
         ids_all = torch.cat([items.reshape(-1)] + pool_ids).contiguous()
         self._table_catch_up(ids_all)                      # lazy table optimizer: the rows this step reads, up to date first
         fused_pos = isinstance(self.item_id_proj_tower, nn.Identity)
+        # the negative pools: gathered and L2-normalised in one pass (bf16 out) when the table rows are what the loss sees
+        fused_negs = fused_pos and FUSED_NEG_GATHER and torch.is_grad_enabled() and not self.dense_embedding_grad
         rows_items, rows_negs, x = EmbeddingGatherFn.apply(self.item_embedding.weight,
                                               self.position_embedding.weight if fused_pos else None, ids_all,
-                                              n_item_ids, L, L + P, self)
+                                              n_item_ids, L, L + P, self, fused_negs)
         if not fused_pos:
             rows_all = self.item_id_proj_tower(torch.cat([rows_items, rows_negs]))
             rows_items, rows_negs = rows_all[:n_item_ids], rows_all[n_item_ids:]
@@ -277,7 +280,11 @@ class HSTU(MultiHeadDecoding, BaseModel):
         e_rows = rows_items                                   # targets, [B*(L+P), D] fp32
         # data parallel: the negatives' gradient rows leave for their all-reduce from inside this backward (fused_pos:
         # they are rows of the table itself), underneath the encoder backward
-        negs_pools = L2NormFn.apply(rows_negs.contiguous(), self if fused_pos else None).view(len(pools), n_pool, D)
+        if fused_negs:
+            negs_pools = GatherL2NormFn.apply(rows_negs, self.item_embedding.weight.detach(), ids_all[n_item_ids:], self)
+        else:
+            negs_pools = L2NormFn.apply(rows_negs.contiguous(), self if fused_pos else None)
+        negs_pools = negs_pools.view(len(pools), n_pool, D)
 
         key_valid = mask[:, :L].to(torch.uint8).contiguous()
         # everything of the loss that waits for nothing the encoder makes (token lists, row maps, the false-negative bit table of

@@ -367,12 +367,20 @@ class EmbeddingGatherFn(Function):
     """
 
     @staticmethod
-    def forward(ctx, table, pos_table, ids_all, n_item_ids, L, window, holder):
+    def forward(ctx, table, pos_table, ids_all, n_item_ids, L, window, holder, negs_elsewhere=False):
         D = table.shape[1]
+        n_neg = ids_all.numel() - n_item_ids
+        ctx.save_for_backward(ids_all)
+        ctx.meta = (n_item_ids, L, window, holder, table.shape[0], D)
+        if negs_elsewhere and pos_table is not None:
+            # ONE launch (mhr_embedding_gather_step): item windows as fp32 rows + position-added x, the negative pools gathered
+            # AND L2-normalised to bf16 with no fp32 copy of their rows.  The normalised pools enter autograd through
+            # GatherL2NormFn; this Function's second output is a memory-less stand-in for the pools' raw rows - the gradient
+            # GatherL2NormFn returns for it arrives here as d_negs, exactly like the gradient of real rows would
+            rows, x, negs_n, norms = ops.embedding_gather_step(table, pos_table, ids_all, n_item_ids, L, window)
+            holder._gathered_negs = (negs_n, norms)           # picked up by GatherL2NormFn.forward right behind this call
+            return rows, torch.zeros((), dtype=torch.float32, device=table.device).expand(n_neg, D), x
         rows = torch.empty(ids_all.numel(), D, dtype=torch.float32, device=table.device)
-        B = n_item_ids // window
-        # items part with the fused position add
-        items = ids_all[:n_item_ids].view(B, window)
         # ONE launch: item windows (rows + position-added x) and negative-pool ids (rows only), written in place
         if pos_table is not None:
             _, x = ops.embedding_gather(table, ids_all, torch.float32, pos_table, L, torch.float32, out=rows, window=window,
@@ -380,8 +388,6 @@ class EmbeddingGatherFn(Function):
         else:                                  # projection tower in between: the position add happens after it
             ops.embedding_gather(table, ids_all, torch.float32, out=rows)
             x = torch.zeros(1, device=table.device)
-        ctx.save_for_backward(ids_all)
-        ctx.meta = (n_item_ids, L, window, holder, table.shape[0], D)
         # two outputs over ONE buffer (item windows | negative pools): their gradients arrive as two tensors, so the backward
         # has no slice-backward zero fills and no accumulate pass over the [rows, D] gradient
         return rows[:n_item_ids], rows[n_item_ids:], x
@@ -412,7 +418,7 @@ class EmbeddingGatherFn(Function):
                 ops.embedding_scatter_add(d_negs, ids_all[n_item_ids:].contiguous(), gt)
             if d_x is not None:
                 ops.embedding_scatter_add(d_x.view(-1, D), ids_all[:n_item_ids].view(-1, window)[:, :L].contiguous().view(-1), gt)
-            return gt, d_pos, None, None, None, None, None
+            return gt, d_pos, None, None, None, None, None, None
         if holder._row_slot is None or holder._row_slot.numel() != n_rows:
             holder._row_slot = torch.full((n_rows,), -1, dtype=torch.int32, device=dev)
         from mhr_amd import distributed as dist_
@@ -428,7 +434,7 @@ class EmbeddingGatherFn(Function):
                 holder._pending_rows = []
             holder._pending_rows.append((ids_all, d_rows, n_item_ids, shared))
             holder.sparse_grad = None
-            return None, d_pos, None, None, None, None, None
+            return None, d_pos, None, None, None, None, None, None
         pre, holder._presorted = getattr(holder, "_presorted", None), None
         if pre is not None and pre[0].data_ptr() == ids_all.data_ptr() and pre[0].numel() == ids_all.numel():        # sorted (and the row buffer zeroed) early, underneath the encoder forward
             _, sorted_ids, perm, out_rows = pre
@@ -437,7 +443,7 @@ class EmbeddingGatherFn(Function):
             out_rows = torch.zeros(ids_all.numel(), D, dtype=torch.float32, device=dev)
         ops.sparse_rows_segment_sum(sorted_ids, perm, d_items, d_negs if n_neg_ids else None, d_x, L, window, out_rows, holder._row_slot)
         holder.sparse_grad = SparseRowGrad(sorted_ids, out_rows, holder._row_slot, n_rows)
-        return None, d_pos, None, None, None, None, None
+        return None, d_pos, None, None, None, None, None, None
 
 
 def begin_pending_rows(holder):
@@ -541,6 +547,44 @@ class L2NormFn(Function):
             ctx.holder._shared_pending = (g, dist_.allreduce_sum_begin(g))
             return None, None
         return g, None
+
+
+class GatherL2NormFn(Function):
+    """y = table[ids] / |table[ids]| as bf16 (reference hstu.py:670-672, 752-754: gather the negative pools, then normalise),
+    produced by EmbeddingGatherFn's own launch (mhr_embedding_gather_step) - the fp32 copy of the gathered rows that
+    EmbeddingGatherFn + L2NormFn wrote and read back never exists (33.5 MB each way per step at cfg1); the values are bitwise
+    theirs.  This Function is the autograd face of that half of the launch.  `rows_standin` is EmbeddingGatherFn's
+    memory-less second output: the backward returns the gradient w.r.t. the gathered rows for it, so it reaches the sparse
+    reduction of the embedding backward as d_negs.  The backward re-reads the rows from the table (no optimizer step lies
+    between a step's forward and backward).  Data parallel with `holder`: as L2NormFn, the gradient leaves for its all-reduce
+    from here."""
+
+    @staticmethod
+    def forward(ctx, rows_standin, table, ids, holder):
+        got, holder._gathered_negs = getattr(holder, "_gathered_negs", None), None
+        if got is None or got[0].shape[0] != ids.numel():
+            raise RuntimeError("GatherL2NormFn: no gathered negatives on the holder (call it right behind EmbeddingGatherFn with negs_elsewhere)")
+        y, norms = got
+        ctx.save_for_backward(ids, norms)
+        ctx.table = table
+        ctx.holder = holder
+        ctx.key = _open_f32_grad_slot(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        ids, norms = ctx.saved_tensors
+        slot = _F32_GRAD.pop(ctx.key, None)
+        g32 = slot[1] if slot is not None else None
+        if g32 is not None:                           # the loss left its fp32 gradient; dy is the placeholder unless others add to it
+            dy = g32 if all(st == 0 for st in dy.stride()) else g32 + dy.float().reshape(g32.shape)
+        g = ops.l2norm_rows_indexed_bwd(dy.reshape(ids.numel(), -1).float().contiguous(), ctx.table, ids, norms)
+        ctx.table = None
+        from mhr_amd import distributed as dist_
+        if ctx.holder is not None and dist_.world_size() > 1 and dist_.OVERLAP:
+            ctx.holder._shared_pending = (g, dist_.allreduce_sum_begin(g))
+            return None, None, None, None
+        return g, None, None, None
 
 
 class NceLossFn(Function):

@@ -57,6 +57,128 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
   }
 }
 
+// One launch for everything a training step reads from the item table (reference hstu.py:637-643 item windows + position
+// add, 670-672 / 752-754 negative pools gathered and L2-normalised): workgroups [0, grid_items) run the item-window gather
+// above on ids[0, n_item_ids); workgroups [grid_items, ...) turn ids[n_item_ids, n_ids) into normalised bf16 rows + their norms
+// (one wave per row, the row in registers: the fp32 copy of the negatives' rows is never written).  The normalisation is
+// l2norm_kernel's arithmetic in its order (csrc/norm.hip), so the values are bitwise gather + mhr_l2norm_rows.
+template <int NC>
+__global__ __launch_bounds__(256) void gather_step_kernel(const float* __restrict__ table, int64_t n_rows, int dim,
+                                                          const int64_t* __restrict__ ids, int64_t n_ids, int64_t n_item_ids,
+                                                          float* __restrict__ out, const float* __restrict__ pos, int seq_len,
+                                                          int window_len, float* __restrict__ x_out, bf16_t* __restrict__ neg_out,
+                                                          float* __restrict__ neg_norms, int grid_items) {
+  const int lane = threadIdx.x & 63;
+  if ((int)blockIdx.x < grid_items) {
+    const int64_t wave = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)grid_items * 4;
+    constexpr int U = 4;
+    for (int64_t r0 = wave * U; r0 < n_item_ids; r0 += n_waves * U) {
+      int64_t id[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        int64_t v = r0 + u < n_item_ids ? ids[r0 + u] : 0;
+        if (v < 0 || v >= n_rows) {
+          if (lane == 0) atomicAdd(&g_bad_ids, 1u);
+          v = v < 0 ? 0 : n_rows - 1;
+        }
+        id[u] = v;
+      }
+      for (int c = lane * 4; c < dim; c += 256) {
+        f32x4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (r0 + u < n_item_ids) v[u] = *reinterpret_cast<const f32x4*>(table + id[u] * dim + c);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int64_t r = r0 + u;
+          if (r >= n_item_ids) continue;
+          *reinterpret_cast<f32x4*>(out + r * dim + c) = v[u];
+          const int64_t b = r / window_len;
+          const int l = (int)(r - b * window_len);
+          if (l < seq_len) {
+            const f32x4 p = *reinterpret_cast<const f32x4*>(pos + (int64_t)l * dim + c);
+            *reinterpret_cast<f32x4*>(x_out + (b * seq_len + l) * dim + c) = v[u] + p;
+          }
+        }
+      }
+    }
+    return;
+  }
+  const int64_t n_neg = n_ids - n_item_ids;
+  const int64_t wave0 = (int64_t)((int)blockIdx.x - grid_items) * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t n_waves = (int64_t)((int)gridDim.x - grid_items) * 4;
+  constexpr int U = 2;                                     // rows in flight per wave
+  for (int64_t r0 = wave0 * U; r0 < n_neg; r0 += n_waves * U) {
+    f32x4 v[U][NC];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int64_t id = r0 + u < n_neg ? ids[n_item_ids + r0 + u] : 0;
+      if (id < 0 || id >= n_rows) {
+        if (lane == 0) atomicAdd(&g_bad_ids, 1u);
+        id = id < 0 ? 0 : n_rows - 1;
+      }
+#pragma unroll
+      for (int i = 0; i < NC; ++i) {
+        const int c = lane * 4 + i * 256;
+        v[u][i] = c < dim ? *reinterpret_cast<const f32x4*>(table + id * dim + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (r0 + u >= n_neg) continue;
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < NC; ++i)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s += v[u][i][k] * v[u][i][k];
+      const float nrm = sqrtf(wave_sum(s));
+      const float inv = 1.0f / nrm;
+#pragma unroll
+      for (int i = 0; i < NC; ++i) {
+        const int c = lane * 4 + i * 256;
+        if (c < dim) {
+          f32x4 y = {v[u][i][0] * inv, v[u][i][1] * inv, v[u][i][2] * inv, v[u][i][3] * inv};
+          Vec4IO<bf16_t>::store(neg_out + (r0 + u) * dim + c, y);
+        }
+      }
+      if (lane == 0) neg_norms[r0 + u] = nrm;
+    }
+  }
+}
+
+extern "C" int mhr_embedding_gather_step(const float* table, int64_t n_rows, int dim, const int64_t* ids, int64_t n_ids,
+                                         int64_t n_item_ids, float* rows_out, const float* pos_table, int seq_len, int window_len,
+                                         float* x_out, void* neg_out, float* neg_norms, void* stream) {
+  MHR_REQUIRE(table && ids && rows_out && pos_table && x_out, "embedding_gather_step: null pointer");
+  MHR_REQUIRE(dim > 0 && dim % 4 == 0 && dim <= 2048, "embedding_gather_step: dim=%d unsupported (multiple of 4, <= 2048)", dim);
+  MHR_REQUIRE(n_rows > 0 && n_item_ids >= 0 && n_ids >= n_item_ids && window_len > 0 && seq_len > 0 && seq_len <= window_len &&
+              n_item_ids % window_len == 0, "embedding_gather_step: bad sizes (n_ids=%lld n_item_ids=%lld window=%d seq=%d)",
+              (long long)n_ids, (long long)n_item_ids, window_len, seq_len);
+  MHR_REQUIRE(n_ids == n_item_ids || (neg_out && neg_norms), "embedding_gather_step: negative ids without neg_out / neg_norms");
+  if (n_ids == 0) return MHR_OK;
+  const int grid_items = n_item_ids ? mhr_grid_for(n_item_ids, 16) : 0;
+  const int grid_negs = n_ids > n_item_ids ? mhr_grid_for(n_ids - n_item_ids, 8) : 0;
+  hipStream_t s = (hipStream_t)stream;
+#define LG(NC)                                                                                                              \
+  hipLaunchKernelGGL((gather_step_kernel<NC>), dim3(grid_items + grid_negs), dim3(256), 0, s, table, n_rows, dim, ids, n_ids, \
+                     n_item_ids, rows_out, pos_table, seq_len, window_len, x_out, (bf16_t*)neg_out, neg_norms, grid_items)
+  const int nc = (dim + 255) / 256;
+  if (nc <= 1) LG(1);
+  else if (nc <= 2) LG(2);
+  else if (nc <= 4) LG(4);
+  else LG(8);
+#undef LG
+  MHR_CHECK_LAUNCH("embedding_gather_step");
+  return MHR_OK;
+}
+
+unsigned int* mhr_bad_id_counter_addr() {
+  static unsigned int* addr = nullptr;
+  if (!addr && hipGetSymbolAddress((void**)&addr, HIP_SYMBOL(g_bad_ids)) != hipSuccess) addr = nullptr;
+  return addr;
+}
+
 extern "C" int mhr_bad_id_count(int64_t* host_count, int reset) {
   MHR_REQUIRE(host_count, "bad_id_count: null pointer");
   unsigned int c = 0;

@@ -43,6 +43,10 @@ static inline int mhr_grid_for(int64_t work_items, int per_block, int max_blocks
   return (int)b;
 }
 
+// device address of the counter of item ids outside [0, n_rows) that the gather kernels met (csrc/embedding.hip; read by
+// mhr_bad_id_count): kernels of other translation units that index the item table count into it too
+unsigned int* mhr_bad_id_counter_addr();
+
 // ---- device helpers ----------------------------------------------------------------------
 __device__ __forceinline__ float bf2f(bf16_t x) { return (float)x; }
 __device__ __forceinline__ bf16_t f2bf(float x) { return (bf16_t)x; }   // v_cvt_pk_bf16_f32: RNE, NaN stays NaN

@@ -649,6 +649,61 @@ __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict
   }
 }
 
+// The backward reading its rows THROUGH an id list: x[r] = table[ids[r]] - the negative pools of a training step are
+// gathered AND normalised by mhr_embedding_gather_step (csrc/embedding.hip; reference hstu.py:670-672, 752-754) without an
+// fp32 copy of the gathered rows, so the backward re-reads them from the table (no optimizer step lies between a step's
+// forward and backward).  Same arithmetic in the same order as l2norm_bwd_kernel.  Ids outside [0, n_src) are clamped (the
+// forward counted them).
+__device__ __forceinline__ int64_t clamp_count_id(int64_t v, int64_t n_src, int lane, unsigned int* __restrict__ bad) {
+  if (v < 0 || v >= n_src) {
+    if (lane == 0 && bad) atomicAdd(bad, 1u);
+    v = v < 0 ? 0 : n_src - 1;
+  }
+  return v;
+}
+
+template <int NC>
+__global__ __launch_bounds__(256) void l2norm_indexed_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ table,
+                                                                 int64_t n_src, const int64_t* __restrict__ ids,
+                                                                 const float* __restrict__ norms, float* __restrict__ dx,
+                                                                 int64_t rows, int dim) {
+  WAVE_ROW_LOOP(rows) {
+    const int64_t src = clamp_count_id(ids[row], n_src, lane, nullptr);
+    RowRegs<NC> rx, rg;
+    load_row<float, NC>(table + src * dim, dim, lane, rx);
+    load_row<float, NC>(dy + row * dim, dim, lane, rg);
+    const float inv = 1.0f / norms[row];
+    float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; ++i)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        rx.v[i][k] *= inv;
+        dot += rx.v[i][k] * rg.v[i][k];
+      }
+    dot = wave_sum(dot);
+#pragma unroll
+    for (int i = 0; i < NC; ++i)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) rg.v[i][k] = (rg.v[i][k] - rx.v[i][k] * dot) * inv;
+    store_row<float, NC>(dx + row * dim, dim, lane, rg);
+  }
+}
+
+extern "C" int mhr_l2norm_rows_indexed_bwd(const float* dy, const float* table, int64_t n_src_rows, const int64_t* ids,
+                                           const float* norms, float* dx, int64_t rows, int dim, void* stream) {
+  MHR_REQUIRE(dy && table && ids && norms && dx, "l2norm_rows_indexed_bwd: null pointer");
+  MHR_REQUIRE(dim > 0 && dim % 4 == 0 && dim <= 2048 && n_src_rows > 0, "l2norm_rows_indexed_bwd: dim=%d unsupported", dim);
+  if (rows == 0) return MHR_OK;
+  hipStream_t s = (hipStream_t)stream;
+  int grid = mhr_grid_for(rows, 4);
+#define LIB(NC) hipLaunchKernelGGL((l2norm_indexed_bwd_kernel<NC>), dim3(grid), dim3(256), 0, s, dy, table, n_src_rows, ids, norms, dx, rows, dim)
+  DISPATCH_NC(dim, LIB);
+#undef LIB
+  MHR_CHECK_LAUNCH("l2norm_rows_indexed_bwd");
+  return MHR_OK;
+}
+
 extern "C" int mhr_l2norm_rows_bwd(const float* dy, const float* x, const float* norms, float* dx, int64_t rows, int dim,
                                    void* stream) {
   MHR_REQUIRE(dy && x && norms && dx, "l2norm_rows_bwd: null pointer");

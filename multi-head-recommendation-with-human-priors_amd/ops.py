@@ -327,6 +327,37 @@ def l2norm_rows_bwd(dy, x, norms):
     return dx
 
 
+def embedding_gather_step(table, pos_table, ids_all, n_item_ids, seq_len, window):
+    """One launch for a training step's table reads: item windows -> (rows fp32 [n_item_ids, D], x fp32 [B, seq_len, D] with the
+    position add); negative-pool ids -> (normalised bf16 rows [n_neg, D], norms fp32 [n_neg])."""
+    _chk(table, "table", torch.float32)
+    _chk(pos_table, "pos_table", torch.float32)
+    _chk(ids_all, "ids_all", torch.int64)
+    D = table.shape[1]
+    dev = table.device
+    n = ids_all.numel()
+    n_neg = n - n_item_ids
+    rows = torch.empty(n_item_ids, D, dtype=torch.float32, device=dev)
+    x = torch.empty(n_item_ids // window, seq_len, D, dtype=torch.float32, device=dev)
+    negs = torch.empty(n_neg, D, dtype=torch.bfloat16, device=dev)
+    norms = torch.empty(n_neg, dtype=torch.float32, device=dev)
+    _timed_call("mhr_embedding_gather_step", table.data_ptr(), table.shape[0], D, ids_all.data_ptr(), n, n_item_ids, rows.data_ptr(),
+                pos_table.data_ptr(), seq_len, window, x.data_ptr(), negs.data_ptr(), norms.data_ptr(), _stream())
+    return rows, x, negs, norms
+
+
+def l2norm_rows_indexed_bwd(dy, table, ids, norms):
+    """dx of y = table[ids] / |table[ids]| w.r.t. the gathered rows (fp32 [n, D]); the rows are re-read from the table."""
+    _chk(dy, "dy", torch.float32)
+    _chk(table, "table", torch.float32)
+    _chk(ids, "ids", torch.int64)
+    D = table.shape[1]
+    dx = torch.empty(ids.numel(), D, dtype=torch.float32, device=table.device)
+    lib.call("mhr_l2norm_rows_indexed_bwd", dy.data_ptr(), table.data_ptr(), table.shape[0], ids.data_ptr(), norms.data_ptr(),
+             dx.data_ptr(), ids.numel(), D, _stream())
+    return dx
+
+
 # ------------------------------------------------------------------------------------------------
 # attention
 # ------------------------------------------------------------------------------------------------

@@ -66,7 +66,7 @@ def _oracle_weights(model):
     return HO.tie_repeated_resblocks(w), params
 
 
-def _train_step_vs_mixed_oracle(model, ocfg, batch, tag, grad_tol=1.5e-2, min_cos=0.999):
+def _train_step_vs_mixed_oracle(model, ocfg, batch, tag, grad_tol=1.5e-2, min_cos=0.999, table_tol=8e-3):
     model.train()
     w, params = _oracle_weights(model)
     HO.MIXED = bf16_round
@@ -103,7 +103,7 @@ def _train_step_vs_mixed_oracle(model, ocfg, batch, tag, grad_tol=1.5e-2, min_co
     terr = float((dense - gref).abs().max()) / float(gref.abs().max())
     print(f"[{tag}] loss {got:.6f} vs oracle {want:.6f} (rel {abs(got - want) / abs(want):.2e}); worst dense-grad err {worst:.2e}, "
           f"table-grad err {terr:.2e}")
-    assert terr < 8e-3, (tag, terr)
+    assert terr < table_tol, (tag, terr)
     model.zero_grad()
     model.sparse_grad = None
 
@@ -202,7 +202,9 @@ def test_cfg1_assembled_train_step_vs_mixed_oracle(rec):
     # GEMM as bf16, and that rounding noise accumulates towards the input.  Measured at this shape: max-element error 1.2e-2
     # (layer 7) ... 3.2e-2 (layers 0-1, position table), mean error <= 6e-3, cosine with the oracle's gradient >= 0.9996 for
     # every parameter (heads 6e-3 / 0.99996).  Two layers (cfg0, the golden fixtures) stay inside 1.5e-2.
-    _train_step_vs_mixed_oracle(model, ocfg, batch, "cfg1", grad_tol=5e-2, min_cos=0.999)
+    # (the item table's gradient rows carry the encoder-input gradient of their positions - the deepest point of the chain:
+    # 1.7e-2 of the max measured, 4.5e-4 at cfg0's two layers)
+    _train_step_vs_mixed_oracle(model, ocfg, batch, "cfg1", grad_tol=5e-2, min_cos=0.999, table_tol=4e-2)
 
 
 def test_cfg1_eval_batch_vs_oracle_decode(rec):

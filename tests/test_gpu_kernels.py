@@ -62,6 +62,43 @@ def test_gather_and_pos(ops):
 
 
 
+@pytest.mark.parametrize("D,B,L,P,n_neg", [(256, 7, 20, 3, 1000), (64, 5, 50, 1, 333), (1024, 2, 6, 2, 61), (16, 3, 8, 1, 9)])
+def test_gather_step_is_gather_plus_l2norm_bitwise(ops, D, B, L, P, n_neg):
+    """mhr_embedding_gather_step - item windows (fp32 rows + position-added x) and negative pools (gathered AND L2-normalised
+    to bf16, no fp32 copy) in ONE launch (reference hstu.py:637-643, 670-672, 752-754) - gives bit for bit what the two-step
+    path gives (gather, then mhr_l2norm_rows), and the indexed backward what mhr_l2norm_rows_bwd gives on the gathered rows;
+    out-of-range ids are clamped and counted on both halves."""
+    g = torch.Generator().manual_seed(D + n_neg)
+    N = 3000
+    table = torch.randn(N, D, generator=g) * 0.02
+    pos = torch.randn(L + 1, D, generator=g)
+    items = torch.randint(0, N, (B, L + P), generator=g)
+    negs = torch.randint(0, N, (n_neg,), generator=g)
+    ids_all = torch.cat([items.flatten(), negs])
+    n_item = items.numel()
+    rows, x, yn, norms = ops.embedding_gather_step(dev(table), dev(pos), dev(ids_all), n_item, L, L + P)
+    torch.cuda.synchronize()
+    assert torch.equal(rows.cpu(), table[items.flatten()])
+    assert torch.equal(x.cpu(), table[items[:, :L]] + pos[:L][None])
+    rows_n, _ = ops.embedding_gather(dev(table), dev(negs), torch.float32)
+    y2, n2 = ops.l2norm_rows(rows_n, torch.bfloat16, want_norms=True)
+    assert torch.equal(yn, y2) and torch.equal(norms, n2)
+    ref = table[negs].double()
+    assert rel_err(yn.float().cpu().double(), ref / ref.norm(dim=1, keepdim=True)) < 2 ** -8
+    dy = dev(torch.randn(n_neg, D, generator=g))
+    dx = ops.l2norm_rows_indexed_bwd(dy, dev(table), dev(negs), norms)
+    dx2 = ops.l2norm_rows_bwd(dy, rows_n, n2)
+    assert torch.equal(dx, dx2)
+    # ids outside the table: clamped and counted, items and negatives alike
+    ops.bad_id_count()
+    bad = ids_all.clone()
+    bad[1], bad[n_item + 2] = N + 5, -3
+    rows_b, _, yn_b, _ = ops.embedding_gather_step(dev(table), dev(pos), dev(bad), n_item, L, L + P)
+    torch.cuda.synchronize()
+    assert ops.bad_id_count() == 2
+    assert torch.equal(rows_b.cpu()[1], table[N - 1]) and torch.equal(yn_b[n_item - n_item + 2], ops.l2norm_rows(dev(table[0:1].contiguous()), torch.bfloat16)[0])
+
+
 def test_gather_counts_ids_outside_the_table(ops):
     """nn.Embedding raises on an id outside [0, N) (reference hstu.py:413, 637); the gather kernel clamps, counts, and the
     host asks where it synchronises anyway (Trainer._check_nan raises IndexError)."""
