@@ -591,6 +591,22 @@ int mhr_catalog_score_emit_wide(const void* users_packed, int n_rows, const void
                                 const float* tau, float* cand_val, int32_t* cand_idx, int32_t* cand_cnt, int n_slices,
                                 int cap_s, void* stream);
 int mhr_catalog_wide_slices(int n_rows);
+
+/* Workspace queries (host functions, no launch).  The library allocates nothing: every entry point takes its operands, outputs
+ * and scratch as caller-owned buffers whose shapes are stated with the declaration.  The only scratch whose SIZE depends on a
+ * choice made inside the library is the scorers' candidate lists (how the item tiles are split into slices); these return the
+ * total bytes of (cand_val f32, cand_idx i32, cand_cnt i32) for a launch - lay them out in that order:
+ *   mhr_catalog_emit_slices(n_rows, n_sel_items)            n_slices to pass to mhr_catalog_score_emit_sliced
+ *                                                           (n_sel_items = items the pass scores: ceil((n_items - begin) / stride))
+ *   ..._emit_sliced_workspace_bytes(n_rows, n_sel_items, cap_s)   2 n_slices lists of cap_s slots per row
+ *   ..._emit_wide_workspace_bytes(n_rows, cap_s)                  4 mhr_catalog_wide_slices(n_rows) lists of cap_s slots per row
+ *   ..._emit_workspace_bytes(n_rows, cap)                         one list of cap slots per row
+ *   ..._rows_dense_workspace_bytes(n_list, n_items)               one slot per (listed row, item) */
+int mhr_catalog_emit_slices(int n_rows, int64_t n_sel_items);
+int64_t mhr_catalog_score_emit_sliced_workspace_bytes(int n_rows, int64_t n_sel_items, int cap_s);
+int64_t mhr_catalog_score_emit_wide_workspace_bytes(int n_rows, int cap_s);
+int64_t mhr_catalog_score_emit_workspace_bytes(int n_rows, int cap);
+int64_t mhr_catalog_score_rows_dense_workspace_bytes(int n_list, int64_t n_items);
 /* Rows {row_begin + j * row_stride, j < n_sel} of x [n_rows, dim] bf16 (dim % 64 == 0) -> packed tile images
  * [ceil(n_sel / (32 tiles_per_block))][dim / 64][tiles_per_block][4096 B] (32 rows x 64 features each, XOR-swizzled like
  * the LDS tiles; rows past n_sel / n_rows are zero).  out: mhr_pack_tiles_bytes(n_sel, dim, tiles_per_block) bytes. */

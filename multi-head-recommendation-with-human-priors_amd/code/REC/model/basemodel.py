@@ -29,7 +29,10 @@ def all_gather_ids(ids, group=None):
     if _world() > 1:
         ids = ids.contiguous()
         out = torch.empty((_world(),) + tuple(ids.shape), dtype=ids.dtype, device=ids.device)
-        dist.all_gather_into_tensor(out.view(-1), ids.view(-1), group=group)      # straight into the stacked output (RCCL and gloo alike)
+        dst, src = out.view(-1), ids.view(-1)
+        # straight into the stacked output (RCCL and gloo alike); under the Trainer's step capture a host call of the replay plan
+        from mhr_amd import distributed as D
+        D.run_collective(lambda: dist.all_gather_into_tensor(dst, src, group=group))
         return out
     return ids.unsqueeze(0)
 

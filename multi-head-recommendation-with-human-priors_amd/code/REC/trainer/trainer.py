@@ -78,6 +78,14 @@ class _GraphSegments:
         self.plan.append(("join", None))
         self._open()
 
+    def host_call(self, fn):
+        """Work the HOST must issue at this point of every replay (a collective of the data-parallel exchange,
+        mhr_amd.distributed.Handle): the running segment ends here, fn is recorded, the next segment begins.  fn is NOT run
+        now - a capture executes nothing; every rank captures the same step, so nobody waits for a collective that never comes."""
+        self._close()
+        self.plan.append(("host", fn))
+        self._open()
+
     def end(self):
         try:
             if self.cur is not None:
@@ -92,6 +100,8 @@ class _GraphSegments:
         for kind, g in self.plan:
             if kind == "main":
                 g.replay()
+            elif kind == "host":
+                g()
             elif kind == "side":
                 self.ev_fork.record(cur)
                 self.side.wait_event(self.ev_fork)
@@ -140,11 +150,20 @@ class _StepGraph:
         gc_was = gc.isenabled()
         gc.disable()
         try:
+            from mhr_amd import distributed as D
             model._graph_segments = graph
             graph.begin()
+            D.CAPTURE = graph if tr.world > 1 else None    # data parallel: collectives become host calls of the replay plan
+            # a host call ends the running capture and begins the next - legal only on the thread that began it, and the
+            # autograd engine runs a device's backward nodes on a worker thread of its own: data-parallel captures (whose
+            # backward starts the shared-negative all-reduce) keep the backward on this thread
+            import contextlib
+            same_thread = torch.autograd.set_multithreading_enabled(False) if tr.world > 1 else contextlib.nullcontext()
             try:
-                out = tr._eager_step(self.static)
+                with same_thread:
+                    out = tr._eager_step(self.static)
             finally:
+                D.CAPTURE = None
                 graph.end()
         finally:
             model._graph_segments = None
@@ -296,7 +315,8 @@ class Trainer(object):
     def _graph_ok(self, data):
         m = self.model
         return (self.config.get("hip_graph", True) and os.environ.get("MHR_HIP_GRAPH", "1") != "0"
-                and self.accumulate_grad == 1 and self.world == 1 and getattr(m, "graph_capable", False)
+                and self.accumulate_grad == 1 and (self.world == 1 or os.environ.get("MHR_DP_GRAPH", "1") != "0")
+                and getattr(m, "graph_capable", False)
                 and self.optimizer.graph_capable() and isinstance(data, (tuple, list))
                 and all(torch.is_tensor(t) and t.is_cuda for t in data) and m.training
                 and not getattr(m, "dense_embedding_grad", False) and not getattr(self, "_graph_failed", False))

@@ -781,6 +781,29 @@ extern "C" int mhr_catalog_score_emit_sliced(const void* users, int n_rows, cons
   return MHR_OK;
 }
 
+// Workspace queries (SURVEY.md 8b contract: no allocation inside, sizes queried): the scorers' candidate lists are the only
+// caller-provided scratch whose size depends on a choice made here (how the item tiles are split into slices).
+extern "C" int mhr_catalog_emit_slices(int n_rows, int64_t n_sel_items) {
+  // about 512 workgroups (2 per CU), a multiple of 8 (one slice group per XCD), never more slices than item tiles
+  const int64_t n_tiles = (n_sel_items + 31) / 32;
+  const int R = (n_rows + 255) / 256;
+  int SL = 64 / (R < 1 ? 1 : R);
+  if (SL < 1) SL = 1;
+  while (SL > 1 && 8 * (int64_t)(SL - 1) >= n_tiles) --SL;
+  return 8 * SL;
+}
+
+extern "C" int64_t mhr_catalog_score_emit_sliced_workspace_bytes(int n_rows, int64_t n_sel_items, int cap_s) {
+  if (n_rows <= 0 || n_sel_items <= 0 || cap_s <= 0) return 0;
+  const int64_t lists = (int64_t)n_rows * 2 * mhr_catalog_emit_slices(n_rows, n_sel_items);
+  return lists * cap_s * 8 + lists * 4;                     // cand_val f32 + cand_idx i32 per slot, cand_cnt i32 per list
+}
+
+extern "C" int64_t mhr_catalog_score_emit_workspace_bytes(int n_rows, int cap) {
+  if (n_rows <= 0 || cap <= 0) return 0;
+  return (int64_t)n_rows * cap * 8 + (int64_t)n_rows * 4;  // one list per row (cand_cnt must be zeroed by the caller)
+}
+
 extern "C" int mhr_topk_select_sliced(const float* cand_val, const int32_t* cand_idx, const int32_t* cand_cnt, int n_slices,
                                       int cap_s, int n_rows, int H, const int32_t* hist_ptr, const int64_t* hist_items, int k,
                                       float* out_val, int64_t* out_idx, float* kth_val, int32_t* count_out, int32_t* status,

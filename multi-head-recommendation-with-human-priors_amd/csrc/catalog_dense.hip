@@ -111,3 +111,8 @@ extern "C" int mhr_catalog_score_rows_dense(const void* users, const void* items
   MHR_CHECK_LAUNCH("catalog_score_rows_dense");
   return MHR_OK;
 }
+
+extern "C" int64_t mhr_catalog_score_rows_dense_workspace_bytes(int n_list, int64_t n_items) {
+  if (n_list <= 0 || n_items <= 0) return 0;
+  return (int64_t)n_list * n_items * 8 + (int64_t)n_list * 4;   // out_val f32 + out_idx i32 per (row, item), out_cnt i32 per row
+}

@@ -271,6 +271,13 @@ extern "C" int mhr_pack_tiles(const void* x, int64_t n_rows, int dim, int64_t ro
   return MHR_OK;
 }
 
+extern "C" int mhr_catalog_wide_slices(int n_rows);
+extern "C" int64_t mhr_catalog_score_emit_wide_workspace_bytes(int n_rows, int cap_s) {
+  if (n_rows <= 0 || cap_s <= 0) return 0;
+  const int64_t lists = (int64_t)n_rows * 4 * mhr_catalog_wide_slices(n_rows);
+  return lists * cap_s * 8 + lists * 4;
+}
+
 extern "C" int mhr_catalog_wide_slices(int n_rows) {
   const int R = (n_rows + 127) / 128;
   int U = 1;

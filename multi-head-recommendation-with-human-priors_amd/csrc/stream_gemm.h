@@ -120,14 +120,7 @@ struct LaneAddr {
     }
   }
   __device__ __forceinline__ bf16x8 read_a(const unsigned char* tile, int ks) const {
-#ifdef EXP_NOSREAD
-    u32x4_t c;   // volatile moves: not hoistable, so the register pressure matches the real kernel
-    asm volatile("v_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %4\n\tv_mov_b32 %3, %5"
-                 : "=&v"(c.x), "=&v"(c.y), "=&v"(c.z), "=&v"(c.w) : "v"(a[ks & 7]), "v"(t[0][ks & 3]));
-    return __builtin_bit_cast(bf16x8, c);
-#else
     return *reinterpret_cast<const bf16x8*>(tile + a[ks & 7] + 256 * (ks >> 3));
-#endif
   }
   // Transposed fragment straight from the row-major swizzled tile with ds_read_b64_tr_b16 (cdna guide T10): the
   // B operand of a product that sums over the ROW index of an accumulator tile (rows = this tile's 32 rows):
@@ -404,23 +397,17 @@ __device__ __forceinline__ void mma_tile_tr_asm(const TrAddr<NKS>& ta, bf16x8 g0
     constexpr int dc = decltype(dc_c)::value;
     constexpr int imm = OFF + 256 * (dc >> 2), s1 = 16 * T::ROW_BYTES;
     u32x2* q = r[dc % (P + 1)];
-#ifdef EXP_NOTR
-    q[0] = q[1] = q[2] = q[3] = u32x2{ta.t[0][dc & 3], ta.t[1][dc & 3]};
-#else
     q[0] = ds_read_tr_asm<imm>(ta.t[0][dc & 3]);
     q[1] = ds_read_tr_asm<imm>(ta.t[1][dc & 3]);
     q[2] = ds_read_tr_asm<imm + s1>(ta.t[0][dc & 3]);
     q[3] = ds_read_tr_asm<imm + s1>(ta.t[1][dc & 3]);
-#endif
   };
   auto step = [&](auto dc_c) {
     constexpr int dc = decltype(dc_c)::value;
     if constexpr (dc + P < ND) issue(std::integral_constant<int, dc + P>{});
     constexpr int ahead = (ND - 1 - dc) < P ? (ND - 1 - dc) : P;     // chunks issued after this one
     u32x2* q = r[dc % (P + 1)];
-#ifndef EXP_NOTRWAIT
     wait_lgkm<4 * ahead>(q[0], q[1], q[2], q[3]);
-#endif
     const u32x4 b0 = {q[0].x, q[0].y, q[1].x, q[1].y}, b1 = {q[2].x, q[2].y, q[3].x, q[3].y};
     out[dc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g0, __builtin_bit_cast(bf16x8, b0), out[dc], 0, 0, 0);
     out[dc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g1, __builtin_bit_cast(bf16x8, b1), out[dc], 0, 0, 0);
@@ -442,18 +429,6 @@ __device__ __forceinline__ void mma_tile_tr_asm(const TrAddr<NKS>& ta, bf16x8 g0
 // overlaps the LDS latency).  `pack(g0, g1)` converts the finished epilogue into the two A fragments of G(t-1).
 // LDS return order is issue order, so `s_waitcnt lgkmcnt(n)` with n = reads issued after the one needed is exact.
 // ---------------------------------------------------------------------------------------------------------
-#ifdef EXP_NOLDS
-__device__ __forceinline__ u32x4 exp_mov4(uint32_t addr) {
-  u32x4 v;
-  asm volatile("v_mov_b32 %0, %4\n\tv_mov_b32 %1, %4\n\tv_mov_b32 %2, %4\n\tv_mov_b32 %3, %4" : "=&v"(v.x), "=&v"(v.y), "=&v"(v.z), "=&v"(v.w) : "v"(addr));
-  return v;
-}
-__device__ __forceinline__ u32x2 exp_mov2(uint32_t addr) {
-  u32x2 v;
-  asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %2" : "=&v"(v.x), "=&v"(v.y) : "v"(addr));
-  return v;
-}
-#endif
 template <int IMM>
 __device__ __forceinline__ u32x4 ds_read_b128_asm(uint32_t addr) {
   static_assert(IMM >= 0 && IMM < 65536, "LDS offset field is 16 bits");
@@ -567,23 +542,14 @@ __device__ __forceinline__ void tile_step_split(const RowAddr<NKS>& ra, const Tr
   float even = 0.f;
   auto issue_a = [&](auto ks_c) {
     constexpr int ks = decltype(ks_c)::value;
-#ifdef EXP_NOLDS
-    a[ks % (PA + 1)] = exp_mov4(ra.a[ks & 7]);
-#else
     a[ks % (PA + 1)] = ds_read_b128_asm<OFF_CUR + 256 * (ks >> 3)>(ra.a[ks & 7]);
-#endif
   };
   auto issue_t = [&](auto c_c) {
     constexpr int c = decltype(c_c)::value, dc = c % ND, sw = c / ND;
     constexpr int imm = OFF_PRV + 256 * (dc >> 2) + sw * 16 * T::ROW_BYTES;
     u32x2* q = r[c % (PT + 1)];
-#ifdef EXP_NOLDS
-    q[0] = exp_mov2(ta.t[0][dc & 3]);
-    q[1] = exp_mov2(ta.t[1][dc & 3]);
-#else
     q[0] = ds_read_tr_asm<imm>(ta.t[0][dc & 3]);
     q[1] = ds_read_tr_asm<imm>(ta.t[1][dc & 3]);
-#endif
   };
   auto element = [&](int e) {
     const float g = epi(e);
@@ -796,27 +762,16 @@ __device__ __forceinline__ void tile_step(const RowAddr<NKS>& ra, const TrAddr<N
   float even = 0.f;
   auto issue_a = [&](auto ks_c) {
     constexpr int ks = decltype(ks_c)::value;
-#ifdef EXP_NOLDS   // experiment: no LDS traffic from the tile step (values are garbage; timing only)
-    a[ks % (PA + 1)] = exp_mov4(ra.a[ks & 7]);
-#else
     a[ks % (PA + 1)] = ds_read_b128_asm<OFF_CUR + 256 * (ks >> 3)>(ra.a[ks & 7]);
-#endif
   };
   auto issue_t = [&](auto dc_c) {
     constexpr int dc = decltype(dc_c)::value;
     constexpr int imm = OFF_PRV + 256 * (dc >> 2), s1 = 16 * T::ROW_BYTES;
     u32x2* q = r[dc % (PT + 1)];
-#ifdef EXP_NOLDS
-    q[0] = exp_mov2(ta.t[0][dc & 3]);
-    q[1] = exp_mov2(ta.t[1][dc & 3]);
-    q[2] = exp_mov2(ta.t[0][dc & 3]);
-    q[3] = exp_mov2(ta.t[1][dc & 3]);
-#else
     q[0] = ds_read_tr_asm<imm>(ta.t[0][dc & 3]);
     q[1] = ds_read_tr_asm<imm>(ta.t[1][dc & 3]);
     q[2] = ds_read_tr_asm<imm + s1>(ta.t[0][dc & 3]);
     q[3] = ds_read_tr_asm<imm + s1>(ta.t[1][dc & 3]);
-#endif
   };
   static_for<PA>(issue_a);
   ready(std::integral_constant<int, PA>{});

@@ -26,6 +26,66 @@ OVERLAP = os.environ.get("MHR_DP_OVERLAP", "1") != "0"
 ROWS_WIRE_DTYPE = torch.float32 if os.environ.get("MHR_DP_WIRE", "bf16") == "fp32" else torch.bfloat16
 
 
+# While the Trainer captures a step as a sequence of hipGraphs (REC/trainer/trainer.py:_GraphSegments) this is that object:
+# a collective is then not issued but recorded as a HOST CALL of the replay plan - the running graph segment is closed in front
+# of it, the next one opened behind it - and so is every `wait()` on its handle.  A replayed data-parallel step is therefore
+# graph, collective, graph, ..., each graph one cheap launch, the collectives issued by the host exactly where the host-issued
+# step issues them (same order, same overlap).  The tensors a recorded collective touches live in the capture's memory pool:
+# the same addresses at every replay.
+CAPTURE = None
+
+
+class Handle:
+    """Work handle of an asynchronous collective.  `wait()` orders the CURRENT stream behind the collective without blocking the
+    host (RCCL); under capture both the issue and the wait become host calls of the replay plan."""
+
+    def __init__(self, issue, start=True):
+        self._issue, self._work = issue, None
+        if not start:
+            return
+        if CAPTURE is not None:
+            CAPTURE.host_call(self._start)
+        else:
+            self._start()
+
+    @staticmethod
+    def group(issues):
+        """Handles of several collectives issued back to back: ONE host call of a replay plan starts them all (each keeps its
+        own wait)."""
+        hs = [Handle(fn, start=False) for fn in issues]
+
+        def start_all():
+            for h in hs:
+                h._start()
+        if CAPTURE is not None:
+            CAPTURE.host_call(start_all)
+        else:
+            start_all()
+        return hs
+
+    def _start(self):
+        self._work = self._issue()
+
+    def _wait_now(self):
+        w, self._work = self._work, None
+        if w is not None:
+            w.wait()
+
+    def wait(self):
+        if CAPTURE is not None:
+            CAPTURE.host_call(self._wait_now)
+        else:
+            self._wait_now()
+
+
+def run_collective(fn):
+    """A blocking-style collective (the current stream is ordered behind it when fn returns): a host call under capture."""
+    if CAPTURE is not None:
+        CAPTURE.host_call(fn)
+    else:
+        fn()
+
+
 def world_size():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
@@ -48,7 +108,7 @@ def allreduce_sum_begin(t):
     kernels launched in between overlap it.  Nobody may touch `t` until then."""
     if world_size() == 1:
         return None
-    return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)
+    return Handle(lambda: dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True))
 
 
 class RowExchange:
@@ -96,7 +156,8 @@ def begin_row_exchange(ids_all, d_rows, n_private, wire_dtype=None, shared_pendi
     ids_out[W * n_private:] = shared_ids
     # gathers go straight into the output (no per-rank list + concatenation); gloo implements all_gather_into_tensor too, so
     # the two-rank CPU / one-card tests run exactly the layout and wait-ordering code that ships over RCCL
-    w_ids = [dist.all_gather_into_tensor(ids_out[:W * n_private], priv_ids, async_op=True)]
+    ids_dst, rows_dst, rows_src = ids_out[:W * n_private], rows_priv.view(-1), priv_rows.view(-1)
+    issues = [lambda: dist.all_gather_into_tensor(ids_dst, priv_ids, async_op=True)]
     w_rows = []
     if shared_pending is not None:
         shared_rows, w_sh = shared_pending
@@ -105,9 +166,10 @@ def begin_row_exchange(ids_all, d_rows, n_private, wire_dtype=None, shared_pendi
     else:
         shared_rows = d_rows[n_private:].contiguous()
         if n_sh:
-            w_rows.append(dist.all_reduce(shared_rows, op=dist.ReduceOp.SUM, async_op=True))
-    w_rows.append(dist.all_gather_into_tensor(rows_priv.view(-1), priv_rows.view(-1), async_op=True))
-    return RowExchange(ids_out, rows_priv, shared_rows, w_ids, w_rows)
+            issues.append(lambda: dist.all_reduce(shared_rows, op=dist.ReduceOp.SUM, async_op=True))
+    issues.append(lambda: dist.all_gather_into_tensor(rows_dst, rows_src, async_op=True))
+    hs = Handle.group(issues)                                  # ids, [shared rows], private rows: issued in this order
+    return RowExchange(ids_out, rows_priv, shared_rows, hs[:1], w_rows + hs[1:])
 
 
 def exchange_sparse_rows(ids_all, d_rows, n_private, wire_dtype=None, shared_pending=None):

@@ -19,8 +19,10 @@ def _parse_header():
     with open(HEADER) as f:
         text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
     sigs = {}
-    for m in re.finditer(r"\b(?:int|int64_t)\s+(mhr_[a-z0-9_]+)\s*\(([^;]*?)\)\s*;", text, flags=re.S):
-        name, params = m.group(1), m.group(2).strip()
+    for m in re.finditer(r"\b(int|int64_t)\s+(mhr_[a-z0-9_]+)\s*\(([^;]*?)\)\s*;", text, flags=re.S):
+        name, params = m.group(2), m.group(3).strip()
+        if m.group(1) == "int64_t":
+            RETURNS_INT64.add(name)
         args = []
         if params and params != "void":
             for prm in params.split(","):
@@ -41,8 +43,8 @@ def _parse_header():
     return sigs
 
 
+RETURNS_INT64 = set()              # size queries (filled from the header: functions declared `int64_t mhr_...`)
 SIGNATURES = _parse_header()
-RETURNS_INT64 = {"mhr_pack_tiles_bytes"}
 
 
 def declared_symbols():

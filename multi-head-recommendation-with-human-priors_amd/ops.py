@@ -1011,12 +1011,9 @@ def topk_select(cand, cap, k):
 
 
 def _slices_for(n_rows, n_tiles):
-    """item slices of the sliced emit: about 512 workgroups (2 per CU), a multiple of 8 (one per XCD), <= n_tiles."""
-    R = (n_rows + 255) // 256
-    SL = max(1, 64 // R)
-    while SL > 1 and 8 * (SL - 1) >= n_tiles:
-        SL -= 1
-    return 8 * SL
+    """item slices of the sliced emit: about 512 workgroups (2 per CU), a multiple of 8 (one per XCD), <= n_tiles - decided by
+    the library (mhr_catalog_emit_slices; its workspace query sizes the candidate lists)."""
+    return int(lib.load().mhr_catalog_emit_slices(int(n_rows), int(n_tiles) * 32))
 
 
 def catalog_emit_sliced(users, items, n_items, tag_bits, row_bits, tau, cap_s, item_begin=0, item_stride=1):

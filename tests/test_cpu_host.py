@@ -40,6 +40,24 @@ def test_library_exports_every_declared_symbol(built_lib):
     assert rc == -1 and b"dim=48" in dll.mhr_last_error()
 
 
+def test_workspace_queries(built_lib):
+    """The C ABI's size queries are host functions (no launch): SURVEY.md 8b - the library allocates nothing, the caller sizes
+    the scorers' candidate lists from these."""
+    import mhr_amd.lib as L
+    dll = L.load()
+    # 1024 (user, head) rows over 453 938 items: 4 row tiles -> 16 slice groups x 8 XCDs = 128 slices, 2 lists per slice
+    assert dll.mhr_catalog_emit_slices(1024, 453938) == 128
+    assert dll.mhr_catalog_emit_slices(4, 453938) == 512 and dll.mhr_catalog_emit_slices(4, 100) == 8
+    cap_s = 48
+    assert dll.mhr_catalog_score_emit_sliced_workspace_bytes(1024, 453938, cap_s) == 1024 * 256 * (cap_s * 8 + 4)
+    nw = dll.mhr_catalog_wide_slices(4096)
+    assert dll.mhr_catalog_score_emit_wide_workspace_bytes(4096, 32) == 4096 * 4 * nw * (32 * 8 + 4)
+    assert dll.mhr_catalog_score_emit_workspace_bytes(64, 4096) == 64 * (4096 * 8 + 4)
+    assert dll.mhr_catalog_score_rows_dense_workspace_bytes(24, 453938) == 24 * (453938 * 8 + 4)
+    assert dll.mhr_catalog_score_emit_sliced_workspace_bytes(0, 10, 10) == 0
+    assert "mhr_pack_tiles_bytes" in L.RETURNS_INT64 and "mhr_catalog_score_rows_dense_workspace_bytes" in L.RETURNS_INT64
+
+
 def test_product_path_has_no_cpu_fallback(built_lib):
     import mhr_amd  # noqa: F401
     from mhr_amd import ops

@@ -679,6 +679,78 @@ def test_data_parallel_train_step_two_ranks_one_card(rec, tmp_path, overlap):
     assert (np.abs(r[0]["table_g"]).sum(1) > 0).sum() == (np.abs(want_table).sum(1) > 0).sum()   # same touched rows
 
 
+DP_GRAPH_SCRIPT = r'''
+import os, sys, time
+import numpy as np, torch, torch.distributed as dist
+root, code, out_dir, tag = sys.argv[1:5]
+sys.path.insert(0, root); sys.path.insert(0, code)
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+import mhr_amd.synth as synth
+from REC.config.configurator import Config, apply_run_fixups
+from REC.trainer import Trainer
+from REC.utils import get_model
+cfgd = synth.base_config(**eval(open(os.path.join(out_dir, "cfg.txt")).read()), device=dev)
+cfg = apply_run_fixups(Config(config_dict=cfgd))
+data = synth.SyntheticData(cfg, 3000, dev, seed=11, rank=rank, world=world)
+cfg["int_to_category"] = data.int_to_category
+torch.manual_seed(5)
+model = get_model("HSTU")(cfg, data).to(dev)
+tr = Trainer(cfg); tr.setup_model(model); tr.train_step = 30
+batches = [data.train_batch(8) for _ in range(4)]
+losses = []
+for i in range(12):
+    losses.append(float(tr.train_step_fn(batches[i % 4])["loss"]))
+model.sync_table()
+torch.cuda.synchronize()
+st = tr._step_graph
+plan = [k for k, _ in st.graph.plan] if (st is not None and st.graph is not None) else []
+np.savez(os.path.join(out_dir, f"{tag}{rank}.npz"), table=model.item_embedding.weight.detach().cpu().numpy(),
+         flat=tr.optimizer.flat_w.cpu().numpy(), losses=np.array(losses), graph_active=np.array(bool(tr.graph_active)),
+         replays=np.array(st.n if st is not None else 0), host_calls=np.array(sum(k == "host" for k in plan)))
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_data_parallel_steps_replay_from_graph_segments_around_the_exchange(rec, tmp_path):
+    """W = 2 (gloo ranks sharing the card): after three host-issued steps the data-parallel step is captured as hipGraph
+    segments with the collectives of the exchange as host calls between them (REC/trainer/trainer.py:_GraphSegments.host_call,
+    mhr_amd.distributed.Handle) - id all-gather in front of the gather, the shared-negative all-reduce from inside the backward,
+    bucket all-reduce + row exchange in front of the optimizer.  The replicas stay bitwise identical and the run is the run the
+    host-issued data-parallel steps make (MHR_DP_GRAPH=0), up to float-atomic noise (reference trainer.py:494-536)."""
+    import subprocess
+    kw = dict(MAX_ITEM_LIST_LENGTH=16, pred_len=2, eval_pred_len=2, n_layers=2, n_heads=2, item_embedding_size=64,
+              hstu_embedding_size=64, num_negatives=256, total_iters=100, eval_interval=0, checkpoint_dir=None,
+              save_model_note="t", hidden_dropout_prob=0.1, attn_dropout_prob=0.0, loss='prior', num_prior_head=3,
+              medusa_num_layers=1, eval_num_cats=3)
+    (tmp_path / "cfg.txt").write_text(repr(kw))
+    script = tmp_path / "dp_graph.py"
+    script.write_text(DP_GRAPH_SCRIPT)
+    res = {}
+    for tag, flag, port in (("graph", "1", 29651), ("host", "0", 29652)):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2", HSA_ENABLE_IPC_MODE_LEGACY="0",
+                   MHR_DP_GRAPH=flag)
+        procs = [subprocess.Popen([sys.executable, str(script), ROOT, CODE, str(tmp_path), tag], env=dict(env, RANK=str(r)),
+                                  stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+        outs = [p.communicate(timeout=600) for p in procs]
+        for p, (o, e) in zip(procs, outs):
+            assert p.returncode == 0, (tag, o[-2000:], e[-4000:])
+        res[tag] = [np.load(tmp_path / f"{tag}{i}.npz") for i in range(2)]
+    g, h = res["graph"], res["host"]
+    assert bool(g[0]["graph_active"]) and bool(g[1]["graph_active"]) and int(g[0]["replays"]) == 12 - 3
+    assert int(g[0]["host_calls"]) >= 5                                  # id gather, shared all-reduce, bucket, row exchange, waits
+    assert not bool(h[0]["graph_active"])
+    for r_ in (g, h):                                                   # replicas stay replicas, bit for bit
+        assert np.array_equal(r_[0]["table"], r_[1]["table"]) and np.array_equal(r_[0]["flat"], r_[1]["flat"])
+    np.testing.assert_allclose(g[0]["losses"][:6], h[0]["losses"][:6], rtol=2e-3)      # same masks, same schedule, same exchange
+    np.testing.assert_allclose(g[0]["losses"], h[0]["losses"], rtol=2e-2)
+    scale = np.abs(h[0]["flat"]).max()
+    assert np.abs(g[0]["flat"] - h[0]["flat"]).mean() <= 1e-3 * scale and np.abs(g[0]["flat"] - h[0]["flat"]).max() <= 0.1 * scale
+
+
 def test_gradient_accumulation_matches_separate_micro_batches(rec):
     """accumulate_grad = 2 (reference trainer.py:521-533): the gradient the optimizer sees after two micro-batches is the
     sum of the two halves' gradients - dense parameters in the flat buffer, item-table rows from ONE deferred reduction."""
