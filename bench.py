@@ -56,6 +56,9 @@ def parse(argv=None):
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the evented pass (per-kernel HIP events)")
     ap.add_argument("--no-graph", action="store_true", help="issue every launch from the host (no hipGraph replay of the step)")
     ap.add_argument("--event-steps", type=int, default=10, help="steps of the evented pass (outside the timed region)")
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="one GPU: time the table-side kernels of the optimizer step (id sort, row buffer, segment sum + fix-up, lazy row "
+                         "AdamW) on W ranks' worth of exchanged ids / rows - the part of a data-parallel step that does not shrink with W")
     return ap.parse_args(argv)
 
 
@@ -524,6 +527,50 @@ def main():
             return r
         return None
 
+    def emulate_world(Wem, iters=10):
+        """What every rank does with the exchanged gradient rows of W ranks (reference: the dense 116 M-parameter all-reduce +
+        FusedAdam of trainer.py:292-299, 532-536; here SURVEY 8e's sparse exchange): sort W x B (L + P) private ids + the shared
+        negative ids, zero the row buffer, segment-sum (bf16 private rows off the wire, fp32 shared block), lazy AdamW on the
+        touched rows.  Unmeasured on multi-GPU hardware: this is the same kernels on one card fed the W-rank id / row volume."""
+        opt = trainer.optimizer
+        B = cfg["train_batch_size"]
+        n_pools = C if (cfg["loss"] == "prior" and cfg.get("neg_sample_by_cat")) else 1
+        n_priv, n_sh = B * (L + P), n_pools * cfg["num_negatives"]
+        if model._row_slot is None:
+            model._row_slot = torch.full((N,), -1, dtype=torch.int32, device=dev)
+        res = {}
+        for w_ in sorted({1, Wem}):
+            ids = torch.cat([data._zipf((w_ * n_priv,)), data._uniform_items((n_sh,))]).contiguous()
+            rows_priv = (torch.randn(w_ * n_priv, D, device=dev) * 1e-3).to(torch.bfloat16 if w_ > 1 else torch.float32)
+            rows_sh = torch.randn(n_sh, D, device=dev) * 1e-3
+            ev = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(iters)]
+            for it in range(iters + 2):
+                e = ev[max(0, it - 2)]
+                e[0].record()
+                sorted_ids, perm = torch.sort(ids)
+                e[1].record()
+                out_rows = torch.zeros(ids.numel(), D, dtype=torch.float32, device=dev)
+                e[2].record()
+                ops.sparse_rows_segment_sum(sorted_ids, perm, rows_priv, rows_sh, None, 0, 0, out_rows, model._row_slot)
+                e[3].record()
+                opt.step_count += 1
+                opt._push_consts(opt.step_count, 1e-4)
+                opt._lazy_call(1, sorted_ids, out_rows, model._row_slot, 1.0 / w_)
+                if opt.step_count % 64 == 0:
+                    opt._lagging = True
+                    opt.flush_table()
+                e[4].record()
+            torch.cuda.synchronize()
+            med = lambda a, b: sorted(x[a].elapsed_time(x[b]) for x in ev)[iters // 2]   # noqa: E731
+            uniq = int(torch.unique(ids).numel())
+            res[f"W{w_}"] = {"ids": int(ids.numel()), "unique_ids": uniq, "sort_ms": round(med(0, 1), 4), "zero_rows_ms": round(med(1, 2), 4),
+                            "segment_sum_ms": round(med(2, 3), 4), "adam_rows_lazy_ms": round(med(3, 4), 4), "total_ms": round(med(0, 4), 4)}
+        opt._lagging = True
+        opt.flush_table()
+        res["note"] = ("one card, synthetic W-rank volume (Zipf(1.05) private ids per rank, bf16 private rows as on the wire, fp32 shared "
+                       "block); no collective runs - multi-GPU behaviour stays unmeasured until a SCALE record exists")
+        return res
+
     rc_fail = None
     legs = {}
     main_leg = legs[args.mode] = run_leg(args.mode, args.warmup, args.steps, args.event_steps)
@@ -555,6 +602,13 @@ def main():
         if getattr(trainer, "graph_failure", None):
             out["graph_failure"] = trainer.graph_failure
         out["host_enqueue_ms_per_step"] = round(1000 * main_leg["host_enqueue"] / args.steps, 3)
+        st_ = getattr(trainer, "_step_graph", None)
+        if world > 1 and st_ is not None and st_.graph is not None and st_.n:
+            # data parallel: the replay plan's host calls ARE the collectives (issue + stream waits); with the gloo rehearsal backend
+            # a wait blocks the host until the GPU has produced the data, with RCCL it only orders streams
+            out["host_in_collectives_ms_per_step"] = round(1000 * st_.graph.host_s / max(1, st_.graph.n_replays), 3)
+            out["graph_segments_per_step"] = sum(1 for k_, _ in st_.graph.plan if k_ in ("main", "side"))
+            out["collective_host_calls_per_step"] = sum(1 for k_, _ in st_.graph.plan if k_ == "host")
         if main_leg["host_alone"] == main_leg["host_alone"]:
             out["host_issue_ms_idle_queue"] = round(1000 * main_leg["host_alone"], 3)
         last = main_leg["last"]
@@ -620,6 +674,8 @@ def main():
             if cr:
                 eo["roofline"] = cr
             out["eval"] = eo
+        if args.emulate_world > 1 and world == 1 and args.mode == "train" and getattr(trainer.optimizer, "lazy", False):
+            out["emulated_world"] = emulate_world(args.emulate_world)
         if not args.no_cpu_baseline and world == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline(dict(spec["cfg"]), N)

@@ -40,6 +40,7 @@ class _GraphSegments:
         self.main = torch.cuda.Stream(device=device)
         self.side = torch.cuda.Stream(device=device)
         self.plan, self.cur, self.pool = [], None, None
+        self.host_s, self.n_replays = 0.0, 0          # host time spent inside the plan's host calls (the collectives), replays
         self.ev_fork, self.ev_side = torch.cuda.Event(), torch.cuda.Event()
 
     def begin(self):
@@ -96,12 +97,15 @@ class _GraphSegments:
                 ctx.__exit__(None, None, None)
 
     def replay(self):
+        self.n_replays += 1
         cur = torch.cuda.current_stream()
         for kind, g in self.plan:
             if kind == "main":
                 g.replay()
             elif kind == "host":
+                t0 = time.perf_counter()
                 g()
+                self.host_s += time.perf_counter() - t0
             elif kind == "side":
                 self.ev_fork.record(cur)
                 self.side.wait_event(self.ev_fork)

@@ -267,6 +267,16 @@ extern "C" int mhr_embedding_scatter_add_bwd(const void* grad_rows, int grad_dty
 // data-parallel replicas, which each run this reduction on the same exchanged list, stay bitwise identical.
 constexpr int SEG_CHUNK = 32;
 
+// Latency, not bandwidth, bounded the first form of this kernel (one dependent perm load and one row load at a time per wave:
+// 0.57 TB/s on the 245 k-row list of an 8-rank exchange): a chunk's 32 ids and source-row indices now arrive with ONE coalesced
+// load per wave and are broadcast lane by lane (v_readlane), and the rows are fetched EIGHT positions at a time before they are
+// added - in list order, from zero, exactly as before, so the sums keep their bits.
+__device__ __forceinline__ int64_t readlane64(int64_t v, int l) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)v >> 32), l);
+  return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
 template <typename AT, typename BT>
 __global__ __launch_bounds__(256) void segment_sum_kernel(const int64_t* __restrict__ sorted_ids,
                                                           const int64_t* __restrict__ perm, int64_t n_ids,
@@ -279,47 +289,91 @@ __global__ __launch_bounds__(256) void segment_sum_kernel(const int64_t* __restr
   const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
   const int64_t n_chunks = (n_ids + SEG_CHUNK - 1) / SEG_CHUNK;
+  constexpr int U = 8;                                           // positions whose rows are in flight together
   for (int64_t ch = wave; ch < n_chunks; ch += n_waves) {
-    const int64_t i0 = ch * SEG_CHUNK, i1 = min(n_ids, i0 + SEG_CHUNK);
-    for (int64_t j = i0; j < i1;) {
-      const int64_t id = sorted_ids[j];
-      int64_t e = j + 1;
-      while (e < i1 && sorted_ids[e] == id) ++e;
-      const bool from_before = (j == i0) && i0 > 0 && sorted_ids[i0 - 1] == id;
-      // ids outside the table (a data-layer bug; nn.Embedding would have raised in the forward) get no slot: their
-      // rows stay out of the update instead of writing row_slot out of bounds
-      if (!from_before && lane == 0 && id >= 0 && id < n_rows) row_slot[id] = (int32_t)j;
-      for (int c = lane * 4; c < dim; c += 256) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int64_t q = j; q < e; ++q) {
-          const int64_t r = perm[q];
-          if (r < n_a) {
-            acc += Vec4IO<AT>::load(ga + r * dim + c);
-            if (xg) {
-              int64_t b = r / window_len;
-              int l = (int)(r - b * window_len);
-              if (l < seq_len) acc += *reinterpret_cast<const f32x4*>(xg + (b * seq_len + l) * dim + c);
+    const int64_t i0 = ch * SEG_CHUNK;
+    const int n_here = (int)(min(n_ids, i0 + SEG_CHUNK) - i0);
+    // lanes 0 .. 31: the chunk's ids and source rows; lane 32: the id in front of the chunk (a run may come in from the left)
+    int64_t my_id = -1, my_src = 0;
+    if (lane < n_here) {
+      my_id = sorted_ids[i0 + lane];
+      my_src = perm[i0 + lane];
+    } else if (lane == 32 && i0 > 0) {
+      my_id = sorted_ids[i0 - 1];
+    }
+    const int64_t id_before = readlane64(my_id, 32);
+    const bool has_before = i0 > 0;
+    for (int c0 = 0; c0 < dim; c0 += 256) {
+      const int c = c0 + lane * 4;
+      const bool col = c < dim;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      int run_head = 0;                                          // position (in the chunk) the open run started at
+      int64_t run_id = readlane64(my_id, 0);
+      for (int p0 = 0; p0 < n_here; p0 += U) {
+        f32x4 v[U], vx[U];
+        bool use_x[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+          vx[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+          use_x[u] = false;
+          if (p0 + u < n_here && col) {
+            const int64_t r = readlane64(my_src, p0 + u);
+            if (r < n_a) {
+              v[u] = Vec4IO<AT>::load(ga + r * dim + c);
+              if (xg) {
+                const int64_t b = r / window_len;
+                const int l = (int)(r - b * window_len);
+                if (l < seq_len) {
+                  vx[u] = *reinterpret_cast<const f32x4*>(xg + (b * seq_len + l) * dim + c);
+                  use_x[u] = true;
+                }
+              }
+            } else if (r - n_a < n_b) {
+              v[u] = Vec4IO<BT>::load(gb + (r - n_a) * dim + c);
             }
-          } else if (r - n_a < n_b) {
-            acc += Vec4IO<BT>::load(gb + (r - n_a) * dim + c);
           }
         }
-        *reinterpret_cast<f32x4*>(out_rows + j * dim + c) = acc;     // whole run, or this chunk's partial of a cut run
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int p = p0 + u;
+          if (p >= n_here) break;
+          const int64_t id = readlane64(my_id, p);
+          if (id != run_id) {                                    // the open run ends in front of p: store it, open the next
+            if (col) *reinterpret_cast<f32x4*>(out_rows + (i0 + run_head) * dim + c) = acc;
+            acc = f32x4{0.f, 0.f, 0.f, 0.f};
+            run_head = p;
+            run_id = id;
+          }
+          acc += v[u];
+          if (use_x[u]) acc += vx[u];
+        }
       }
-      j = e;
+      if (col) *reinterpret_cast<f32x4*>(out_rows + (i0 + run_head) * dim + c) = acc;   // whole run, or this chunk's partial of a cut run
+    }
+    // slots: every run that STARTS in this chunk (ids outside the table - a data-layer bug; nn.Embedding would have raised in
+    // the forward - get none: their rows stay out of the update instead of writing row_slot out of bounds)
+    const int64_t up = __shfl_up(my_id, 1, 64);                  // (all lanes: no shuffle under divergence)
+    if (lane < n_here) {
+      const int64_t left = lane == 0 ? (has_before ? id_before : my_id - 1) : up;
+      if (left != my_id && my_id >= 0 && my_id < n_rows) row_slot[my_id] = (int32_t)(i0 + lane);
     }
   }
 }
 
-// Second pass: the wave of the chunk in which a cut run STARTS walks the run's later chunks in order, adds their partials
-// (stored at the chunks' first positions) to the head row and clears them, so non-head rows are zero again.
-__global__ __launch_bounds__(256) void segment_fixup_kernel(const int64_t* __restrict__ sorted_ids, int64_t n_ids,
-                                                            float* __restrict__ out_rows, int dim) {
-  const int lane = threadIdx.x & 63;
-  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
+// Second pass: the WORKGROUP of the chunk in which a cut run STARTS adds the run's partials (stored at the first positions of
+// its later chunks) to the head row and clears them, so non-head rows are zero again.  Under Zipf ids one item can own a tenth
+// of an exchanged list (21 k of 213 k positions at eight ranks: a run over 660 chunks): one wave walking those partials one
+// after the other was the serial tail of the whole reduction, so the run's chunk range is dealt to the 16 waves of the
+// workgroup in contiguous pieces - each summed in chunk order - and the 16 piece sums are added to the head in wave order.
+// The association order is fixed by the list alone: bitwise reproducible, identical on every data-parallel replica.
+constexpr int FIX_WAVES = 16;
+__global__ __launch_bounds__(64 * FIX_WAVES) void segment_fixup_kernel(const int64_t* __restrict__ sorted_ids, int64_t n_ids,
+                                                                       float* __restrict__ out_rows, int dim) {
+  __shared__ f32x4 piece[FIX_WAVES][64];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t n_chunks = (n_ids + SEG_CHUNK - 1) / SEG_CHUNK;
-  for (int64_t ch = wave; ch + 1 < n_chunks; ch += n_waves) {
+  for (int64_t ch = blockIdx.x; ch + 1 < n_chunks; ch += gridDim.x) {
     const int64_t i0 = ch * SEG_CHUNK, i1 = i0 + SEG_CHUNK;
     const int64_t id = sorted_ids[i1 - 1];
     if (sorted_ids[i1] != id) continue;                          // the chunk's last run ends with the chunk
@@ -327,23 +381,50 @@ __global__ __launch_bounds__(256) void segment_fixup_kernel(const int64_t* __res
     int64_t head = i1 - 1;
     while (head > i0 && sorted_ids[head - 1] == id) --head;
     int64_t last = ch + 1;                                       // chunks ch + 1 .. last hold partials of this run
-    while (last + 1 < n_chunks && sorted_ids[(last + 1) * SEG_CHUNK] == id) ++last;
-    constexpr int U = 16;                                        // partial rows in flight (a hot id under Zipf spans ~70 chunks)
-    for (int c = lane * 4; c < dim; c += 256) {
-      f32x4 acc = *reinterpret_cast<const f32x4*>(out_rows + head * dim + c);
-      for (int64_t k0 = ch + 1; k0 <= last; k0 += U) {
+    if (last + 1 < n_chunks && sorted_ids[(last + 1) * SEG_CHUNK] == id) {
+      // a long run: gallop, then bisect for the last chunk whose first position still holds this id (ids are sorted)
+      int64_t lo = last + 1, step = 1;
+      while (lo + step < n_chunks && sorted_ids[(lo + step) * SEG_CHUNK] == id) {
+        lo += step;
+        step <<= 1;
+      }
+      int64_t hi = min(n_chunks - 1, lo + step);               // lo holds the id; hi may not
+      while (lo < hi) {
+        const int64_t mid = (lo + hi + 1) >> 1;
+        if (sorted_ids[mid * SEG_CHUNK] == id) lo = mid;
+        else hi = mid - 1;
+      }
+      last = lo;
+    }
+    const int64_t K = last - ch;                                 // partial rows of this run
+    const int64_t per = (K + FIX_WAVES - 1) / FIX_WAVES;
+    const int64_t k_lo = ch + 1 + wave * per, k_hi = min(last, k_lo + per - 1);
+    constexpr int U = 8;                                         // partial rows in flight per wave
+    for (int c0 = 0; c0 < dim; c0 += 256) {
+      const int c = c0 + lane * 4;
+      const bool col = c < dim;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      for (int64_t k0 = k_lo; k0 <= k_hi; k0 += U) {
         f32x4 v[U];
 #pragma unroll
         for (int u = 0; u < U; ++u)
-          if (k0 + u <= last) v[u] = *reinterpret_cast<const f32x4*>(out_rows + (k0 + u) * SEG_CHUNK * dim + c);
+          if (k0 + u <= k_hi && col) v[u] = *reinterpret_cast<const f32x4*>(out_rows + (k0 + u) * SEG_CHUNK * dim + c);
 #pragma unroll
         for (int u = 0; u < U; ++u)
-          if (k0 + u <= last) {
+          if (k0 + u <= k_hi && col) {
             acc += v[u];
             *reinterpret_cast<f32x4*>(out_rows + (k0 + u) * SEG_CHUNK * dim + c) = f32x4{0.f, 0.f, 0.f, 0.f};
           }
       }
-      *reinterpret_cast<f32x4*>(out_rows + head * dim + c) = acc;
+      piece[wave][lane] = acc;
+      __syncthreads();
+      if (wave == 0 && col) {
+        f32x4 tot = *reinterpret_cast<const f32x4*>(out_rows + head * dim + c);
+        const int n_pieces = (int)min((int64_t)FIX_WAVES, (K + per - 1) / per);
+        for (int w = 0; w < n_pieces; ++w) tot += piece[w][lane];
+        *reinterpret_cast<f32x4*>(out_rows + head * dim + c) = tot;
+      }
+      __syncthreads();
     }
   }
 }
@@ -373,7 +454,8 @@ extern "C" int mhr_sparse_rows_segment_sum(const int64_t* sorted_ids, const int6
 #undef LAUNCH
   MHR_CHECK_LAUNCH("sparse_rows_segment_sum");
   if (n_ids > SEG_CHUNK) {
-    hipLaunchKernelGGL(segment_fixup_kernel, dim3(grid), dim3(256), 0, s, sorted_ids, n_ids, out_rows, dim);
+    const int fgrid = mhr_grid_for((n_ids + SEG_CHUNK - 1) / SEG_CHUNK, 1);       // one workgroup per chunk that may head a cut run
+    hipLaunchKernelGGL(segment_fixup_kernel, dim3(fgrid), dim3(64 * FIX_WAVES), 0, s, sorted_ids, n_ids, out_rows, dim);
     MHR_CHECK_LAUNCH("sparse_rows_segment_sum (fix-up)");
   }
   return MHR_OK;
