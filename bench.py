@@ -56,6 +56,7 @@ def parse(argv=None):
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the evented pass (per-kernel HIP events)")
     ap.add_argument("--no-graph", action="store_true", help="issue every launch from the host (no hipGraph replay of the step)")
     ap.add_argument("--event-steps", type=int, default=10, help="steps of the evented pass (outside the timed region)")
+    ap.add_argument("--pretrain-steps", type=int, default=0, help="eval mode: take this many train steps first (diagnostic)")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="one GPU: time the table-side kernels of the optimizer step (id sort, row buffer, segment sum + fix-up, lazy row "
                          "AdamW) on W ranks' worth of exchanged ids / rows - the part of a data-parallel step that does not shrink with W")
@@ -333,6 +334,37 @@ def _attach_traffic(roof, mode, standard_shape):
         roof["traffic_source"] = os.path.relpath(files[-1], ROOT)
 
 
+def _attach_rocprof(roof, kernel_name, flops=None, nbytes=None):
+    """The same launch as rocprofv3 saw it (profiles/<round>_full_launch.json, condensed from the kernel trace of this command by
+    tools/summarize_profiles.py): `rocprof_launch_ms` and the fraction that follows from it, next to the HIP-event figure of this
+    run.  The two are different runs on possibly different boxes (the MFMA clock under load differs box to box)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_full_launch.json")))
+    if not files:
+        return
+    rec = json.load(open(files[-1]))["kernels"].get(kernel_name)
+    if not rec:
+        return
+    ms = rec["median_ns"] * 1e-6
+    roof["rocprof_launch_ms"] = round(ms, 4)
+    if roof.get("bound") == "mfma" and flops:
+        roof["frac_rocprof"] = round(flops / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4)
+    elif nbytes:
+        roof["frac_rocprof"] = round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    roof["rocprof_source"] = os.path.relpath(files[-1], ROOT)
+
+
+def _gpu_clocks():
+    """Current shader / memory clocks as rocm-smi reports them right after the timed legs (a child process; best effort)."""
+    try:
+        r = subprocess.run(["rocm-smi", "--showclocks", "--json"], capture_output=True, text=True, timeout=20)
+        d = json.loads(r.stdout)
+        card = next(iter(d.values()))
+        return {k: v for k, v in card.items() if "sclk" in k.lower() or "mclk" in k.lower()}
+    except Exception:  # noqa: BLE001
+        return None
+
+
 # ------------------------------------------------------------------------------------------------
 def main():
     args = parse()
@@ -476,6 +508,8 @@ def main():
                           {"launches_per_step": launches / leg["event_steps"],
                            "all_launches_ms_per_step": round(mean_ms * launches / leg["event_steps"], 4)})
                 _attach_traffic(r, "eval", standard and args.config == "cfg1")
+                if standard and args.config == "cfg1" and Bev == 256:
+                    _attach_rocprof(r, "catalog_emit_sliced_kernel", flops=flops)
                 return r
         return None
 
@@ -524,6 +558,8 @@ def main():
             else:
                 continue
             _attach_traffic(r, "train", standard and args.config == "cfg1")
+            if standard and args.config == "cfg1" and name in KERNEL_NAMES:
+                _attach_rocprof(r, KERNEL_NAMES[name][0], flops=r.get("algorithmic_flops_per_launch"), nbytes=r.get("algorithmic_bytes_per_launch"))
             return r
         return None
 
@@ -573,6 +609,12 @@ def main():
 
     rc_fail = None
     legs = {}
+    if args.mode == "eval" and args.pretrain_steps:
+        model.train()
+        pb = [data.train_batch(cfg["train_batch_size"]) for _ in range(4)]
+        for i in range(args.pretrain_steps):
+            trainer.train_step_fn(pb[i % 4])
+        torch.cuda.synchronize()
     main_leg = legs[args.mode] = run_leg(args.mode, args.warmup, args.steps, args.event_steps)
     graph_expected = bool(args.mode == "train" and not args.no_graph and (trainer._graph_ok(main_leg["batches"][0]) or getattr(trainer, "_graph_failed", False)))
     graph_on = bool(getattr(trainer, "graph_active", False))
@@ -673,9 +715,14 @@ def main():
             cr = catalog_roofline(ev, Bev)
             if cr:
                 eo["roofline"] = cr
+            eo["kernel_ms_per_step"] = {k: round(v[2] / ev["event_steps"], 3) for k, v in sorted(ev["prof"].items(), key=lambda kv: -kv[1][2])}
+            eo["host_enqueue_ms_per_step"] = round(1000 * ev["host_enqueue"] / ev["steps"], 3)
             out["eval"] = eo
         if args.emulate_world > 1 and world == 1 and args.mode == "train" and getattr(trainer.optimizer, "lazy", False):
             out["emulated_world"] = emulate_world(args.emulate_world)
+        clk = _gpu_clocks()
+        if clk:
+            out["gpu_clocks_after_run"] = clk
         if not args.no_cpu_baseline and world == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline(dict(spec["cfg"]), N)

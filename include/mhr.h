@@ -592,6 +592,29 @@ int mhr_catalog_score_emit_wide(const void* users_packed, int n_rows, const void
                                 int cap_s, void* stream);
 int mhr_catalog_wide_slices(int n_rows);
 
+/* Sampled-softmax logit contractions at feature dims beyond 256 (dim a multiple of 64, up to 8192; model/IDNet/hstu.py:600-619
+ * = model/HLLM/hllm.py:378-397 + F.cross_entropy hstu.py:697, 833; log counters hstu.py:621-629): the wide scorer's LDS-tiled
+ * MFMA GEMM (256 negatives x 128 tokens per workgroup, packed tile images, loader + consumer waves) with the loss arithmetic in
+ * its epilogue - no [N_tok, n_neg] logit block in memory.  Operands: mhr_pack_tiles images of L2-normalised bf16 rows - the
+ * token rows (queries or targets, [n_rows, dim]) with tiles_per_block = 4, the negatives ([n_neg, dim]) with tiles_per_block = 8.
+ * Per-token arrays hold t_pad = ceil(n_rows / 128) * 128 entries; n_tiles = ceil(n_neg / 256) * 8.
+ *   fix_bits:   bits [n_tiles * 2, t_pad] uint16: bit g of word ((tile * 2 + lane half) * t_pad + token) = cos(target, negative) > thres
+ *               for the g-th negative that accumulator layout gives the lane (the two consumers below read the same layout).
+ *   fwd:        per token tot = sum_j keep exp(scale (s_j - 1)), #kept, #{kept s_j > s_pos} as partials [n_lists, t_pad]
+ *               (n_lists = 4 * mhr_catalog_wide_slices(n_rows); plain stores, no atomics), then in the same call
+ *               lse = scale + log(tot + exp(scale (s_pos - 1))), loss = lse - scale s_pos (0 beyond n_live_dev[0]),
+ *               n_valid = #kept + 1, rank (both optional).  bits NULL: nothing suppressed.  scale_dev: device scalar exp(logit_scale).
+ *   grad_tile:  g [n_rows, ldg] bf16 = keep * w[token] * exp(scale s - lse[token]) (0 beyond n_live_dev[0] and for padding
+ *               negatives): the operand of the plain gradient products dQ = G N and dN = G^T Q.  ldg % 4 == 0, ldg >= n_neg. */
+int mhr_nce_wide_fix_bits(const void* targets_packed, int n_rows, const void* negs_packed, int n_neg, int dim, float thres,
+                          uint16_t* bits, void* stream);
+int mhr_nce_wide_fwd(const void* queries_packed, int n_rows, const void* negs_packed, int n_neg, int dim, const uint16_t* bits,
+                     const float* s_pos, const float* scale_dev, const int32_t* n_live_dev, float* part_tot, int32_t* part_nv,
+                     int32_t* part_rk, float* lse, float* loss, int32_t* n_valid, int32_t* rank, void* stream);
+int mhr_nce_wide_grad_tile(const void* queries_packed, int n_rows, const void* negs_packed, int n_neg, int dim, const uint16_t* bits,
+                           const float* lse, const float* w, const float* scale_dev, const int32_t* n_live_dev, void* g_bf16,
+                           int64_t ldg, void* stream);
+
 /* Workspace queries (host functions, no launch).  The library allocates nothing: every entry point takes its operands, outputs
  * and scratch as caller-owned buffers whose shapes are stated with the declaration.  The only scratch whose SIZE depends on a
  * choice made inside the library is the scorers' candidate lists (how the item tiles are split into slices); these return the

@@ -599,7 +599,7 @@ class NceSaved:
     """Tensors the forward keeps for the backward (all preallocated at token capacity)."""
     __slots__ = ("qn", "pn", "supp", "q_inv", "p_inv", "s_pos", "lse", "loss", "n_valid", "rank", "negs",
                  "n_tok_dev", "tok_cap", "cap", "thres", "dim", "n_neg", "groups", "q_idx", "p_idx", "bucket_idx", "n_buckets",
-                 "bucket_sum", "bucket_cnt", "u", "wide", "scale_dev", "cap_eff",
+                 "bucket_sum", "bucket_cnt", "u", "wide", "scale_dev", "cap_eff", "wide_pack",
                  # query-row sharing (nce_shared.hip): row-level state of the streaming kernels + the maps between rows and tokens
                  "shared", "tok2row", "row_first", "n_row_dev", "row_cap", "fix_words", "fix_slot", "fix_any", "n_p_rows", "row_q",
                  "window", "bwd_bufs",

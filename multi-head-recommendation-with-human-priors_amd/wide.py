@@ -16,6 +16,7 @@ Reference: model/IDNet/hstu.py:600-629 (nce_loss, logs), 697/833 (cross entropy)
 collector.py:245 (scores, masks, per-head top-k).
 """
 import math
+import os
 
 import torch
 
@@ -51,8 +52,27 @@ def _live_cap(sv):
     return min(sv.cap, -(-max(n_max, 1) // 256) * 256)
 
 
+MFMA_NCE = os.environ.get("MHR_NCE_WIDE_MFMA", "1") != "0"     # 0: the library-GEMM + fp32-chunk form of the logit products
+
+
+def _mfma_path(sv, D):
+    """The hand-written contraction (csrc/nce_wide.hip) serves every feature dim that is a multiple of 64; REMI's
+    hard-negative loss keeps the dense chunk path (its two-pass logsumexp epilogue)."""
+    return MFMA_NCE and D % 64 == 0 and D <= 8192 and sv.ihn_beta <= 0
+
+
+def _pad_rows(x, t_pad):
+    """[n] per-token vector -> [t_pad] (the wide kernels read whole 128-token blocks)."""
+    if x.shape[0] == t_pad:
+        return x.contiguous()
+    out = torch.zeros(t_pad, dtype=x.dtype, device=x.device)
+    out[:x.shape[0]] = x
+    return out
+
+
 def nce_fwd_wide(sv, q_rows, p_rows, negs, logit_scale, want_logs, bucket_idx, loss, n_valid, rank):
     """Fills sv (qn, pn, q_inv, p_inv, s_pos, lse, bucket sums) and loss / n_valid / rank [G, cap] in place."""
+    from . import ops
     G, cap, thres = sv.groups, sv.cap, sv.thres
     scale = _scale(logit_scale)
     sv.scale_dev = scale
@@ -63,12 +83,41 @@ def nce_fwd_wide(sv, q_rows, p_rows, negs, logit_scale, want_logs, bucket_idx, l
         n_valid.zero_()
         rank.zero_()
     st = _stream()
+    D = q_rows.shape[1]
+    mfma = _mfma_path(sv, D)
+    sv.wide_pack = [None] * G if mfma else None
+    dev = negs.device
     for g in range(G):
         qn, qi = _norm_rows(q_rows, sv.q_idx[g, :cap_eff])
         pn, pi = _norm_rows(p_rows, sv.p_idx[g, :cap_eff])
         sv.qn[g, :cap_eff], sv.pn[g, :cap_eff], sv.q_inv[g, :cap_eff], sv.p_inv[g, :cap_eff] = qn, pn, qi, pi
         s_pos = (qn.float() * pn.float()).sum(-1).contiguous()
         sv.s_pos[g, :cap_eff] = s_pos
+        if mfma:
+            # hand-written contraction: targets x negatives -> false-negative bits, queries x negatives -> the per-token sums
+            # (one launch each on the packed tile images; no logit block, no library GEMM)
+            n_neg = sv.n_neg
+            t_pad = -(-cap_eff // 128) * 128
+            n_tiles = -(-n_neg // 256) * 8
+            negs_p = ops.pack_tiles(negs[g].contiguous(), n_sel=n_neg, tiles_per_block=8)
+            q_p = ops.pack_tiles(qn.contiguous(), tiles_per_block=4)
+            p_p = ops.pack_tiles(pn.contiguous(), tiles_per_block=4)
+            bits = torch.empty(n_tiles * 2, t_pad, dtype=torch.int16, device=dev)
+            lib.call("mhr_nce_wide_fix_bits", p_p.data_ptr(), cap_eff, negs_p.data_ptr(), n_neg, D, float(thres), bits.data_ptr(), st)
+            n_lists = 4 * lib.load().mhr_catalog_wide_slices(cap_eff)
+            part = torch.empty(3, n_lists, t_pad, dtype=torch.float32, device=dev)
+            sp_pad = _pad_rows(s_pos, t_pad)
+            lse_g, loss_g = torch.empty(t_pad, dtype=torch.float32, device=dev), torch.empty(t_pad, dtype=torch.float32, device=dev)
+            nv_g = torch.empty(t_pad, dtype=torch.int32, device=dev) if want_logs else None
+            rk_g = torch.empty(t_pad, dtype=torch.int32, device=dev) if want_logs else None
+            ops._timed_call("mhr_nce_wide_fwd", q_p.data_ptr(), cap_eff, negs_p.data_ptr(), n_neg, D, bits.data_ptr(), sp_pad.data_ptr(),
+                            scale.data_ptr(), sv.n_tok_dev[g:g + 1].data_ptr(), part[0].data_ptr(), part[1].view(torch.int32).data_ptr(),
+                            part[2].view(torch.int32).data_ptr(), lse_g.data_ptr(), loss_g.data_ptr(), ops._ptr(nv_g), ops._ptr(rk_g), st)
+            sv.lse[g, :cap_eff], loss[g, :cap_eff] = lse_g[:cap_eff], loss_g[:cap_eff]
+            if want_logs:
+                n_valid[g, :cap_eff], rank[g, :cap_eff] = nv_g[:cap_eff], rk_g[:cap_eff]
+            sv.wide_pack[g] = (negs_p, bits, t_pad)
+            continue
         ngt = negs[g, :sv.n_neg].t()
         for c0 in range(0, cap_eff, CHUNK):
             c1 = min(cap_eff, c0 + CHUNK)
@@ -102,16 +151,33 @@ def nce_bwd_wide(sv, w_tok, logit_scale, dq_rows, dp_rows, d_negs, d_logit_scale
     dls = torch.zeros((), dtype=torch.float32, device=dev)
     st = _stream()
     w_tok = w_tok.contiguous()
+    from . import ops
+    D = sv.qn.shape[-1]
     for g in range(G):
         ng = sv.negs[g, :sv.n_neg]
         ngt = ng.t()
-        for c0 in range(0, cap_eff, CHUNK):
-            c1 = min(cap_eff, c0 + CHUNK)
+        pack = sv.wide_pack[g] if getattr(sv, "wide_pack", None) is not None else None
+        step = cap_eff if pack is not None else CHUNK          # the hand-written tile producer covers all live rows in one launch
+        for c0 in range(0, cap_eff, step):
+            c1 = min(cap_eff, c0 + step)
             qn, pn = sv.qn[g, c0:c1], sv.pn[g, c0:c1]
-            s = _mm(qn, ngt)
-            fx = _mm(pn, ngt)
-            gmat = torch.empty(c1 - c0, sv.n_neg, dtype=torch.bfloat16, device=dev)
-            if sv.ihn_beta > 0:
+            if pack is not None:
+                # softmax-gradient tile straight from the MFMA accumulators (recomputed cosines, saved suppression bits)
+                negs_p, bits, t_pad = pack
+                ldg = -(-sv.n_neg // 4) * 4
+                gfull = torch.empty(cap_eff, ldg, dtype=torch.bfloat16, device=dev)
+                q_p = ops.pack_tiles(qn.contiguous(), tiles_per_block=4)
+                ops._timed_call("mhr_nce_wide_grad_tile", q_p.data_ptr(), cap_eff, negs_p.data_ptr(), sv.n_neg, D, bits.data_ptr(),
+                                _pad_rows(sv.lse[g, :cap_eff], t_pad).data_ptr(), _pad_rows(w_tok[g, :cap_eff], t_pad).data_ptr(),
+                                scale.data_ptr(), sv.n_tok_dev[g:g + 1].data_ptr(), gfull.data_ptr(), ldg, st)
+                gmat = gfull[:, :sv.n_neg]
+            else:
+                s = _mm(qn, ngt)
+                fx = _mm(pn, ngt)
+                gmat = torch.empty(c1 - c0, sv.n_neg, dtype=torch.bfloat16, device=dev)
+            if pack is not None:
+                pass
+            elif sv.ihn_beta > 0:
                 lib.call("mhr_ihn_dense_bwd", s.data_ptr(), fx.data_ptr(), s.shape[1], sv.n_neg, sv.lse[g, c0:c1].data_ptr(),
                          sv.ihn_num[g, c0:c1].data_ptr(), sv.ihn_imp[g, c0:c1].data_ptr(), w_tok[g, c0:c1].data_ptr(),
                          scale.data_ptr(), float(thres), float(sv.ihn_beta), sv.n_tok_dev[g:g + 1].data_ptr(), c0, c1 - c0,
@@ -120,7 +186,8 @@ def nce_bwd_wide(sv, w_tok, logit_scale, dq_rows, dp_rows, d_negs, d_logit_scale
                 lib.call("mhr_nce_dense_bwd", s.data_ptr(), fx.data_ptr(), s.shape[1], sv.n_neg, sv.lse[g, c0:c1].data_ptr(),
                          w_tok[g, c0:c1].data_ptr(), scale.data_ptr(), float(thres), sv.n_tok_dev[g:g + 1].data_ptr(), c0, c1 - c0,
                          gmat.data_ptr(), sv.n_neg, st)
-            del s, fx
+            if pack is None:
+                del s, fx
             dq_raw = _mm(gmat, ng)                                                               # sum_j g_ij n_j
             if d_negs is not None:
                 d_negs[g, :sv.n_neg] += scale * _mm(gmat.t(), qn)

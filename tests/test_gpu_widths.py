@@ -111,6 +111,18 @@ def test_sampled_softmax_full_width(ops, D, G, n_neg, cap, n_live):
     sv = ops.nce_fwd(q_rows, q_idx, p_rows, p_idx, negs, n_tok, cap, ls, 0.99, want_logs=True)
     torch.cuda.synchronize()
     loss = sv.loss.cpu()
+    # the logit contractions ran in the hand-written LDS-tiled MFMA kernels (csrc/nce_wide.hip), not as library GEMMs over fp32
+    # logit chunks: packed negatives + suppression bits were kept for the backward; and the two forms agree
+    assert sv.wide_pack is not None and all(p_ is not None for p_ in sv.wide_pack)
+    from mhr_amd import wide as wide_mod
+    try:
+        wide_mod.MFMA_NCE = False
+        sv_lib = ops.nce_fwd(q_rows, q_idx, p_rows, p_idx, negs, n_tok, cap, ls, 0.99, want_logs=True)
+    finally:
+        wide_mod.MFMA_NCE = True
+    assert sv_lib.wide_pack is None
+    assert float((sv_lib.loss.cpu() - loss).abs().max()) <= 1e-4 * float(loss.abs().max())
+    assert torch.equal(sv_lib.n_valid, sv.n_valid) and int((sv_lib.rank != sv.rank).sum()) <= 2      # (a rank flips only at an fp32 tie with s+)
     w = torch.rand(G, cap, device="cuda", generator=g)
     outs = []
     for scale in (1.0, 2.5):

@@ -120,6 +120,36 @@ def mfma_util(rnd, mode=""):
         print("wrote", p)
 
 
+def full_launches(rnd):
+    """Per-launch durations of the kernels whose bench roofline is priced on ONE launch of a step, from the rocprofv3 kernel
+    TRACE of the same command (the --stats table averages a kernel's launches: the catalog scorer runs three per eval step, two
+    of them small threshold-sample passes).  For each kernel: the median of the step's LARGEST launch -> profiles/<rnd>_full_launch.json;
+    bench.py prints it next to its own HIP-event figure (`rocprof_launch_ms`, `frac_rocprof`)."""
+    out = {}
+    for leg, names, per_step in (("eval", ("catalog_emit_sliced_kernel", "catalog_emit_wide_kernel"), 3),
+                                 ("train", ("nce_fwd_d_kernel", "nce_bwd_n_kernel", "gather_step_kernel", "hstu_attn_bwd_kernel",
+                                            "hstu_attn_fwd_kernel"), None)):
+        f = newest(os.path.join(ROOT, "gpurun_out", f"prof_{rnd}_{leg}", "*", "*_kernel_trace.csv"))
+        if f is None:
+            continue
+        durs = {}
+        for r in csv.DictReader(open(f)):
+            k = short(r["Kernel_Name"])
+            if k in names:
+                durs.setdefault(k, []).append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        for k, d in durs.items():
+            d.sort(reverse=True)
+            top = d[:max(1, len(d) // per_step)] if per_step else d      # one full launch per step: the largest third
+            out[k] = {"leg": leg, "launches_traced": len(d), "launches_used": len(top), "median_ns": top[len(top) // 2],
+                      "min_ns": top[-1], "max_ns": top[0]}
+    if out:
+        p = os.path.join(ROOT, "profiles", f"{rnd}_full_launch.json")
+        json.dump({"how": "rocprofv3 --kernel-trace of `python bench.py [--mode eval] --no-cpu-baseline --no-host-probe --no-kernel-events "
+                          "--steps 20 --warmup 5`: per-launch End - Start; scorer: median over the largest launch of each step",
+                   "kernels": out}, open(p, "w"), indent=1)
+        print("wrote", p)
+
+
 def readme(rnd):
     """profiles/README.md from the condensed files + the bench lines (gpurun_out/bench_<rnd>_{train,eval}.json)."""
     P = os.path.join(ROOT, "profiles")
@@ -209,4 +239,9 @@ if __name__ == "__main__":
     traffic(rnd, "eval_")
     mfma_util(rnd)
     mfma_util(rnd, "eval_")
+    full_launches(rnd)
+    for extra in ("emu", "dp2_gloo"):                       # bench --emulate-world / the two-rank gloo rehearsal lines, if the set made them
+        f = os.path.join(ROOT, "gpurun_out", f"bench_{rnd}_{extra}.json")
+        if os.path.exists(f) and os.path.getsize(f):
+            json.dump(json.loads(open(f).read().strip().splitlines()[-1]), open(os.path.join(ROOT, "profiles", f"{rnd}_bench_{extra}.json"), "w"), indent=1)
     readme(rnd)

@@ -30,8 +30,8 @@ if sys.argv[1] == "build":
         shutil.copytree(os.path.join(ROOT, "include"), os.path.join(OUT, "src", "include"))    # csrc includes ../../include/mhr.h
         subprocess.check_call(["patch", "-p0", "-d", pkg, "-i", os.path.join(ROOT, "tools", "exp_variants.patch")])
         csrc = os.path.join(pkg, "csrc")
-    srcs = sorted(glob.glob(os.path.join(csrc, "*.hip")))
-    subprocess.check_call([ge.HIPCC] + ge.HIP_FLAGS + ["-shared"] + ["-D" + d for d in defs] + ["-I", os.path.join(ROOT, "include"), "-o", LIB] + srcs)
+    # same flags and the same parallel per-file compile as the product build, objects kept per variant (incremental rebuilds)
+    ge.build_hip_library(csrc=csrc, build_dir=os.path.join(OUT, "obj"), lib=LIB, extra_flags=["-D" + d for d in defs])
     print("built", LIB)
 else:
     sys.path.insert(0, ROOT)
