@@ -167,9 +167,10 @@ def nce_bwd_wide(sv, w_tok, logit_scale, dq_rows, dp_rows, d_negs, d_logit_scale
                 ldg = -(-sv.n_neg // 4) * 4
                 gfull = torch.empty(cap_eff, ldg, dtype=torch.bfloat16, device=dev)
                 q_p = ops.pack_tiles(qn.contiguous(), tiles_per_block=4)
+                lse_pad, w_pad = _pad_rows(sv.lse[g, :cap_eff], t_pad), _pad_rows(w_tok[g, :cap_eff], t_pad)   # (named: alive across the call)
                 ops._timed_call("mhr_nce_wide_grad_tile", q_p.data_ptr(), cap_eff, negs_p.data_ptr(), sv.n_neg, D, bits.data_ptr(),
-                                _pad_rows(sv.lse[g, :cap_eff], t_pad).data_ptr(), _pad_rows(w_tok[g, :cap_eff], t_pad).data_ptr(),
-                                scale.data_ptr(), sv.n_tok_dev[g:g + 1].data_ptr(), gfull.data_ptr(), ldg, st)
+                                lse_pad.data_ptr(), w_pad.data_ptr(), scale.data_ptr(), sv.n_tok_dev[g:g + 1].data_ptr(),
+                                gfull.data_ptr(), ldg, st)
                 gmat = gfull[:, :sv.n_neg]
             else:
                 s = _mm(qn, ngt)

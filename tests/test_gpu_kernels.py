@@ -365,7 +365,8 @@ from kernel_oracles import nce_oracle as _nce_oracle        # the pinned HO.nce_
 @pytest.mark.parametrize("D,n_tok,n_neg,dtype", [(16, 37, 30, torch.float32), (64, 200, 96, torch.bfloat16),
                                                  (256, 300, 512, torch.bfloat16), (256, 129, 8192, torch.bfloat16),
                                                  (32, 90, 128, torch.float32), (128, 140, 320, torch.bfloat16),   # every tile-step shape
-                                                 (512, 150, 96, torch.float32)])     # 512: the generic-width (library GEMM) path
+                                                 (512, 150, 96, torch.float32),      # beyond 256: the LDS-tiled MFMA path (nce_wide.hip)
+                                                 (320, 200, 300, torch.bfloat16), (1024, 70, 61, torch.bfloat16)])   # ragged: 5 chunks / 61 negatives
 def test_nce_fwd_bwd(ops, D, n_tok, n_neg, dtype):
     g = torch.Generator().manual_seed(8 + D)
     n_src = 2 * n_tok
