@@ -227,7 +227,7 @@ def test_cfg1_eval_batch_vs_oracle_decode(rec):
 # ----------------------------------------------------------------------------------------------------------------------
 # the exact top-k's rare path: rows that cannot be certified
 # ----------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("D", [256, 64])
+@pytest.mark.parametrize("D", [256, 64, 512])                        # 512: the wide scorer's threshold / margin bookkeeping
 def test_exact_topk_uncertified_rows_take_the_dense_hip_path(rec, D):
     """2 000 IDENTICAL item rows near the users' direction: the margin set of every row holds more near-ties than the candidate
     list has slots, no row can be certified, and all of them go through `mhr_catalog_score_rows_dense` + the exact select
