@@ -388,10 +388,11 @@ int mhr_nce_bwd_tokens(const void* qn, const void* pn, const float* u, int dim, 
                        const float* lse, const float* w, const float* q_inv, const float* p_inv, const float* s_pos,
                        const int32_t* q_idx, const int32_t* p_idx,
                        float* dq_rows, float* dp_rows, float* d_logit_scale, float* lw_out,
-                       const int32_t* w_bucket, int n_buckets, void* stream);
+                       const int32_t* w_bucket, int n_buckets, int64_t* dq_fix, int64_t* dp_fix,
+                       float* dls_part, void* stream);
 int mhr_nce_bwd_negs(const void* qn, const void* negs, const uint32_t* supp, int n_neg, int dim, int n_groups,
                      const int32_t* n_tok_dev, int tok_cap, const float* logit_scale_dev,
-                     const float* lw, float* d_negs, void* stream);
+                     const float* lw, float* d_negs, int64_t* dn_fix, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Sampled softmax with QUERY-ROW SHARING (csrc/nce_shared.hip; same reference lines as mhr_nce_fwd, plus the window
@@ -450,7 +451,7 @@ int mhr_nce_shared_bwd_rows(const void* qn_row, const float* u_row, const float*
                             const float* w, const float* s_pos, const int32_t* p_idx, float* dq_rows,
                             float* d_logit_scale, float* lw_row, const int32_t* w_bucket, int n_buckets,
                             const void* negs, int n_neg, const uint32_t* fix_words, int64_t n_p_rows,
-                            const int32_t* fix_slot_of_row, const int32_t* fix_any, float* d_negs, int exclusive_rows, void* stream);
+                            const int32_t* fix_slot_of_row, const int32_t* fix_any, float* d_negs, int exclusive_rows, int64_t* dn_fix, float* dls_part, void* stream);
 int mhr_nce_shared_bwd_targets(const void* qn_row, int row_cap, const int32_t* tok2row, const int32_t* tok_of_slot,
                                const int32_t* n_tok_dev, int n_groups, int n_slots, int tok_cap, int seq_len,
                                int pred_len, const void* pn, const float* p_inv, int dim,
@@ -614,6 +615,25 @@ int mhr_nce_wide_fwd(const void* queries_packed, int n_rows, const void* negs_pa
 int mhr_nce_wide_grad_tile(const void* queries_packed, int n_rows, const void* negs_packed, int n_neg, int dim, const uint16_t* bits,
                            const float* lse, const float* w, const float* scale_dev, const int32_t* n_live_dev, void* g_bf16,
                            int64_t ldg, void* stream);
+
+/* Deterministic mode.  By default a few reductions of the loss backward add with float atomics from workgroups that arrive in any
+ * order (the negative-side gradient tiles of mhr_nce_bwd_negs, the suppressed-pair corrections and d(logit_scale) of
+ * mhr_nce_shared_bwd_rows, the per-offset loss sums of mhr_nce_finalize, the column sums of mhr_sum_rows_*): two runs of the same
+ * step differ in the last bits.  mhr_set_deterministic(1) (process-wide, host side) makes the launchers that need no extra buffer
+ * pick an order-independent form (mhr_sum_rows_*: one row range per column block; mhr_nce_finalize: one workgroup per group with
+ * a fixed-order fold), and the two entry points with the optional arguments below then give one value whatever the arrival order:
+ *   dn_fix    int64 [n_groups, n_neg, dim], zeroed: fixed-point (2^-40) accumulators that take what would be added to d_negs
+ *             atomically; mhr_det_flush(dn_fix, d_negs, n) adds them into d_negs and zeroes them again;
+ *   dq_fix / dp_fix (mhr_nce_bwd_tokens)  int64 shadows of dq_rows / dp_rows, zeroed; flushed the same way;
+ *   dls_part  float, zeroed: one partial of d(logit_scale) per workgroup ([n_groups, 1024], mhr_nce_shared_bwd_rows) or per wave
+ *             ([n_groups, 2048, 4], mhr_nce_bwd_tokens), without the factor exp(param);
+ *             mhr_det_sum_into(dls_part, n, logit_scale_dev, 1, d_logit_scale) folds them in index order and applies
+ *             exp(clamp(param, 0, ln 100)).
+ * Same mathematics, one rounding more per accumulated value; bitwise reproducible run to run (and replayed vs host-issued). */
+int mhr_set_deterministic(int on);
+int mhr_get_deterministic(void);
+int mhr_det_flush(int64_t* acc, float* dst, int64_t n, void* stream);
+int mhr_det_sum_into(const float* parts, int64_t n, const float* scale_dev, int exp_clamped_scale, float* dst, void* stream);
 
 /* Workspace queries (host functions, no launch).  The library allocates nothing: every entry point takes its operands, outputs
  * and scratch as caller-owned buffers whose shapes are stated with the declaration.  The only scratch whose SIZE depends on a

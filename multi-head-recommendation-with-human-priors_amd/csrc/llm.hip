@@ -237,6 +237,7 @@ static int sum_rows_launch(const void* x, bool f32, int64_t rows, int64_t cols, 
   int64_t splits = 1;
   // (measured: [25600, 1024] 128 workgroups 15.9 us, 256: 21 us, 512: 33 us; [25600, 256] 64 workgroups 16.7 us, 128: 28 us)
   while (splits < 64 && col_blocks * splits < 128 && rows / (splits * 2) >= 64) splits *= 2;
+  if (mhr_deterministic()) splits = 1;             // one row range per column block: a plain read-modify-write, one fixed order
   const int64_t rpb = (rows + splits - 1) / splits;
   const dim3 grid((unsigned)col_blocks, (unsigned)((rows + rpb - 1) / rpb));
   if (f32)
@@ -264,6 +265,7 @@ extern "C" int mhr_sum_rows_many(const int64_t* ptrs, int n, int64_t rows, int64
   // 256 workgroups 22 us, 512: 30 us, 1024: 53 us, 2048: 103 us)
   while (splits < 1024 && col_blocks * splits * n < 256 && rows / (splits * 2) >= 64) splits *= 2;
   if (splits < 2 && rows >= 128) splits = 2;        // (>= 2 row ranges: the atomic path; one range would do a plain read-modify-write)
+  if (mhr_deterministic()) splits = 1;              // deterministic mode: the plain read-modify-write, one fixed order per column
   const int64_t rpb = (rows + splits - 1) / splits;
   hipLaunchKernelGGL(sum_rows_many_kernel, dim3((unsigned)col_blocks, (unsigned)((rows + rpb - 1) / rpb), (unsigned)n), dim3(256), 0,
                      (hipStream_t)stream, ptrs, n, rows, cols, rpb);

@@ -47,7 +47,18 @@ static inline int mhr_grid_for(int64_t work_items, int per_block, int max_blocks
 // mhr_bad_id_count): kernels of other translation units that index the item table count into it too
 unsigned int* mhr_bad_id_counter_addr();
 
+// Deterministic mode (mhr_set_deterministic): launchers that would split a reduction over workgroups adding with float atomics
+// pick an order-independent form instead (one row range per column block; fixed-point accumulators; ordered partial sums).
+int mhr_deterministic();
+
 // ---- device helpers ----------------------------------------------------------------------
+// Order-independent accumulation: fixed-point int64 atomics (integer addition is associative, so the sum has one value whatever
+// order the workgroups arrive in).  2^-40 resolution, |sum| < 2^23 - gradient magnitudes; mhr_det_flush converts back.
+#define MHR_DET_SCALE 1099511627776.0f
+__device__ __forceinline__ void det_atomic_add(long long* acc, float v) {
+  atomicAdd(reinterpret_cast<unsigned long long*>(acc), (unsigned long long)__float2ll_rn(v * MHR_DET_SCALE));
+}
+
 __device__ __forceinline__ float bf2f(bf16_t x) { return (float)x; }
 __device__ __forceinline__ bf16_t f2bf(float x) { return (bf16_t)x; }   // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
 

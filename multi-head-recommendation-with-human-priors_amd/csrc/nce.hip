@@ -914,7 +914,10 @@ __global__ __launch_bounds__(256) void nce_bwd_rows_kernel(const bf16_t* qn, con
                                                            const int32_t* p_idx, float* __restrict__ dq_rows,
                                                            float* __restrict__ dp_rows, float* __restrict__ d_logit_scale,
                                                            float* __restrict__ lw_out, const int32_t* __restrict__ w_bucket,
-                                                           int n_buckets) {
+                                                           int n_buckets, long long* __restrict__ dq_fix,
+                                                           long long* __restrict__ dp_fix, float* __restrict__ dls_part) {
+  // dq_fix / dp_fix / dls_part (deterministic mode, include/mhr.h): fixed-point accumulators shadowing dq_rows / dp_rows and one
+  // d(logit_scale) partial per wave - what would be float atomics in arrival order becomes order-independent
   constexpr int TB = 8;            // consecutive tokens per wave pass (loads in flight; runs sharing a head row are combined)
   constexpr int NC = 4;            // 64-column chunks (dim <= 256)
   {
@@ -964,7 +967,10 @@ __global__ __launch_bounds__(256) void nce_bwd_rows_kernel(const bf16_t* qn, con
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
           const int d = c * 64 + lane;
-          if (d < dim) atomicAdd(qdst + d, accq[c]);
+          if (d < dim) {
+            if (dq_fix) det_atomic_add(dq_fix + (int64_t)run_row * dim + d, accq[c]);
+            else atomicAdd(qdst + d, accq[c]);
+          }
         }
       }
     };
@@ -1002,12 +1008,18 @@ __global__ __launch_bounds__(256) void nce_bwd_rows_kernel(const bf16_t* qn, con
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
         const int d = c * 64 + lane;
-        if (d < dim) atomicAdd(pdst + d, (dpn[c] - pv[b][c] * dot_p) * ip[b]);
+        if (d < dim) {
+          if (dp_fix) det_atomic_add(dp_fix + (int64_t)pi[b] * dim + d, (dpn[c] - pv[b][c] * dot_p) * ip[b]);
+          else atomicAdd(pdst + d, (dpn[c] - pv[b][c] * dot_p) * ip[b]);
+        }
       }
     }
     flush();
   }
-  if (lane == 0 && d_logit_scale && dls != 0.f) atomicAdd(d_logit_scale, dls * scale);   // d/d(param), scale = exp(param)
+  if (lane == 0 && d_logit_scale) {
+    if (dls_part) dls_part[((int64_t)blockIdx.z * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)] = dls;   // (x exp(param) at the fold)
+    else if (dls != 0.f) atomicAdd(d_logit_scale, dls * scale);   // d/d(param), scale = exp(param)
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1018,7 +1030,7 @@ __global__ __launch_bounds__(256, 1) void nce_bwd_n_kernel(const bf16_t* qn, con
                                                            const uint32_t* supp, int n_neg,
                                                            const int32_t* n_tok_dev, int tok_cap,
                                                            const float* __restrict__ logit_scale_dev,
-                                                           const float* lw, float* d_negs) {
+                                                           const float* lw, float* d_negs, long long* dn_fix) {
   using T = sg::Tile<NKS>;
   constexpr int ND = (NKS + 1) / 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1031,6 +1043,7 @@ __global__ __launch_bounds__(256, 1) void nce_bwd_n_kernel(const bf16_t* qn, con
     qn += to * T::DIM; negs += grp * (int64_t)((n_neg + 31) & ~31) * T::DIM;
     if constexpr (SUPP) supp += grp * (int64_t)((n_neg + 31) >> 5) * tok_cap;
     n_tok_dev += grp; lw += to; d_negs += grp * (int64_t)n_neg * T::DIM;
+    if (dn_fix) dn_fix += grp * (int64_t)n_neg * T::DIM;
   }
   const int n_tok = min(*n_tok_dev, tok_cap);
   const int n_tok_tiles = (n_tok + 31) >> 5;
@@ -1149,7 +1162,10 @@ __global__ __launch_bounds__(256, 1) void nce_bwd_n_kernel(const bf16_t* qn, con
 #pragma unroll
       for (int dc = 0; dc < ND; ++dc) {
         const int d = dc * 32 + r;
-        if (d < T::DIM) atomicAdd(d_negs + (int64_t)nj * T::DIM + d, scale * dn[dc][g]);
+        if (d < T::DIM) {
+          if (dn_fix) det_atomic_add(dn_fix + (int64_t)nj * T::DIM + d, scale * dn[dc][g]);     // order-independent (mhr.h)
+          else atomicAdd(d_negs + (int64_t)nj * T::DIM + d, scale * dn[dc][g]);
+        }
       }
     }
   }
@@ -1336,6 +1352,40 @@ extern "C" int mhr_nce_fix_bits(const void* p_rows, int io_dtype, int64_t n_p_ro
   return MHR_OK;
 }
 
+// Deterministic form of the per-(group, offset) loss sums (mhr_set_deterministic): ONE workgroup per group; thread t adds the losses of
+// tokens t, t + 256, ... into its own column of an LDS table (in token order), then every bucket's 256 column sums are folded in
+// a fixed order - no atomics.  The regular kernel adds block partials with float atomics (LDS, then global).
+constexpr int DET_MAX_BUCKETS = 32;
+__global__ __launch_bounds__(256) void nce_bucket_sums_det_kernel(const float* __restrict__ loss, const int32_t* __restrict__ bucket_idx,
+                                                                  const int32_t* __restrict__ n_tok_dev, int tok_cap, int n_buckets,
+                                                                  float* __restrict__ bucket_sum, float* __restrict__ bucket_cnt) {
+  extern __shared__ float sp[];                               // [n_buckets][256] sums, then [n_buckets][256] counts
+  float* cp = sp + n_buckets * 256;
+  const int g = blockIdx.x, tid = threadIdx.x;
+  const int64_t to = (int64_t)g * tok_cap;
+  const int n_tok = min(n_tok_dev[g], tok_cap);
+  for (int b = 0; b < n_buckets; ++b) sp[b * 256 + tid] = cp[b * 256 + tid] = 0.f;
+  for (int tk = tid; tk < n_tok; tk += 256) {
+    const int b = bucket_idx[to + tk];
+    if (b >= 0 && b < n_buckets) {
+      sp[b * 256 + tid] += loss[to + tk];
+      cp[b * 256 + tid] += 1.0f;
+    }
+  }
+  __syncthreads();
+  const int wave = tid >> 6, lane = tid & 63;
+  for (int b = wave; b < n_buckets; b += 4) {
+    float s4 = ((sp[b * 256 + lane] + sp[b * 256 + 64 + lane]) + (sp[b * 256 + 128 + lane] + sp[b * 256 + 192 + lane]));
+    float c4 = ((cp[b * 256 + lane] + cp[b * 256 + 64 + lane]) + (cp[b * 256 + 128 + lane] + cp[b * 256 + 192 + lane]));
+    s4 = wave_sum(s4);
+    c4 = wave_sum(c4);
+    if (lane == 0 && c4 != 0.f) {
+      bucket_sum[g * n_buckets + b] += s4;
+      bucket_cnt[g * n_buckets + b] += c4;
+    }
+  }
+}
+
 extern "C" int mhr_nce_finalize(const float* sum, const float* s_pos, int n_groups, const int32_t* n_tok_dev, int tok_cap,
                                 const float* logit_scale_dev, float* loss, float* lse, int32_t* n_valid,
                                 const int32_t* bucket_idx, int n_buckets, float* bucket_sum, float* bucket_cnt, void* stream) {
@@ -1343,9 +1393,17 @@ extern "C" int mhr_nce_finalize(const float* sum, const float* s_pos, int n_grou
   MHR_REQUIRE(tok_cap > 0 && n_groups >= 1 && n_groups <= 65535, "nce_finalize: bad sizes");
   MHR_REQUIRE(!bucket_idx || (bucket_sum && bucket_cnt && n_buckets >= 1 && n_buckets <= MAX_BUCKETS),
               "nce_finalize: bucket sums need bucket_sum, bucket_cnt and 1 <= n_buckets <= %d", MAX_BUCKETS);
+  const bool det = bucket_idx && mhr_deterministic();
+  MHR_REQUIRE(!det || n_buckets <= DET_MAX_BUCKETS, "nce_finalize: deterministic mode supports at most %d buckets", DET_MAX_BUCKETS);
   hipLaunchKernelGGL(nce_finalize_kernel, dim3((tok_cap + 255) / 256, n_groups), dim3(256), 0, (hipStream_t)stream, sum, s_pos,
-                     n_tok_dev, tok_cap, logit_scale_dev, loss, lse, n_valid, bucket_idx, n_buckets, bucket_sum, bucket_cnt);
+                     n_tok_dev, tok_cap, logit_scale_dev, loss, lse, n_valid, det ? nullptr : bucket_idx, n_buckets, bucket_sum,
+                     bucket_cnt);
   MHR_CHECK_LAUNCH("nce_finalize");
+  if (det) {
+    hipLaunchKernelGGL(nce_bucket_sums_det_kernel, dim3(n_groups), dim3(256), (size_t)2 * n_buckets * 256 * sizeof(float),
+                       (hipStream_t)stream, loss, bucket_idx, n_tok_dev, tok_cap, n_buckets, bucket_sum, bucket_cnt);
+    MHR_CHECK_LAUNCH("nce_finalize (deterministic bucket sums)");
+  }
   return MHR_OK;
 }
 
@@ -1353,7 +1411,8 @@ extern "C" int mhr_nce_bwd_tokens(const void* qn, const void* pn, const float* u
                                   const int32_t* n_tok_dev, int tok_cap, const float* logit_scale_dev, const float* lse,
                                   const float* w, const float* q_inv, const float* p_inv, const float* s_pos,
                                   const int32_t* q_idx, const int32_t* p_idx, float* dq_rows, float* dp_rows,
-                                  float* d_logit_scale, float* lw_out, const int32_t* w_bucket, int n_buckets, void* stream) {
+                                  float* d_logit_scale, float* lw_out, const int32_t* w_bucket, int n_buckets, int64_t* dq_fix,
+                                  int64_t* dp_fix, float* dls_part, void* stream) {
   MHR_REQUIRE(qn && pn && u && n_tok_dev && logit_scale_dev && lse && w && q_inv && p_inv && s_pos,
               "nce_bwd_tokens: null input pointer");
   MHR_REQUIRE(q_idx && p_idx && dq_rows && dp_rows, "nce_bwd_tokens: null index/output pointer");
@@ -1363,14 +1422,14 @@ extern "C" int mhr_nce_bwd_tokens(const void* qn, const void* pn, const float* u
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(nce_bwd_rows_kernel, dim3(blocks, 1, n_groups), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qn,
                      (const bf16_t*)pn, u, dim, n_tok_dev, tok_cap, logit_scale_dev, lse, w, q_inv, p_inv, s_pos, q_idx, p_idx,
-                     dq_rows, dp_rows, d_logit_scale, lw_out, w_bucket, n_buckets);
+                     dq_rows, dp_rows, d_logit_scale, lw_out, w_bucket, n_buckets, (long long*)dq_fix, (long long*)dp_fix, dls_part);
   MHR_CHECK_LAUNCH("nce_bwd_tokens");
   return MHR_OK;
 }
 
 extern "C" int mhr_nce_bwd_negs(const void* qn, const void* negs, const uint32_t* supp, int n_neg, int dim, int n_groups,
                                 const int32_t* n_tok_dev, int tok_cap, const float* logit_scale_dev, const float* lw,
-                                float* d_negs, void* stream) {
+                                float* d_negs, int64_t* dn_fix, void* stream) {
   MHR_REQUIRE(qn && negs && n_tok_dev && logit_scale_dev && lw && d_negs, "nce_bwd_negs: null pointer");
   MHR_REQUIRE(tok_cap % 32 == 0, "nce_bwd_negs: tok_cap=%d must be a multiple of 32", tok_cap);
   int nks;
@@ -1387,10 +1446,12 @@ extern "C" int mhr_nce_bwd_negs(const void* qn, const void* negs, const uint32_t
     size_t lds_n = 4 * (sg::Tile<NKS>::BYTES + 1024);                                                                  \
     if (supp)                                                                                                          \
       hipLaunchKernelGGL((nce_bwd_n_kernel<NKS, true>), dim3(neg_groups, splits, n_groups), dim3(256), lds_n, s,       \
-                         (const bf16_t*)qn, (const bf16_t*)negs, supp, n_neg, n_tok_dev, tok_cap, logit_scale_dev, lw, d_negs); \
+                         (const bf16_t*)qn, (const bf16_t*)negs, supp, n_neg, n_tok_dev, tok_cap, logit_scale_dev, lw, d_negs, \
+                         (long long*)dn_fix);                                                                          \
     else                                                                                                               \
       hipLaunchKernelGGL((nce_bwd_n_kernel<NKS, false>), dim3(neg_groups, splits, n_groups), dim3(256), lds_n, s,      \
-                         (const bf16_t*)qn, (const bf16_t*)negs, supp, n_neg, n_tok_dev, tok_cap, logit_scale_dev, lw, d_negs); \
+                         (const bf16_t*)qn, (const bf16_t*)negs, supp, n_neg, n_tok_dev, tok_cap, logit_scale_dev, lw, d_negs, \
+                         (long long*)dn_fix);                                                                          \
   }
   NKS_SWITCH(nks, L_);
 #undef L_

@@ -339,7 +339,8 @@ __global__ __launch_bounds__(256) void shared_bwd_rows_kernel(
     const int32_t* __restrict__ p_idx, float* __restrict__ dq_rows, float* __restrict__ d_logit_scale,
     float* __restrict__ lw_row, const int32_t* __restrict__ w_bucket, int n_buckets, const bf16_t* __restrict__ negs, int n_neg,
     const uint32_t* __restrict__ fixw, int n_rows_pad, int n_p_rows, const int32_t* __restrict__ slot_of_row,
-    const int32_t* __restrict__ fix_any, float* __restrict__ d_negs, int exclusive_rows) {
+    const int32_t* __restrict__ fix_any, float* __restrict__ d_negs, int exclusive_rows, long long* __restrict__ dn_fix,
+    float* __restrict__ dls_part) {
   const int n_tiles = (n_neg + 31) >> 5;
   {
     const int64_t grp = blockIdx.z, to = grp * tok_cap, ro = grp * row_cap;
@@ -351,6 +352,7 @@ __global__ __launch_bounds__(256) void shared_bwd_rows_kernel(
     fix_any += grp * (int64_t)n_rows_pad;
     if (slot_of_row) slot_of_row += grp * (int64_t)n_p_rows;
     if (d_negs) d_negs += grp * (int64_t)n_neg * dim;
+    if (dn_fix) dn_fix += grp * (int64_t)n_neg * dim;
   }
   const int n_row = min(*n_row_dev, row_cap - 1);
   // A HALF-wave per (group, row): two rows per wave, lane hl of a half = token hl of ITS row in the scalar round and the 8
@@ -500,7 +502,10 @@ __global__ __launch_bounds__(256) void shared_bwd_rows_kernel(
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
               const int d = c * 64 + lane;
-              if (d < dim) atomicAdd(d_negs + (int64_t)j * dim + d, gneg * qc[c]);
+              if (d < dim) {
+                if (dn_fix) det_atomic_add(dn_fix + (int64_t)j * dim + d, gneg * qc[c]);       // order-independent (deterministic mode)
+                else atomicAdd(d_negs + (int64_t)j * dim + d, gneg * qc[c]);
+              }
             }
           }
         });
@@ -576,7 +581,10 @@ __global__ __launch_bounds__(256) void shared_bwd_rows_kernel(
   __syncthreads();
   if (threadIdx.x == 0 && d_logit_scale) {
     const float t = (s_dls[0] + s_dls[1]) + (s_dls[2] + s_dls[3]);
-    if (t != 0.f) atomicAdd(d_logit_scale, t * scale);       // d/d(param), scale = exp(param)
+    // deterministic mode: this workgroup's partial into its own slot; mhr_det_sum_into folds the slots in index order and applies
+    // the factor exp(param)
+    if (dls_part) dls_part[(int64_t)blockIdx.z * gridDim.x + blockIdx.x] = t;
+    else if (t != 0.f) atomicAdd(d_logit_scale, t * scale);       // d/d(param), scale = exp(param)
   }
 }
 
@@ -773,7 +781,7 @@ extern "C" int mhr_nce_shared_bwd_rows(const void* qn_row, const float* u_row, c
                                        float* d_logit_scale, float* lw_row, const int32_t* w_bucket, int n_buckets,
                                        const void* negs, int n_neg, const uint32_t* fix_words, int64_t n_p_rows,
                                        const int32_t* fix_slot_of_row, const int32_t* fix_any, float* d_negs, int exclusive_rows,
-                                       void* stream) {
+                                       int64_t* dn_fix, float* dls_part, void* stream) {
   MHR_REQUIRE(qn_row && u_row && q_inv_row && row_q && row_first && n_row_dev && pn && logit_scale_dev && lse && w && s_pos,
               "nce_shared_bwd_rows: null input pointer");
   MHR_REQUIRE(p_idx && dq_rows && lw_row && negs && fix_words && fix_any, "nce_shared_bwd_rows: null index/output pointer");
@@ -788,7 +796,7 @@ extern "C" int mhr_nce_shared_bwd_rows(const void* qn_row, const float* u_row, c
                      (const bf16_t*)qn_row, u_row, q_inv_row, row_q, row_first, n_row_dev, row_cap, (const bf16_t*)pn, dim, tok_cap,
                      logit_scale_dev, lse, w, s_pos, p_idx, dq_rows, d_logit_scale, lw_row, w_bucket, n_buckets,
                      (const bf16_t*)negs, n_neg, fix_words, n_rows_pad, (int)n_p_rows, fix_slot_of_row, fix_any, d_negs,
-                     exclusive_rows ? 1 : 0);
+                     exclusive_rows ? 1 : 0, (long long*)dn_fix, dls_part);
   MHR_CHECK_LAUNCH("nce_shared_bwd_rows");
   return MHR_OK;
 }

@@ -611,6 +611,24 @@ _ROW_IOTA = {}
 
 
 SHARE_ROWS = os.environ.get("MHR_NCE_SHARE_ROWS", "1") != "0"
+DETERMINISTIC = False
+
+
+def set_deterministic(on):
+    """Order-independent reductions in the loss backward (include/mhr.h: deterministic mode): fixed-point accumulators for the
+    negative-side gradient, ordered partial sums for d(logit_scale), single-range column sums, a fixed-order fold of the per-offset
+    loss sums.  Bitwise reproducible steps (run to run, replayed vs host-issued) for the row-sharing sampled softmax (loss =
+    'prior' with pred_len > 1: cfg1); a few per cent slower.  Process-wide; also MHR_DETERMINISTIC=1 in the environment."""
+    global DETERMINISTIC
+    DETERMINISTIC = bool(on)
+    lib.call("mhr_set_deterministic", 1 if on else 0)
+
+
+if os.environ.get("MHR_DETERMINISTIC", "0") == "1":
+    try:
+        set_deterministic(True)
+    except RuntimeError:          # (library not built yet: lib.load() raises at the first real use anyway)
+        DETERMINISTIC = True
 _ZERO_FIX = {}
 
 
@@ -938,6 +956,10 @@ def nce_bwd(sv, w, logit_scale, q_idx, p_idx, dq_rows, dp_rows, d_negs=None, d_l
         if lw_row is None:                   # (+inf: a row the kernels do not visit contributes nothing to the negative-side product)
             lw_row = torch.full((G, sv.row_cap), float("inf"), dtype=torch.float32, device=dev)
         assert lw_row.shape == (G, sv.row_cap)
+        dn_fix = dls_part = None
+        if DETERMINISTIC and sv.window is not None:
+            dn_fix = torch.zeros(d_negs.shape, dtype=torch.int64, device=dev) if want_negs else None
+            dls_part = torch.zeros(G * 1024, dtype=torch.float32, device=dev)
         if sv.window is not None:            # window-structured lists: sums formed where they land, no per-token atomics
             tos, L_, P_ = sv.window
             _timed_call("mhr_nce_shared_bwd_rows", sv.qn.data_ptr(), sv.u.data_ptr(), sv.q_inv.data_ptr(), sv.row_q.data_ptr(),
@@ -945,7 +967,9 @@ def nce_bwd(sv, w, logit_scale, q_idx, p_idx, dq_rows, dp_rows, d_negs=None, d_l
                         logit_scale.data_ptr(), sv.lse.data_ptr(), w.data_ptr(), sv.s_pos.data_ptr(), sv.p_idx.data_ptr(),
                         dq_rows.data_ptr(), d_logit_scale.data_ptr(), lw_row.data_ptr(), wb_ptr, nb, sv.negs.data_ptr(), sv.n_neg,
                         sv.fix_words.data_ptr(), sv.n_p_rows, _ptr(sv.fix_slot), sv.fix_any.data_ptr(), dn_ptr,
-                        1 if exclusive_q_rows else 0, st)
+                        1 if exclusive_q_rows else 0, _ptr(dn_fix), _ptr(dls_part), st)
+            if dls_part is not None:         # the workgroups' partials of d(logit_scale), folded in index order
+                lib.call("mhr_det_sum_into", dls_part.data_ptr(), dls_part.numel(), logit_scale.data_ptr(), 1, d_logit_scale.data_ptr(), st)
             _timed_call("mhr_nce_shared_bwd_targets", sv.qn.data_ptr(), sv.row_cap, sv.tok2row.data_ptr(), tos.data_ptr(),
                         sv.n_tok_dev.data_ptr(), G, tos.shape[1], cap, int(L_), int(P_), sv.pn.data_ptr(), sv.p_inv.data_ptr(), D,
                         logit_scale.data_ptr(), sv.lse.data_ptr(), w.data_ptr(), sv.s_pos.data_ptr(), wb_ptr, nb, sv.n_p_rows,
@@ -963,17 +987,32 @@ def nce_bwd(sv, w, logit_scale, q_idx, p_idx, dq_rows, dp_rows, d_negs=None, d_l
                          lw_row.data_ptr(), st)
         if want_negs:
             _timed_call("mhr_nce_bwd_negs", sv.qn.data_ptr(), sv.negs.data_ptr(), _ptr(sv.supp), sv.n_neg, D, G,
-                        sv.n_row_dev.data_ptr(), sv.row_cap, logit_scale.data_ptr(), lw_row.data_ptr(), d_negs.data_ptr(), st)
+                        sv.n_row_dev.data_ptr(), sv.row_cap, logit_scale.data_ptr(), lw_row.data_ptr(), d_negs.data_ptr(),
+                        _ptr(dn_fix), st)
+            if dn_fix is not None:           # fixed-point accumulators (tiles + suppressed-pair corrections) -> d_negs
+                lib.call("mhr_det_flush", dn_fix.data_ptr(), d_negs.data_ptr(), d_negs.numel(), st)
         return d_negs, d_logit_scale
     lw = torch.empty(G, cap, dtype=torch.float32, device=dev)     # lse log2e - log2 w: written by bwd_tokens, read by bwd_negs
+    dq_fix = dp_fix = dls_part = dn_fix = None
+    if DETERMINISTIC:             # order-independent accumulation (include/mhr.h: deterministic mode)
+        dq_fix = torch.zeros(dq_rows.shape, dtype=torch.int64, device=dev)
+        dp_fix = torch.zeros(dp_rows.shape, dtype=torch.int64, device=dev)
+        dls_part = torch.zeros(G * 2048 * 4, dtype=torch.float32, device=dev)
+        dn_fix = torch.zeros(d_negs.shape, dtype=torch.int64, device=dev) if want_negs else None
     _timed_call("mhr_nce_bwd_tokens", sv.qn.data_ptr(), sv.pn.data_ptr(), sv.u.data_ptr(), D,
                 G, sv.n_tok_dev.data_ptr(), cap, logit_scale.data_ptr(), sv.lse.data_ptr(), w.data_ptr(), sv.q_inv.data_ptr(),
                 sv.p_inv.data_ptr(), sv.s_pos.data_ptr(), sv.q_idx.data_ptr(), sv.p_idx.data_ptr(), dq_rows.data_ptr(),
                 dp_rows.data_ptr(), d_logit_scale.data_ptr(), lw.data_ptr(), sv.bucket_idx.data_ptr() if bucketed else 0,
-                sv.n_buckets if bucketed else 0, st)
+                sv.n_buckets if bucketed else 0, _ptr(dq_fix), _ptr(dp_fix), _ptr(dls_part), st)
+    if dq_fix is not None:
+        lib.call("mhr_det_flush", dq_fix.data_ptr(), dq_rows.data_ptr(), dq_rows.numel(), st)
+        lib.call("mhr_det_flush", dp_fix.data_ptr(), dp_rows.data_ptr(), dp_rows.numel(), st)
+        lib.call("mhr_det_sum_into", dls_part.data_ptr(), dls_part.numel(), logit_scale.data_ptr(), 1, d_logit_scale.data_ptr(), st)
     if want_negs:
         _timed_call("mhr_nce_bwd_negs", sv.qn.data_ptr(), sv.negs.data_ptr(), sv.supp.data_ptr(), sv.n_neg, D, G,
-                    sv.n_tok_dev.data_ptr(), cap, logit_scale.data_ptr(), lw.data_ptr(), d_negs.data_ptr(), st)
+                    sv.n_tok_dev.data_ptr(), cap, logit_scale.data_ptr(), lw.data_ptr(), d_negs.data_ptr(), _ptr(dn_fix), st)
+        if dn_fix is not None:
+            lib.call("mhr_det_flush", dn_fix.data_ptr(), d_negs.data_ptr(), d_negs.numel(), st)
     return d_negs, d_logit_scale
 
 

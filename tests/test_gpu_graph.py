@@ -123,6 +123,46 @@ def test_replayed_steps_follow_the_host_issued_trajectory(rec, loss):
     assert abs(lg[10] - lg[4]) > 0 or loss == "nce"
 
 
+@pytest.mark.parametrize("loss", ["prior", "nce"])
+def test_deterministic_mode_makes_replayed_and_host_issued_runs_bitwise_equal(rec, loss):
+    """`ops.set_deterministic(True)` (include/mhr.h: deterministic mode): the float-atomic reductions of the loss backward - the
+    negative-side gradient tiles, the suppressed-pair corrections, d(logit_scale), the per-offset loss sums, the bias column sums -
+    take their order-independent forms.  Two host-issued runs then agree bit for bit, and so do a replayed and a host-issued run
+    over all 70 steps (across the lazy table's flush): a stale replayed constant, a wrong dropout counter or a missed weight
+    refresh cannot hide behind atomic noise any more."""
+    from mhr_amd import ops
+    dev = torch.device("cuda", 0)
+    over = dict(loss=loss) if loss == "prior" else dict(loss="nce", num_prior_head=1, medusa_num_layers=0, eval_num_cats=1, pred_len=1,
+                                                        eval_pred_len=1)
+    ops.set_deterministic(True)
+    try:
+        tr_a, m_a, data = _trainer(rec, False, dev, **over)
+        tr_b, m_b, _ = _trainer(rec, False, dev, **over)
+        tr_g, m_g, _ = _trainer(rec, True, dev, **over)
+        batches = [data.train_batch(16) for _ in range(6)]
+        n_steps = 70
+        la, lb, lg = [], [], []
+        for i in range(n_steps):
+            b = batches[i % len(batches)]
+            la.append(float(tr_a.train_step_fn(b)["loss"]))
+            lb.append(float(tr_b.train_step_fn(b)["loss"]))
+            lg.append(float(tr_g.train_step_fn(b)["loss"]))
+        assert tr_g.graph_active and tr_g._step_graph.n == n_steps - 3
+        assert la == lb, [i for i in range(n_steps) if la[i] != lb[i]][:5]                 # host-issued twice: same bits
+        assert la == lg, [i for i in range(n_steps) if la[i] != lg[i]][:5]                 # replayed: same bits
+        sd_a, sd_b, sd_g = m_a.state_dict(), m_b.state_dict(), m_g.state_dict()
+        for k in sd_a:
+            assert torch.equal(sd_a[k], sd_b[k]), k
+            assert torch.equal(sd_a[k], sd_g[k]), k
+        assert torch.equal(tr_a.optimizer.flat_m, tr_g.optimizer.flat_m) and torch.equal(tr_a.optimizer.t_v, tr_g.optimizer.t_v)
+        assert la[-1] < la[0]
+    finally:
+        ops.set_deterministic(False)
+    # and the default mode is the fast one again
+    from mhr_amd import lib
+    assert lib.load().mhr_get_deterministic() == 0
+
+
 def test_host_issued_steps_interleave_with_replays(rec):
     """bench.py's evented pass issues steps from the host between replays: counters, lazy-table state and the constants'
     history are shared, so the run is the same run."""
