@@ -454,7 +454,7 @@ def main():
             trainer.compute_item_feature(data.item_tags)
 
             def step(i, eager=False):
-                fused, pu, pi, tt, _ = trainer._full_sort_batch_eval(batches[i % len(batches)])
+                fused, pu, pi, tt, _ = trainer._full_sort_batch_eval(batches[i % len(batches)], graph=False if eager else None)
                 trainer.eval_collector.eval_batch_collect(fused, pu, pi)
                 return None
         ops.PROFILE = None
@@ -641,7 +641,8 @@ def main():
                        "global_batch": world * B, "seq_len": L, "parallelism": f"dp{world}"},
         }
         assert out["n_gpus"] == args.gpus
-        out["graph_active"] = graph_on
+        out["graph_active"] = graph_on if args.mode == "train" else any(
+            g_.graph is not None for g_ in trainer.__dict__.get("_eval_graphs", {}).values())
         out["graph_expected"] = bool(graph_expected)
         if getattr(trainer, "graph_failure", None):
             out["graph_failure"] = trainer.graph_failure
@@ -719,6 +720,7 @@ def main():
                 eo["roofline"] = cr
             eo["kernel_ms_per_step"] = {k: round(v[2] / ev["event_steps"], 3) for k, v in sorted(ev["prof"].items(), key=lambda kv: -kv[1][2])}
             eo["host_enqueue_ms_per_step"] = round(1000 * ev["host_enqueue"] / ev["steps"], 3)
+            eo["graph_active"] = any(g_.graph is not None for g_ in trainer.__dict__.get("_eval_graphs", {}).values())
             out["eval"] = eo
         if args.emulate_world > 1 and world == 1 and args.mode == "train" and getattr(trainer.optimizer, "lazy", False):
             out["emulated_world"] = emulate_world(args.emulate_world)

@@ -399,11 +399,13 @@ class HSTU(MultiHeadDecoding, BaseModel):
 
     @torch.no_grad()
     def predict_topk(self, item_seq, all_item_feature, all_item_tags, target_tags, history=None, k=200,
-                     suppress_history=True, stats=None):
+                     suppress_history=True, stats=None, defer=False):
         """Fused eval: encoder -> heads -> catalog scoring with tag / pad / history masks -> exact per-head top-k.
-        Replaces reference hstu.py:965-1015 + trainer.py:724-726 + collector.py:245 without the [B,H,N] tensor."""
+        Replaces reference hstu.py:965-1015 + trainer.py:724-726 + collector.py:245 without the [B,H,N] tensor.
+        defer=True: enqueue everything up to the decode's one verification read and return finish() -> FusedTopK (what the
+        Trainer's replayed evaluation step captures)."""
         return self._decode_topk(self._last_hidden(item_seq), all_item_feature, all_item_tags, target_tags, history, k,
-                                 suppress_history, stats, self.item_num)
+                                 suppress_history, stats, self.item_num, defer=defer)
 
     @torch.no_grad()
     def predict(self, item_seq, time_seq, all_item_feature, all_item_tags, target_tags, save_for_eval=False):

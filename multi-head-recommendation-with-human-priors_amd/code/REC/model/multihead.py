@@ -539,7 +539,7 @@ class MultiHeadDecoding:
 
     @torch.no_grad()
     def _decode_topk(self, last, all_item_feature, all_item_tags, target_tags, history, k, suppress_history, stats, n_ids,
-                     heads_n=None):
+                     heads_n=None, defer=False):
         """Heads at the last position -> catalog scoring with tag / pad / history / switch masks -> exact per-head top-k.
         Replaces reference hstu.py:915-1015 + trainer.py:724-726 + collector.py:245 without the [B,H,N] tensor."""
         from mhr_amd import ops
@@ -569,9 +569,21 @@ class MultiHeadDecoding:
         if self.exact_fp32_topk:
             # ranked on fp32 scores like the reference (hstu.py:965-979 + collector.py:245): bf16 scorer for the candidates
             # within 2^-7 of the k-th score, fp32 re-score of those, exact select (ops.catalog_topk_exact)
+            if defer:
+                # everything up to the verification read is enqueued (capturable); finish() reads the flags, repairs the rare rows
+                vals, idx, fin = ops.catalog_topk_exact(heads_n.reshape(B * H, -1).float().contiguous(), H, items_bf, self._item_cache[3],
+                                                        tag_bits, row_bits, hist_ptr, hist_items, k, n_items=all_item_feature.shape[0],
+                                                        defer=True)
+
+                def finish():
+                    v, i = fin()
+                    return FusedTopK(v.view(B, H, k), i.view(B, H, k), logs)
+                return finish
             vals, idx = ops.catalog_topk_exact(heads_n.reshape(B * H, -1).float().contiguous(), H, items_bf, self._item_cache[3],
                                                tag_bits, row_bits, hist_ptr, hist_items, k, n_items=all_item_feature.shape[0],
                                                stats=stats)
+        elif defer:
+            raise ValueError("deferred decode needs exact_fp32_topk")
         else:
             vals, idx = ops.catalog_topk(users, H, items_bf, tag_bits, row_bits, hist_ptr, hist_items, k, stats=stats,
                                          n_items=all_item_feature.shape[0])

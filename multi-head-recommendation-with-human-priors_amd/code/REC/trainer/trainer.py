@@ -217,6 +217,59 @@ class _StepGraph:
         return self.out
 
 
+class _EvalGraph:
+    """One evaluation step - encoder, heads, full-catalog multi-head scoring, exact per-head top-k up to its verification
+    flags - captured as a hipGraph and replayed (reference trainer.py:698-729 + hstu.py:874-1016 + collector.py:245 per batch).
+    Issued launch by launch the step costs the host 2.4 ms for 2.0 ms of GPU work and ends in a blocking read, so the two add up;
+    replayed, the host's part is one graph launch in front of that read.  Static inputs: the id window, the target tags and the
+    batch's history pairs PADDED to a capacity (pad pairs carry user id B: they sort behind every real user and fall outside the
+    CSR offsets the kernels read).  The flags are read after the replay; the rare repair (rows re-run exactly) runs eagerly on the
+    graph's tensors.  Graphs bake the pointers of the cached item table / bf16 weight casts: `Trainer.compute_item_feature` drops
+    them."""
+    WARM, HIST_BLOCK = 2, 8192
+
+    def __init__(self, trainer, key):
+        self.tr, self.key = trainer, key
+        self.warm, self.graph, self.static, self.finish = 0, None, None, None
+
+    @staticmethod
+    def hist_capacity(n):
+        return max(_EvalGraph.HIST_BLOCK, -(-n // _EvalGraph.HIST_BLOCK) * _EvalGraph.HIST_BLOCK)
+
+    def _pad_hist(self, hu, hi, cap, B):
+        n = hu.numel()
+        if n == cap:
+            return hu, hi
+        return (torch.cat([hu, hu.new_full((cap - n,), B)]), torch.cat([hi, hi.new_zeros(cap - n)]))
+
+    def run(self, item_seq, target_tags, hu, hi, k):
+        tr = self.tr
+        m = tr.model.module
+        B = item_seq.shape[0]
+        cap = self.key[-1]
+        hu, hi = self._pad_hist(hu, hi, cap, B)
+        if self.graph is None:
+            if self.warm < self.WARM:                # host-issued first: caches (item table casts, row bits, allocator pools)
+                self.warm += 1
+                return m.predict_topk(item_seq, tr.item_feature, tr.all_item_tags, target_tags, (hu, hi), k=k)
+            try:
+                self.static = (item_seq.clone(), target_tags.clone(), hu.clone(), hi.clone())
+                g = torch.cuda.CUDAGraph()
+                m.sync_table()
+                with torch.cuda.graph(g):
+                    self.finish = m.predict_topk(self.static[0], tr.item_feature, tr.all_item_tags, self.static[1],
+                                                 (self.static[2], self.static[3]), k=k, defer=True)
+                self.graph = g
+            except Exception as e:  # noqa: BLE001 - an evaluation step that cannot be captured still runs, launch by launch
+                tr._eval_graph_failed = f"{type(e).__name__}: {e}"
+                tr.logger.warning(f"hipGraph capture of the evaluation step failed ({tr._eval_graph_failed}); continuing host-issued")
+                self.graph = self.static = self.finish = None
+                return m.predict_topk(item_seq, tr.item_feature, tr.all_item_tags, target_tags, (hu, hi), k=k)
+        torch._foreach_copy_(list(self.static), [item_seq, target_tags, hu, hi], non_blocking=True)
+        self.graph.replay()
+        return self.finish()                         # the decode's one host read (+ the rare exact re-run of flagged rows)
+
+
 class Trainer(object):
     def __init__(self, config):
         self.config = config
@@ -450,6 +503,7 @@ class Trainer(object):
             orig_tags = item_tags
         self.eval_collector.set_all_tags(orig_tags.long())
         self.all_item_tags = item_tags.long().transpose(0, 1).contiguous()
+        self.__dict__.pop("_eval_graphs", None)          # captured evaluation steps read the previous table / weight casts
 
     @torch.no_grad()
     def cache_item_tower(self, item_loader):
@@ -460,14 +514,42 @@ class Trainer(object):
         return self.item_feature
 
     @torch.no_grad()
-    def _full_sort_batch_eval(self, batched_data, stats=None):
+    def _full_sort_batch_eval(self, batched_data, stats=None, graph=None):
+        """-> (FusedTopK, positive_u, item_target, target_tags, outlier_users).  After two host-issued batches of a shape the step
+        is replayed from a hipGraph (`_EvalGraph`); its FusedTopK then lives in the graph's static tensors and is overwritten by the
+        next batch - consume it (the Collector does) or clone it.  graph=False forces the launch-by-launch form."""
         _, item_seq, item_target, history_index, positive_u, time_seq, target_tags, outlier_users = batched_data
         dev = self.device
         item_seq, item_target, target_tags = item_seq.to(dev), item_target.to(dev), target_tags.to(dev)
         hist = history_index if self.config.get("suppress_history", True) else None
-        fused = self.model.module.predict_topk(item_seq, self.item_feature, self.all_item_tags, target_tags, hist,
-                                               k=max(self.config["topk"]), stats=stats)
+        k = max(self.config["topk"])
+        if stats is None and graph is not False and hist is not None and self._eval_graph_ok(item_seq):
+            hu, hi = hist[0].to(dev), hist[1].to(dev)
+            key = (tuple(item_seq.shape), tuple(target_tags.shape), _EvalGraph.hist_capacity(hu.numel()))
+            graphs = self.__dict__.setdefault("_eval_graphs", OrderedDict())
+            eg = graphs.get(key)
+            if eg is None:
+                if len(graphs) >= 4:
+                    graphs.popitem(last=False)
+                eg = graphs[key] = _EvalGraph(self, key)
+            fused = eg.run(item_seq, target_tags, hu, hi, k)
+        else:
+            fused = self.model.module.predict_topk(item_seq, self.item_feature, self.all_item_tags, target_tags, hist, k=k, stats=stats)
         return fused, positive_u, item_target, target_tags, outlier_users
+
+    def _eval_graph_ok(self, item_seq):
+        """The evaluation step can be replayed: streaming decode (feature dim <= 256, a catalog beyond the small-catalog path),
+        fp32-ranked top-k with its deferred verification, static head constraints (no prior given at test time, no prior switch)."""
+        m = self.model.module
+        from mhr_amd import ops
+        # OFF by default: measured at cfg1 (B = 256, one MI355X) the replayed step is no faster than the host-issued one (2.36 vs
+        # 2.30 ms) - the step is GPU-bound and ends in the decode's verification read either way; it frees 2.3 ms of host time per
+        # batch for whoever needs the host (`hip_graph_eval: True` / MHR_HIP_GRAPH_EVAL=1)
+        return ((self.config.get("hip_graph_eval", False) or os.environ.get("MHR_HIP_GRAPH_EVAL", "0") == "1")
+                and item_seq.is_cuda and type(m).__name__ == "HSTU" and getattr(m, "_hstu_embedding_dim", 0) in ops.STREAM_DIMS
+                and getattr(m, "exact_fp32_topk", False) and m.item_num > 4096 and not getattr(m, "prior_given_at_test", False)
+                and getattr(m, "prior_switch", None) is None and isinstance(m.item_id_proj_tower, torch.nn.Identity)
+                and not getattr(self, "_eval_graph_failed", None))
 
     @torch.no_grad()
     def evaluate(self, eval_data, load_best_model=False, show_progress=False, init_model=False, item_tags=None):

@@ -1248,14 +1248,17 @@ BF16_SCORE_ERR = 2.0 ** -8       # |u_bf16 . i_bf16 - u . i| for unit vectors u,
 
 
 def catalog_topk_exact(users_f32, H, items_bf, items_f32, tag_bits, row_bits, hist_ptr, hist_items, k, n_items=None, stats=None,
-                       target=None):
+                       target=None, defer=False):
     """Per-row top-k ranked on FP32 scores of fp32 operands - the reference's score path (hstu.py:965-979: fp32 normalise,
     fp32 matmul; collector.py:245 torch.topk) - without a [B, H, N] tensor.  The bf16 scorer finds every candidate whose bf16
     score lies within 2^-7 of the k-th bf16 score (a superset of the fp32 top-k: the two scores differ by at most 2^-8),
     `mhr_rescore_f32` re-scores those few hundred candidates per row from the fp32 rows, and the exact select picks k by
     (fp32 value desc, index asc).  Rows whose margin set cannot be certified (more than 1024 near-ties) fall back to dense
     fp32 scoring of that row.  users_f32 [B*H, D] fp32 normalised; items_bf [>= N, D] bf16 / items_f32 [N, D] fp32 normalised.
-    target: the bf16 pass's candidate budget per row (catalog_topk; tests shrink it to force its repair path)."""
+    target: the bf16 pass's candidate budget per row (catalog_topk; tests shrink it to force its repair path).
+    defer=True: enqueue everything WITHOUT the host read and return (values, indices, finish): finish() reads the two flags, repairs
+    the rare rows in place and returns the final (values, indices) - the split the replayed evaluation step needs (everything in
+    front of finish() is capturable: REC/trainer/trainer.py:_EvalGraph)."""
     n_rows, D = users_f32.shape
     N = items_f32.shape[0] if n_items is None else int(n_items)
     dev = users_f32.device
@@ -1300,19 +1303,28 @@ def catalog_topk_exact(users_f32, H, items_bf, items_f32, tag_bits, row_bits, hi
                  2 * BF16_SCORE_ERR, n_rows, full.data_ptr(), flags[1:2].data_ptr(), _stream())
         return ov, oi, cnt, full
 
+    if defer and not deferred:
+        raise ValueError("catalog_topk_exact(defer=True) needs the streaming scorer's deferred check (feature dim <= 256, N > 4096, no stats)")
     ov, oi, cnt, full = attempt(deferred)
-    got = flags.tolist()                                                  # the one host sync
-    if deferred and got[0]:
-        ov, oi, cnt, full = attempt(False)
-        got = flags.tolist()
-    if stats is not None:
-        stats["margin_mean"] = float(cnt.float().mean())
-        stats["uncertified_rows"] = int(full.sum())
-    if got[1]:                                                            # a handful of rows at most: every fp32 score kept
-        rows = torch.nonzero(full).flatten().int()
-        fv, fi = dense_rows_topk(users_f32, H, items_f32, N, tag_bits, row_bits, hist_ptr, hist_items, rows, k)
-        ov[rows.long()], oi[rows.long()] = fv, fi
-    return ov, oi
+
+    def finish():
+        nonlocal ov, oi, cnt, full
+        got = flags.tolist()                                              # the one host sync
+        if deferred and got[0]:
+            ov, oi, cnt, full = attempt(False)
+            got = flags.tolist()
+        if stats is not None:
+            stats["margin_mean"] = float(cnt.float().mean())
+            stats["uncertified_rows"] = int(full.sum())
+        if got[1]:                                                        # a handful of rows at most: every fp32 score kept
+            rows = torch.nonzero(full).flatten().int()
+            fv, fi = dense_rows_topk(users_f32, H, items_f32, N, tag_bits, row_bits, hist_ptr, hist_items, rows, k)
+            ov[rows.long()], oi[rows.long()] = fv, fi
+        return ov, oi
+
+    if defer:
+        return ov, oi, finish
+    return finish()
 
 
 def multihead_merge_dedup(vals, idx, B, H, k):

@@ -163,6 +163,50 @@ def test_deterministic_mode_makes_replayed_and_host_issued_runs_bitwise_equal(re
     assert lib.load().mhr_get_deterministic() == 0
 
 
+def test_replayed_evaluation_step_gives_the_host_issued_results(rec):
+    """Trainer.evaluate replays the evaluation step (encoder -> heads -> full-catalog decode up to its verification flags) from a
+    hipGraph after two host-issued batches; histories of different lengths share a padded capacity.  Same metrics, same per-head
+    lists as the launch-by-launch form (reference trainer.py:698-729, 985-990)."""
+    import mhr_amd.synth as synth
+    from REC.config.configurator import Config, apply_run_fixups
+    from REC.trainer import Trainer
+    from REC.utils import get_model
+    dev = torch.device("cuda", 0)
+    res, lists = {}, {}
+    for mode in (True, False):
+        torch.manual_seed(1)
+        cfgd = synth.base_config(MAX_ITEM_LIST_LENGTH=20, pred_len=4, eval_pred_len=4, n_layers=2, n_heads=2, item_embedding_size=64,
+                                 hstu_embedding_size=64, loss='prior', medusa_num_layers=1, num_prior_head=3, num_segment_head=1,
+                                 eval_num_cats=3, num_negatives=64, topk=[5, 10, 20], device=dev, total_iters=4, eval_interval=0,
+                                 checkpoint_dir=None, save_model_note="t", hidden_dropout_prob=0.0, hip_graph_eval=mode)
+        cfg = apply_run_fixups(Config(config_dict=cfgd))
+        N = 6000
+        data = synth.SyntheticData(cfg, N, dev)
+        cfg["int_to_category"] = data.int_to_category
+        model = get_model("HSTU")(cfg, data).to(dev)
+        tr = Trainer(cfg)
+        tr.setup_model(model)
+        batches = [data.eval_batch(8, hist_extra=10 + 7 * i) for i in range(7)]     # histories of different lengths
+
+        class Loader(list):
+            item_tags = data.item_tags
+        res[mode] = tr.evaluate(Loader(batches))
+        tr.compute_item_feature(data.item_tags)
+        model.eval()
+        lists[mode] = []
+        for b in batches:                               # (a replayed step's lists live in the graph's static tensors: clone)
+            f = tr._full_sort_batch_eval(b)[0]
+            lists[mode].append((f.indices.clone(), f.values.clone()))
+        if mode:
+            gs = [g for g in tr._eval_graphs.values() if g.graph is not None]
+            assert len(gs) == 1 and getattr(tr, "_eval_graph_failed", None) is None
+        else:
+            assert "_eval_graphs" not in tr.__dict__
+    assert res[True] == res[False]
+    for a, b in zip(lists[True], lists[False]):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
 def test_host_issued_steps_interleave_with_replays(rec):
     """bench.py's evented pass issues steps from the host between replays: counters, lazy-table state and the constants'
     history are shared, so the run is the same run."""
