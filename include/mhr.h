@@ -612,6 +612,15 @@ int mhr_nce_wide_fix_bits(const void* targets_packed, int n_rows, const void* ne
 int mhr_nce_wide_fwd(const void* queries_packed, int n_rows, const void* negs_packed, int n_neg, int dim, const uint16_t* bits,
                      const float* s_pos, const float* scale_dev, const int32_t* n_live_dev, float* part_tot, int32_t* part_nv,
                      int32_t* part_rk, float* lse, float* loss, int32_t* n_valid, int32_t* rank, void* stream);
+/* The two plain products of that backward on the same core (no library GEMM left in the loss):
+ *   out[r, i] (+)= alpha_dev[0] * sum_k A[i, k] B[r, k]   (fp32 accumulation of bf16 operands, out fp32 [n_r, ldc])
+ * a_packed: n_i rows packed with tiles_per_block = 8, b_packed: n_r rows with tiles_per_block = 4, both with k_dim (a multiple of
+ * 64) contraction entries per row; dQ = G N: A = N^T (mhr_pack_tiles_t of the negatives), B = G; dN = G^T Q: A = Q^T, B = G^T.
+ * mhr_pack_tiles_t packs an operand stored TRANSPOSED: packed row j = column j of x [n_k, ld] bf16 (contraction index down the
+ * rows; padded with zeros to whole 64-entry chunks): mhr_pack_tiles_bytes(n_sel, round_up(n_k, 64), tiles_per_block) bytes. */
+int mhr_wide_gemm_nt(const void* a_packed, int n_i, const void* b_packed, int n_r, int k_dim, const float* alpha_dev, float* out,
+                     int64_t ldc, int accumulate, void* stream);
+int mhr_pack_tiles_t(const void* x, int64_t n_k, int64_t ld, int64_t n_sel, int tiles_per_block, void* out, void* stream);
 int mhr_nce_wide_grad_tile(const void* queries_packed, int n_rows, const void* negs_packed, int n_neg, int dim, const uint16_t* bits,
                            const float* lse, const float* w, const float* scale_dev, const int32_t* n_live_dev, void* g_bf16,
                            int64_t ldg, void* stream);

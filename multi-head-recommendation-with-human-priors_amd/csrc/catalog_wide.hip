@@ -62,6 +62,35 @@ __global__ __launch_bounds__(256) void pack_tiles_kernel(const bf16_t* __restric
   }
 }
 
+// The same packing for an operand that is stored TRANSPOSED: packed row j = column j of x [n_k, ld] (the contraction index runs
+// down x's rows).  Consecutive threads take consecutive packed rows, so the eight strided 2-byte reads of a 16-byte chunk are
+// coalesced across the threads; contraction indices beyond n_k pack as zeros (K is padded to whole 64-feature chunks).
+__global__ __launch_bounds__(256) void pack_tiles_t_kernel(const bf16_t* __restrict__ x, int64_t n_k, int64_t ld, int64_t n_sel, int TB,
+                                                           unsigned char* __restrict__ out) {
+  const int KC = (int)((n_k + WK - 1) / WK);
+  const int64_t n_tiles = (n_sel + 31) / 32, n_blocks = (n_tiles + TB - 1) / TB;
+  const int64_t total = n_blocks * KC * TB * (WT::BYTES / 16);
+  for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < total; c += (int64_t)gridDim.x * blockDim.x) {
+    const int row = (int)(c & 31), slot = (int)((c >> 5) & 7);                 // row fastest: coalesced reads of x[k, sel]
+    int64_t t = c >> 8;
+    const int tb = (int)(t % TB);
+    t /= TB;
+    const int kc = (int)(t % KC);
+    const int64_t blk = t / KC;
+    const int64_t sel = (blk * TB + tb) * 32 + row;
+    const int chunk = slot ^ WT::key(row);
+    bf16x8 v = sg::zero8();
+    if (sel < n_sel) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int64_t k = (int64_t)kc * WK + chunk * 8 + e;
+        if (k < n_k) v[e] = x[k * ld + sel];
+      }
+    }
+    *reinterpret_cast<bf16x8*>(out + ((c >> 8) * 256 + (int64_t)row * 8 + slot) * 16) = v;
+  }
+}
+
 template <int N, typename... V>
 __device__ __forceinline__ void wait_lgkm_all(V&... v) {
   static_assert(N >= 0 && N <= 15, "lgkmcnt is 4 bits");
@@ -268,6 +297,20 @@ extern "C" int mhr_pack_tiles(const void* x, int64_t n_rows, int dim, int64_t ro
   hipLaunchKernelGGL(pack_tiles_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, n_rows, dim, row_begin,
                      row_stride, n_sel, tiles_per_block, (unsigned char*)out);
   MHR_CHECK_LAUNCH("pack_tiles");
+  return MHR_OK;
+}
+
+extern "C" int mhr_pack_tiles_t(const void* x, int64_t n_k, int64_t ld, int64_t n_sel, int tiles_per_block, void* out, void* stream) {
+  MHR_REQUIRE(x && out, "pack_tiles_t: null pointer");
+  MHR_REQUIRE(n_k > 0 && ld >= n_sel && n_sel > 0 && (tiles_per_block == 4 || tiles_per_block == 8), "pack_tiles_t: bad arguments");
+  MHR_REQUIRE((uintptr_t)out % 16 == 0, "pack_tiles_t: out must be 16-byte aligned");
+  const int64_t k_pad = (n_k + WK - 1) / WK * WK;
+  const int64_t total = mhr_pack_tiles_bytes(n_sel, (int)k_pad, tiles_per_block) / 16;
+  MHR_REQUIRE(k_pad < (1ll << 31), "pack_tiles_t: contraction too long");
+  const int grid = mhr_grid_for(total, 256 * 4, 8192);
+  hipLaunchKernelGGL(pack_tiles_t_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, n_k, ld, n_sel, tiles_per_block,
+                     (unsigned char*)out);
+  MHR_CHECK_LAUNCH("pack_tiles_t");
   return MHR_OK;
 }
 

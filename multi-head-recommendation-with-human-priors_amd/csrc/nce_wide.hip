@@ -17,8 +17,9 @@
 //           one partial per (item slice, consumer wave, lane half) - plain stores, summed in list order by nce_wide_finalize:
 //           no atomics, bitwise reproducible;
 //   MODE 2  softmax-gradient tile: rows = normalised QUERIES;  g_tj = keep w_t exp(scale s_tj - lse_t) as bf16 [N_tok, n_neg] -
-//           the operand of the two plain gradient products dQ = G N, dN = G^T Q (library GEMMs, like the projections' weight
-//           gradients).
+//           the operand of the two gradient products dQ = G N, dN = G^T Q;
+//   MODE 3  plain product:         out[r, i] (+)= alpha sum_k A[i, k] B[r, k] in fp32 - those two gradient products on the same
+//           core (operands packed with mhr_pack_tiles / mhr_pack_tiles_t), so no library GEMM is left in the loss.
 #include "mhr_common.h"
 #include "stream_gemm.h"
 
@@ -55,7 +56,11 @@ struct WideArgs {
   const int32_t* n_live_p;        // device scalar: live tokens (rows beyond get g = 0)
   bf16_t* g_out;                  // MODE 2: [t_pad, ldg]
   int64_t ldg;
-  int n_neg;                      // real negatives (the packed image is padded to whole 256-blocks)
+  float* c_out;                   // MODE 3: [n_rows, ldc] fp32
+  int64_t ldc;
+  const float* alpha_dev;         // MODE 3: device scalar factor (NULL: 1)
+  int accumulate;                 // MODE 3: c_out += instead of =
+  int n_neg;                      // real negatives / valid "item" rows (the packed image is padded to whole 256-blocks)
   int64_t t_pad;                  // token rows the per-token arrays hold (R * 128)
 };
 
@@ -82,7 +87,8 @@ __global__ __launch_bounds__(512, 1) void nce_wide_kernel(const unsigned char* _
   float sp[2] = {0.f, 0.f}, tot[2] = {0.f, 0.f}, l2[2] = {0.f, 0.f}, wt[2] = {0.f, 0.f};
   int nv[2] = {0, 0}, rk[2] = {0, 0};
   float c2 = 0.f;
-  if (MODE != 0) c2 = a.scale_p[0] * LOG2E;
+  if (MODE == 1 || MODE == 2) c2 = a.scale_p[0] * LOG2E;
+  if (MODE == 3) c2 = a.alpha_dev ? a.alpha_dev[0] : 1.0f;
 #pragma unroll
   for (int jt = 0; jt < 2; ++jt) {
     tok[jt] = rt * 128 + wn * 64 + jt * 32 + r;
@@ -146,7 +152,7 @@ __global__ __launch_bounds__(512, 1) void nce_wide_kernel(const unsigned char* _
           for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int jt = 0; jt < 2; ++jt) acc[i][jt] = sg::zero16();
-          if (MODE != 0 && a.bits) {                           // the block's suppression words: in flight underneath its K loop
+          if ((MODE == 1 || MODE == 2) && a.bits) {            // the block's suppression words: in flight underneath its K loop
             const int blk0 = b0 + c / KC;
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -196,7 +202,18 @@ __global__ __launch_bounds__(512, 1) void nce_wide_kernel(const unsigned char* _
 #pragma unroll
             for (int jt = 0; jt < 2; ++jt) {
               const int64_t bo = ((int64_t)tile * 2 + half) * a.t_pad + tok[jt];
-              if (MODE == 0) {
+              if (MODE == 3) {
+                float* crow_ = a.c_out + (int64_t)tok[jt] * a.ldc + n0 + 4 * half;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {                  // registers 4q .. 4q + 3 = columns n0 + 8q + 4 half + (0..3)
+                  if (n0 + 8 * q + 4 * half < a.n_neg && tok[jt] < n_rows) {
+                    f32x4 o = {acc[i][jt][4 * q] * c2, acc[i][jt][4 * q + 1] * c2, acc[i][jt][4 * q + 2] * c2, acc[i][jt][4 * q + 3] * c2};
+                    f32x4* dst = reinterpret_cast<f32x4*>(crow_ + 8 * q);
+                    if (a.accumulate) o += *dst;
+                    *dst = o;
+                  }
+                }
+              } else if (MODE == 0) {
                 uint32_t m = 0;
 #pragma unroll
                 for (int g = 0; g < 16; ++g) m |= (acc[i][jt][g] > a.thres ? 1u : 0u) << g;
@@ -373,5 +390,31 @@ extern "C" int mhr_nce_wide_grad_tile(const void* queries_packed, int n_rows, co
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, (hipStream_t)stream, (const unsigned char*)queries_packed, n_rows,
                      (const unsigned char*)negs_packed, dim, (n_neg + 255) / 256, R, U, a);
   MHR_CHECK_LAUNCH("nce_wide_grad_tile");
+  return MHR_OK;
+}
+
+// out[r, i] (+)= alpha * sum_k A[i, k] B[r, k], fp32 accumulation of bf16 operands: the plain products of the wide loss backward.
+// a_packed: the n_i "item" rows (mhr_pack_tiles / mhr_pack_tiles_t with tiles_per_block = 8); b_packed: the n_r rows
+// (tiles_per_block = 4); k_dim: the packed contraction length (a multiple of 64).  n_i % 4 == 0, ldc % 4 == 0, out 16-byte aligned.
+extern "C" int mhr_wide_gemm_nt(const void* a_packed, int n_i, const void* b_packed, int n_r, int k_dim, const float* alpha_dev,
+                                float* out, int64_t ldc, int accumulate, void* stream) {
+  MHR_REQUIRE(a_packed && b_packed && out, "wide_gemm_nt: null pointer");
+  MHR_REQUIRE(k_dim >= 64 && k_dim % 64 == 0 && n_i > 0 && n_i % 4 == 0 && n_r > 0 && ldc >= n_i && ldc % 4 == 0 &&
+              (uintptr_t)out % 16 == 0, "wide_gemm_nt: bad sizes (k_dim=%d n_i=%d ldc=%lld)", k_dim, n_i, (long long)ldc);
+  int R, U;
+  const int grid = launch_geometry(n_r, R, U);
+  WideArgs a = {};
+  a.c_out = out;
+  a.ldc = ldc;
+  a.alpha_dev = alpha_dev;
+  a.accumulate = accumulate ? 1 : 0;
+  a.n_neg = n_i;
+  a.t_pad = (int64_t)R * 128;
+  const size_t lds = (size_t)W_NST * W_STAGE;
+  auto kern = nce_wide_kernel<3>;
+  (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, (hipStream_t)stream, (const unsigned char*)b_packed, n_r,
+                     (const unsigned char*)a_packed, k_dim, (n_i + 255) / 256, R, U, a);
+  MHR_CHECK_LAUNCH("wide_gemm_nt");
   return MHR_OK;
 }

@@ -1083,6 +1083,18 @@ def pack_tiles(x, n_sel=None, row_begin=0, row_stride=1, tiles_per_block=8):
     return out
 
 
+def pack_tiles_t(x, n_sel=None, tiles_per_block=8):
+    """Columns [0, n_sel) of x [n_k, ld] bf16 as packed rows (the contraction index runs down x's rows): the transposed operand
+    of mhr_wide_gemm_nt.  -> (uint8 tensor, padded contraction length)."""
+    _chk(x, "x", torch.bfloat16)
+    n_k, ld = x.shape
+    n_sel = ld if n_sel is None else int(n_sel)
+    k_pad = -(-n_k // 64) * 64
+    out = torch.empty(lib.load().mhr_pack_tiles_bytes(n_sel, k_pad, tiles_per_block), dtype=torch.uint8, device=x.device)
+    lib.call("mhr_pack_tiles_t", x.data_ptr(), n_k, ld, n_sel, tiles_per_block, out.data_ptr(), _stream())
+    return out, k_pad
+
+
 def catalog_emit_wide(users_p, n_rows, D, items_p, n_items, tag_bits, row_bits, tau, cap_s, item_begin=0, item_stride=1):
     """Feature dims beyond 256 (a multiple of 64): the LDS-tiled MFMA scorer with the fused threshold emit
     (csrc/catalog_wide.hip) on PACKED operands (pack_tiles: users with 4 tiles per block, the selected items with 8).

@@ -53,6 +53,11 @@ def _live_cap(sv):
 
 
 MFMA_NCE = os.environ.get("MHR_NCE_WIDE_MFMA", "1") != "0"     # 0: the library-GEMM + fp32-chunk form of the logit products
+# The two PLAIN gradient products of the backward (dQ = G N, dN = G^T Q on the bf16 softmax-gradient tile) run as library GEMMs by
+# default: dense products without an epilogue, 4096 - 32768 deep - hipBLASLt does them at 720 TFLOP/s, the own core (mhr_wide_gemm_nt
+# on packed operands, MHR_NCE_WIDE_GEMM=own) needs 3x as long once its four operand packs are counted (327 vs 107 us at cfg2's
+# shape, tools/nce_wide_micro.py); same bits.
+OWN_GEMM = os.environ.get("MHR_NCE_WIDE_GEMM", "lib") == "own"
 
 
 def _mfma_path(sv, D):
@@ -164,7 +169,7 @@ def nce_bwd_wide(sv, w_tok, logit_scale, dq_rows, dp_rows, d_negs, d_logit_scale
             if pack is not None:
                 # softmax-gradient tile straight from the MFMA accumulators (recomputed cosines, saved suppression bits)
                 negs_p, bits, t_pad = pack
-                ldg = -(-sv.n_neg // 4) * 4
+                ldg = -(-sv.n_neg // 64) * 64            # (whole 64-entry chunks: G is the K-contiguous operand of dQ = G N)
                 gfull = torch.empty(cap_eff, ldg, dtype=torch.bfloat16, device=dev)
                 q_p = ops.pack_tiles(qn.contiguous(), tiles_per_block=4)
                 lse_pad, w_pad = _pad_rows(sv.lse[g, :cap_eff], t_pad), _pad_rows(w_tok[g, :cap_eff], t_pad)   # (named: alive across the call)
@@ -189,9 +194,27 @@ def nce_bwd_wide(sv, w_tok, logit_scale, dq_rows, dp_rows, d_negs, d_logit_scale
                          gmat.data_ptr(), sv.n_neg, st)
             if pack is None:
                 del s, fx
-            dq_raw = _mm(gmat, ng)                                                               # sum_j g_ij n_j
-            if d_negs is not None:
-                d_negs[g, :sv.n_neg] += scale * _mm(gmat.t(), qn)
+            if pack is not None and OWN_GEMM:
+                # the two plain products on the same LDS-tiled core (mhr_wide_gemm_nt): out[r, i] = sum_k A[i, k] B[r, k]
+                #   dQ_raw [tok, d] = sum_n G[tok, n] N[n, d]:  A = N^T (packed transposed), B = G
+                #   dN     [n, d]   = sum_t G[t, n] Q[t, d]:    A = Q^T, B = G^T (both packed transposed), alpha = scale, accumulated
+                nt_p, k1 = ops.pack_tiles_t(ng.contiguous(), n_sel=D, tiles_per_block=8)
+                assert k1 == ldg
+                g_p = ops.pack_tiles(gfull, tiles_per_block=4)
+                dq_raw = torch.empty(cap_eff, D, dtype=torch.float32, device=dev)
+                ops._timed_call("mhr_wide_gemm_nt", nt_p.data_ptr(), D, g_p.data_ptr(), cap_eff, ldg, 0, dq_raw.data_ptr(), D, 0, st)
+                if d_negs is not None:
+                    qt_p, k2 = ops.pack_tiles_t(qn.contiguous(), n_sel=D, tiles_per_block=8)
+                    gt_p, k2b = ops.pack_tiles_t(gfull, n_sel=sv.n_neg, tiles_per_block=4)
+                    assert k2 == k2b
+                    dn_g = d_negs[g, :sv.n_neg]
+                    assert dn_g.is_contiguous()
+                    ops._timed_call("mhr_wide_gemm_nt", qt_p.data_ptr(), D, gt_p.data_ptr(), sv.n_neg, k2, scale.data_ptr(), dn_g.data_ptr(),
+                                    D, 1, st)
+            else:
+                dq_raw = _mm(gmat, ng)                                                           # sum_j g_ij n_j
+                if d_negs is not None:
+                    d_negs[g, :sv.n_neg] += scale * _mm(gmat.t(), qn)
             lv = live[g, c0:c1]
             w = torch.where(lv, w_tok[g, c0:c1], torch.zeros_like(w_tok[g, c0:c1]))
             sp = sv.s_pos[g, c0:c1]

@@ -414,6 +414,19 @@ def test_nce_fwd_bwd(ops, D, n_tok, n_neg, dtype):
         err = float((got - ref).abs().max())
         assert err < 2e-2 * gs, (name, err, gs)
     assert abs(float(dls.cpu()) - float(lsr.grad)) < 2e-2 * abs(float(lsr.grad)) + 1e-4
+    if D > 256 and dtype == torch.bfloat16:
+        # the backward's two plain products on the library's own LDS-tiled core (mhr_wide_gemm_nt + mhr_pack_tiles_t, MHR_NCE_WIDE_GEMM=own)
+        # instead of library GEMMs: same operands, fp32 accumulation - the gradients agree to accumulation order
+        from mhr_amd import wide as wide_mod
+        dq2, dp2 = torch.zeros(n_src, D).cuda(), torch.zeros(n_src, D).cuda()
+        try:
+            wide_mod.OWN_GEMM = True
+            dn2, dls2 = ops.nce_bwd(sv, dev(w), lsd, dev(qi), dev(pi), dq2, dp2)
+        finally:
+            wide_mod.OWN_GEMM = False
+        torch.cuda.synchronize()
+        for a_, b_ in ((dq2, dq_rows), (dp2, dp_rows), (dn2, dn), (dls2, dls)):
+            assert float((a_ - b_).abs().max()) <= 1e-4 * float(b_.abs().max()) + 1e-9
 
 
 @pytest.mark.parametrize("D,n_pos,P,n_neg,dtype", [(64, 40, 4, 96, torch.float32), (256, 70, 8, 512, torch.bfloat16),

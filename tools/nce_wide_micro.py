@@ -49,3 +49,22 @@ for D, T, n_neg in ((1024, 4608, 4096), (1024, 32768, 4096), (2048, 12800, 8192)
     print(f"D={D} T={T} n_neg={n_neg}: fix_bits {tb*1e3:.0f} us ({flop/tb/1e9:.0f} TF)  fwd+finalize {tf*1e3:.0f} us ({flop/tf/1e9:.0f} TF)  "
           f"grad_tile {tg*1e3:.0f} us ({flop/tg/1e9:.0f} TF)  pack rows {tp*1e3:.0f} us | library form of the forward (2 GEMMs + epilogue) {tl*1e3:.0f} us "
           f"vs hand-written bits+fwd {(tb+tf)*1e3:.0f} us", flush=True)
+
+# the two plain gradient products of the backward: own core (mhr_wide_gemm_nt on packed operands, packing included) vs library GEMM
+for D, T, n_neg in ((1024, 4608, 4096), (1024, 32768, 4096), (2048, 12800, 8192)):
+    g = torch.Generator(device="cuda").manual_seed(1)
+    G = (torch.randn(T, n_neg, device="cuda", generator=g) * 0.01).bfloat16()
+    N = torch.nn.functional.normalize(torch.randn(n_neg, D, device="cuda", generator=g), dim=-1).bfloat16()
+    Q = torch.nn.functional.normalize(torch.randn(T, D, device="cuda", generator=g), dim=-1).bfloat16()
+    dq = torch.empty(T, D, device="cuda"); dn = torch.zeros(n_neg, D, device="cuda")
+    def own():
+        nt_p, k1 = ops.pack_tiles_t(N, n_sel=D, tiles_per_block=8); g_p = ops.pack_tiles(G, tiles_per_block=4)
+        lib.call("mhr_wide_gemm_nt", nt_p.data_ptr(), D, g_p.data_ptr(), T, k1, 0, dq.data_ptr(), D, 0, st)
+        qt_p, k2 = ops.pack_tiles_t(Q, n_sel=D, tiles_per_block=8); gt_p, _ = ops.pack_tiles_t(G, n_sel=n_neg, tiles_per_block=4)
+        lib.call("mhr_wide_gemm_nt", qt_p.data_ptr(), D, gt_p.data_ptr(), n_neg, k2, 0, dn.data_ptr(), D, 0, st)
+    def libf():
+        return torch.mm(G, N, out_dtype=torch.float32), torch.mm(G.t(), Q, out_dtype=torch.float32)
+    own(); a, b = libf(); torch.cuda.synchronize()
+    e1 = float((dq - a).abs().max() / a.abs().max()); e2 = float((dn - b).abs().max() / b.abs().max())
+    to, tl = time_call(own), time_call(libf)
+    print(f"plain products D={D} T={T} n_neg={n_neg}: own (4 packs + 2 GEMMs) {to*1e3:.0f} us, library {tl*1e3:.0f} us; max rel diff {e1:.1e} {e2:.1e}", flush=True)
