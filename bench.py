@@ -392,6 +392,12 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+    elif os.environ.get("MHR_FORCE_DP", "0") == "1":
+        # one-GPU rehearsal of the data-parallel step on RCCL itself: a process group of ONE rank, every collective of the exchange
+        # a real RCCL call issued between the replayed graph segments (mhr_amd.distributed.FORCE_DP)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     import mhr_amd.synth as synth
     from mhr_amd import ops
     from REC.config.configurator import Config, apply_run_fixups
@@ -648,7 +654,7 @@ def main():
             out["graph_failure"] = trainer.graph_failure
         out["host_enqueue_ms_per_step"] = round(1000 * main_leg["host_enqueue"] / args.steps, 3)
         st_ = getattr(trainer, "_step_graph", None)
-        if world > 1 and st_ is not None and st_.graph is not None and st_.n:
+        if (world > 1 or os.environ.get("MHR_FORCE_DP", "0") == "1") and st_ is not None and st_.graph is not None and st_.n:
             # data parallel: the replay plan's host calls ARE the collectives (issue + stream waits); with the gloo rehearsal backend
             # a wait blocks the host until the GPU has produced the data, with RCCL it only orders streams
             out["host_in_collectives_ms_per_step"] = round(1000 * st_.graph.host_s / max(1, st_.graph.n_replays), 3)
@@ -735,7 +741,7 @@ def main():
         print(json.dumps(out), flush=True)
         if out.get("graph_expected") and not out["graph_active"] and world == 1:
             rc_fail = "bench.py: the train step was expected to replay from a hipGraph and did not"
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
     if rc_fail:

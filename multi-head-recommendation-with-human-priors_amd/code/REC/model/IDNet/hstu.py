@@ -335,7 +335,7 @@ class HSTU(MultiHeadDecoding, BaseModel):
         parallel / accumulating steps sort the exchanged ids of all micro-batches at the optimizer step)."""
         from mhr_amd import distributed as dist_
         self._presorted = None
-        if dist_.world_size() > 1 or getattr(self, "accumulate_rows", False) or getattr(self, "dense_embedding_grad", False):
+        if dist_.active() or getattr(self, "accumulate_rows", False) or getattr(self, "dense_embedding_grad", False):
             return
         sorted_ids, perm = torch.sort(ids_all)
         rows = torch.zeros(ids_all.numel(), self.item_embedding.weight.shape[1], dtype=torch.float32, device=ids_all.device)

@@ -26,13 +26,13 @@ def all_gather_ids(ids, group=None):
     8-byte ids and re-gathering rows locally is numerically identical to the reference's autograd all_gather of
     fp32 embeddings (hstu.py:673, 755) - the negatives' gradient rows are then summed by the sparse embedding
     reduction - and moves D*4/8 times fewer bytes over xGMI with no backward collective."""
-    if _world() > 1:
+    from mhr_amd import distributed as D_
+    if D_.active():
         ids = ids.contiguous()
         out = torch.empty((_world(),) + tuple(ids.shape), dtype=ids.dtype, device=ids.device)
         dst, src = out.view(-1), ids.view(-1)
         # straight into the stacked output (RCCL and gloo alike); under the Trainer's step capture a host call of the replay plan
-        from mhr_amd import distributed as D
-        D.run_collective(lambda: dist.all_gather_into_tensor(dst, src, group=group))
+        D_.run_collective(lambda: dist.all_gather_into_tensor(dst, src, group=group))
         return out
     return ids.unsqueeze(0)
 

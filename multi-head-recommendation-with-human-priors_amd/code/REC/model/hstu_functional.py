@@ -422,7 +422,7 @@ class EmbeddingGatherFn(Function):
         if holder._row_slot is None or holder._row_slot.numel() != n_rows:
             holder._row_slot = torch.full((n_rows,), -1, dtype=torch.int32, device=dev)
         from mhr_amd import distributed as dist_
-        if dist_.world_size() > 1 or getattr(holder, "accumulate_rows", False):
+        if dist_.active() or getattr(holder, "accumulate_rows", False):
             # data parallel / gradient accumulation: fold the input-side gradient into the rows and defer the reduction
             # until the optimizer asks for it (HSTU.finish_sparse_grad: cross-rank exchange, then ONE segment-sum over the
             # rows of every micro-batch since the last step)
@@ -543,7 +543,7 @@ class L2NormFn(Function):
             dy = dy.float()
             g = (dy - n * (n * dy).sum(-1, keepdim=True)) / norms[:, None]
         from mhr_amd import distributed as dist_
-        if ctx.holder is not None and dist_.world_size() > 1 and dist_.OVERLAP:
+        if ctx.holder is not None and dist_.active() and dist_.OVERLAP:
             ctx.holder._shared_pending = (g, dist_.allreduce_sum_begin(g))
             return None, None
         return g, None
@@ -581,7 +581,7 @@ class GatherL2NormFn(Function):
         g = ops.l2norm_rows_indexed_bwd(dy.reshape(ids.numel(), -1).float().contiguous(), ctx.table, ids, norms)
         ctx.table = None
         from mhr_amd import distributed as dist_
-        if ctx.holder is not None and dist_.world_size() > 1 and dist_.OVERLAP:
+        if ctx.holder is not None and dist_.active() and dist_.OVERLAP:
             ctx.holder._shared_pending = (g, dist_.allreduce_sum_begin(g))
             return None, None, None, None
         return g, None, None, None

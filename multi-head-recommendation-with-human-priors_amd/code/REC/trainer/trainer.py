@@ -21,6 +21,11 @@ from REC.utils import early_stopping
 from REC.utils.lr_scheduler import cosine_warmup_factor
 
 
+def _dp_active():
+    from mhr_amd import distributed as D
+    return D.active()
+
+
 class _GraphSegments:
     """The captured step as a SEQUENCE of single-stream hipGraphs instead of one graph with branches.
 
@@ -157,12 +162,12 @@ class _StepGraph:
             from mhr_amd import distributed as D
             model._graph_segments = graph
             graph.begin()
-            D.CAPTURE = graph if tr.world > 1 else None    # data parallel: collectives become host calls of the replay plan
+            D.CAPTURE = graph if D.active() else None      # data parallel: collectives become host calls of the replay plan
             # a host call ends the running capture and begins the next - legal only on the thread that began it, and the
             # autograd engine runs a device's backward nodes on a worker thread of its own: data-parallel captures (whose
             # backward starts the shared-negative all-reduce) keep the backward on this thread
             import contextlib
-            same_thread = torch.autograd.set_multithreading_enabled(False) if tr.world > 1 else contextlib.nullcontext()
+            same_thread = torch.autograd.set_multithreading_enabled(False) if D.active() else contextlib.nullcontext()
             try:
                 with same_thread:
                     out = tr._eager_step(self.static)
@@ -372,7 +377,7 @@ class Trainer(object):
     def _graph_ok(self, data):
         m = self.model
         return (self.config.get("hip_graph", True) and os.environ.get("MHR_HIP_GRAPH", "1") != "0"
-                and self.accumulate_grad == 1 and (self.world == 1 or os.environ.get("MHR_DP_GRAPH", "1") != "0")
+                and self.accumulate_grad == 1 and (not _dp_active() or os.environ.get("MHR_DP_GRAPH", "1") != "0")
                 and getattr(m, "graph_capable", False)
                 and self.optimizer.graph_capable() and isinstance(data, (tuple, list))
                 and all(torch.is_tensor(t) and t.is_cuda for t in data) and m.training

@@ -90,6 +90,18 @@ def world_size():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+# MHR_FORCE_DP=1: take the data-parallel code path even with ONE rank (an initialised process group of size 1): every collective
+# of the exchange is then a real RCCL call on real buffers - id all-gather, early shared-negative all-reduce, bucket all-reduce,
+# row exchange, and their replay as host calls between hipGraph segments - which is as far as a one-GPU box can rehearse the
+# multi-GPU step on RCCL itself (two RCCL ranks cannot share a card; the cross-rank arithmetic is covered by the gloo tests).
+FORCE_DP = os.environ.get("MHR_FORCE_DP", "0") == "1"
+
+
+def active():
+    """The step takes the data-parallel path (more than one rank, or MHR_FORCE_DP with an initialised group)."""
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or FORCE_DP)
+
+
 def rank():
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
@@ -106,7 +118,7 @@ def allreduce_sum_begin(t):
     """Start an in-place SUM all-reduce of `t` on the collective stream and return its work handle (None when not data
     parallel).  `handle.wait()` orders the CURRENT stream after the collective without blocking the host (RCCL), so
     kernels launched in between overlap it.  Nobody may touch `t` until then."""
-    if world_size() == 1:
+    if not active():
         return None
     return Handle(lambda: dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True))
 
@@ -146,7 +158,7 @@ def begin_row_exchange(ids_all, d_rows, n_private, wire_dtype=None, shared_pendi
     """
     W = world_size()
     wire = ROWS_WIRE_DTYPE if wire_dtype is None else wire_dtype
-    if W == 1:
+    if not active():
         return RowExchange(ids_all, d_rows[:n_private], d_rows[n_private:])
     priv_ids, priv_rows = ids_all[:n_private].contiguous(), d_rows[:n_private].to(wire).contiguous()
     shared_ids = ids_all[n_private:]

@@ -685,9 +685,12 @@ import numpy as np, torch, torch.distributed as dist
 root, code, out_dir, tag = sys.argv[1:5]
 sys.path.insert(0, root); sys.path.insert(0, code)
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-dist.init_process_group("gloo", rank=rank, world_size=world)
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(dev)
+if os.environ.get("BACKEND", "gloo") == "nccl":
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+else:
+    dist.init_process_group("gloo", rank=rank, world_size=world)
 import mhr_amd.synth as synth
 from REC.config.configurator import Config, apply_run_fixups
 from REC.trainer import Trainer
@@ -749,6 +752,39 @@ def test_data_parallel_steps_replay_from_graph_segments_around_the_exchange(rec,
     np.testing.assert_allclose(g[0]["losses"], h[0]["losses"], rtol=2e-2)
     scale = np.abs(h[0]["flat"]).max()
     assert np.abs(g[0]["flat"] - h[0]["flat"]).mean() <= 1e-3 * scale and np.abs(g[0]["flat"] - h[0]["flat"]).max() <= 0.1 * scale
+
+
+def test_rccl_one_rank_rehearsal_of_the_replayed_data_parallel_step(rec, tmp_path):
+    """A one-GPU box cannot host two RCCL ranks, but with MHR_FORCE_DP=1 a single rank takes the whole data-parallel path on
+    RCCL ITSELF (backend nccl, world size 1): id all-gather, the shared-negative all-reduce started inside the backward, bucket
+    all-reduce, row exchange - issued by the host between the hipGraph segments of the replayed step, on buffers of the graph's
+    memory pool, with RCCL's watchdog thread alive during the captures.  (The cross-rank arithmetic is the two-rank gloo
+    tests'.)  Replayed = host-issued = a plain one-rank run, up to the bf16 rows on the wire and float-atomic noise."""
+    import subprocess
+    kw = dict(MAX_ITEM_LIST_LENGTH=16, pred_len=2, eval_pred_len=2, n_layers=2, n_heads=2, item_embedding_size=64,
+              hstu_embedding_size=64, num_negatives=256, total_iters=100, eval_interval=0, checkpoint_dir=None,
+              save_model_note="t", hidden_dropout_prob=0.1, attn_dropout_prob=0.0, loss='prior', num_prior_head=3,
+              medusa_num_layers=1, eval_num_cats=3)
+    (tmp_path / "cfg.txt").write_text(repr(kw))
+    script = tmp_path / "dp_graph.py"
+    script.write_text(DP_GRAPH_SCRIPT)
+    res = {}
+    for tag, force, flag, port in (("graph", "1", "1", 29661), ("host", "1", "0", 29662), ("plain", "0", "1", 29663)):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="1", RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0",
+                   MHR_DP_GRAPH=flag, MHR_FORCE_DP=force, BACKEND="nccl", MHR_DP_WIRE="fp32")
+        p = subprocess.run([sys.executable, str(script), ROOT, CODE, str(tmp_path), tag], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, (tag, p.stdout[-2000:], p.stderr[-4000:])
+        res[tag] = np.load(tmp_path / f"{tag}0.npz")
+    g, h, pl = res["graph"], res["host"], res["plain"]
+    assert bool(g["graph_active"]) and int(g["replays"]) == 12 - 3 and int(g["host_calls"]) >= 5       # the collectives were host calls of the plan
+    assert not bool(h["graph_active"]) and int(h["host_calls"]) == 0
+    assert bool(pl["graph_active"]) and int(pl["host_calls"]) == 0                                       # no exchange without the switch
+    for a in (g, h):
+        np.testing.assert_allclose(a["losses"][:6], pl["losses"][:6], rtol=2e-3)
+        np.testing.assert_allclose(a["losses"], pl["losses"], rtol=3e-2)
+        assert np.all(np.isfinite(a["flat"])) and np.all(np.isfinite(a["table"]))
+        scale = np.abs(pl["flat"]).max()
+        assert np.abs(a["flat"] - pl["flat"]).mean() <= 1e-3 * scale
 
 
 def test_gradient_accumulation_matches_separate_micro_batches(rec):

@@ -9,6 +9,7 @@ python bench.py --steps 50 --warmup 10 > gpurun_out/bench_${R}_train.json 2> gpu
 python bench.py --mode eval --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/bench_${R}_eval.json 2> gpurun_out/bench_${R}_eval.err
 python bench.py --steps 30 --warmup 10 --no-cpu-baseline --no-eval-leg --emulate-world 8 > gpurun_out/bench_${R}_emu.json 2> gpurun_out/bench_${R}_emu.err
 MHR_DIST_BACKEND=gloo python bench.py --gpus 2 --steps 20 --warmup 8 --no-cpu-baseline --no-eval-leg --no-kernel-events --no-host-probe > gpurun_out/bench_${R}_dp2_gloo.json 2> gpurun_out/bench_${R}_dp2_gloo.err
+MHR_FORCE_DP=1 python bench.py --steps 30 --warmup 10 --no-cpu-baseline --no-eval-leg --no-kernel-events > gpurun_out/bench_${R}_dp1_rccl.json 2> gpurun_out/bench_${R}_dp1_rccl.err
 echo bench lines done
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${R}_train -- python bench.py --no-cpu-baseline --no-host-probe --no-eval-leg --no-kernel-events --steps 20 --warmup 5 > gpurun_out/prof1.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${R}_eval -- python bench.py --mode eval --no-cpu-baseline --no-host-probe --no-kernel-events --steps 20 --warmup 5 > gpurun_out/prof_eval.log 2>&1

@@ -240,7 +240,7 @@ if __name__ == "__main__":
     mfma_util(rnd)
     mfma_util(rnd, "eval_")
     full_launches(rnd)
-    for extra in ("emu", "dp2_gloo"):                       # bench --emulate-world / the two-rank gloo rehearsal lines, if the set made them
+    for extra in ("emu", "dp2_gloo", "dp1_rccl"):                       # bench --emulate-world / the two-rank gloo rehearsal lines, if the set made them
         f = os.path.join(ROOT, "gpurun_out", f"bench_{rnd}_{extra}.json")
         if os.path.exists(f) and os.path.getsize(f):
             json.dump(json.loads(open(f).read().strip().splitlines()[-1]), open(os.path.join(ROOT, "profiles", f"{rnd}_bench_{extra}.json"), "w"), indent=1)
