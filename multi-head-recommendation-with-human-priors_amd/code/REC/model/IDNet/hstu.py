@@ -128,6 +128,7 @@ class HSTU(MultiHeadDecoding, BaseModel):
         self._pending_rows = None
         self._shared_pending = None
         self._row_exchange = None
+        self._dp_ids = None
         self._bf16_cache = {}
         self._step_seed = 0
         self._seed_dev = None              # device int64[1] while the Trainer captures the step as a hipGraph
@@ -262,7 +263,17 @@ class HSTU(MultiHeadDecoding, BaseModel):
 
         # which negative pools the loss reads (reference hstu.py:669-670, 751-752); ids are shared across ranks
         pools = self._negative_pools(neg_items.shape[1])
-        pool_ids = all_gather_pool_ids(neg_items, pools)
+        from mhr_amd import distributed as dist_
+        # data parallel: this rank's item-window ids ride the id all-gather of the negative pools, so every rank knows the ids of
+        # ALL ranks' gradient rows now - the id sort of the sparse-row reduction runs early (below), the backward exchanges rows only
+        dp_ids = (dist_.active() and torch.is_grad_enabled() and not getattr(self, "accumulate_rows", False)
+                  and not self.dense_embedding_grad)
+        if dp_ids:
+            pool_ids, items_all = all_gather_pool_ids(neg_items, pools, extra=items.reshape(-1))
+            self._dp_ids = torch.cat([items_all.reshape(-1)] + pool_ids).contiguous()       # the exchange's layout: private ids in rank order, then the shared ids
+        else:
+            pool_ids = all_gather_pool_ids(neg_items, pools)
+            self._dp_ids = None
         n_pool = pool_ids[0].numel()
         n_item_ids = B * (L + P)
         ids_all = torch.cat([items.reshape(-1)] + pool_ids).contiguous()
@@ -297,7 +308,7 @@ class HSTU(MultiHeadDecoding, BaseModel):
         if early_prep:
             stages = self._early_loss_stages(st, pools, mask, pos_tags, e_rows, negs_pools, n_q_rows=B * self.medusa_num_heads * L)
             stages.insert(0, self._clamp_logit_scale)            # (read by the loss kernels only: behind the join)
-            stages.append(lambda: self._presort_ids(ids_all))
+            stages.append(lambda: self._presort_ids(ids_all if self._dp_ids is None else self._dp_ids))
 
         def run_stages():
             with torch.no_grad():
@@ -335,7 +346,9 @@ class HSTU(MultiHeadDecoding, BaseModel):
         parallel / accumulating steps sort the exchanged ids of all micro-batches at the optimizer step)."""
         from mhr_amd import distributed as dist_
         self._presorted = None
-        if dist_.active() or getattr(self, "accumulate_rows", False) or getattr(self, "dense_embedding_grad", False):
+        if getattr(self, "accumulate_rows", False) or getattr(self, "dense_embedding_grad", False):
+            return
+        if dist_.active() and ids_all is not self._dp_ids:       # data parallel: only the exchanged id list (all ranks' ids) can be pre-sorted
             return
         sorted_ids, perm = torch.sort(ids_all)
         rows = torch.zeros(ids_all.numel(), self.item_embedding.weight.shape[1], dtype=torch.float32, device=ids_all.device)
@@ -348,6 +361,7 @@ class HSTU(MultiHeadDecoding, BaseModel):
         self._pending_rows = None
         self._shared_pending = None
         self._row_exchange = None
+        self._dp_ids = None
         self.sparse_grad = None
 
     def begin_sparse_exchange(self):

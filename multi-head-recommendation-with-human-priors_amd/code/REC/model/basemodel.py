@@ -37,15 +37,23 @@ def all_gather_ids(ids, group=None):
     return ids.unsqueeze(0)
 
 
-def all_gather_pool_ids(neg_items, pools, group=None):
+def all_gather_pool_ids(neg_items, pools, group=None, extra=None):
     """neg_items [B, n_pools, n_neg] int64, `pools` = the pool indices the loss reads: ONE id all-gather for all of
     them (the reference gathers the embeddings of each pool separately inside its per-category loop,
-    hstu.py:669-673, 751-755).  Returns a list of [W*B*n_neg] id vectors, rank-major like all_gather_ids(pool)."""
+    hstu.py:669-673, 751-755).  Returns a list of [W*B*n_neg] id vectors, rank-major like all_gather_ids(pool).
+    extra (optional int64 vector, e.g. the rank's own item-window ids): rides the same collective; returns (list, [W, extra.numel()]) -
+    every rank then knows the ids of ALL ranks' gradient rows in the forward already, so the sparse-row reduction's id sort can run
+    early and the backward's exchange moves rows only."""
     # (no `neg_items[:, list]`: indexing with a Python list uploads an index tensor - a blocking copy, 2.3 ms of host stall per step)
     sel = torch.stack([neg_items[:, p] for p in pools], dim=1)                         # [B, G, n_neg]
-    g = all_gather_ids(sel, group=group)                                               # [W, B, G, n_neg]
-    g = g.permute(2, 0, 1, 3).reshape(len(pools), -1)
-    return [g[i] for i in range(len(pools))]
+    if extra is None:
+        g = all_gather_ids(sel, group=group)                                           # [W, B, G, n_neg]
+        g = g.permute(2, 0, 1, 3).reshape(len(pools), -1)
+        return [g[i] for i in range(len(pools))]
+    n_sel = sel.numel()
+    both = all_gather_ids(torch.cat([sel.reshape(-1), extra.reshape(-1)]), group=group)   # [W, n_sel + n_extra]
+    g = both[:, :n_sel].reshape((both.shape[0],) + tuple(sel.shape)).permute(2, 0, 1, 3).reshape(len(pools), -1)
+    return [g[i] for i in range(len(pools))], both[:, n_sel:]
 
 
 def l2_norm(x, eps=1e-6):

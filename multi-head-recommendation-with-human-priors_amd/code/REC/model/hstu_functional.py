@@ -399,7 +399,8 @@ class EmbeddingGatherFn(Function):
         dev = ids_all.device
         n_neg_ids = ids_all.numel() - n_item_ids
         d_items = d_items.contiguous() if d_items is not None else torch.zeros(n_item_ids, D, device=dev)
-        if n_neg_ids:
+        early_shared = getattr(holder, "_shared_pending", None) is not None        # (data parallel: the negatives' gradient is elsewhere)
+        if n_neg_ids and not early_shared:
             d_negs = d_negs.contiguous() if d_negs is not None else torch.zeros(n_neg_ids, D, device=dev)
         d_x = d_x.contiguous() if (d_x is not None and d_x.dim() == 3) else None
         d_pos = None
@@ -426,10 +427,15 @@ class EmbeddingGatherFn(Function):
             # data parallel / gradient accumulation: fold the input-side gradient into the rows and defer the reduction
             # until the optimizer asks for it (HSTU.finish_sparse_grad: cross-rank exchange, then ONE segment-sum over the
             # rows of every micro-batch since the last step)
-            d_rows = torch.cat([d_items, d_negs]) if n_neg_ids else d_items
+            shared, holder._shared_pending = getattr(holder, "_shared_pending", None), None
+            if shared is not None or not n_neg_ids:
+                # the shared-negative block already left for its all-reduce (GatherL2NormFn / L2NormFn backward): only the
+                # rank-private rows are handed on - no zero block, no concatenation (33 + 60 MB at cfg1)
+                d_rows = d_items
+            else:
+                d_rows = torch.cat([d_items, d_negs])
             if d_x is not None:
                 d_rows[:n_item_ids].view(-1, window, D)[:, :L] += d_x
-            shared, holder._shared_pending = getattr(holder, "_shared_pending", None), None
             if holder._pending_rows is None:
                 holder._pending_rows = []
             holder._pending_rows.append((ids_all, d_rows, n_item_ids, shared))
@@ -470,7 +476,8 @@ def begin_pending_rows(holder):
         ids_all = torch.cat([p[0][:p[2]] for p in pend] + [p[0][p[2]:] for p in pend])
         d_rows = torch.cat([p[1][:p[2]] for p in pend] + shared_rows)
         shared = (d_rows[n_private:], None) if any_reduced else None
-    holder._row_exchange = dist_.begin_row_exchange(ids_all, d_rows, n_private, shared_pending=shared)
+    ids_pre = getattr(holder, "_dp_ids", None) if len(pend) == 1 else None          # exchanged in the forward (HSTU.forward)
+    holder._row_exchange = dist_.begin_row_exchange(ids_all, d_rows, n_private, shared_pending=shared, ids_pre=ids_pre)
 
 
 def reduce_pending_rows(holder):
@@ -478,9 +485,15 @@ def reduce_pending_rows(holder):
     if getattr(holder, "_row_exchange", None) is None:
         begin_pending_rows(holder)
     ex, holder._row_exchange, holder._pending_rows = holder._row_exchange, None, None
-    sorted_ids, perm = torch.sort(ex.wait_ids())
-    rows_priv, rows_shared = ex.wait_rows()
-    out_rows = torch.zeros(sorted_ids.numel(), rows_shared.shape[1], dtype=torch.float32, device=rows_shared.device)
+    ids = ex.wait_ids()
+    pre, holder._presorted = getattr(holder, "_presorted", None), None
+    if pre is not None and pre[0] is ids:             # all ranks' ids were exchanged in the forward: sorted (and the row buffer zeroed) early
+        _, sorted_ids, perm, out_rows = pre
+        rows_priv, rows_shared = ex.wait_rows()
+    else:
+        sorted_ids, perm = torch.sort(ids)
+        rows_priv, rows_shared = ex.wait_rows()
+        out_rows = torch.zeros(sorted_ids.numel(), rows_shared.shape[1], dtype=torch.float32, device=rows_shared.device)
     ops.sparse_rows_segment_sum(sorted_ids, perm, rows_priv.contiguous(), rows_shared.contiguous() if rows_shared.numel() else None,
                                 None, 0, 0, out_rows, holder._row_slot)
     holder.sparse_grad = SparseRowGrad(sorted_ids, out_rows, holder._row_slot, holder._row_slot.numel())
@@ -543,7 +556,7 @@ class L2NormFn(Function):
             dy = dy.float()
             g = (dy - n * (n * dy).sum(-1, keepdim=True)) / norms[:, None]
         from mhr_amd import distributed as dist_
-        if ctx.holder is not None and dist_.active() and dist_.OVERLAP:
+        if ctx.holder is not None and dist_.active() and dist_.OVERLAP and not getattr(ctx.holder, "dense_embedding_grad", False):
             ctx.holder._shared_pending = (g, dist_.allreduce_sum_begin(g))
             return None, None
         return g, None
@@ -581,7 +594,7 @@ class GatherL2NormFn(Function):
         g = ops.l2norm_rows_indexed_bwd(dy.reshape(ids.numel(), -1).float().contiguous(), ctx.table, ids, norms)
         ctx.table = None
         from mhr_amd import distributed as dist_
-        if ctx.holder is not None and dist_.active() and dist_.OVERLAP:
+        if ctx.holder is not None and dist_.active() and dist_.OVERLAP and not getattr(ctx.holder, "dense_embedding_grad", False):
             ctx.holder._shared_pending = (g, dist_.allreduce_sum_begin(g))
             return None, None, None, None
         return g, None, None, None

@@ -145,14 +145,16 @@ class RowExchange:
         return self._rows_priv, self._rows_shared
 
 
-def begin_row_exchange(ids_all, d_rows, n_private, wire_dtype=None, shared_pending=None):
+def begin_row_exchange(ids_all, d_rows, n_private, wire_dtype=None, shared_pending=None, ids_pre=None):
     """Start combining the per-rank embedding-gradient rows of a step; returns a RowExchange.
 
     ids_all [R] int64 / d_rows [R, D] fp32: the first `n_private` entries are rank-private (positives: every rank has
     its own users), the rest are the shared negatives (same ids, same order on every rank after the id all-gather).
     `shared_pending` = (rows [n_shared, D] fp32, work): the shared block's all-reduce was already started earlier in
     the backward (the negatives' gradient is complete before the encoder backward runs, so it travels underneath it);
-    d_rows[n_private:] is then ignored.  The collectives are issued asynchronously in the order ids, shared rows,
+    d_rows[n_private:] is then ignored (d_rows may hold the private rows only).  `ids_pre`: the exchanged id list
+    [W*n_private + n_shared] when it was already all-gathered in the forward (HSTU.forward) - no id collective here.
+    The collectives are issued asynchronously in the order ids, shared rows,
     private rows: the caller sorts the ids while the rows are still on the wire.  The caller sums duplicates in fp32
     and scales by 1/W (DDP's gradient mean) inside the fused Adam.
     """
@@ -163,13 +165,15 @@ def begin_row_exchange(ids_all, d_rows, n_private, wire_dtype=None, shared_pendi
     priv_ids, priv_rows = ids_all[:n_private].contiguous(), d_rows[:n_private].to(wire).contiguous()
     shared_ids = ids_all[n_private:]
     n_sh = shared_ids.numel()
-    ids_out = torch.empty(W * n_private + n_sh, dtype=ids_all.dtype, device=ids_all.device)
+    have_ids = ids_pre is not None and ids_pre.numel() == W * n_private + n_sh
+    ids_out = ids_pre if have_ids else torch.empty(W * n_private + n_sh, dtype=ids_all.dtype, device=ids_all.device)
     rows_priv = torch.empty(W * n_private, d_rows.shape[1], dtype=wire, device=d_rows.device)
-    ids_out[W * n_private:] = shared_ids
+    if not have_ids:
+        ids_out[W * n_private:] = shared_ids
     # gathers go straight into the output (no per-rank list + concatenation); gloo implements all_gather_into_tensor too, so
     # the two-rank CPU / one-card tests run exactly the layout and wait-ordering code that ships over RCCL
     ids_dst, rows_dst, rows_src = ids_out[:W * n_private], rows_priv.view(-1), priv_rows.view(-1)
-    issues = [lambda: dist.all_gather_into_tensor(ids_dst, priv_ids, async_op=True)]
+    issues = [] if have_ids else [lambda: dist.all_gather_into_tensor(ids_dst, priv_ids, async_op=True)]
     w_rows = []
     if shared_pending is not None:
         shared_rows, w_sh = shared_pending
@@ -180,8 +184,9 @@ def begin_row_exchange(ids_all, d_rows, n_private, wire_dtype=None, shared_pendi
         if n_sh:
             issues.append(lambda: dist.all_reduce(shared_rows, op=dist.ReduceOp.SUM, async_op=True))
     issues.append(lambda: dist.all_gather_into_tensor(rows_dst, rows_src, async_op=True))
-    hs = Handle.group(issues)                                  # ids, [shared rows], private rows: issued in this order
-    return RowExchange(ids_out, rows_priv, shared_rows, hs[:1], w_rows + hs[1:])
+    hs = Handle.group(issues)                                  # [ids], [shared rows], private rows: issued in this order
+    n_id = 0 if have_ids else 1
+    return RowExchange(ids_out, rows_priv, shared_rows, hs[:n_id], w_rows + hs[n_id:])
 
 
 def exchange_sparse_rows(ids_all, d_rows, n_private, wire_dtype=None, shared_pending=None):
