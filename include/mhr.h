@@ -212,6 +212,26 @@ int mhr_hstu_attn_bwd(const void* q_pre, const void* k_pre, const void* v_pre, i
                       void* dq, void* dk, void* dv, int64_t d_stride,
                       int B, int L, int n_heads, int head_dim, int apply_silu, void* stream);
 
+/* Sequence layout of a batch of masks, computed once per batch and shared by every layer's attention launches:
+ * first_block[b] = the 32-row block holding sequence b's first valid key (ceil(L/32) when it has none); seq_order (optional) =
+ * the sequences sorted by it, most live blocks first (stable).  The reference's loaders pad at the FRONT (data/dataset/
+ * trainset.py:111-137, evalset.py:34-41), so blocks before first_block take part in nothing: their outputs and gradients are
+ * exactly zero.  The *_seq entries take both arrays (either may be NULL): the resident kernels then skip staging, tile pairs
+ * and epilogues of the dead blocks (writing the zeros) and run the sequences in seq_order; results are bit-identical to the
+ * plain entries, which are the *_seq entries with both NULL. */
+int mhr_attn_seq_layout(const uint8_t* key_valid, int B, int L, int32_t* first_block, int32_t* seq_order, void* stream);
+int mhr_hstu_attn_fwd_seq(const void* q, const void* k, const void* v, int64_t row_stride,
+                          const uint8_t* key_valid, void* out,
+                          void* act_q, void* act_k, void* act_v, int64_t act_stride,
+                          int B, int L, int n_heads, int head_dim, int apply_silu,
+                          const int32_t* first_block, const int32_t* seq_order, void* stream);
+int mhr_hstu_attn_bwd_seq(const void* q_pre, const void* k_pre, const void* v_pre, int64_t row_stride,
+                          const void* act_q, const void* act_k, const void* act_v, int64_t act_stride,
+                          const uint8_t* key_valid, const void* d_out,
+                          void* dq, void* dk, void* dv, int64_t d_stride,
+                          int B, int L, int n_heads, int head_dim, int apply_silu,
+                          const int32_t* first_block, const int32_t* seq_order, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * LLM decoder blocks of the HLLM twin: the user decoder `user_llm(inputs_embeds=...)`
  * (model/HLLM/hllm.py:501-502, 781-783) and the item tower (hllm.py:399-464) are Llama-style stacks

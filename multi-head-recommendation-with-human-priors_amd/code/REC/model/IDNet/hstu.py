@@ -197,6 +197,7 @@ class HSTU(MultiHeadDecoding, BaseModel):
     def _encode(self, x, key_valid, training=None, want_bf16=False):
         """x [B,L,D] fp32, key_valid [B,L] uint8 -> [B,L,D] fp32 (reference hstu.py:221-328); want_bf16: (out, its bf16 copy -
         the operand of the decoding heads' GEMM, written by the last residual add's own pass)."""
+        from mhr_amd import ops
         from REC.model.hstu_functional import (AddCastFn, AddLayerNormFn, HSTUCoreFn, LayerNormFn, LayerNormResidualFn, SplitKLinearFn,
                                                WeightGradStack)
         B, L, D = x.shape
@@ -205,6 +206,8 @@ class HSTU(MultiHeadDecoding, BaseModel):
         p = self._linear_dropout_rate if training else 0.0
         layers = self._hstu._attention_layers
         n = len(layers)
+        if ops.SEQ_LAYOUT and n and getattr(key_valid, "_mhr_layout", None) is None:
+            key_valid._mhr_layout = ops.attn_seq_layout(key_valid, B, L)     # front padding: the layers skip the dead blocks
         # training with the fused optimizer in its one-backward-per-step mode: the layers' weight-gradient products are formed
         # for all layers at once at the step (WeightGradStack); the kernels below write their operands straight into its slices
         stack = None

@@ -322,11 +322,13 @@ class HSTUCoreFn(Function):
     def forward(ctx, h, key_valid, B, L, n_heads, head_dim, eps, dropout_p, seed, seed_dev=None, o_out=None, dh_out=None):
         D = n_heads * head_dim
         # the activated q / k / v are NOT saved: the backward recomputes silu() while it stages them (h is kept anyway)
-        a, _ = ops.hstu_attn_fwd(h, key_valid, B, L, n_heads, head_dim, apply_silu=True, save_act=False)
+        layout = getattr(key_valid, "_mhr_layout", None)         # (HSTU._encode: once per batch, shared by the layers)
+        a, _ = ops.hstu_attn_fwd(h, key_valid, B, L, n_heads, head_dim, apply_silu=True, save_act=False, layout=layout)
         o, mean, rstd = ops.ln_gate_fwd(h, a, D, torch.bfloat16, eps, dropout_p, seed, seed_dev, out=o_out)
         ctx.dh_out = dh_out                      # (the caller's buffer for the gradient of h: WeightGradStack)
         ctx.save_for_backward(h, key_valid, a, mean, rstd)
         ctx.cfg = (B, L, n_heads, head_dim, dropout_p, seed, seed_dev)
+        ctx.layout = layout
         return o
 
     @staticmethod
@@ -336,7 +338,7 @@ class HSTUCoreFn(Function):
         D = n_heads * head_dim
         dh = torch.empty_like(h) if ctx.dh_out is None else ctx.dh_out.view(h.shape)
         da = ops.ln_gate_bwd(d_o.contiguous(), h, a, mean, rstd, dh, D, dropout_p, seed, seed_dev)
-        ops.hstu_attn_bwd(h, None, key_valid, da, dh, B, L, n_heads, head_dim, apply_silu=True)
+        ops.hstu_attn_bwd(h, None, key_valid, da, dh, B, L, n_heads, head_dim, apply_silu=True, layout=ctx.layout)
         return (dh,) + (None,) * 11
 
 

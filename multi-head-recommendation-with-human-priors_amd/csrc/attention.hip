@@ -57,7 +57,9 @@ __device__ unsigned long long g_attn_stamps[16];
 // to the neighbouring head - so with the natural order (b * n_heads + head, n_heads = 8) the heads of one sequence land on
 // eight different XCDs and every line is fetched from HBM once per head that touches it.  This decode keeps all heads of a
 // sequence on one XCD (b = 8 * (slot / n_heads) + xcd): the neighbours' halves are L2 hits.
-__device__ __forceinline__ void decode_seq_head(int n_heads, int& b, int& head) {
+// seq_order (optional): the sequence a slot runs - sequences sorted by their live length, longest first, so that where a launch
+// needs more than one round of workgroups (the backward: two per CU) the dispatcher hands out the heavy ones first.
+__device__ __forceinline__ void decode_seq_head(int n_heads, int& b, int& head, const int32_t* __restrict__ seq_order = nullptr) {
   const int n_wg = gridDim.x, i = blockIdx.x;
   const int full = (n_wg / (8 * n_heads)) * (8 * n_heads);          // whole groups of 8 sequences; the remainder keeps the plain order
   if (i < full) {
@@ -68,6 +70,7 @@ __device__ __forceinline__ void decode_seq_head(int n_heads, int& b, int& head) 
     b = i / n_heads;
     head = i % n_heads;
   }
+  if (seq_order) b = __builtin_amdgcn_readfirstlane(seq_order[b]);       // (keeps b - and every address built on it - scalar)
 }
 
 template <int NKS, int ND>
@@ -76,7 +79,8 @@ __global__ __launch_bounds__(256) void hstu_attn_fwd_kernel(const bf16_t* __rest
                                                             const uint8_t* __restrict__ key_valid, bf16_t* __restrict__ out,
                                                             int64_t out_stride, bf16_t* act_q, bf16_t* act_k, bf16_t* act_v,
                                                             int64_t act_stride, int L, int n_heads, int hd, int apply_silu,
-                                                            float inv_n) {
+                                                            float inv_n, const int32_t* __restrict__ first_block,
+                                                            const int32_t* __restrict__ seq_order) {
   using T = sg::Tile<NKS>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int Lp = (L + 31) & ~31, nb = Lp >> 5;
@@ -85,7 +89,7 @@ __global__ __launch_bounds__(256) void hstu_attn_fwd_kernel(const bf16_t* __rest
   uint32_t* vmask = reinterpret_cast<uint32_t*>(Vt + nb * T::BYTES);
 
   int b, head;
-  decode_seq_head(n_heads, b, head);
+  decode_seq_head(n_heads, b, head, seq_order);
   const int64_t row0 = (int64_t)b * L;
   const bf16_t* qp = q + row0 * stride + head * hd;
   const bf16_t* kp = k + row0 * stride + head * hd;
@@ -96,9 +100,13 @@ __global__ __launch_bounds__(256) void hstu_attn_fwd_kernel(const bf16_t* __rest
   const bool do_silu = apply_silu != 0;
 
   FSTAMP(0)
-  stage_tiles<NKS>(Kt, kp, stride, L, Lp, hd, do_silu, ak, act_stride);
-  stage_tiles<NKS>(Vt, vp, stride, L, Lp, hd, do_silu, av, act_stride);
+  // leading all-padding blocks: not staged, no tile pairs, zeros written (with saved activations everything is staged: the caller
+  // wants silu(q | k | v) of every row)
+  const int kb0 = (aq || !first_block) ? 0 : min(nb, __builtin_amdgcn_readfirstlane(first_block[b]));
+  stage_tiles<NKS>(Kt, kp, stride, L, Lp, hd, do_silu, ak, act_stride, kb0 * 32);
+  stage_tiles<NKS>(Vt, vp, stride, L, Lp, hd, do_silu, av, act_stride, kb0 * 32);
   build_valid_mask(vmask, key_valid + row0, L, nb);
+  zero_head_rows(out + row0 * out_stride + head * hd, out_stride, min(L, kb0 * 32), hd);
   __syncthreads();
   FSTAMP(1)
 
@@ -109,7 +117,7 @@ __global__ __launch_bounds__(256) void hstu_attn_fwd_kernel(const bf16_t* __rest
     // snake from the HEAVY end (query block qb costs qb + 1 tile pairs): blocks nb-1 .. nb-4 to waves 0..3, the next four to
     // waves 3..0, ...  Dealt from the light end, nb = 7 (L = 200) came out as 1 / 9 / 9 / 9 pairs per wave instead of 7 each.
     const int qb = nb - 1 - ((it & 1) ? it * 4 + (3 - wave) : it * 4 + wave);
-    if (qb < 0) continue;
+    if (qb < kb0) continue;                          // (below the sequence, or an all-padding block: zeros already written)
     const int qrow = qb * 32 + r;
     bf16x8 qf[NKS];
 #pragma unroll
@@ -187,7 +195,7 @@ __global__ __launch_bounds__(256, ALL4 ? 2 : (NKS <= 2 ? ATTN_BWD_WG : 1)) void 
     const bf16_t* __restrict__ act_q, const bf16_t* __restrict__ act_k, const bf16_t* __restrict__ act_v, int64_t act_stride,
     const uint8_t* __restrict__ key_valid, const bf16_t* __restrict__ d_out, int64_t do_stride, bf16_t* __restrict__ dq,
     bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, int64_t d_stride, int L, int n_heads, int hd, int apply_silu,
-    float inv_n) {
+    float inv_n, const int32_t* __restrict__ first_block, const int32_t* __restrict__ seq_order) {
   using T = sg::Tile<NKS>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int Lp = (L + 31) & ~31, nb = Lp >> 5;
@@ -202,7 +210,7 @@ __global__ __launch_bounds__(256, ALL4 ? 2 : (NKS <= 2 ? ATTN_BWD_WG : 1)) void 
   float* gscratch = reinterpret_cast<float*>(tail + ((nb * 4 + 15) & ~15)) + (threadIdx.x >> 6) * (32 * GS);
 
   int b, head;
-  decode_seq_head(n_heads, b, head);
+  decode_seq_head(n_heads, b, head, seq_order);
   const int64_t row0 = (int64_t)b * L;
   const int hoff = head * hd;
   // without saved activations (act_q == nullptr) silu(q), silu(k), silu(v) are recomputed from the pre-activation values
@@ -222,9 +230,18 @@ __global__ __launch_bounds__(256, ALL4 ? 2 : (NKS <= 2 ? ATTN_BWD_WG : 1)) void 
   bf16_t* dv_h = dv + row0 * d_stride + hoff;
 
   ASTAMP(0)
-  if (ALL4) stage_tiles4<NKS>(Tq, aq, a_stride, redo, Tdo, dop, do_stride, false, Tk, ak, a_stride, redo, Tv, av, a_stride, redo, L, Lp, hd);
-  else stage_tiles2<NKS>(Tq, aq, a_stride, redo, Tdo, dop, do_stride, false, L, Lp, hd);
+  // leading all-padding blocks (attn_tiles.h: leading_dead_blocks): their dq / dk / dv are zero - not staged, no tile pairs, no
+  // SiLU' epilogue, the zeros written directly
+  const int kb0 = first_block ? min(nb, __builtin_amdgcn_readfirstlane(first_block[b])) : 0;
+  if (ALL4) stage_tiles4<NKS>(Tq, aq, a_stride, redo, Tdo, dop, do_stride, false, Tk, ak, a_stride, redo, Tv, av, a_stride, redo, L, Lp, hd, kb0 * 32);
+  else stage_tiles2<NKS>(Tq, aq, a_stride, redo, Tdo, dop, do_stride, false, L, Lp, hd, kb0 * 32);
   build_valid_mask(vmask, key_valid + row0, L, nb);
+  {
+    const int n_dead = min(L, kb0 * 32);
+    zero_head_rows(dq_h, d_stride, n_dead, hd);
+    zero_head_rows(dk_h, d_stride, n_dead, hd);
+    zero_head_rows(dv_h, d_stride, n_dead, hd);
+  }
   __syncthreads();
   ASTAMP(1)
 
@@ -233,8 +250,8 @@ __global__ __launch_bounds__(256, ALL4 ? 2 : (NKS <= 2 ? ATTN_BWD_WG : 1)) void 
   la.init(lane);
 
   // ---- pass A: dK, dV for key block kb (keys on the lanes) -----------------------------------------
-  for (int it = 0; it * 4 < nb; ++it) {
-    const int kb = (it & 1) ? it * 4 + wave : it * 4 + (3 - wave);   // early key blocks are the heavy ones
+  for (int it = 0; it * 4 < nb - kb0; ++it) {
+    const int kb = kb0 + ((it & 1) ? it * 4 + wave : it * 4 + (3 - wave));   // early (live) key blocks are the heavy ones
     if (kb >= nb) continue;
     const int key = kb * 32 + r;
     const bool kvalid = (vmask[kb] >> r) & 1u;
@@ -322,13 +339,13 @@ __global__ __launch_bounds__(256, ALL4 ? 2 : (NKS <= 2 ? ATTN_BWD_WG : 1)) void 
   if (!ALL4) {
     __syncthreads();                      // everyone is done reading the Q / dO tiles
     ASTAMP(8)
-    stage_tiles2<NKS>(Tk, ak, a_stride, redo, Tv, av, a_stride, redo, L, Lp, hd);
+    stage_tiles2<NKS>(Tk, ak, a_stride, redo, Tv, av, a_stride, redo, L, Lp, hd, kb0 * 32);
     __syncthreads();
   }
   ASTAMP(9)
   for (int it = 0; it * 4 < nb; ++it) {
     const int qb = nb - 1 - ((it & 1) ? it * 4 + (3 - wave) : it * 4 + wave);     // snake from the heavy end (see the forward)
-    if (qb < 0) continue;
+    if (qb < kb0) continue;                          // (below the sequence, or an all-padding block: zeros already written)
     const int qcol = qb * 32 + r;
     GradPre qpre[ND];
 #pragma unroll
@@ -418,9 +435,68 @@ int mhr_attn_stream_bwd(const void* q_pre, const void* k_pre, const void* v_pre,
                         void* dq, void* dk, void* dv, int64_t d_stride, int B, int L, int n_heads, int head_dim, int apply_silu,
                         hipStream_t s);
 
-extern "C" int mhr_hstu_attn_fwd(const void* q, const void* k, const void* v, int64_t row_stride, const uint8_t* key_valid,
-                                 void* out, void* act_q, void* act_k, void* act_v, int64_t act_stride, int B, int L,
-                                 int n_heads, int head_dim, int apply_silu, void* stream) {
+namespace {
+
+// first_block[b] = index of the 32-row block holding the first valid key of sequence b (nb when none); counts[.] feed the
+// counting sort below.  One wave per sequence, ballots over the mask bytes.
+__global__ __launch_bounds__(64) void seq_first_block_kernel(const uint8_t* __restrict__ key_valid, int L, int nb,
+                                                             int32_t* __restrict__ first_block) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const uint8_t* kv = key_valid + (int64_t)b * L;
+  int first = nb;
+  for (int j0 = 0; j0 < L && first == nb; j0 += 64) {
+    const int j = j0 + lane;
+    const unsigned long long m = __ballot(j < L && kv[j] != 0);
+    if (m) first = (j0 + __builtin_ctzll(m)) >> 5;
+  }
+  if (lane == 0) first_block[b] = first;
+}
+
+// seq_order: sequences by first_block ascending (most live blocks first), ties in index order - a counting sort in one
+// workgroup (B and nb are small: a batch of sequences, L / 32 buckets).
+__global__ __launch_bounds__(256) void seq_order_kernel(const int32_t* __restrict__ first_block, int B, int nb,
+                                                        int32_t* __restrict__ seq_order) {
+  extern __shared__ int32_t cnt[];                      // nb + 1 buckets
+  for (int i = threadIdx.x; i <= nb; i += 256) cnt[i] = 0;
+  __syncthreads();
+  for (int b = threadIdx.x; b < B; b += 256) atomicAdd(&cnt[first_block[b]], 1);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int i = 0; i <= nb; ++i) {
+      const int c = cnt[i];
+      cnt[i] = run;
+      run += c;
+    }
+  }
+  __syncthreads();
+  // stable within a bucket: thread t places the sequences of bucket t in index order
+  for (int bucket = threadIdx.x; bucket <= nb; bucket += 256) {
+    int at = cnt[bucket];
+    for (int b = 0; b < B; ++b)
+      if (first_block[b] == bucket) seq_order[at++] = b;
+  }
+}
+
+}  // namespace
+
+extern "C" int mhr_attn_seq_layout(const uint8_t* key_valid, int B, int L, int32_t* first_block, int32_t* seq_order,
+                                   void* stream) {
+  MHR_REQUIRE(key_valid && first_block, "attn_seq_layout: null pointer");
+  MHR_REQUIRE(B > 0 && L > 0 && L <= 131072, "attn_seq_layout: bad sizes");
+  const int nb = (L + 31) / 32;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(seq_first_block_kernel, dim3(B), dim3(64), 0, s, key_valid, L, nb, first_block);
+  if (seq_order)
+    hipLaunchKernelGGL(seq_order_kernel, dim3(1), dim3(256), (size_t)(nb + 1) * sizeof(int32_t), s, first_block, B, nb, seq_order);
+  MHR_CHECK_LAUNCH("attn_seq_layout");
+  return MHR_OK;
+}
+
+extern "C" int mhr_hstu_attn_fwd_seq(const void* q, const void* k, const void* v, int64_t row_stride, const uint8_t* key_valid,
+                                     void* out, void* act_q, void* act_k, void* act_v, int64_t act_stride, int B, int L,
+                                     int n_heads, int head_dim, int apply_silu, const int32_t* first_block,
+                                     const int32_t* seq_order, void* stream) {
   MHR_REQUIRE(q && k && v && key_valid && out, "hstu_attn_fwd: null pointer");
   AttnShape sh;
   MHR_REQUIRE(attn_shape(head_dim, sh), "hstu_attn_fwd: head_dim=%d unsupported (multiple of 8, <= 128)", head_dim);
@@ -445,7 +521,7 @@ extern "C" int mhr_hstu_attn_fwd(const void* q, const void* k, const void* v, in
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     hipLaunchKernelGGL(kern, dim3(B * n_heads), dim3(256), lds, s, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, \
                        row_stride, key_valid, (bf16_t*)out, out_stride, (bf16_t*)act_q, (bf16_t*)act_k, (bf16_t*)act_v, \
-                       act_stride, L, n_heads, head_dim, apply_silu, inv_n);                                           \
+                       act_stride, L, n_heads, head_dim, apply_silu, inv_n, first_block, seq_order);                   \
   }
   ATTN_DISPATCH(sh, L_);
 #undef L_
@@ -453,10 +529,18 @@ extern "C" int mhr_hstu_attn_fwd(const void* q, const void* k, const void* v, in
   return MHR_OK;
 }
 
-extern "C" int mhr_hstu_attn_bwd(const void* q_pre, const void* k_pre, const void* v_pre, int64_t row_stride,
-                                 const void* act_q, const void* act_k, const void* act_v, int64_t act_stride,
-                                 const uint8_t* key_valid, const void* d_out, void* dq, void* dk, void* dv, int64_t d_stride,
-                                 int B, int L, int n_heads, int head_dim, int apply_silu, void* stream) {
+extern "C" int mhr_hstu_attn_fwd(const void* q, const void* k, const void* v, int64_t row_stride, const uint8_t* key_valid,
+                                 void* out, void* act_q, void* act_k, void* act_v, int64_t act_stride, int B, int L,
+                                 int n_heads, int head_dim, int apply_silu, void* stream) {
+  return mhr_hstu_attn_fwd_seq(q, k, v, row_stride, key_valid, out, act_q, act_k, act_v, act_stride, B, L, n_heads, head_dim,
+                               apply_silu, nullptr, nullptr, stream);
+}
+
+extern "C" int mhr_hstu_attn_bwd_seq(const void* q_pre, const void* k_pre, const void* v_pre, int64_t row_stride,
+                                     const void* act_q, const void* act_k, const void* act_v, int64_t act_stride,
+                                     const uint8_t* key_valid, const void* d_out, void* dq, void* dk, void* dv,
+                                     int64_t d_stride, int B, int L, int n_heads, int head_dim, int apply_silu,
+                                     const int32_t* first_block, const int32_t* seq_order, void* stream) {
   MHR_REQUIRE(key_valid && d_out && dq && dk && dv, "hstu_attn_bwd: null pointer");
   MHR_REQUIRE((act_q != nullptr) == (act_k != nullptr) && (act_k != nullptr) == (act_v != nullptr),
               "hstu_attn_bwd: act_q/act_k/act_v must be all set or all null");
@@ -490,7 +574,7 @@ extern "C" int mhr_hstu_attn_bwd(const void* q_pre, const void* k_pre, const voi
     hipLaunchKernelGGL(kern, dim3(B * n_heads), dim3(256), lds, s, (const bf16_t*)q_pre, (const bf16_t*)k_pre,          \
                        (const bf16_t*)v_pre, row_stride, (const bf16_t*)act_q, (const bf16_t*)act_k, (const bf16_t*)act_v, \
                        act_stride, key_valid, (const bf16_t*)d_out, do_stride, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv,   \
-                       d_stride, L, n_heads, head_dim, apply_silu, inv_n);                                             \
+                       d_stride, L, n_heads, head_dim, apply_silu, inv_n, first_block, seq_order);                     \
   }
 #define L_(NKS, ND)                \
   if (all4) L__(NKS, ND, true)     \
@@ -500,6 +584,14 @@ extern "C" int mhr_hstu_attn_bwd(const void* q_pre, const void* k_pre, const voi
 #undef L__
   MHR_CHECK_LAUNCH("hstu_attn_bwd");
   return MHR_OK;
+}
+
+extern "C" int mhr_hstu_attn_bwd(const void* q_pre, const void* k_pre, const void* v_pre, int64_t row_stride,
+                                 const void* act_q, const void* act_k, const void* act_v, int64_t act_stride,
+                                 const uint8_t* key_valid, const void* d_out, void* dq, void* dk, void* dv, int64_t d_stride,
+                                 int B, int L, int n_heads, int head_dim, int apply_silu, void* stream) {
+  return mhr_hstu_attn_bwd_seq(q_pre, k_pre, v_pre, row_stride, act_q, act_k, act_v, act_stride, key_valid, d_out, dq, dk, dv,
+                               d_stride, B, L, n_heads, head_dim, apply_silu, nullptr, nullptr, stream);
 }
 
 #ifdef MHR_STAMP

@@ -45,13 +45,13 @@ __device__ __forceinline__ void pack_acc(const f32x16& x, bf16x8& f0, bf16x8& f1
 // (ds_read_b64_tr_b16: operand summed over the ROW index) - so no transposed copy is ever built.
 template <int NKS>
 __device__ __forceinline__ void stage_tiles(unsigned char* dst, const bf16_t* src, int64_t stride, int L, int Lp, int hd,
-                                            bool do_silu, bf16_t* act, int64_t act_stride) {
-  using T = sg::Tile<NKS>;
+                                            bool do_silu, bf16_t* act, int64_t act_stride, int m_begin = 0) {
+  using T = sg::Tile<NKS>;   // (m_begin: rows below it are not staged - the leading all-padding blocks of a sequence, see leading_dead_blocks)
   // four 16-byte chunks per thread in flight: all loads of a batch are issued before the first SiLU / LDS store (one chunk per
   // iteration left every staging at 3-4 dependent global round trips, and a backward workgroup stages four operands)
   constexpr int U = 4;
   const int total = Lp * T::CH, nt = blockDim.x;
-  for (int c0 = threadIdx.x; c0 < total; c0 += U * nt) {
+  for (int c0 = m_begin * T::CH + threadIdx.x; c0 < total; c0 += U * nt) {
     bf16x8 val[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -78,11 +78,11 @@ __device__ __forceinline__ void stage_tiles(unsigned char* dst, const bf16_t* sr
 template <int NKS>
 __device__ __forceinline__ void stage_tiles2(unsigned char* dst_a, const bf16_t* src_a, int64_t stride_a, bool silu_a,
                                              unsigned char* dst_b, const bf16_t* src_b, int64_t stride_b, bool silu_b,
-                                             int L, int Lp, int hd) {
+                                             int L, int Lp, int hd, int m_begin = 0) {
   using T = sg::Tile<NKS>;
   constexpr int U = 4;
   const int total = Lp * T::CH, nt = blockDim.x;
-  for (int c0 = threadIdx.x; c0 < total; c0 += U * nt) {
+  for (int c0 = m_begin * T::CH + threadIdx.x; c0 < total; c0 += U * nt) {
     bf16x8 va[U], vb[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -115,7 +115,7 @@ template <int NKS>
 __device__ __forceinline__ void stage_tiles4(unsigned char* d0, const bf16_t* s0, int64_t st0, bool silu0, unsigned char* d1,
                                              const bf16_t* s1, int64_t st1, bool silu1, unsigned char* d2, const bf16_t* s2,
                                              int64_t st2, bool silu2, unsigned char* d3, const bf16_t* s3, int64_t st3,
-                                             bool silu3, int L, int Lp, int hd) {
+                                             bool silu3, int L, int Lp, int hd, int m_begin = 0) {
   using T = sg::Tile<NKS>;
   constexpr int U = 4;
   const int total = Lp * T::CH, nt = blockDim.x;
@@ -123,7 +123,7 @@ __device__ __forceinline__ void stage_tiles4(unsigned char* d0, const bf16_t* s0
   const bf16_t* src[4] = {s0, s1, s2, s3};
   const int64_t st[4] = {st0, st1, st2, st3};
   const bool sl[4] = {silu0, silu1, silu2, silu3};
-  for (int c0 = threadIdx.x; c0 < total; c0 += U * nt) {
+  for (int c0 = m_begin * T::CH + threadIdx.x; c0 < total; c0 += U * nt) {
     bf16x8 v[4][U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -199,6 +199,21 @@ __device__ __forceinline__ void store_grad_tile(float* scratch, const f32x16& ac
     if (row_base + r < n_rows && f0 < n_cols) *reinterpret_cast<bf16x8*>(out + (int64_t)(row_base + r) * out_stride + f0) = w;
   }
   __builtin_amdgcn_wave_barrier();
+}
+
+// Leading 32-row blocks of a sequence that hold no valid key (mhr_attn_seq_layout computes them once per batch).  With front
+// padding (evalset.py:34-41, trainset.py:111-137: the valid items sit at the END of the window) those blocks take part in nothing:
+// as keys they are masked, as queries every key at or before them is masked, so their outputs and gradients are exactly zero - the
+// kernels skip staging, tile pairs and the gradient epilogues of them and write the zeros directly (measured before: a backward
+// over sequences with 32 valid keys of 200 took 70 % of the time of full sequences).
+
+// zero rows [0, n_rows) of a head's slice (hd columns, a multiple of 8) of a [*, stride] bf16 matrix: 16-byte stores
+__device__ __forceinline__ void zero_head_rows(bf16_t* out, int64_t stride, int n_rows, int hd) {
+  const int ch = hd >> 3;
+  for (int c = threadIdx.x; c < n_rows * ch; c += blockDim.x) {
+    const int m = c / ch, j = c - m * ch;
+    *reinterpret_cast<bf16x8*>(out + (int64_t)m * stride + j * 8) = zero8();
+  }
 }
 
 __device__ __forceinline__ void build_valid_mask(uint32_t* vmask, const uint8_t* kv, int L, int nb) {

@@ -361,7 +361,28 @@ def l2norm_rows_indexed_bwd(dy, table, ids, norms):
 # ------------------------------------------------------------------------------------------------
 # attention
 # ------------------------------------------------------------------------------------------------
-def hstu_attn_fwd(h, key_valid, B, L, n_heads, head_dim, apply_silu=True, save_act=True):
+SEQ_LAYOUT = os.environ.get("MHR_ATTN_SEQ_LAYOUT", "1") != "0"   # skip leading all-padding blocks + longest-sequences-first launch order
+
+
+def attn_seq_layout(key_valid, B, L, order=True):
+    """(first_block [B] int32, seq_order [B] int32 | None) of a batch of masks: the 32-row block holding each sequence's first
+    valid key, and the sequences ordered by it (most live blocks first).  Computed once per batch, read by every layer's
+    attention launches (`layout=` of hstu_attn_fwd / hstu_attn_bwd)."""
+    _chk(key_valid, "key_valid", torch.uint8)
+    first = torch.empty(B, dtype=torch.int32, device=key_valid.device)
+    order_t = torch.empty(B, dtype=torch.int32, device=key_valid.device) if order else None
+    lib.call("mhr_attn_seq_layout", key_valid.data_ptr(), B, L, first.data_ptr(), order_t.data_ptr() if order else 0, _stream())
+    return first, order_t
+
+
+def _layout_ptrs(layout):
+    if layout is None:
+        return 0, 0
+    first, order = layout
+    return first.data_ptr(), (order.data_ptr() if order is not None else 0)
+
+
+def hstu_attn_fwd(h, key_valid, B, L, n_heads, head_dim, apply_silu=True, save_act=True, layout=None):
     """h [B*L, 4*D] bf16 pre-activation uvqk (column blocks u|v|q|k).  Returns (out [B*L, D], act [B*L, 3*D] (q|k|v))."""
     _chk(h, "h", torch.bfloat16)
     _chk(key_valid, "key_valid", torch.uint8)
@@ -373,24 +394,26 @@ def hstu_attn_fwd(h, key_valid, B, L, n_heads, head_dim, apply_silu=True, save_a
     out = torch.empty(B * L, D, dtype=torch.bfloat16, device=h.device)
     act = torch.empty(B * L, 3 * D, dtype=torch.bfloat16, device=h.device) if save_act else None
     aq = act.data_ptr() if save_act else 0
-    _timed_call("mhr_hstu_attn_fwd", q_ptr, k_ptr, v_ptr, stride, key_valid.data_ptr(), out.data_ptr(),
+    fb, so = _layout_ptrs(layout)
+    _timed_call("mhr_hstu_attn_fwd_seq", q_ptr, k_ptr, v_ptr, stride, key_valid.data_ptr(), out.data_ptr(),
              aq, aq + D * esz if save_act else 0, aq + 2 * D * esz if save_act else 0, 3 * D,
-             B, L, n_heads, head_dim, 1 if apply_silu else 0, _stream())
+             B, L, n_heads, head_dim, 1 if apply_silu else 0, fb, so, _stream())
     return out, act
 
 
-def hstu_attn_bwd(h, act, key_valid, d_out, dh, B, L, n_heads, head_dim, apply_silu=True):
+def hstu_attn_bwd(h, act, key_valid, d_out, dh, B, L, n_heads, head_dim, apply_silu=True, layout=None):
     """writes dv|dq|dk into dh[:, D:4D] (pre-activation gradients).  act = None: the activated q / k / v are recomputed
     from h inside the kernel (apply_silu only)."""
     D = n_heads * head_dim
     esz = 2
     base, dbase = h.data_ptr(), dh.data_ptr()
     abase = act.data_ptr() if act is not None else 0
-    _timed_call("mhr_hstu_attn_bwd", base + 2 * D * esz, base + 3 * D * esz, base + D * esz, h.stride(0),
+    fb, so = _layout_ptrs(layout)
+    _timed_call("mhr_hstu_attn_bwd_seq", base + 2 * D * esz, base + 3 * D * esz, base + D * esz, h.stride(0),
              abase, abase + D * esz if act is not None else 0, abase + 2 * D * esz if act is not None else 0,
              act.stride(0) if act is not None else 0, key_valid.data_ptr(), d_out.data_ptr(),
              dbase + 2 * D * esz, dbase + 3 * D * esz, dbase + D * esz, dh.stride(0),
-             B, L, n_heads, head_dim, 1 if apply_silu else 0, _stream())
+             B, L, n_heads, head_dim, 1 if apply_silu else 0, fb, so, _stream())
     return dh
 
 

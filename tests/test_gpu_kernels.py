@@ -341,6 +341,44 @@ def test_hstu_attention_fwd_bwd(ops, B, L, Hh, hd):
     assert torch.equal(dh2, dh)
 
 
+@pytest.mark.parametrize("B,L,Hh,hd", [(5, 200, 8, 32), (4, 70, 2, 64), (3, 33, 2, 16), (6, 300, 2, 64), (2, 512, 2, 64)])
+def test_hstu_attention_sequence_layout_is_bitwise_neutral(ops, B, L, Hh, hd):
+    """Front-padded batches (the loaders' layout, trainset.py:111-137): with the per-batch layout (first live block per sequence,
+    longest-first order) the kernels skip the dead blocks and reorder the launch - outputs and gradients keep every bit, the
+    dead rows are written as zeros.  Sequences: full, empty, one valid key, a block boundary, a hole after the first key."""
+    D = Hh * hd
+    g = torch.Generator().manual_seed(91 + L)
+    h = dev(bf(torch.randn(B * L, 4 * D, generator=g)))
+    d_out = dev(bf(torch.randn(B * L, D, generator=g) * 0.5))
+    lens = [L, 0, 1, min(L, 32), L // 2, L - 1][:B]
+    valid = torch.zeros(B, L, dtype=torch.bool)
+    for b, n in enumerate(lens):
+        valid[b, L - n:] = True
+    if B > 4:
+        valid[4, L - lens[4] + 1: L - lens[4] + 40] = False                          # a hole right after the first valid key
+    kv = dev(valid.to(torch.uint8))
+    first, order = ops.attn_seq_layout(kv, B, L)
+    nb = (L + 31) // 32
+    want_first = [((L - n) // 32 if n else nb) for n in lens]
+    assert first.cpu().tolist() == want_first
+    assert sorted(order.cpu().tolist()) == list(range(B))
+    fo = [want_first[i] for i in order.cpu().tolist()]
+    assert fo == sorted(fo)                                                          # most live blocks first
+    res = []
+    for layout in (None, (first, None), (first, order)):
+        out, _ = ops.hstu_attn_fwd(h, kv, B, L, Hh, hd, save_act=False, layout=layout)
+        dh = torch.full((B * L, 4 * D), 7.0, dtype=torch.bfloat16, device="cuda")    # (the kernels must WRITE the dead rows)
+        ops.hstu_attn_bwd(h, None, kv, d_out, dh, B, L, Hh, hd, layout=layout)
+        res.append((out, dh))
+    torch.cuda.synchronize()
+    for out, dh in res[1:]:
+        assert torch.equal(out, res[0][0])
+        assert torch.equal(dh, res[0][1])
+    o3 = res[2][0].view(B, L, D)
+    for b, n in enumerate(lens):
+        assert float(o3[b, : L - n].float().abs().max() if n < L else 0.0) == 0.0
+
+
 def test_hstu_attention_golden(ops):
     """The reference's own attention outputs (tests/golden/attention_unit.npz), bf16 tolerance."""
     from conftest import load_golden

@@ -40,8 +40,14 @@ while time.time() - t0 < budget:
         dh = torch.zeros_like(h)
         ops.hstu_attn_bwd(h, None, kv, d_out, dh, B, L, Hh, hd)
         res[mode] = (out, dh)
+    os.environ["MHR_ATTN_STREAM"] = "0"                     # resident form with the per-batch sequence layout: bit-identical
+    lay = ops.attn_seq_layout(kv, B, L, order=rng.random() < 0.5)
+    out, _ = ops.hstu_attn_fwd(h, kv, B, L, Hh, hd, save_act=False, layout=lay)
+    dh = torch.full_like(h, 3.0); dh[:, :D] = 0
+    ops.hstu_attn_bwd(h, None, kv, d_out, dh, B, L, Hh, hd, layout=lay)
     torch.cuda.synchronize()
     (o0, d0), (o1, d1) = res["0"], res["1"]
+    assert torch.equal(out, o0) and torch.equal(dh, d0), (B, L, Hh, hd, kind, "layout")
     assert torch.equal(o0, o1), (B, L, Hh, hd, kind)
     assert bool(torch.isfinite(d0.float()).all()) and bool(torch.isfinite(d1.float()).all()), (B, L, Hh, hd, kind)
     scale = float(d0.float().abs().max()) + 1e-12

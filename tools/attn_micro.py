@@ -13,9 +13,16 @@ g = torch.Generator(device="cuda").manual_seed(0)
 h = (torch.randn(B * L, 4 * D, device="cuda", generator=g) * 0.5).bfloat16()
 lens = torch.randint(L // 4, L + 1, (B,), device="cuda", generator=g)
 if os.environ.get("FULL"): lens[:] = L
+if os.environ.get("LEN"): lens[:] = int(os.environ["LEN"])                  # every sequence this long (how the kernels' time depends on the valid length)
 kv = (torch.arange(L, device="cuda")[None, :] >= (L - lens)[:, None]).to(torch.uint8).contiguous()   # front padded
 d_out = (torch.randn(B * L, D, device="cuda", generator=g) * 0.1).bfloat16()
 dh = torch.zeros_like(h)
+lay = None
+if os.environ.get("LAYOUT", "1") != "0":                                    # LAYOUT=0: plain launch; ORDER=0: dead-block skip without the reordering
+    lay = ops.attn_seq_layout(kv, B, L, order=os.environ.get("ORDER", "1") != "0")
+import functools
+ops.hstu_attn_fwd = functools.partial(ops.hstu_attn_fwd, layout=lay)
+ops.hstu_attn_bwd = functools.partial(ops.hstu_attn_bwd, layout=lay)
 for _ in range(3):
     out, act = ops.hstu_attn_fwd(h, kv, B, L, H, hd, save_act=not os.environ.get("NOACT"))
     ops.hstu_attn_bwd(h, act, kv, d_out, dh, B, L, H, hd)
