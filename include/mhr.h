@@ -212,6 +212,17 @@ int mhr_hstu_attn_bwd(const void* q_pre, const void* k_pre, const void* v_pre, i
                       void* dq, void* dk, void* dv, int64_t d_stride,
                       int B, int L, int n_heads, int head_dim, int apply_silu, void* stream);
 
+/* Token-rows projection of the encoder layers: C[M,N] (bf16) = A[M,K] (bf16, row stride lda) . W^T + bias[N] (bf16, optional),
+ * fp32 accumulation - reference model/IDNet/hstu.py:236-239 (`torch.mm(normed_x, self._uvqk)`), hstu.py:281-288
+ * (`self._o(...)`) and their input gradients, under bf16-mixed autocast.  W is stored [N,K] (w_is_kn = 0: an nn.Linear
+ * weight in its forward) or [K,N] (w_is_kn = 1: the `_uvqk` parameter; an nn.Linear weight in its input gradient), row
+ * stride ldw.  K in {64, 128, 256} (the stationary operand lives in registers), N a multiple of 8 (of 256 with w_is_kn),
+ * leading dimensions multiples of 8 elements, 16-byte aligned operands; mhr_rows_gemm_supported answers whether a shape is
+ * covered (the caller uses the library GEMM otherwise, as for every other dense projection). */
+int mhr_rows_gemm_supported(int M, int N, int K, int w_is_kn);
+int mhr_rows_gemm(const void* a, int64_t lda, const void* w, int64_t ldw, int w_is_kn, const void* bias,
+                  void* c, int64_t ldc, int M, int N, int K, void* stream);
+
 /* Sequence layout of a batch of masks, computed once per batch and shared by every layer's attention launches:
  * first_block[b] = the 32-row block holding sequence b's first valid key (ceil(L/32) when it has none); seq_order (optional) =
  * the sequences sorted by it, most live blocks first (stable).  The reference's loaders pad at the FRONT (data/dataset/

@@ -199,7 +199,7 @@ class HSTU(MultiHeadDecoding, BaseModel):
         the operand of the decoding heads' GEMM, written by the last residual add's own pass)."""
         from mhr_amd import ops
         from REC.model.hstu_functional import (AddCastFn, AddLayerNormFn, HSTUCoreFn, LayerNormFn, LayerNormResidualFn, SplitKLinearFn,
-                                               WeightGradStack)
+                                               WeightGradStack, ROWS_GEMM, _rows_gemm_pays)
         B, L, D = x.shape
         x2 = x.reshape(B * L, D)
         training = self.training if training is None else training
@@ -236,7 +236,7 @@ class HSTU(MultiHeadDecoding, BaseModel):
                                      sl(stack and stack.o, i), sl(stack and stack.dh, i))
                 y = SplitKLinearFn.apply(o, layer._o.weight, layer._o.bias, True, None, (stack, "o", i) if stack is not None else None)
             else:
-                h = xn @ cached[0]
+                h = ops.rows_gemm(xn, cached[0], None, w_is_kn=True) if (ROWS_GEMM and _rows_gemm_pays(xn, cached[0])) else xn @ cached[0]
                 o = HSTUCoreFn.apply(h, key_valid, B, L, self._num_heads, self._dqk, layer._eps, p, seed)
                 y = F.linear(o, cached[1], cached[2])
             if i + 1 < n:                      # residual add + the next layer's LayerNorm in one pass

@@ -154,6 +154,20 @@ class WeightGradStack:
         self.seen = {"uvqk": set(), "o": set()}
 
 
+ROWS_GEMM = os.environ.get("MHR_ROWS_GEMM", "1") != "0"
+
+
+def _rows_gemm_pays(x, w_kn):
+    """The hand-written token-rows projection (ops.rows_gemm) where it beats the library product: the wide-output, K = 256
+    uvqk shape with enough rows to amortise the stationary operand's load (measured at cfg1: 23 us against 31 us; the
+    [M, 256] x [256, 256] products and K = 64 are faster in the library)."""
+    M, K = x.shape
+    N = w_kn.shape[1]
+    return (K == 256 and N >= 1024 and M >= 8192 and x.dtype == torch.bfloat16 and w_kn.dtype == torch.bfloat16
+            and x.stride(1) == 1 and w_kn.is_contiguous() and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0 and w_kn.data_ptr() % 16 == 0
+            and ops.rows_gemm_supported(M, N, K, True))
+
+
 class SplitKLinearFn(Function):
     """y = x @ W (w_is_nk=False, W [K, N]) or x @ W.T + b (w_is_nk=True, W [N, K], the nn.Linear layout), bf16 GEMMs on
     fp32 master weights (reference hstu.py:236-239 under bf16-mixed autocast).
@@ -173,7 +187,12 @@ class SplitKLinearFn(Function):
         if b is not None:
             sh = getattr(b, "_mhr_bf16", None)
             bb = sh if (sh is not None and b._version == b._mhr_ver) else b.to(torch.bfloat16)
-        y = torch.nn.functional.linear(x, wb, bb) if w_is_nk else x @ wb
+        if w_is_nk:
+            y = torch.nn.functional.linear(x, wb, bb)
+        elif ROWS_GEMM and _rows_gemm_pays(x, wb):
+            y = ops.rows_gemm(x, wb, None, w_is_kn=True)     # the uvqk projection: weight stationary, token rows streamed
+        else:
+            y = x @ wb
         ctx.save_for_backward(x, wb)
         ctx.w_is_nk, ctx.has_bias = w_is_nk, b is not None
         # parameters whose .grad is a view of the optimizer's flat gradient buffer receive their gradient in place

@@ -162,18 +162,8 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
-  static_assert(N >= 0 && N <= 10, "extend wait_vmcnt");
-  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  static_assert(N >= 0 && N <= 63, "vmcnt is 6 bits");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
 __device__ __forceinline__ void ring_barrier() {
@@ -475,7 +465,8 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
 // lgkmcnt waits) and one sched_barrier per k-step: hipcc's own schedule of the builtin form leaves the MFMAs waiting on
 // `s_waitcnt lgkmcnt(0)` after short read batches.  OFF: compile-time byte offset of the tile in the ring whose LDS
 // addresses are in `ra`.
-template <int NKS, int RF, int OFF>
+// SWAP: the stationary fragment is the A operand - acc holds S (stationary rows on the registers, streamed rows on the lanes).
+template <int NKS, int RF, int OFF, bool SWAP = false>
 __device__ __forceinline__ void mma_tile_asm(const RowAddr<NKS>& ra, const bf16x8 (&frag)[RF][NKS], f32x16 (&acc)[RF]) {
   constexpr int PA = NKS < 4 ? NKS : 4;
   u32x4 a[PA + 1];
@@ -491,7 +482,9 @@ __device__ __forceinline__ void mma_tile_asm(const RowAddr<NKS>& ra, const bf16x
     wait_lgkm1<a_after>(a[ks % (PA + 1)]);
     const bf16x8 av = __builtin_bit_cast(bf16x8, a[ks % (PA + 1)]);
 #pragma unroll
-    for (int f = 0; f < RF; ++f) acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, frag[f][ks], acc[f], 0, 0, 0);
+    for (int f = 0; f < RF; ++f)
+      acc[f] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag[f][ks], av, acc[f], 0, 0, 0)
+                    : __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, frag[f][ks], acc[f], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
   };
   static_for<NKS>(step);

@@ -361,6 +361,31 @@ def l2norm_rows_indexed_bwd(dy, table, ids, norms):
 # ------------------------------------------------------------------------------------------------
 # attention
 # ------------------------------------------------------------------------------------------------
+def rows_gemm_supported(M, N, K, w_is_kn=False):
+    return K in (64, 128, 256) and N > 0 and N % (256 if w_is_kn else 8) == 0 and M > 0          # (= mhr_rows_gemm_supported)
+
+
+def rows_gemm(a, w, bias=None, out=None, w_is_kn=False):
+    """out [M, N] bf16 = a [M, K] @ w.T (w [N, K]; w_is_kn: a @ w with w [K, N]) (+ bias [N] bf16): the encoder's token-rows
+    projections (hstu.py:236-239, 281-288) with the weight stationary in registers and the token rows streaming through LDS."""
+    for t_, nm in ((a, "a"), (w, "w")):                       # (rows may be a column block of a wider buffer: row strides are passed on)
+        if not (t_.is_cuda and t_.dtype == torch.bfloat16 and t_.dim() == 2 and t_.stride(1) == 1):
+            raise ValueError(f"rows_gemm: {nm} must be a 2-d bf16 device tensor with unit inner stride")
+    M, K = a.shape
+    N = w.shape[1] if w_is_kn else w.shape[0]
+    if (w.shape[0] if w_is_kn else w.shape[1]) != K:
+        raise ValueError("rows_gemm: inner dimensions differ")
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=a.device)
+    elif out.shape != (M, N) or out.dtype != torch.bfloat16 or out.stride(1) != 1:
+        raise ValueError("rows_gemm: out must be [M, N] bf16 with unit inner stride")
+    if bias is not None:
+        _chk(bias, "bias", torch.bfloat16)
+    _timed_call("mhr_rows_gemm", a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), 1 if w_is_kn else 0,
+                bias.data_ptr() if bias is not None else 0, out.data_ptr(), out.stride(0), M, N, K, _stream())
+    return out
+
+
 SEQ_LAYOUT = os.environ.get("MHR_ATTN_SEQ_LAYOUT", "1") != "0"   # skip leading all-padding blocks + longest-sequences-first launch order
 
 

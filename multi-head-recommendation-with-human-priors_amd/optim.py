@@ -89,7 +89,8 @@ class FusedAdamW:
         names, uniq = [n for n, _ in order], [p for _, p in order]
         self.dense = uniq
         self.layout = [[n, p.numel()] for n, p in zip(names, uniq)]     # order of the flat buffers (checked on load)
-        sizes = [(p.numel() + 3) // 4 * 4 for p in self.dense]          # keep every view 16-byte aligned
+        sizes = [(p.numel() + 7) // 8 * 8 for p in self.dense]          # every view 16-byte aligned, fp32 and the bf16 shadow alike
+        self.pad = 8                                                     # (recorded with the state: older checkpoints padded to 4)
         total = (sum(sizes) + 7) // 8 * 8                               # (whole 8-column groups for the batched partial sum)
         self.flat_w = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
@@ -407,7 +408,7 @@ class FusedAdamW:
 
     def state_dict(self):
         self.flush_table()
-        sd = {"step": self.step_count, "flat_m": self.flat_m, "flat_v": self.flat_v, "layout": self.layout}
+        sd = {"step": self.step_count, "flat_m": self.flat_m, "flat_v": self.flat_v, "layout": self.layout, "pad": self.pad}
         if self.table is not None:
             sd.update(t_m=self.t_m, t_v=self.t_v)
         return sd
@@ -430,7 +431,17 @@ class FusedAdamW:
             raise RuntimeError("optimizer state was saved for a different parameter layout (names / sizes / order of the flat "
                                "moment buffers differ): refusing to load it onto the wrong parameters")
         self.step_count = int(sd["step"])
-        for k in ("flat_m", "flat_v") + (("t_m", "t_v") if self.table is not None else ()):
+        pad = int(sd.get("pad", 4))                      # padding of each parameter's slot in the saved flat buffers
+        for k in ("flat_m", "flat_v"):
+            if pad == self.pad:
+                getattr(self, k).copy_(sd[k])
+            else:                                        # same parameters in the same order, other slot sizes: slot by slot
+                src, dst, so, do = sd[k], getattr(self, k), 0, 0
+                for _, n in self.layout:
+                    dst[do:do + n].copy_(src[so:so + n])
+                    so += (n + pad - 1) // pad * pad
+                    do += (n + self.pad - 1) // self.pad * self.pad
+        for k in (("t_m", "t_v") if self.table is not None else ()):
             getattr(self, k).copy_(sd[k])
         if self.lazy:                                    # a checkpoint is a flushed state: every row stands at `step`
             self.last_step.fill_(self.step_count)

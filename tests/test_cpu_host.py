@@ -133,6 +133,18 @@ def test_optimizer_state_without_layout_record_is_refused_when_the_order_differs
         bad = dict(sd, layout=[[n + "_x", k] for n, k in sd["layout"]])
         with pytest.raises(RuntimeError, match="layout"):
             opt.load_state_dict(bad)
+        # a state saved when every parameter's slot was padded to 4 elements (no 'pad' record): loaded slot by slot
+        opt.flat_m.copy_(torch.arange(opt.flat_m.numel(), dtype=torch.float32))
+        want = [opt.flat_m[p._mhr_flat_off:p._mhr_flat_off + p.numel()].clone() for p in opt.dense]
+        packed4 = torch.cat([torch.cat([w_, w_.new_zeros((-w_.numel()) % 4)]) for w_ in want])
+        sd4 = {k: v for k, v in opt.state_dict().items() if k != "pad"}
+        sd4["flat_m"] = packed4
+        sd4["flat_v"] = packed4.clone()
+        opt.flat_m.zero_()
+        opt.load_state_dict(sd4)
+        for p, w_ in zip(opt.dense, want):
+            assert torch.equal(opt.flat_m[p._mhr_flat_off:p._mhr_flat_off + p.numel()], w_)
+            assert p._mhr_flat_off % 8 == 0                           # fp32 views and bf16 shadows both 16-byte aligned
 
 
 def test_unknown_head_interaction_raises():

@@ -379,6 +379,33 @@ def test_hstu_attention_sequence_layout_is_bitwise_neutral(ops, B, L, Hh, hd):
         assert float(o3[b, : L - n].float().abs().max() if n < L else 0.0) == 0.0
 
 
+@pytest.mark.parametrize("M,N,K,bias,lda_pad,kn", [(25600, 1024, 256, False, 0, False), (800, 256, 256, True, 0, False),
+                                                   (77, 256, 256, True, 0, False), (1000, 72, 64, True, 0, False),
+                                                   (64, 256, 128, False, 0, False), (333, 1024, 256, False, 256, False),
+                                                   (32, 8, 64, True, 0, False), (4097, 520, 256, True, 0, False),
+                                                   (25600, 1024, 256, False, 0, True), (999, 256, 256, True, 0, True),
+                                                   (640, 256, 64, False, 0, True), (96, 512, 128, True, 128, True)])
+def test_rows_gemm_against_the_fp32_product(ops, M, N, K, bias, lda_pad, kn):
+    """ops.rows_gemm (hstu.py:236-239 / 281-288 under bf16 autocast: bf16 operands, fp32 accumulation, bf16 result) against
+    the fp32 product of the same bf16 operands: within one bf16 rounding of it (the summation order differs from the
+    reference's library GEMM, as two library GEMMs differ from each other).  Ragged M / N, strided rows (a column block of a
+    wider buffer), all three supported K, both weight layouts ([N, K] and [K, N])."""
+    g = torch.Generator().manual_seed(5 + M + N)
+    a_full = bf(torch.randn(M, K + lda_pad, generator=g) * 0.5)
+    a = a_full[:, :K]
+    w = bf(torch.randn(N, K, generator=g) * K ** -0.5)
+    b = bf(torch.randn(N, generator=g) * 0.1) if bias else None
+    out = torch.full((M + 1, N), 7.0, dtype=torch.bfloat16, device="cuda")             # one guard row behind the result
+    w_dev = dev(w.t().contiguous()) if kn else dev(w)
+    ops.rows_gemm(dev(a_full)[:, :K], w_dev, dev(b) if bias else None, out=out[:M], w_is_kn=kn)
+    torch.cuda.synchronize()
+    ref = a.float() @ w.float().t() + (b.float() if bias else 0.0)
+    got = out[:M].float().cpu()
+    tol = 2 ** -8 * ref.abs().clamp_min(1e-3) + 1e-6                                     # half an ulp of bf16 + accumulation slack
+    assert bool(((got - ref).abs() <= 2 * tol).all()), float(((got - ref).abs() / tol).max())
+    assert float(out[M].float().abs().max()) == 7.0 and float(out[M].float().abs().min()) == 7.0
+
+
 def test_hstu_attention_golden(ops):
     """The reference's own attention outputs (tests/golden/attention_unit.npz), bf16 tolerance."""
     from conftest import load_golden
