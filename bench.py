@@ -355,12 +355,19 @@ def _attach_rocprof(roof, kernel_name, flops=None, nbytes=None):
 
 
 def _gpu_clocks():
-    """Current shader / memory clocks as rocm-smi reports them right after the timed legs (a child process; best effort)."""
+    """Current shader / memory clocks right after the timed legs, read from the card's sysfs files (`pp_dpm_sclk` / `pp_dpm_mclk`,
+    the level marked `*`) - no child process: a process that has initialised the GPU must not exec another program on this pool
+    (rocm-smi is a script: fork + exec).  Best effort: None where the files are not readable."""
     try:
-        r = subprocess.run(["rocm-smi", "--showclocks", "--json"], capture_output=True, text=True, timeout=20)
-        d = json.loads(r.stdout)
-        card = next(iter(d.values()))
-        return {k: v for k, v in card.items() if "sclk" in k.lower() or "mclk" in k.lower()}
+        import torch
+        pr = torch.cuda.get_device_properties(torch.cuda.current_device())
+        dev = f"/sys/bus/pci/devices/{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        out = {}
+        for name in ("sclk", "mclk"):
+            with open(f"{dev}/pp_dpm_{name}") as f:
+                cur = [ln.split(":", 1)[1].replace("*", "").strip() for ln in f if ln.rstrip().endswith("*")]
+            out[name] = cur[0] if cur else None
+        return out
     except Exception:  # noqa: BLE001
         return None
 
@@ -526,7 +533,15 @@ def main():
         prof, B = leg["prof"], leg["B"]
         es = leg["event_steps"]
         batches = leg["batches"]
-        for name, (launches, mean_ms, total_ms) in sorted(prof.items(), key=lambda kv: -kv[1][2]):
+        order = sorted(prof.items(), key=lambda kv: -kv[1][2])
+        # The sampled softmax's two streaming kernels take the same time to within a few per cent; which of them is "largest" flips
+        # from box to box.  While they are within 5 % of each other the line prices the FORWARD (as every earlier round's line did)
+        # and carries the negative-side backward beside it (`roofline_pair`), so that the fraction stays comparable run to run.
+        pair = [kv for kv in order if kv[0] in ("mhr_nce_fwd", "mhr_nce_bwd_negs")]
+        if order and len(pair) == 2 and order[0][0] == "mhr_nce_bwd_negs" and pair[1][1][2] >= 0.95 * pair[0][1][2]:
+            order = [pair[1], pair[0]] + [kv for kv in order if kv[0] not in ("mhr_nce_fwd", "mhr_nce_bwd_negs")]
+        second = None
+        for name, (launches, mean_ms, total_ms) in order:
             if name in ("mhr_nce_fwd", "mhr_nce_bwd_negs"):
                 # ONE launch serves all groups (prior categories).  The P prediction offsets of a position share one query
                 # row (reference hstu.py:682-690: head c's embedding at (b, l) is the query of tokens (b, l, 0..P-1)), so the
@@ -568,8 +583,17 @@ def main():
             _attach_traffic(r, "train", standard and args.config == "cfg1")
             if standard and args.config == "cfg1" and name in KERNEL_NAMES:
                 _attach_rocprof(r, KERNEL_NAMES[name][0], flops=r.get("algorithmic_flops_per_launch"), nbytes=r.get("algorithmic_bytes_per_launch"))
+            if second is None and name in ("mhr_nce_fwd", "mhr_nce_bwd_negs") and len(pair) == 2:
+                second = r                       # first of the pair: keep going for its partner
+                continue
+            if second is not None:
+                if name in ("mhr_nce_fwd", "mhr_nce_bwd_negs"):
+                    second["roofline_pair"] = {k: r[k] for k in ("kernel", "achieved", "frac", "launch_ms", "algorithmic_flops_per_launch",
+                                                                 "executed_flops_per_launch", "frac_rocprof") if k in r}
+                    return second
+                continue
             return r
-        return None
+        return second
 
     def emulate_world(Wem, iters=10):
         """What every rank does with the exchanged gradient rows of W ranks (reference: the dense 116 M-parameter all-reduce +
