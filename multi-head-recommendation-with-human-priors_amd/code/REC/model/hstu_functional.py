@@ -155,6 +155,7 @@ class WeightGradStack:
 
 
 ROWS_GEMM = os.environ.get("MHR_ROWS_GEMM", "1") != "0"
+ROWS_GEMM_MIN_M = int(os.environ.get("MHR_ROWS_GEMM_MIN_M", "8192"))    # rows from which the stationary operand's load is amortised
 
 
 def _rows_gemm_pays(x, w_kn):
@@ -163,7 +164,7 @@ def _rows_gemm_pays(x, w_kn):
     [M, 256] x [256, 256] products and K = 64 are faster in the library)."""
     M, K = x.shape
     N = w_kn.shape[1]
-    return (K == 256 and N >= 1024 and M >= 8192 and x.dtype == torch.bfloat16 and w_kn.dtype == torch.bfloat16
+    return (K == 256 and N >= 1024 and M >= ROWS_GEMM_MIN_M and x.dtype == torch.bfloat16 and w_kn.dtype == torch.bfloat16
             and x.stride(1) == 1 and w_kn.is_contiguous() and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0 and w_kn.data_ptr() % 16 == 0
             and ops.rows_gemm_supported(M, N, K, True))
 

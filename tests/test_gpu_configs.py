@@ -207,6 +207,21 @@ def test_cfg1_assembled_train_step_vs_mixed_oracle(rec):
     _train_step_vs_mixed_oracle(model, ocfg, batch, "cfg1", grad_tol=5e-2, min_cos=0.999, table_tol=4e-2)
 
 
+def test_cfg1_assembled_train_step_through_the_hand_written_uvqk_projection(rec, monkeypatch):
+    """The same comparison with the eight uvqk projections on `mhr_rows_gemm` (the step routes them there from 8192 token rows
+    on - B = 128 in the bench; here the threshold is lowered to this batch's 800 rows) - and a count that they really went there."""
+    from REC.model import hstu_functional as HF
+    from mhr_amd import ops
+    cfg, ocfg, data, model, N = _build("cfg1", seed=21)
+    batch = data.train_batch(4)
+    calls = []
+    real = ops.rows_gemm
+    monkeypatch.setattr(HF, "ROWS_GEMM_MIN_M", 1)
+    monkeypatch.setattr(ops, "rows_gemm", lambda *a, **k: (calls.append(a[0].shape), real(*a, **k))[1])
+    _train_step_vs_mixed_oracle(model, ocfg, batch, "cfg1 (rows_gemm)", grad_tol=5e-2, min_cos=0.999, table_tol=4e-2)
+    assert len(calls) >= cfg["n_layers"] and all(tuple(c) == (4 * 200, 256) for c in calls), calls
+
+
 def test_cfg1_eval_batch_vs_oracle_decode(rec):
     cfg, ocfg, data, model, N = _build("cfg1", seed=22)
     eb = data.eval_batch(6)
