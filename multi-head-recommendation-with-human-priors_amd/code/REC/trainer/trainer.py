@@ -48,6 +48,16 @@ class _GraphSegments:
         self.host_s, self.n_replays = 0.0, 0          # host time spent inside the plan's host calls (the collectives), replays
         self.ev_fork, self.ev_side = torch.cuda.Event(), torch.cuda.Event()
 
+    @staticmethod
+    def _capture_mode():
+        """With a process group alive, RCCL's watchdog THREAD polls the events of finished collectives (`hipEventQuery`) whenever
+        it likes - a call the default 'global' capture mode forbids to every thread of the process while a capture is open
+        (seen once: `operation not permitted when stream is capturing` thrown in the watchdog, process aborted, one-rank RCCL
+        rehearsal).  'thread_local' confines the check to the capturing thread; begin / cut / end of a capture all happen on it
+        (data-parallel captures run the backward single-threaded for that reason)."""
+        import torch.distributed as dist
+        return "thread_local" if (dist.is_available() and dist.is_initialized()) else "global"
+
     def begin(self):
         torch.cuda.synchronize()
         torch.cuda.empty_cache()
@@ -59,7 +69,7 @@ class _GraphSegments:
         g = torch.cuda.CUDAGraph()
         if self.pool is None:
             self.pool = torch.cuda.graph_pool_handle()
-        g.capture_begin(pool=self.pool)
+        g.capture_begin(pool=self.pool, capture_error_mode=self._capture_mode())
         self.cur = g
 
     def _close(self):
@@ -71,7 +81,7 @@ class _GraphSegments:
         self._close()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.stream(self.side):
-            g.capture_begin(pool=torch.cuda.graph_pool_handle())
+            g.capture_begin(pool=torch.cuda.graph_pool_handle(), capture_error_mode=self._capture_mode())
             try:
                 fn()
             finally:
@@ -167,7 +177,8 @@ class _StepGraph:
             # autograd engine runs a device's backward nodes on a worker thread of its own: data-parallel captures (whose
             # backward starts the shared-negative all-reduce) keep the backward on this thread
             import contextlib
-            same_thread = torch.autograd.set_multithreading_enabled(False) if D.active() else contextlib.nullcontext()
+            same_thread = (torch.autograd.set_multithreading_enabled(False)
+                           if (D.active() or _GraphSegments._capture_mode() == "thread_local") else contextlib.nullcontext())
             try:
                 with same_thread:
                     out = tr._eager_step(self.static)
