@@ -151,10 +151,16 @@ int mhr_add_cast(const float* x, const void* y_bf16, float* out, void* out_bf16,
 /* Residual add fused with the next layer's LayerNorm (model/IDNet/hstu.py:286-287 then 241):
  *   x_out = x + y,  xn = LN(x_out)      x, x_out f32 [rows, dim]; y, xn bf16; mean / rstd [rows] saved for the backward.
  * Backward: total = d_xout + LN'(d_xn)  written as dx (f32, gradient of x) and dy (bf16, gradient of y). */
+/* first_row / seq_len (optional, here and in mhr_ln_gate_*): rows = B * seq_len token rows of front-padded sequences and
+ * first_row[b] = index of sequence b's first valid key (mhr_attn_seq_layout).  Rows in front of it - except a sequence's last
+ * row, which the decode reads - take part in nothing (no valid key reads them, loss and decode skip them, every gradient that
+ * reaches them is exactly zero): their operands are not loaded but read as zeros and the zeros the arithmetic produces are
+ * written.  Live rows keep every bit; NULL: all rows live. */
 int mhr_add_layernorm_fwd(const float* x, const void* y_bf16, float* x_out, void* xn_bf16, float* mean, float* rstd,
-                          int64_t rows, int dim, float eps, void* stream);
+                          int64_t rows, int dim, float eps, const int32_t* first_row, int seq_len, void* stream);
 int mhr_add_layernorm_bwd(const void* d_xn_bf16, const float* x_out, const float* mean, const float* rstd,
-                          const float* d_xout, float* dx, void* dy_bf16, int64_t rows, int dim, void* stream);
+                          const float* d_xout, float* dx, void* dy_bf16, int64_t rows, int dim,
+                          const int32_t* first_row, int seq_len, void* stream);
 
 /* o = silu(u) * LayerNorm(a) * dropmask   (hstu.py:277-285).  u is a column block of the uvqk GEMM
  * output: u[r,c] = u_base[r*u_stride + c] (pre-activation; SiLU applied here).  a [rows, dim].
@@ -163,12 +169,14 @@ int mhr_add_layernorm_bwd(const void* d_xn_bf16, const float* x_out, const float
  * at capture: the effective seed is (step_seed[0] * 1000003 + seed) & (2^63 - 1), NULL: `seed` as given. */
 int mhr_ln_gate_fwd(const void* u_base, int64_t u_stride, const void* a, int dtype, void* o, int o_dtype,
                     float* mean, float* rstd, int64_t rows, int dim, float eps,
-                    float dropout_p, uint64_t seed, const int64_t* step_seed, void* stream);
+                    float dropout_p, uint64_t seed, const int64_t* step_seed,
+                    const int32_t* first_row, int seq_len, void* stream);
 /* Backward of the above: given d_o, writes du (pre-activation gradient, into a column block with
  * row stride du_stride) and da. */
 int mhr_ln_gate_bwd(const void* d_o, int do_dtype, const void* u_base, int64_t u_stride, const void* a, int dtype,
                     const float* mean, const float* rstd, void* du_base, int64_t du_stride, void* da,
-                    int64_t rows, int dim, float dropout_p, uint64_t seed, const int64_t* step_seed, void* stream);
+                    int64_t rows, int dim, float dropout_p, uint64_t seed, const int64_t* step_seed,
+                    const int32_t* first_row, int seq_len, void* stream);
 
 /* y[r,:] = x[r,:] / ||x[r,:]||_2  (hstu.py:605-606, 672, 966, 975, 1021); optional norms out ([rows] f32). */
 int mhr_l2norm_rows(const void* x, int x_dtype, void* y, int y_dtype, float* norms, int64_t rows, int dim, void* stream);
@@ -230,7 +238,8 @@ int mhr_rows_gemm(const void* a, int64_t lda, const void* w, int64_t ldw, int w_
  * exactly zero.  The *_seq entries take both arrays (either may be NULL): the resident kernels then skip staging, tile pairs
  * and epilogues of the dead blocks (writing the zeros) and run the sequences in seq_order; results are bit-identical to the
  * plain entries, which are the *_seq entries with both NULL. */
-int mhr_attn_seq_layout(const uint8_t* key_valid, int B, int L, int32_t* first_block, int32_t* seq_order, void* stream);
+int mhr_attn_seq_layout(const uint8_t* key_valid, int B, int L, int32_t* first_block, int32_t* seq_order,
+                        int32_t* first_row /* optional: index of the first valid key, L when none */, void* stream);
 int mhr_hstu_attn_fwd_seq(const void* q, const void* k, const void* v, int64_t row_stride,
                           const uint8_t* key_valid, void* out,
                           void* act_q, void* act_k, void* act_v, int64_t act_stride,

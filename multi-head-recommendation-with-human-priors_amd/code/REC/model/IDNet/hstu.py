@@ -194,6 +194,13 @@ class HSTU(MultiHeadDecoding, BaseModel):
             opt.last_step.fill_(opt.step_count)
         return out
 
+    def _dead_rows_allowed(self):
+        """May the encoder leave the rows in front of a sequence's first valid key unread?  Yes while nothing reads the hidden
+        states of padding positions: the sampled-softmax tokens, the decode and the last-position switch are all on valid rows.
+        The prior switch's category loss over ALL positions (reference hstu.py:757-806: a BCE over [batch, seq_len] without a
+        mask, unless `switch_last_only`) does read them - and sends gradient into them - so those models keep every row."""
+        return getattr(self, "prior_switch", None) is None or bool(getattr(self, "switch_last_only", False))
+
     def _encode(self, x, key_valid, training=None, want_bf16=False):
         """x [B,L,D] fp32, key_valid [B,L] uint8 -> [B,L,D] fp32 (reference hstu.py:221-328); want_bf16: (out, its bf16 copy -
         the operand of the decoding heads' GEMM, written by the last residual add's own pass)."""
@@ -208,6 +215,9 @@ class HSTU(MultiHeadDecoding, BaseModel):
         n = len(layers)
         if ops.SEQ_LAYOUT and n and getattr(key_valid, "_mhr_layout", None) is None:
             key_valid._mhr_layout = ops.attn_seq_layout(key_valid, B, L)     # front padding: the layers skip the dead blocks
+        lay = getattr(key_valid, "_mhr_layout", None)
+        # rows in front of a sequence's first valid key: the layers' row-wise kernels do not load them (zeros in, zeros out)
+        dead = (lay[2], L) if (ops.DEAD_ROWS and lay is not None and len(lay) > 2 and self._dead_rows_allowed()) else None
         # training with the fused optimizer in its one-backward-per-step mode: the layers' weight-gradient products are formed
         # for all layers at once at the step (WeightGradStack); the kernels below write their operands straight into its slices
         stack = None
@@ -240,7 +250,7 @@ class HSTU(MultiHeadDecoding, BaseModel):
                 o = HSTUCoreFn.apply(h, key_valid, B, L, self._num_heads, self._dqk, layer._eps, p, seed)
                 y = F.linear(o, cached[1], cached[2])
             if i + 1 < n:                      # residual add + the next layer's LayerNorm in one pass
-                x2, xn = AddLayerNormFn.apply(x2, y, layers[i + 1]._eps, sl(stack and stack.xn, i + 1), sl(stack and stack.dy, i))
+                x2, xn = AddLayerNormFn.apply(x2, y, layers[i + 1]._eps, sl(stack and stack.xn, i + 1), sl(stack and stack.dy, i), dead)
             elif want_bf16 and y.dtype == torch.bfloat16 and x2.numel() % 8 == 0:
                 x2, x16 = AddCastFn.apply(x2, y, sl(stack and stack.dy, i))
                 return x2.view(B, L, D), x16.view(B, L, D)

@@ -62,10 +62,12 @@ class AddLayerNormFn(Function):
     (reference hstu.py:286-287, 241).  x fp32, y bf16 -> x_out fp32, xn bf16."""
 
     @staticmethod
-    def forward(ctx, x, y, eps, xn_out=None, dy_out=None):
-        x_out, xn, mean, rstd = ops.add_layernorm_fwd(x.contiguous(), y.contiguous(), eps, xn_out=xn_out)
+    def forward(ctx, x, y, eps, xn_out=None, dy_out=None, dead=None):
+        # dead = (first_row, L): rows in front of a sequence's first valid key are not loaded (ops._dead_args) - forward and backward
+        x_out, xn, mean, rstd = ops.add_layernorm_fwd(x.contiguous(), y.contiguous(), eps, xn_out=xn_out, dead=dead)
         ctx.save_for_backward(x_out, mean, rstd)
         ctx.dy_out = dy_out                      # (the caller's buffer for the gradient of y: WeightGradStack)
+        ctx.dead = dead
         return x_out, xn
 
     @staticmethod
@@ -75,8 +77,9 @@ class AddLayerNormFn(Function):
             d_xout = torch.zeros_like(x_out)
         if d_xn is None:
             d_xn = torch.zeros(x_out.shape, dtype=torch.bfloat16, device=x_out.device)
-        dx, dy = ops.add_layernorm_bwd(d_xn.contiguous(), x_out, mean, rstd, d_xout.contiguous().float(), dy_out=ctx.dy_out)
-        return dx, dy, None, None, None
+        dx, dy = ops.add_layernorm_bwd(d_xn.contiguous(), x_out, mean, rstd, d_xout.contiguous().float(), dy_out=ctx.dy_out,
+                                       dead=ctx.dead)
+        return dx, dy, None, None, None, None
 
 
 class AddCastFn(Function):
@@ -344,11 +347,12 @@ class HSTUCoreFn(Function):
         # the activated q / k / v are NOT saved: the backward recomputes silu() while it stages them (h is kept anyway)
         layout = getattr(key_valid, "_mhr_layout", None)         # (HSTU._encode: once per batch, shared by the layers)
         a, _ = ops.hstu_attn_fwd(h, key_valid, B, L, n_heads, head_dim, apply_silu=True, save_act=False, layout=layout)
-        o, mean, rstd = ops.ln_gate_fwd(h, a, D, torch.bfloat16, eps, dropout_p, seed, seed_dev, out=o_out)
+        dead = (layout[2], L) if (ops.DEAD_ROWS and layout is not None and len(layout) > 2) else None
+        o, mean, rstd = ops.ln_gate_fwd(h, a, D, torch.bfloat16, eps, dropout_p, seed, seed_dev, out=o_out, dead=dead)
         ctx.dh_out = dh_out                      # (the caller's buffer for the gradient of h: WeightGradStack)
         ctx.save_for_backward(h, key_valid, a, mean, rstd)
         ctx.cfg = (B, L, n_heads, head_dim, dropout_p, seed, seed_dev)
-        ctx.layout = layout
+        ctx.layout, ctx.dead = layout, dead
         return o
 
     @staticmethod
@@ -357,7 +361,7 @@ class HSTUCoreFn(Function):
         B, L, n_heads, head_dim, dropout_p, seed, seed_dev = ctx.cfg
         D = n_heads * head_dim
         dh = torch.empty_like(h) if ctx.dh_out is None else ctx.dh_out.view(h.shape)
-        da = ops.ln_gate_bwd(d_o.contiguous(), h, a, mean, rstd, dh, D, dropout_p, seed, seed_dev)
+        da = ops.ln_gate_bwd(d_o.contiguous(), h, a, mean, rstd, dh, D, dropout_p, seed, seed_dev, dead=ctx.dead)
         ops.hstu_attn_bwd(h, None, key_valid, da, dh, B, L, n_heads, head_dim, apply_silu=True, layout=ctx.layout)
         return (dh,) + (None,) * 11
 

@@ -440,16 +440,19 @@ namespace {
 // first_block[b] = index of the 32-row block holding the first valid key of sequence b (nb when none); counts[.] feed the
 // counting sort below.  One wave per sequence, ballots over the mask bytes.
 __global__ __launch_bounds__(64) void seq_first_block_kernel(const uint8_t* __restrict__ key_valid, int L, int nb,
-                                                             int32_t* __restrict__ first_block) {
+                                                             int32_t* __restrict__ first_block, int32_t* __restrict__ first_row) {
   const int b = blockIdx.x, lane = threadIdx.x;
   const uint8_t* kv = key_valid + (int64_t)b * L;
-  int first = nb;
-  for (int j0 = 0; j0 < L && first == nb; j0 += 64) {
+  int first = L;                                        // index of the first valid key (L: none)
+  for (int j0 = 0; j0 < L && first == L; j0 += 64) {
     const int j = j0 + lane;
     const unsigned long long m = __ballot(j < L && kv[j] != 0);
-    if (m) first = (j0 + __builtin_ctzll(m)) >> 5;
+    if (m) first = j0 + __builtin_ctzll(m);
   }
-  if (lane == 0) first_block[b] = first;
+  if (lane == 0) {
+    first_block[b] = first < L ? first >> 5 : nb;
+    if (first_row) first_row[b] = first;
+  }
 }
 
 // seq_order: sequences by first_block ascending (most live blocks first), ties in index order - a counting sort in one
@@ -481,12 +484,12 @@ __global__ __launch_bounds__(256) void seq_order_kernel(const int32_t* __restric
 }  // namespace
 
 extern "C" int mhr_attn_seq_layout(const uint8_t* key_valid, int B, int L, int32_t* first_block, int32_t* seq_order,
-                                   void* stream) {
+                                   int32_t* first_row, void* stream) {
   MHR_REQUIRE(key_valid && first_block, "attn_seq_layout: null pointer");
   MHR_REQUIRE(B > 0 && L > 0 && L <= 131072, "attn_seq_layout: bad sizes");
   const int nb = (L + 31) / 32;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(seq_first_block_kernel, dim3(B), dim3(64), 0, s, key_valid, L, nb, first_block);
+  hipLaunchKernelGGL(seq_first_block_kernel, dim3(B), dim3(64), 0, s, key_valid, L, nb, first_block, first_row);
   if (seq_order)
     hipLaunchKernelGGL(seq_order_kernel, dim3(1), dim3(256), (size_t)(nb + 1) * sizeof(int32_t), s, first_block, B, nb, seq_order);
   MHR_CHECK_LAUNCH("attn_seq_layout");

@@ -56,6 +56,33 @@ __device__ __forceinline__ void row_stats(const RowRegs<NC>& r, int dim, int lan
   rstd = rsqrtf(var + eps);
 }
 
+// Rows in front of a sequence's first valid key (the loaders pad at the FRONT: trainset.py:111-137, evalset.py:34-41) take part in
+// nothing: no valid key reads them, the loss and the decode skip them, and every gradient that reaches them is exactly zero.
+// Given `first_row[b]` (mhr_attn_seq_layout) and the sequence length the row-wise kernels of the encoder do not LOAD such rows:
+// their operands read as zeros, the arithmetic runs unchanged and writes the zeros it produces (so the weight-gradient products
+// over all rows meet finite operands whose partner is zero).  The last row of a sequence always counts as live - the decode
+// reads it even from an all-padding sequence.  first_row == NULL: every row is live.
+__device__ __forceinline__ bool row_is_live(const int32_t* __restrict__ first_row, int seq_len, int64_t row) {
+  if (!first_row) return true;
+  const int r32 = (int)row, b = r32 / seq_len, l = r32 - b * seq_len;
+  return l >= min(first_row[b], seq_len - 1);
+}
+template <typename T, int NC>
+__device__ __forceinline__ void load_row_if(bool live, const T* p, int dim, int lane, RowRegs<NC>& r) {
+  if (live) {
+    load_row<T, NC>(p, dim, lane, r);
+  } else {
+#pragma unroll
+    for (int i = 0; i < NC; ++i) r.v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+}
+__device__ __forceinline__ bf16x8 load8_if(bool live, const bf16_t* p) {
+  bf16x8 z;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) z[i] = (bf16_t)0.0f;
+  return live ? *reinterpret_cast<const bf16x8*>(p) : z;
+}
+
 #define WAVE_ROW_LOOP(rows)                                                                                         \
   const int lane = threadIdx.x & 63;                                                                                \
   const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); \
@@ -198,11 +225,13 @@ template <int NC>
 __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const float* __restrict__ x, const bf16_t* __restrict__ y,
                                                          float* __restrict__ x_out, bf16_t* __restrict__ xn,
                                                          float* __restrict__ mean_o, float* __restrict__ rstd_o,
-                                                         int64_t rows, int dim, float eps) {
+                                                         int64_t rows, int dim, float eps, const int32_t* __restrict__ first_row,
+                                                         int seq_len) {
   WAVE_ROW_LOOP(rows) {
     RowRegs<NC> r, b;
-    load_row<float, NC>(x + row * dim, dim, lane, r);
-    load_row<bf16_t, NC>(y + row * dim, dim, lane, b);
+    const bool live = row_is_live(first_row, seq_len, row);
+    load_row_if<float, NC>(live, x + row * dim, dim, lane, r);
+    load_row_if<bf16_t, NC>(live, y + row * dim, dim, lane, b);
 #pragma unroll
     for (int i = 0; i < NC; ++i)
 #pragma unroll
@@ -226,13 +255,15 @@ template <int NC>
 __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const bf16_t* __restrict__ d_xn, const float* __restrict__ x_out,
                                                          const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
                                                          const float* __restrict__ d_xout, float* __restrict__ dx,
-                                                         bf16_t* __restrict__ dy, int64_t rows, int dim) {
+                                                         bf16_t* __restrict__ dy, int64_t rows, int dim,
+                                                         const int32_t* __restrict__ first_row, int seq_len) {
   WAVE_ROW_LOOP(rows) {
     RowRegs<NC> g, xv, o;
-    load_row<bf16_t, NC>(d_xn + row * dim, dim, lane, g);
-    load_row<float, NC>(x_out + row * dim, dim, lane, xv);
-    load_row<float, NC>(d_xout + row * dim, dim, lane, o);
-    const float mean = mean_i[row], rstd = rstd_i[row];
+    const bool live = row_is_live(first_row, seq_len, row);
+    load_row_if<bf16_t, NC>(live, d_xn + row * dim, dim, lane, g);
+    load_row_if<float, NC>(live, x_out + row * dim, dim, lane, xv);
+    load_row_if<float, NC>(live, d_xout + row * dim, dim, lane, o);
+    const float mean = live ? mean_i[row] : 0.f, rstd = live ? rstd_i[row] : 0.f;
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
@@ -258,15 +289,19 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const bf16_t* __restric
   }
 }
 
+#define MHR_REQUIRE_SEQ(name)                                                                                        \
+  MHR_REQUIRE(!first_row || (seq_len > 0 && rows % seq_len == 0 && rows < (1ll << 31)), name ": first_row needs rows = B * seq_len")
+
 extern "C" int mhr_add_layernorm_fwd(const float* x, const void* y_bf16, float* x_out, void* xn_bf16, float* mean, float* rstd,
-                                     int64_t rows, int dim, float eps, void* stream) {
+                                     int64_t rows, int dim, float eps, const int32_t* first_row, int seq_len, void* stream) {
+  MHR_REQUIRE_SEQ("add_layernorm_fwd");
   MHR_REQUIRE(x && y_bf16 && x_out && xn_bf16 && mean && rstd, "add_layernorm_fwd: null pointer");
   MHR_REQUIRE(dim > 0 && dim % 4 == 0 && dim <= 2048, "add_layernorm_fwd: dim=%d unsupported", dim);
   if (rows <= 0) return MHR_OK;
   const int grid = mhr_grid_for(rows, 4);
 #define L(NC)                                                                                                          \
   hipLaunchKernelGGL((add_ln_fwd_kernel<NC>), dim3(grid), dim3(256), 0, (hipStream_t)stream, x, (const bf16_t*)y_bf16, \
-                     x_out, (bf16_t*)xn_bf16, mean, rstd, rows, dim, eps)
+                     x_out, (bf16_t*)xn_bf16, mean, rstd, rows, dim, eps, first_row, seq_len)
   DISPATCH_NC(dim, L);
 #undef L
   MHR_CHECK_LAUNCH("add_layernorm_fwd");
@@ -274,14 +309,16 @@ extern "C" int mhr_add_layernorm_fwd(const float* x, const void* y_bf16, float* 
 }
 
 extern "C" int mhr_add_layernorm_bwd(const void* d_xn_bf16, const float* x_out, const float* mean, const float* rstd,
-                                     const float* d_xout, float* dx, void* dy_bf16, int64_t rows, int dim, void* stream) {
+                                     const float* d_xout, float* dx, void* dy_bf16, int64_t rows, int dim,
+                                     const int32_t* first_row, int seq_len, void* stream) {
+  MHR_REQUIRE_SEQ("add_layernorm_bwd");
   MHR_REQUIRE(d_xn_bf16 && x_out && mean && rstd && d_xout && dx && dy_bf16, "add_layernorm_bwd: null pointer");
   MHR_REQUIRE(dim > 0 && dim % 4 == 0 && dim <= 2048, "add_layernorm_bwd: dim=%d unsupported", dim);
   if (rows <= 0) return MHR_OK;
   const int grid = mhr_grid_for(rows, 4);
 #define L(NC)                                                                                                              \
   hipLaunchKernelGGL((add_ln_bwd_kernel<NC>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)d_xn_bf16, x_out, \
-                     mean, rstd, d_xout, dx, (bf16_t*)dy_bf16, rows, dim)
+                     mean, rstd, d_xout, dx, (bf16_t*)dy_bf16, rows, dim, first_row, seq_len)
   DISPATCH_NC(dim, L);
 #undef L
   MHR_CHECK_LAUNCH("add_layernorm_bwd");
@@ -296,12 +333,14 @@ __global__ __launch_bounds__(256) void ln_gate_fwd_kernel(const T* __restrict__ 
                                                           OT* __restrict__ o, float* __restrict__ mean_o,
                                                           float* __restrict__ rstd_o, int64_t rows, int dim, float eps,
                                                           float p, float keep_scale, uint64_t seed,
-                                                          const int64_t* __restrict__ step_seed) {
+                                                          const int64_t* __restrict__ step_seed,
+                                                          const int32_t* __restrict__ first_row, int seq_len) {
   seed = mhr_step_seed(seed, step_seed);
   WAVE_ROW_LOOP(rows) {
     RowRegs<NC> av, uv;
-    load_row<T, NC>(a + row * dim, dim, lane, av);
-    load_row<T, NC>(u + row * u_stride, dim, lane, uv);
+    const bool live = row_is_live(first_row, seq_len, row);
+    load_row_if<T, NC>(live, a + row * dim, dim, lane, av);
+    load_row_if<T, NC>(live, u + row * u_stride, dim, lane, uv);
     float mean, rstd;
     row_stats<NC>(av, dim, lane, eps, mean, rstd);
 #pragma unroll
@@ -331,14 +370,16 @@ __global__ __launch_bounds__(256) void ln_gate_bwd_kernel(const GT* __restrict__
                                                           const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
                                                           T* __restrict__ du, int64_t du_stride, T* __restrict__ da,
                                                           int64_t rows, int dim, float p, float keep_scale, uint64_t seed,
-                                                          const int64_t* __restrict__ step_seed) {
+                                                          const int64_t* __restrict__ step_seed,
+                                                          const int32_t* __restrict__ first_row, int seq_len) {
   seed = mhr_step_seed(seed, step_seed);
   WAVE_ROW_LOOP(rows) {
     RowRegs<NC> g, uv, av;
-    load_row<GT, NC>(d_o + row * dim, dim, lane, g);
-    load_row<T, NC>(u + row * u_stride, dim, lane, uv);
-    load_row<T, NC>(a + row * dim, dim, lane, av);
-    const float mean = mean_i[row], rstd = rstd_i[row];
+    const bool live = row_is_live(first_row, seq_len, row);
+    load_row_if<GT, NC>(live, d_o + row * dim, dim, lane, g);
+    load_row_if<T, NC>(live, u + row * u_stride, dim, lane, uv);
+    load_row_if<T, NC>(live, a + row * dim, dim, lane, av);
+    const float mean = live ? mean_i[row] : 0.f, rstd = live ? rstd_i[row] : 0.f;
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
@@ -389,7 +430,8 @@ template <int RPH>
 __global__ __launch_bounds__(256) void ln_gate_fwd_h256_kernel(const bf16_t* __restrict__ u, int64_t u_stride, const bf16_t* __restrict__ a,
                                                                bf16_t* __restrict__ o, float* __restrict__ mean_o,
                                                                float* __restrict__ rstd_o, int64_t rows, float eps, float p,
-                                                               float keep_scale, uint64_t seed, const int64_t* __restrict__ step_seed) {
+                                                               float keep_scale, uint64_t seed, const int64_t* __restrict__ step_seed,
+                                                               const int32_t* __restrict__ first_row, int seq_len) {
   constexpr int DIM = 256;
   seed = mhr_step_seed(seed, step_seed);
   const int lane = threadIdx.x & 63, hl = lane & 31, hw = lane >> 5;
@@ -399,8 +441,9 @@ __global__ __launch_bounds__(256) void ln_gate_fwd_h256_kernel(const bf16_t* __r
 #pragma unroll
   for (int j = 0; j < RPH; ++j) {
     const int64_t rr = min(row0 + j, rows - 1);
-    av[j] = *reinterpret_cast<const bf16x8*>(a + rr * DIM + hl * 8);
-    uv[j] = *reinterpret_cast<const bf16x8*>(u + rr * u_stride + hl * 8);
+    const bool live = row_is_live(first_row, seq_len, rr);
+    av[j] = load8_if(live, a + rr * DIM + hl * 8);
+    uv[j] = load8_if(live, u + rr * u_stride + hl * 8);
   }
 #pragma unroll
   for (int j = 0; j < RPH; ++j) {
@@ -441,7 +484,8 @@ __global__ __launch_bounds__(256) void ln_gate_bwd_h256_kernel(const bf16_t* __r
                                                                const bf16_t* __restrict__ a, const float* __restrict__ mean_i,
                                                                const float* __restrict__ rstd_i, bf16_t* __restrict__ du, int64_t du_stride,
                                                                bf16_t* __restrict__ da, int64_t rows, float p, float keep_scale,
-                                                               uint64_t seed, const int64_t* __restrict__ step_seed) {
+                                                               uint64_t seed, const int64_t* __restrict__ step_seed,
+                                                               const int32_t* __restrict__ first_row, int seq_len) {
   constexpr int DIM = 256;
   seed = mhr_step_seed(seed, step_seed);
   const int lane = threadIdx.x & 63, hl = lane & 31, hw = lane >> 5;
@@ -452,11 +496,12 @@ __global__ __launch_bounds__(256) void ln_gate_bwd_h256_kernel(const bf16_t* __r
 #pragma unroll
   for (int j = 0; j < RPH; ++j) {
     const int64_t rr = min(row0 + j, rows - 1);
-    gv[j] = *reinterpret_cast<const bf16x8*>(d_o + rr * DIM + hl * 8);
-    av[j] = *reinterpret_cast<const bf16x8*>(a + rr * DIM + hl * 8);
-    uv[j] = *reinterpret_cast<const bf16x8*>(u + rr * u_stride + hl * 8);
-    mean[j] = mean_i[rr];
-    rstd[j] = rstd_i[rr];
+    const bool live = row_is_live(first_row, seq_len, rr);
+    gv[j] = load8_if(live, d_o + rr * DIM + hl * 8);
+    av[j] = load8_if(live, a + rr * DIM + hl * 8);
+    uv[j] = load8_if(live, u + rr * u_stride + hl * 8);
+    mean[j] = live ? mean_i[rr] : 0.f;
+    rstd[j] = live ? rstd_i[rr] : 0.f;
   }
 #pragma unroll
   for (int j = 0; j < RPH; ++j) {
@@ -491,8 +536,9 @@ __global__ __launch_bounds__(256) void ln_gate_bwd_h256_kernel(const bf16_t* __r
 
 extern "C" int mhr_ln_gate_fwd(const void* u_base, int64_t u_stride, const void* a, int dtype, void* o, int o_dtype,
                                float* mean, float* rstd, int64_t rows, int dim, float eps, float dropout_p, uint64_t seed,
-                               const int64_t* step_seed, void* stream) {
+                               const int64_t* step_seed, const int32_t* first_row, int seq_len, void* stream) {
   MHR_REQUIRE(u_base && a && o && mean && rstd, "ln_gate_fwd: null pointer");
+  MHR_REQUIRE_SEQ("ln_gate_fwd");
   MHR_REQUIRE(dim > 0 && dim % 4 == 0 && dim <= 2048 && u_stride >= dim, "ln_gate_fwd: dim=%d / stride unsupported", dim);
   MHR_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "ln_gate_fwd: dropout_p out of range");
   if (rows <= 0) return MHR_OK;
@@ -504,22 +550,22 @@ extern "C" int mhr_ln_gate_fwd(const void* u_base, int64_t u_stride, const void*
     constexpr int RPH = 2;                               // rows per half-wave
     const int64_t waves = (rows + 2 * RPH - 1) / (2 * RPH);
     hipLaunchKernelGGL((ln_gate_fwd_h256_kernel<RPH>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, (const bf16_t*)u_base, u_stride,
-                       (const bf16_t*)a, (bf16_t*)o, mean, rstd, rows, eps, dropout_p, ks, seed, step_seed);
+                       (const bf16_t*)a, (bf16_t*)o, mean, rstd, rows, eps, dropout_p, ks, seed, step_seed, first_row, seq_len);
     MHR_CHECK_LAUNCH("ln_gate_fwd");
     return MHR_OK;
   }
 #define L(NC)                                                                                                             \
   if (tb && ob) hipLaunchKernelGGL((ln_gate_fwd_kernel<bf16_t, bf16_t, NC>), dim3(grid), dim3(256), 0, s,                 \
                                    (const bf16_t*)u_base, u_stride, (const bf16_t*)a, (bf16_t*)o, mean, rstd, rows, dim,  \
-                                   eps, dropout_p, ks, seed, step_seed);                                                            \
+                                   eps, dropout_p, ks, seed, step_seed, first_row, seq_len);                                                            \
   else if (tb) hipLaunchKernelGGL((ln_gate_fwd_kernel<bf16_t, float, NC>), dim3(grid), dim3(256), 0, s,                   \
                                   (const bf16_t*)u_base, u_stride, (const bf16_t*)a, (float*)o, mean, rstd, rows, dim,    \
-                                  eps, dropout_p, ks, seed, step_seed);                                                             \
+                                  eps, dropout_p, ks, seed, step_seed, first_row, seq_len);                                                             \
   else if (ob) hipLaunchKernelGGL((ln_gate_fwd_kernel<float, bf16_t, NC>), dim3(grid), dim3(256), 0, s,                   \
                                   (const float*)u_base, u_stride, (const float*)a, (bf16_t*)o, mean, rstd, rows, dim,     \
-                                  eps, dropout_p, ks, seed, step_seed);                                                             \
+                                  eps, dropout_p, ks, seed, step_seed, first_row, seq_len);                                                             \
   else hipLaunchKernelGGL((ln_gate_fwd_kernel<float, float, NC>), dim3(grid), dim3(256), 0, s, (const float*)u_base,      \
-                          u_stride, (const float*)a, (float*)o, mean, rstd, rows, dim, eps, dropout_p, ks, seed, step_seed)
+                          u_stride, (const float*)a, (float*)o, mean, rstd, rows, dim, eps, dropout_p, ks, seed, step_seed, first_row, seq_len)
   DISPATCH_NC(dim, L);
 #undef L
   MHR_CHECK_LAUNCH("ln_gate_fwd");
@@ -528,8 +574,10 @@ extern "C" int mhr_ln_gate_fwd(const void* u_base, int64_t u_stride, const void*
 
 extern "C" int mhr_ln_gate_bwd(const void* d_o, int do_dtype, const void* u_base, int64_t u_stride, const void* a, int dtype,
                                const float* mean, const float* rstd, void* du_base, int64_t du_stride, void* da,
-                               int64_t rows, int dim, float dropout_p, uint64_t seed, const int64_t* step_seed, void* stream) {
+                               int64_t rows, int dim, float dropout_p, uint64_t seed, const int64_t* step_seed,
+                               const int32_t* first_row, int seq_len, void* stream) {
   MHR_REQUIRE(d_o && u_base && a && mean && rstd && du_base && da, "ln_gate_bwd: null pointer");
+  MHR_REQUIRE_SEQ("ln_gate_bwd");
   MHR_REQUIRE(dim > 0 && dim % 4 == 0 && dim <= 2048 && u_stride >= dim && du_stride >= dim, "ln_gate_bwd: bad dims");
   if (rows <= 0) return MHR_OK;
   hipStream_t s = (hipStream_t)stream;
@@ -542,13 +590,13 @@ extern "C" int mhr_ln_gate_bwd(const void* d_o, int do_dtype, const void* u_base
     const int64_t waves = (rows + 2 * RPH - 1) / (2 * RPH);
     hipLaunchKernelGGL((ln_gate_bwd_h256_kernel<RPH>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, (const bf16_t*)d_o,
                        (const bf16_t*)u_base, u_stride, (const bf16_t*)a, mean, rstd, (bf16_t*)du_base, du_stride, (bf16_t*)da, rows,
-                       dropout_p, ks, seed, step_seed);
+                       dropout_p, ks, seed, step_seed, first_row, seq_len);
     MHR_CHECK_LAUNCH("ln_gate_bwd");
     return MHR_OK;
   }
 #define LK(GT, T, NC)                                                                                                  \
   hipLaunchKernelGGL((ln_gate_bwd_kernel<GT, T, NC>), dim3(grid), dim3(256), 0, s, (const GT*)d_o, (const T*)u_base,    \
-                     u_stride, (const T*)a, mean, rstd, (T*)du_base, du_stride, (T*)da, rows, dim, dropout_p, ks, seed, step_seed)
+                     u_stride, (const T*)a, mean, rstd, (T*)du_base, du_stride, (T*)da, rows, dim, dropout_p, ks, seed, step_seed, first_row, seq_len)
 #define L(NC)                          \
   if (gb && tb) LK(bf16_t, bf16_t, NC); \
   else if (gb) LK(bf16_t, float, NC);   \

@@ -257,7 +257,18 @@ def add_cast(x, y, out16=None):
     return out, out16
 
 
-def add_layernorm_fwd(x, y, eps=1e-6, xn_out=None):
+def _dead_args(dead, rows):
+    """(first_row pointer, seq_len) of a `dead=(first_row [B] int32, L)` row-liveness descriptor (attn_seq_layout): rows in front
+    of a sequence's first valid key are not loaded by the row-wise encoder kernels (they read as zeros, zeros are written)."""
+    if dead is None:
+        return 0, 0
+    first_row, L = dead
+    if first_row.dtype != torch.int32 or first_row.numel() * L != rows:
+        raise ValueError("dead rows: first_row must be int32 [B] with B * L == rows")
+    return first_row.data_ptr(), int(L)
+
+
+def add_layernorm_fwd(x, y, eps=1e-6, xn_out=None, dead=None):
     """x_out = x + y (fp32 + bf16), xn = LN(x_out) bf16.  Returns (x_out, xn, mean, rstd)."""
     _chk(x, "x", torch.float32)
     _chk(y, "y", torch.bfloat16)
@@ -268,11 +279,11 @@ def add_layernorm_fwd(x, y, eps=1e-6, xn_out=None):
     mean = torch.empty(rows, dtype=torch.float32, device=x.device)
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
     lib.call("mhr_add_layernorm_fwd", x.data_ptr(), y.data_ptr(), x_out.data_ptr(), xn.data_ptr(), mean.data_ptr(),
-             rstd.data_ptr(), rows, D, eps, _stream())
+             rstd.data_ptr(), rows, D, eps, *_dead_args(dead, rows), _stream())
     return x_out, xn, mean, rstd
 
 
-def add_layernorm_bwd(d_xn, x_out, mean, rstd, d_xout, dy_out=None):
+def add_layernorm_bwd(d_xn, x_out, mean, rstd, d_xout, dy_out=None, dead=None):
     """-> (dx f32, dy bf16), both = d_xout + LN'(d_xn)."""
     _chk(d_xn, "d_xn", torch.bfloat16)
     _chk(d_xout, "d_xout", torch.float32)
@@ -281,11 +292,11 @@ def add_layernorm_bwd(d_xn, x_out, mean, rstd, d_xout, dy_out=None):
     dx = torch.empty_like(x_out)
     dy = _out_like(dy_out, x_out.shape, torch.bfloat16, x_out.device, "add_layernorm_bwd dy_out")
     lib.call("mhr_add_layernorm_bwd", d_xn.data_ptr(), x_out.data_ptr(), mean.data_ptr(), rstd.data_ptr(), d_xout.data_ptr(),
-             dx.data_ptr(), dy.data_ptr(), rows, D, _stream())
+             dx.data_ptr(), dy.data_ptr(), rows, D, *_dead_args(dead, rows), _stream())
     return dx, dy
 
 
-def ln_gate_fwd(h, a, dim, out_dtype=None, eps=1e-6, dropout_p=0.0, seed=0, seed_dev=None, out=None):
+def ln_gate_fwd(h, a, dim, out_dtype=None, eps=1e-6, dropout_p=0.0, seed=0, seed_dev=None, out=None, dead=None):
     """o = silu(h[:, :dim]) * LN(a) * dropmask.  h [rows, stride] pre-activation, a [rows, dim].
     seed_dev (device int64[1], optional): step counter of a hipGraph-replayed step; `seed` is then the per-layer part."""
     rows = a.numel() // dim
@@ -294,16 +305,17 @@ def ln_gate_fwd(h, a, dim, out_dtype=None, eps=1e-6, dropout_p=0.0, seed=0, seed
     rstd = torch.empty(rows, dtype=torch.float32, device=a.device)
     assert h.dtype == a.dtype
     lib.call("mhr_ln_gate_fwd", h.data_ptr(), h.stride(0), a.data_ptr(), _dt(a), o.data_ptr(), _dt(o), mean.data_ptr(),
-             rstd.data_ptr(), rows, dim, eps, dropout_p, seed, _ptr(seed_dev), _stream())
+             rstd.data_ptr(), rows, dim, eps, dropout_p, seed, _ptr(seed_dev), *_dead_args(dead, rows), _stream())
     return o, mean, rstd
 
 
-def ln_gate_bwd(d_o, h, a, mean, rstd, dh, dim, dropout_p=0.0, seed=0, seed_dev=None):
+def ln_gate_bwd(d_o, h, a, mean, rstd, dh, dim, dropout_p=0.0, seed=0, seed_dev=None, dead=None):
     """writes du into dh[:, :dim]; returns da."""
     rows = a.numel() // dim
     da = torch.empty_like(a)
     lib.call("mhr_ln_gate_bwd", d_o.data_ptr(), _dt(d_o), h.data_ptr(), h.stride(0), a.data_ptr(), _dt(a), mean.data_ptr(),
-             rstd.data_ptr(), dh.data_ptr(), dh.stride(0), da.data_ptr(), rows, dim, dropout_p, seed, _ptr(seed_dev), _stream())
+             rstd.data_ptr(), dh.data_ptr(), dh.stride(0), da.data_ptr(), rows, dim, dropout_p, seed, _ptr(seed_dev),
+             *_dead_args(dead, rows), _stream())
     return da
 
 
@@ -386,24 +398,28 @@ def rows_gemm(a, w, bias=None, out=None, w_is_kn=False):
     return out
 
 
+DEAD_ROWS = os.environ.get("MHR_DEAD_ROWS", "1") != "0"          # row-wise encoder kernels do not load rows in front of a sequence's first valid key
 SEQ_LAYOUT = os.environ.get("MHR_ATTN_SEQ_LAYOUT", "1") != "0"   # skip leading all-padding blocks + longest-sequences-first launch order
 
 
 def attn_seq_layout(key_valid, B, L, order=True):
-    """(first_block [B] int32, seq_order [B] int32 | None) of a batch of masks: the 32-row block holding each sequence's first
-    valid key, and the sequences ordered by it (most live blocks first).  Computed once per batch, read by every layer's
-    attention launches (`layout=` of hstu_attn_fwd / hstu_attn_bwd)."""
+    """(first_block [B] int32, seq_order [B] int32 | None, first_row [B] int32) of a batch of masks: the 32-row block holding each
+    sequence's first valid key, the sequences ordered by it (most live blocks first), and the index of that key (L when none).
+    Computed once per batch, read by every layer's attention launches (`layout=` of hstu_attn_fwd / hstu_attn_bwd) and row-wise
+    kernels (`dead=(first_row, L)`)."""
     _chk(key_valid, "key_valid", torch.uint8)
     first = torch.empty(B, dtype=torch.int32, device=key_valid.device)
+    first_row = torch.empty(B, dtype=torch.int32, device=key_valid.device)
     order_t = torch.empty(B, dtype=torch.int32, device=key_valid.device) if order else None
-    lib.call("mhr_attn_seq_layout", key_valid.data_ptr(), B, L, first.data_ptr(), order_t.data_ptr() if order else 0, _stream())
-    return first, order_t
+    lib.call("mhr_attn_seq_layout", key_valid.data_ptr(), B, L, first.data_ptr(), order_t.data_ptr() if order else 0,
+             first_row.data_ptr(), _stream())
+    return first, order_t, first_row
 
 
 def _layout_ptrs(layout):
     if layout is None:
         return 0, 0
-    first, order = layout
+    first, order = layout[0], layout[1]
     return first.data_ptr(), (order.data_ptr() if order is not None else 0)
 
 

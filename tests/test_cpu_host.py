@@ -147,6 +147,21 @@ def test_optimizer_state_without_layout_record_is_refused_when_the_order_differs
             assert p._mhr_flat_off % 8 == 0                           # fp32 views and bf16 shadows both 16-byte aligned
 
 
+def test_dead_row_skipping_is_off_for_models_whose_switch_loss_reads_padding_positions():
+    """The prior switch's category loss runs over every position of the window, padding included (reference hstu.py:757-806):
+    such models must not let the encoder skip the rows in front of the first valid key."""
+    import REC  # noqa: F401
+    from REC.config.configurator import Config
+    from REC.utils import get_model
+    for name, want in (("hstu_prior_mult", True), ("hstu_nce_tiny", True), ("hstu_switch_inout_asym", False)):
+        g, c = _cfg(name)
+        model = get_model("HSTU")(Config(config_dict=c), FakeData(c))
+        assert model._dead_rows_allowed() is want, name
+        if not want:
+            model.switch_last_only = True
+            assert model._dead_rows_allowed() is True
+
+
 def test_unknown_head_interaction_raises():
     from REC.config.configurator import Config
     from REC.utils import get_model

@@ -357,7 +357,8 @@ def test_hstu_attention_sequence_layout_is_bitwise_neutral(ops, B, L, Hh, hd):
     if B > 4:
         valid[4, L - lens[4] + 1: L - lens[4] + 40] = False                          # a hole right after the first valid key
     kv = dev(valid.to(torch.uint8))
-    first, order = ops.attn_seq_layout(kv, B, L)
+    first, order, first_row = ops.attn_seq_layout(kv, B, L)
+    assert first_row.cpu().tolist() == [L - n for n in lens]
     nb = (L + 31) // 32
     want_first = [((L - n) // 32 if n else nb) for n in lens]
     assert first.cpu().tolist() == want_first
@@ -404,6 +405,60 @@ def test_rows_gemm_against_the_fp32_product(ops, M, N, K, bias, lda_pad, kn):
     tol = 2 ** -8 * ref.abs().clamp_min(1e-3) + 1e-6                                     # half an ulp of bf16 + accumulation slack
     assert bool(((got - ref).abs() <= 2 * tol).all()), float(((got - ref).abs() / tol).max())
     assert float(out[M].float().abs().max()) == 7.0 and float(out[M].float().abs().min()) == 7.0
+
+
+@pytest.mark.parametrize("B,L,D", [(5, 200, 256), (4, 50, 64), (3, 33, 512)])
+def test_row_wise_encoder_kernels_do_not_load_dead_rows(ops, B, L, D):
+    """`dead=(first_row, L)` on add_layernorm_fwd/bwd and ln_gate_fwd/bwd: rows in front of a sequence's first valid key (except
+    its last row) are not loaded - they read as zeros.  So the result must be, bit for bit, the plain kernel's result on inputs
+    whose dead rows were zeroed beforehand; live rows keep every bit of the plain result on the original inputs."""
+    g = torch.Generator().manual_seed(17 + L)
+    lens = [L, 0, 1, L // 2, L - 1][:B]
+    first_row = torch.tensor([L - n for n in lens], dtype=torch.int32, device="cuda")
+    dead_mask = torch.zeros(B, L, dtype=torch.bool)
+    for b, n in enumerate(lens):
+        dead_mask[b, : min(L - n, L - 1)] = True                                   # (the last row always counts as live)
+    dm = dead_mask.view(-1).cuda()
+    rows = B * L
+    dead = (first_row, L)
+
+    def z(t):                                                                      # the same tensor with its dead rows zeroed
+        t = t.clone()
+        t[dm] = 0
+        return t
+
+    x = dev(torch.randn(rows, D, generator=g))
+    y = dev(bf(torch.randn(rows, D, generator=g)))
+    got = ops.add_layernorm_fwd(x, y, 1e-6, dead=dead)
+    want = ops.add_layernorm_fwd(z(x), z(y), 1e-6)
+    plain = ops.add_layernorm_fwd(x, y, 1e-6)
+    for a_, b_, c_ in zip(got, want, plain):
+        assert torch.equal(a_, b_)
+        assert torch.equal(a_[~dm], c_[~dm])
+    assert float(got[0][dm].abs().max() if bool(dm.any()) else 0.0) == 0.0        # zeros written
+
+    x_out, _, mean, rstd = plain
+    d_xn = dev(bf(torch.randn(rows, D, generator=g)))
+    d_xout = dev(torch.randn(rows, D, generator=g))
+    got = ops.add_layernorm_bwd(d_xn, x_out, mean, rstd, d_xout, dead=dead)
+    want = ops.add_layernorm_bwd(z(d_xn), z(x_out), z(mean), z(rstd), z(d_xout))
+    for a_, b_ in zip(got, want):
+        assert torch.equal(a_, b_)
+
+    h = dev(bf(torch.randn(rows, 4 * D, generator=g)))
+    a = dev(bf(torch.randn(rows, D, generator=g)))
+    for p_drop in (0.0, 0.2):
+        o, m2, r2 = ops.ln_gate_fwd(h, a, D, torch.bfloat16, 1e-6, p_drop, 11, dead=dead)
+        ow, mw, rw = ops.ln_gate_fwd(z(h), z(a), D, torch.bfloat16, 1e-6, p_drop, 11)
+        op, mp, rp = ops.ln_gate_fwd(h, a, D, torch.bfloat16, 1e-6, p_drop, 11)
+        assert torch.equal(o, ow) and torch.equal(m2, mw) and torch.equal(r2, rw)
+        assert torch.equal(o[~dm], op[~dm]) and torch.equal(m2[~dm], mp[~dm])
+        d_o = dev(bf(torch.randn(rows, D, generator=g)))
+        dh1, dh2 = torch.zeros_like(h), torch.zeros_like(h)
+        da1 = ops.ln_gate_bwd(d_o, h, a, mp, rp, dh1, D, p_drop, 11, dead=dead)
+        da2 = ops.ln_gate_bwd(z(d_o), z(h), z(a), z(mp), z(rp), dh2, D, p_drop, 11)
+        assert torch.equal(da1, da2) and torch.equal(dh1, dh2)
+    torch.cuda.synchronize()
 
 
 def test_hstu_attention_golden(ops):

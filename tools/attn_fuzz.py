@@ -41,7 +41,7 @@ while time.time() - t0 < budget:
         ops.hstu_attn_bwd(h, None, kv, d_out, dh, B, L, Hh, hd)
         res[mode] = (out, dh)
     os.environ["MHR_ATTN_STREAM"] = "0"                     # resident form with the per-batch sequence layout: bit-identical
-    lay = ops.attn_seq_layout(kv, B, L, order=rng.random() < 0.5)
+    lay = ops.attn_seq_layout(kv, B, L, order=rng.random() < 0.5)[:2]
     out, _ = ops.hstu_attn_fwd(h, kv, B, L, Hh, hd, save_act=False, layout=lay)
     dh = torch.full_like(h, 3.0); dh[:, :D] = 0
     ops.hstu_attn_bwd(h, None, kv, d_out, dh, B, L, Hh, hd, layout=lay)

@@ -19,7 +19,7 @@ d_out = (torch.randn(B * L, D, device="cuda", generator=g) * 0.1).bfloat16()
 dh = torch.zeros_like(h)
 lay = None
 if os.environ.get("LAYOUT", "1") != "0":                                    # LAYOUT=0: plain launch; ORDER=0: dead-block skip without the reordering
-    lay = ops.attn_seq_layout(kv, B, L, order=os.environ.get("ORDER", "1") != "0")
+    lay = ops.attn_seq_layout(kv, B, L, order=os.environ.get("ORDER", "1") != "0")[:2]
 import functools
 ops.hstu_attn_fwd = functools.partial(ops.hstu_attn_fwd, layout=lay)
 ops.hstu_attn_bwd = functools.partial(ops.hstu_attn_bwd, layout=lay)
