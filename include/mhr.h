@@ -155,7 +155,8 @@ int mhr_add_cast(const float* x, const void* y_bf16, float* out, void* out_bf16,
  * first_row[b] = index of sequence b's first valid key (mhr_attn_seq_layout).  Rows in front of it - except a sequence's last
  * row, which the decode reads - take part in nothing (no valid key reads them, loss and decode skip them, every gradient that
  * reaches them is exactly zero): their operands are not loaded but read as zeros and the zeros the arithmetic produces are
- * written.  Live rows keep every bit; NULL: all rows live. */
+ * written.  Live rows keep every bit; NULL: all rows live.  (The half-wave form of mhr_ln_gate_* - dim 256, bf16 - ignores it:
+ * latency-bound one-shot waves gain nothing from skipped loads.) */
 int mhr_add_layernorm_fwd(const float* x, const void* y_bf16, float* x_out, void* xn_bf16, float* mean, float* rstd,
                           int64_t rows, int dim, float eps, const int32_t* first_row, int seq_len, void* stream);
 int mhr_add_layernorm_bwd(const void* d_xn_bf16, const float* x_out, const float* mean, const float* rstd,
