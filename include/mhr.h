@@ -245,13 +245,19 @@ int mhr_hstu_attn_fwd_seq(const void* q, const void* k, const void* v, int64_t r
                           const uint8_t* key_valid, void* out,
                           void* act_q, void* act_k, void* act_v, int64_t act_stride,
                           int B, int L, int n_heads, int head_dim, int apply_silu,
-                          const int32_t* first_block, const int32_t* seq_order, void* stream);
+                          const int32_t* first_block, const int32_t* seq_order, const int32_t* cu_rows, int n_rows_total,
+                          void* stream);
 int mhr_hstu_attn_bwd_seq(const void* q_pre, const void* k_pre, const void* v_pre, int64_t row_stride,
                           const void* act_q, const void* act_k, const void* act_v, int64_t act_stride,
                           const uint8_t* key_valid, const void* d_out,
                           void* dq, void* dk, void* dv, int64_t d_stride,
                           int B, int L, int n_heads, int head_dim, int apply_silu,
-                          const int32_t* first_block, const int32_t* seq_order, void* stream);
+                          const int32_t* first_block, const int32_t* seq_order, const int32_t* cu_rows, int n_rows_total,
+                          void* stream);
+/* cu_rows (optional, int32 [B + 1]): PACKED sequences - the rows of sequence b are cu_rows[b] .. cu_rows[b + 1] - 1 of the
+ * operands (the valid positions of the B windows back to back, no padding rows; key_valid then covers the packed rows); L stays
+ * the window length (LDS budget, the 1 / n of hstu.py:158) and n_rows_total the row count of the operands: the rows behind the last
+ * sequence are written as zeros.  Resident form only. */
 
 /* ------------------------------------------------------------------------------------------
  * LLM decoder blocks of the HLLM twin: the user decoder `user_llm(inputs_embeds=...)`

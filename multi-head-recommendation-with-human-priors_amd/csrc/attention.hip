@@ -78,19 +78,23 @@ __global__ __launch_bounds__(256) void hstu_attn_fwd_kernel(const bf16_t* __rest
                                                             const bf16_t* __restrict__ v, int64_t stride,
                                                             const uint8_t* __restrict__ key_valid, bf16_t* __restrict__ out,
                                                             int64_t out_stride, bf16_t* act_q, bf16_t* act_k, bf16_t* act_v,
-                                                            int64_t act_stride, int L, int n_heads, int hd, int apply_silu,
+                                                            int64_t act_stride, int L_max, int n_heads, int hd, int apply_silu,
                                                             float inv_n, const int32_t* __restrict__ first_block,
-                                                            const int32_t* __restrict__ seq_order) {
+                                                            const int32_t* __restrict__ seq_order,
+                                                            const int32_t* __restrict__ cu_rows, int n_rows_total) {
   using T = sg::Tile<NKS>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  int b, head;
+  decode_seq_head(n_heads, b, head, seq_order);
+  // cu_rows (optional): PACKED sequences - sequence b owns rows cu_rows[b] .. cu_rows[b + 1] - 1 (no padding rows at all);
+  // otherwise B windows of L_max rows.  The LDS budget and 1 / n stay those of L_max.
+  const int64_t row0 = cu_rows ? (int64_t)__builtin_amdgcn_readfirstlane(cu_rows[b]) : (int64_t)b * L_max;
+  const int L = cu_rows ? __builtin_amdgcn_readfirstlane(cu_rows[b + 1]) - (int)row0 : L_max;
   const int Lp = (L + 31) & ~31, nb = Lp >> 5;
   unsigned char* Kt = smem;                       // nb tiles: activated K
   unsigned char* Vt = smem + nb * T::BYTES;       // nb tiles: activated V
   uint32_t* vmask = reinterpret_cast<uint32_t*>(Vt + nb * T::BYTES);
 
-  int b, head;
-  decode_seq_head(n_heads, b, head, seq_order);
-  const int64_t row0 = (int64_t)b * L;
   const bf16_t* qp = q + row0 * stride + head * hd;
   const bf16_t* kp = k + row0 * stride + head * hd;
   const bf16_t* vp = v + row0 * stride + head * hd;
@@ -107,6 +111,10 @@ __global__ __launch_bounds__(256) void hstu_attn_fwd_kernel(const bf16_t* __rest
   stage_tiles<NKS>(Vt, vp, stride, L, Lp, hd, do_silu, av, act_stride, kb0 * 32);
   build_valid_mask(vmask, key_valid + row0, L, nb);
   zero_head_rows(out + row0 * out_stride + head * hd, out_stride, min(L, kb0 * 32), hd);
+  // packed batch: the rows behind the last sequence (up to the buffer's capacity) belong to nobody - the workgroups of the last
+  // sequence write their zeros, so that whatever multiplies them later meets finite values
+  if (cu_rows && b == (int)(gridDim.x / n_heads) - 1)
+    zero_head_rows(out + (row0 + L) * out_stride + head * hd, out_stride, n_rows_total - (int)(row0 + L), hd);
   __syncthreads();
   FSTAMP(1)
 
@@ -194,10 +202,15 @@ __global__ __launch_bounds__(256, ALL4 ? 2 : (NKS <= 2 ? ATTN_BWD_WG : 1)) void 
     const bf16_t* __restrict__ q_pre, const bf16_t* __restrict__ k_pre, const bf16_t* __restrict__ v_pre, int64_t stride,
     const bf16_t* __restrict__ act_q, const bf16_t* __restrict__ act_k, const bf16_t* __restrict__ act_v, int64_t act_stride,
     const uint8_t* __restrict__ key_valid, const bf16_t* __restrict__ d_out, int64_t do_stride, bf16_t* __restrict__ dq,
-    bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, int64_t d_stride, int L, int n_heads, int hd, int apply_silu,
-    float inv_n, const int32_t* __restrict__ first_block, const int32_t* __restrict__ seq_order) {
+    bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, int64_t d_stride, int L_max, int n_heads, int hd, int apply_silu,
+    float inv_n, const int32_t* __restrict__ first_block, const int32_t* __restrict__ seq_order,
+    const int32_t* __restrict__ cu_rows, int n_rows_total) {
   using T = sg::Tile<NKS>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  int b, head;
+  decode_seq_head(n_heads, b, head, seq_order);
+  const int64_t row0 = cu_rows ? (int64_t)__builtin_amdgcn_readfirstlane(cu_rows[b]) : (int64_t)b * L_max;   // (packed sequences: see the forward)
+  const int L = cu_rows ? __builtin_amdgcn_readfirstlane(cu_rows[b + 1]) - (int)row0 : L_max;
   const int Lp = (L + 31) & ~31, nb = Lp >> 5;
   const int img = nb * T::BYTES;
   unsigned char* Tq = smem;                                  // Q tiles
@@ -209,9 +222,6 @@ __global__ __launch_bounds__(256, ALL4 ? 2 : (NKS <= 2 ? ATTN_BWD_WG : 1)) void 
   // gradient tiles leave through a wave-private scratch (store_grad_tile), behind the validity words (16-byte aligned)
   float* gscratch = reinterpret_cast<float*>(tail + ((nb * 4 + 15) & ~15)) + (threadIdx.x >> 6) * (32 * GS);
 
-  int b, head;
-  decode_seq_head(n_heads, b, head, seq_order);
-  const int64_t row0 = (int64_t)b * L;
   const int hoff = head * hd;
   // without saved activations (act_q == nullptr) silu(q), silu(k), silu(v) are recomputed from the pre-activation values
   // while they are staged / loaded: 39 MB less to write in the forward and to read here per layer at cfg1
@@ -241,6 +251,12 @@ __global__ __launch_bounds__(256, ALL4 ? 2 : (NKS <= 2 ? ATTN_BWD_WG : 1)) void 
     zero_head_rows(dq_h, d_stride, n_dead, hd);
     zero_head_rows(dk_h, d_stride, n_dead, hd);
     zero_head_rows(dv_h, d_stride, n_dead, hd);
+    if (cu_rows && b == (int)(gridDim.x / n_heads) - 1) {      // packed batch: the rows behind the last sequence (see the forward)
+      const int n_tail = n_rows_total - (int)(row0 + L);
+      zero_head_rows(dq_h + (int64_t)L * d_stride, d_stride, n_tail, hd);
+      zero_head_rows(dk_h + (int64_t)L * d_stride, d_stride, n_tail, hd);
+      zero_head_rows(dv_h + (int64_t)L * d_stride, d_stride, n_tail, hd);
+    }
   }
   __syncthreads();
   ASTAMP(1)
@@ -499,7 +515,7 @@ extern "C" int mhr_attn_seq_layout(const uint8_t* key_valid, int B, int L, int32
 extern "C" int mhr_hstu_attn_fwd_seq(const void* q, const void* k, const void* v, int64_t row_stride, const uint8_t* key_valid,
                                      void* out, void* act_q, void* act_k, void* act_v, int64_t act_stride, int B, int L,
                                      int n_heads, int head_dim, int apply_silu, const int32_t* first_block,
-                                     const int32_t* seq_order, void* stream) {
+                                     const int32_t* seq_order, const int32_t* cu_rows, int n_rows_total, void* stream) {
   MHR_REQUIRE(q && k && v && key_valid && out, "hstu_attn_fwd: null pointer");
   AttnShape sh;
   MHR_REQUIRE(attn_shape(head_dim, sh), "hstu_attn_fwd: head_dim=%d unsupported (multiple of 8, <= 128)", head_dim);
@@ -514,6 +530,7 @@ extern "C" int mhr_hstu_attn_fwd_seq(const void* q, const void* k, const void* v
   const int64_t out_stride = (int64_t)n_heads * head_dim;
   hipStream_t s = (hipStream_t)stream;
   if (attn_use_stream(lds, ATTN_STREAM_ABOVE_FWD)) {
+    MHR_REQUIRE(!cu_rows, "hstu_attn_fwd: packed sequences (cu_rows) need the resident form (L=%d too long)", L);
     mhr_attn_stream_fwd(q, k, v, row_stride, key_valid, out, act_q, act_k, act_v, act_stride, B, L, n_heads, head_dim, apply_silu, s);
     MHR_CHECK_LAUNCH("hstu_attn_fwd(streamed)");
     return MHR_OK;
@@ -524,7 +541,7 @@ extern "C" int mhr_hstu_attn_fwd_seq(const void* q, const void* k, const void* v
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     hipLaunchKernelGGL(kern, dim3(B * n_heads), dim3(256), lds, s, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, \
                        row_stride, key_valid, (bf16_t*)out, out_stride, (bf16_t*)act_q, (bf16_t*)act_k, (bf16_t*)act_v, \
-                       act_stride, L, n_heads, head_dim, apply_silu, inv_n, first_block, seq_order);                   \
+                       act_stride, L, n_heads, head_dim, apply_silu, inv_n, first_block, seq_order, cu_rows, n_rows_total); \
   }
   ATTN_DISPATCH(sh, L_);
 #undef L_
@@ -536,14 +553,15 @@ extern "C" int mhr_hstu_attn_fwd(const void* q, const void* k, const void* v, in
                                  void* out, void* act_q, void* act_k, void* act_v, int64_t act_stride, int B, int L,
                                  int n_heads, int head_dim, int apply_silu, void* stream) {
   return mhr_hstu_attn_fwd_seq(q, k, v, row_stride, key_valid, out, act_q, act_k, act_v, act_stride, B, L, n_heads, head_dim,
-                               apply_silu, nullptr, nullptr, stream);
+                               apply_silu, nullptr, nullptr, nullptr, 0, stream);
 }
 
 extern "C" int mhr_hstu_attn_bwd_seq(const void* q_pre, const void* k_pre, const void* v_pre, int64_t row_stride,
                                      const void* act_q, const void* act_k, const void* act_v, int64_t act_stride,
                                      const uint8_t* key_valid, const void* d_out, void* dq, void* dk, void* dv,
                                      int64_t d_stride, int B, int L, int n_heads, int head_dim, int apply_silu,
-                                     const int32_t* first_block, const int32_t* seq_order, void* stream) {
+                                     const int32_t* first_block, const int32_t* seq_order, const int32_t* cu_rows, int n_rows_total,
+                                     void* stream) {
   MHR_REQUIRE(key_valid && d_out && dq && dk && dv, "hstu_attn_bwd: null pointer");
   MHR_REQUIRE((act_q != nullptr) == (act_k != nullptr) && (act_k != nullptr) == (act_v != nullptr),
               "hstu_attn_bwd: act_q/act_k/act_v must be all set or all null");
@@ -565,6 +583,7 @@ extern "C" int mhr_hstu_attn_bwd_seq(const void* q_pre, const void* k_pre, const
   const int64_t do_stride = (int64_t)n_heads * head_dim;
   hipStream_t s = (hipStream_t)stream;
   if (attn_use_stream(lds, all4 ? 160 * 1024 : 0)) {       // streamed whenever the four-image form does not apply
+    MHR_REQUIRE(!cu_rows, "hstu_attn_bwd: packed sequences (cu_rows) need the resident form (L=%d too long)", L);
     mhr_attn_stream_bwd(q_pre, k_pre, v_pre, row_stride, act_q, act_k, act_v, act_stride, key_valid, d_out, dq, dk, dv, d_stride, B, L,
                         n_heads, head_dim, apply_silu, s);
     MHR_CHECK_LAUNCH("hstu_attn_bwd(streamed)");
@@ -577,7 +596,7 @@ extern "C" int mhr_hstu_attn_bwd_seq(const void* q_pre, const void* k_pre, const
     hipLaunchKernelGGL(kern, dim3(B * n_heads), dim3(256), lds, s, (const bf16_t*)q_pre, (const bf16_t*)k_pre,          \
                        (const bf16_t*)v_pre, row_stride, (const bf16_t*)act_q, (const bf16_t*)act_k, (const bf16_t*)act_v, \
                        act_stride, key_valid, (const bf16_t*)d_out, do_stride, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv,   \
-                       d_stride, L, n_heads, head_dim, apply_silu, inv_n, first_block, seq_order);                     \
+                       d_stride, L, n_heads, head_dim, apply_silu, inv_n, first_block, seq_order, cu_rows, n_rows_total); \
   }
 #define L_(NKS, ND)                \
   if (all4) L__(NKS, ND, true)     \
@@ -594,7 +613,7 @@ extern "C" int mhr_hstu_attn_bwd(const void* q_pre, const void* k_pre, const voi
                                  const uint8_t* key_valid, const void* d_out, void* dq, void* dk, void* dv, int64_t d_stride,
                                  int B, int L, int n_heads, int head_dim, int apply_silu, void* stream) {
   return mhr_hstu_attn_bwd_seq(q_pre, k_pre, v_pre, row_stride, act_q, act_k, act_v, act_stride, key_valid, d_out, dq, dk, dv,
-                               d_stride, B, L, n_heads, head_dim, apply_silu, nullptr, nullptr, stream);
+                               d_stride, B, L, n_heads, head_dim, apply_silu, nullptr, nullptr, nullptr, 0, stream);
 }
 
 #ifdef MHR_STAMP

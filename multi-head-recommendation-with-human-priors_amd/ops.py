@@ -417,10 +417,12 @@ def attn_seq_layout(key_valid, B, L, order=True):
 
 
 def _layout_ptrs(layout):
+    """(first_block, seq_order, cu_rows) pointers of a layout tuple (first_block | None, seq_order | None, first_row, cu_rows)."""
     if layout is None:
-        return 0, 0
+        return 0, 0, 0
     first, order = layout[0], layout[1]
-    return first.data_ptr(), (order.data_ptr() if order is not None else 0)
+    cu = layout[3] if len(layout) > 3 else None
+    return (first.data_ptr() if first is not None else 0), (order.data_ptr() if order is not None else 0), (cu.data_ptr() if cu is not None else 0)
 
 
 def hstu_attn_fwd(h, key_valid, B, L, n_heads, head_dim, apply_silu=True, save_act=True, layout=None):
@@ -432,13 +434,14 @@ def hstu_attn_fwd(h, key_valid, B, L, n_heads, head_dim, apply_silu=True, save_a
     esz = 2
     base = h.data_ptr()
     v_ptr, q_ptr, k_ptr = base + D * esz, base + 2 * D * esz, base + 3 * D * esz
-    out = torch.empty(B * L, D, dtype=torch.bfloat16, device=h.device)
-    act = torch.empty(B * L, 3 * D, dtype=torch.bfloat16, device=h.device) if save_act else None
+    R = h.shape[0]                               # B * L windows, or the capacity of a packed batch (layout[3] = cu_rows)
+    out = torch.empty(R, D, dtype=torch.bfloat16, device=h.device)
+    act = torch.empty(R, 3 * D, dtype=torch.bfloat16, device=h.device) if save_act else None
     aq = act.data_ptr() if save_act else 0
-    fb, so = _layout_ptrs(layout)
+    fb, so, cu = _layout_ptrs(layout)
     _timed_call("mhr_hstu_attn_fwd_seq", q_ptr, k_ptr, v_ptr, stride, key_valid.data_ptr(), out.data_ptr(),
              aq, aq + D * esz if save_act else 0, aq + 2 * D * esz if save_act else 0, 3 * D,
-             B, L, n_heads, head_dim, 1 if apply_silu else 0, fb, so, _stream())
+             B, L, n_heads, head_dim, 1 if apply_silu else 0, fb, so, cu, R if cu else 0, _stream())
     return out, act
 
 
@@ -449,12 +452,12 @@ def hstu_attn_bwd(h, act, key_valid, d_out, dh, B, L, n_heads, head_dim, apply_s
     esz = 2
     base, dbase = h.data_ptr(), dh.data_ptr()
     abase = act.data_ptr() if act is not None else 0
-    fb, so = _layout_ptrs(layout)
+    fb, so, cu = _layout_ptrs(layout)
     _timed_call("mhr_hstu_attn_bwd_seq", base + 2 * D * esz, base + 3 * D * esz, base + D * esz, h.stride(0),
              abase, abase + D * esz if act is not None else 0, abase + 2 * D * esz if act is not None else 0,
              act.stride(0) if act is not None else 0, key_valid.data_ptr(), d_out.data_ptr(),
              dbase + 2 * D * esz, dbase + 3 * D * esz, dbase + D * esz, dh.stride(0),
-             B, L, n_heads, head_dim, 1 if apply_silu else 0, fb, so, _stream())
+             B, L, n_heads, head_dim, 1 if apply_silu else 0, fb, so, cu, h.shape[0] if cu else 0, _stream())
     return dh
 
 

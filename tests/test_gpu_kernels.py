@@ -470,6 +470,50 @@ def test_row_wise_encoder_kernels_do_not_load_dead_rows(ops, B, L, D):
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("B,L,Hh,hd", [(5, 200, 8, 32), (4, 70, 2, 64), (3, 33, 2, 16)])
+def test_hstu_attention_packed_sequences(ops, B, L, Hh, hd):
+    """`cu_rows`: the valid positions of the windows back to back in one row buffer (no padding rows).  The packed launch
+    must give, for every valid position, what the window launch gives (same products, another 32-row blocking: bf16 rounding
+    apart), and write zeros into the rows behind the last sequence."""
+    D = Hh * hd
+    g = torch.Generator().manual_seed(7 + L)
+    lens = [L, 0, 1, L // 2, L - 1][:B]
+    valid = torch.zeros(B, L, dtype=torch.bool)
+    for b, n in enumerate(lens):
+        valid[b, L - n:] = True
+    h = bf(torch.randn(B * L, 4 * D, generator=g))
+    d_out = bf(torch.randn(B * L, D, generator=g) * 0.5)
+    kv = dev(valid.to(torch.uint8))
+    out_w, _ = ops.hstu_attn_fwd(dev(h), kv, B, L, Hh, hd, save_act=False)
+    dh_w = torch.zeros(B * L, 4 * D, dtype=torch.bfloat16, device="cuda")
+    ops.hstu_attn_bwd(dev(h), None, kv, dev(d_out), dh_w, B, L, Hh, hd)
+    # packed operands
+    sel = valid.view(-1)
+    n_live = int(sel.sum())
+    cap = n_live + 37                                                                 # some rows behind the last sequence
+    hp = torch.zeros(cap, 4 * D, dtype=torch.bfloat16)
+    hp[:n_live] = h[sel]
+    dop = torch.zeros(cap, D, dtype=torch.bfloat16)
+    dop[:n_live] = d_out[sel]
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device="cuda")
+    ones = torch.ones(cap, dtype=torch.uint8, device="cuda")
+    order = torch.tensor(sorted(range(B), key=lambda b: -lens[b]), dtype=torch.int32, device="cuda")
+    for lay in ((None, None, None, cu), (None, order, None, cu)):
+        hp_d = dev(hp)
+        out_p, _ = ops.hstu_attn_fwd(hp_d, ones, B, L, Hh, hd, save_act=False, layout=lay)
+        dh_p = torch.full((cap, 4 * D), 5.0, dtype=torch.bfloat16, device="cuda")
+        dh_p[:, :D] = 0
+        ops.hstu_attn_bwd(hp_d, None, ones, dev(dop), dh_p, B, L, Hh, hd, layout=lay)
+        torch.cuda.synchronize()
+        assert out_p.shape[0] == cap
+        ref, got = out_w.float().cpu()[sel], out_p.float().cpu()[:n_live]
+        assert float((got - ref).abs().max()) <= 2 ** -7 * float(ref.abs().max()) + 1e-6
+        assert float(out_p[n_live:].float().abs().max()) == 0.0                          # tail rows: zeros written
+        gr, gg = dh_w.float().cpu()[sel][:, D:], dh_p.float().cpu()[:n_live, D:]
+        assert float((gg - gr).abs().max()) <= 2e-2 * float(gr.abs().max()) + 1e-6
+        assert float(dh_p[n_live:, D:].float().abs().max()) == 0.0
+
+
 def test_hstu_attention_golden(ops):
     """The reference's own attention outputs (tests/golden/attention_unit.npz), bf16 tolerance."""
     from conftest import load_golden
