@@ -55,6 +55,8 @@ def parse(argv=None):
     ap.add_argument("--no-host-probe", action="store_true", help="skip the 5 untimed steps that measure the host's issue time")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the evented pass (per-kernel HIP events)")
     ap.add_argument("--no-graph", action="store_true", help="issue every launch from the host (no hipGraph replay of the step)")
+    ap.add_argument("--no-pack", action="store_true",
+                    help="train batches without the loader's row-capacity hint: the encoder runs over all B x L window rows")
     ap.add_argument("--event-steps", type=int, default=10, help="steps of the evented pass (outside the timed region)")
     ap.add_argument("--pretrain-steps", type=int, default=0, help="eval mode: take this many train steps first (diagnostic)")
     ap.add_argument("--emulate-world", type=int, default=0,
@@ -424,6 +426,11 @@ def main():
     cfg = apply_run_fixups(Config(config_dict=cfgd))
     N = spec["item_num"]
     data = synth.SyntheticData(cfg, N, dev, seed=2020, rank=rank, world=world)
+    # the loader's host-side count of a batch's valid positions, as a bucketed static capacity on the mask (synth.rows_capacity):
+    # with it the encoder runs over the valid rows only (packed rows, csrc/rows_pack.hip); batches are generated outside the
+    # timed region, as a CPU collate would produce the count for free
+    # (one rank only: data-parallel steps keep the window rows, and a hint would only split their step into per-capacity graphs)
+    data.rows_hint = not args.no_pack and world == 1 and os.environ.get("MHR_FORCE_DP", "0") != "1"
     cfg["int_to_category"] = data.int_to_category
     torch.manual_seed(2020)
     model = get_model("HSTU")(cfg, data).to(dev)
@@ -471,6 +478,15 @@ def main():
                 trainer.eval_collector.eval_batch_collect(fused, pu, pi)
                 return None
         ops.PROFILE = None
+        if mode == "train" and not args.no_graph:
+            # one captured step graph per batch signature (shapes + the packed encoder's row capacity): every signature gets its
+            # three host-issued steps and its capture here, in front of the W warm-up steps - the timed region then only replays
+            seen_caps = {}
+            for bi, bt in enumerate(batches):
+                seen_caps.setdefault(getattr(bt[2], "_mhr_rows_cap", None), bi)
+            for bi in seen_caps.values():
+                for _ in range(4):
+                    step(bi)
         for i in range(warmup):
             step(i)
         sync()
@@ -667,9 +683,15 @@ def main():
                                    f"B={B}/GPU, loss={cfg['loss']}, bf16-mixed, fused AdamW over all parameters"
                                    + (" (item table: lazy replay of gradient-free steps, flushed inside the timed region)"
                                       if getattr(trainer.optimizer, "lazy", False) and args.mode == "train" else "")
-                                   + ("; step replayed from a hipGraph" if graph_on and args.mode == "train" else ""),
+                                   + ("; step replayed from a hipGraph" if graph_on and args.mode == "train" else "")
+                                   + ("; encoder on packed rows (the loader's row capacity, one step graph per capacity)"
+                                      if getattr(data, "rows_hint", False) and args.mode == "train" else ""),
                        "global_batch": world * B, "seq_len": L, "parallelism": f"dp{world}"},
         }
+        if getattr(data, "rows_hint", False) and args.mode == "train":
+            caps = sorted({int(getattr(bt[2], "_mhr_rows_cap", 0) or 0) for bt in main_leg["batches"]})
+            out["packed_rows"] = {"window_rows_per_batch": B * L, "capacities": caps,
+                                  "mean_valid_rows": round(float(sum(float(bt[2][:, :L].sum()) for bt in main_leg["batches"])) / max(1, len(main_leg["batches"])), 1)}
         assert out["n_gpus"] == args.gpus
         out["graph_active"] = graph_on if args.mode == "train" else any(
             g_.graph is not None for g_ in trainer.__dict__.get("_eval_graphs", {}).values())

@@ -259,6 +259,18 @@ int mhr_hstu_attn_bwd_seq(const void* q_pre, const void* k_pre, const void* v_pr
  * the window length (LDS budget, the 1 / n of hstu.py:158) and n_rows_total the row count of the operands: the rows behind the last
  * sequence are written as zeros.  Resident form only. */
 
+/* Packed token rows (csrc/rows_pack.hip): the valid positions of the B windows back to back in a [capacity, dim] buffer, so
+ * that the encoder's layers (hstu.py:221-328) run over the valid rows only - the loaders' front padding (trainset.py:111-137,
+ * evalset.py:34-41) is 37 % of the rows of the synthetic cfg1 batch.  mhr_seq_pack_maps numbers the valid positions sequence by
+ * sequence in window order: cu_rows [B + 1] (sequence b owns packed rows cu_rows[b] .. cu_rows[b + 1] - 1), src_of [capacity]
+ * (window row b L + l of a packed row, -1 behind the last sequence), row_of [B L] (packed row of a window position, -1 for
+ * padding).  capacity is the caller's static bound (a bucketed count known to the loader); positions past it are dropped and
+ * overflow[0] (optional) receives the real count, 0 otherwise.  mhr_rows_gather_masked: out[r] = idx[r] >= 0 ? src[idx[r]] : 0
+ * (f32 or bf16 rows) - pack, unpack and both their backward passes (the map is injective). */
+int mhr_seq_pack_maps(const uint8_t* key_valid, int B, int L, int capacity, int32_t* cu_rows, int32_t* src_of, int32_t* row_of,
+                      int32_t* overflow, void* stream);
+int mhr_rows_gather_masked(const void* src, int dtype, const int32_t* idx, void* out, int64_t n_out, int dim, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * LLM decoder blocks of the HLLM twin: the user decoder `user_llm(inputs_embeds=...)`
  * (model/HLLM/hllm.py:501-502, 781-783) and the item tower (hllm.py:399-464) are Llama-style stacks

@@ -216,8 +216,36 @@ class HSTU(MultiHeadDecoding, BaseModel):
         if ops.SEQ_LAYOUT and n and getattr(key_valid, "_mhr_layout", None) is None:
             key_valid._mhr_layout = ops.attn_seq_layout(key_valid, B, L)     # front padding: the layers skip the dead blocks
         lay = getattr(key_valid, "_mhr_layout", None)
+        key_valid._mhr_dead_ok = self._dead_rows_allowed()
         # rows in front of a sequence's first valid key: the layers' row-wise kernels do not load them (zeros in, zeros out)
         dead = (lay[2], L) if (ops.DEAD_ROWS and lay is not None and len(lay) > 2 and self._dead_rows_allowed()) else None
+        # PACKED rows: the batch carries a static capacity for its valid positions (`_mhr_rows_cap` on the mask: a bucketed count
+        # the loader knows on the host) - the layers then run over the valid rows only, back to back in a [capacity, D] buffer
+        # (csrc/rows_pack.hip), the attention addresses the sequences through cu_rows.  Same condition as the dead rows: nothing
+        # may read the hidden states of padding positions.
+        cap = getattr(key_valid, "_mhr_rows_cap", None)
+        pack = None
+        if (cap is not None and ops.PACK_ROWS and n and lay is not None and self._dead_rows_allowed() and 0 < int(cap) < B * L
+                and D % 8 == 0 and self._packable(L) and not self._dp_active()):
+            from REC.model.hstu_functional import MoveRowsFn
+            cap = int(cap)
+            cu, src_of, row_of, overflow = ops.seq_pack_maps(key_valid, B, L, cap)
+            # a capacity below the batch's valid positions would silently drop rows: the first host-issued steps at a capacity
+            # read the count back (a captured step cannot, and later steps trust the loader)
+            seen = self.__dict__.setdefault("_pack_checked", {})
+            if not torch.cuda.is_current_stream_capturing() and seen.get(cap, 0) < 4:
+                seen[cap] = seen.get(cap, 0) + 1
+                if int(overflow.item()) != 0:
+                    raise RuntimeError(f"packed encoder rows: the batch has {int(overflow.item())} valid positions, "
+                                       f"its capacity hint (_mhr_rows_cap) says {cap}")
+            pack = (src_of, row_of)
+            x2 = MoveRowsFn.apply(x2, src_of, row_of)                      # [cap, D]
+            kv_w = key_valid
+            key_valid = self._ones_u8(cap, x.device)
+            key_valid._mhr_layout = (None, lay[1], None, cu)                # sequences longest first, addressed through cu_rows
+            key_valid._mhr_dead_ok = False
+            dead = None
+        R = x2.shape[0]
         # training with the fused optimizer in its one-backward-per-step mode: the layers' weight-gradient products are formed
         # for all layers at once at the step (WeightGradStack); the kernels below write their operands straight into its slices
         stack = None
@@ -227,7 +255,7 @@ class HSTU(MultiHeadDecoding, BaseModel):
                 and all(getattr(q, "_mhr_direct_grad", False) and q.grad is not None and getattr(q, "_mhr_opt", None) is opt
                         for ly in layers for q in (ly._uvqk, ly._o.weight))
                 and all(tuple(ly._uvqk.shape) == (D, 4 * D) and tuple(ly._o.weight.shape) == (D, D) for ly in layers)):
-            stack = WeightGradStack(opt, [ly._uvqk for ly in layers], [ly._o.weight for ly in layers], B * L, D, x.device)
+            stack = WeightGradStack(opt, [ly._uvqk for ly in layers], [ly._o.weight for ly in layers], R, D, x.device)
         sl = (lambda buf, i: buf[i]) if stack is not None else (lambda buf, i: None)
         if n > 1 and x2.requires_grad and x2.is_contiguous():
             x2, xn = LayerNormResidualFn.apply(x2, layers[0]._eps, True, sl(stack and stack.xn, 0))
@@ -253,10 +281,34 @@ class HSTU(MultiHeadDecoding, BaseModel):
                 x2, xn = AddLayerNormFn.apply(x2, y, layers[i + 1]._eps, sl(stack and stack.xn, i + 1), sl(stack and stack.dy, i), dead)
             elif want_bf16 and y.dtype == torch.bfloat16 and x2.numel() % 8 == 0:
                 x2, x16 = AddCastFn.apply(x2, y, sl(stack and stack.dy, i))
+                if pack is not None:                        # back to the windows: padding positions read as zeros
+                    x2, x16 = MoveRowsFn.apply(x2, pack[1], pack[0]), MoveRowsFn.apply(x16, pack[1], pack[0])
                 return x2.view(B, L, D), x16.view(B, L, D)
             else:
                 x2 = torch.add(x2, y)           # fp32 + bf16 -> fp32 in one kernel
+        if pack is not None:
+            x2 = MoveRowsFn.apply(x2, pack[1], pack[0])
         return (x2.view(B, L, D), None) if want_bf16 else x2.view(B, L, D)
+
+    @staticmethod
+    def _dp_active():
+        """(data-parallel steps keep the window rows: every rank would capture per-capacity graphs of its own around the shared
+        collectives - never exercised)"""
+        from mhr_amd import distributed as dist_
+        return dist_.active()
+
+    def _packable(self, L):
+        """Packed rows need the attention's resident form (sequence offsets are not wired into the streamed one)."""
+        hd = self._dqk
+        nks = (hd + 15) // 16
+        nb = (L + 31) // 32
+        return 2 * nb * 32 * nks * 32 + nb * 4 + 16 <= 64 * 1024 and 4 * nb * 32 * nks * 32 + nb * 4 + 16 + 4 * 32 * 36 * 4 <= 80 * 1024 and nks <= 4
+
+    def _ones_u8(self, n, device):
+        buf = getattr(self, "_ones_buf", None)
+        if buf is None or buf.numel() < n or buf.device != device:
+            buf = self._ones_buf = torch.ones(max(n, 1), dtype=torch.uint8, device=device)
+        return buf[:n]
 
     # ------------------------------------------------------------------------------------------
     # training
@@ -311,6 +363,8 @@ class HSTU(MultiHeadDecoding, BaseModel):
         negs_pools = negs_pools.view(len(pools), n_pool, D)
 
         key_valid = mask[:, :L].to(torch.uint8).contiguous()
+        if getattr(user_mask, "_mhr_rows_cap", None) is not None:  # the loader's static bound on the batch's valid positions (packed rows)
+            key_valid._mhr_rows_cap = user_mask._mhr_rows_cap
         # everything of the loss that waits for nothing the encoder makes (token lists, row maps, the false-negative bit table of
         # the target rows, the accumulators of the loss backward, the id sort of the embedding backward) runs UNDERNEATH the
         # encoder on a second stream: some fifty few-microsecond launches and one 0.2 ms MFMA kernel on 104 workgroups that

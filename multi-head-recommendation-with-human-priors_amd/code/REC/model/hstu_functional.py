@@ -333,6 +333,20 @@ class FusedParamLinearFn(Function):
         return dx, None, None, None
 
 
+class MoveRowsFn(Function):
+    """Rows between the window layout [B L, D] and the packed layout [capacity, D] (ops.seq_pack_maps): y[r] = x[fwd_idx[r]]
+    (zeros where fwd_idx[r] < 0).  The map is injective, so the backward is the same gather through the inverse map."""
+
+    @staticmethod
+    def forward(ctx, x, fwd_idx, bwd_idx):
+        ctx.bwd_idx = bwd_idx
+        return ops.rows_gather_masked(x.contiguous(), fwd_idx)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.rows_gather_masked(dy.contiguous(), ctx.bwd_idx), None, None
+
+
 class HSTUCoreFn(Function):
     """h = LN(x) @ W_uvqk (pre-activation, [B*L, 4D] bf16)  ->  o = silu(u) * LN(attn(silu(q), silu(k), silu(v))) * drop.
 
@@ -347,7 +361,8 @@ class HSTUCoreFn(Function):
         # the activated q / k / v are NOT saved: the backward recomputes silu() while it stages them (h is kept anyway)
         layout = getattr(key_valid, "_mhr_layout", None)         # (HSTU._encode: once per batch, shared by the layers)
         a, _ = ops.hstu_attn_fwd(h, key_valid, B, L, n_heads, head_dim, apply_silu=True, save_act=False, layout=layout)
-        dead = (layout[2], L) if (ops.DEAD_ROWS and layout is not None and len(layout) > 2) else None
+        dead = (layout[2], L) if (ops.DEAD_ROWS and layout is not None and len(layout) > 2 and layout[2] is not None
+                                  and getattr(key_valid, "_mhr_dead_ok", True)) else None
         o, mean, rstd = ops.ln_gate_fwd(h, a, D, torch.bfloat16, eps, dropout_p, seed, seed_dev, out=o_out, dead=dead)
         ctx.dh_out = dh_out                      # (the caller's buffer for the gradient of h: WeightGradStack)
         ctx.save_for_backward(h, key_valid, a, mean, rstd)

@@ -398,6 +398,31 @@ def rows_gemm(a, w, bias=None, out=None, w_is_kn=False):
     return out
 
 
+def seq_pack_maps(key_valid, B, L, capacity):
+    """(cu_rows [B+1], src_of [capacity], row_of [B*L], overflow [1]) int32 of a batch of masks (mhr_seq_pack_maps)."""
+    _chk(key_valid, "key_valid", torch.uint8)
+    dev = key_valid.device
+    cu = torch.empty(B + 1, dtype=torch.int32, device=dev)
+    src_of = torch.empty(capacity, dtype=torch.int32, device=dev)
+    row_of = torch.empty(B * L, dtype=torch.int32, device=dev)
+    overflow = torch.empty(1, dtype=torch.int32, device=dev)
+    lib.call("mhr_seq_pack_maps", key_valid.data_ptr(), B, L, int(capacity), cu.data_ptr(), src_of.data_ptr(), row_of.data_ptr(),
+             overflow.data_ptr(), _stream())
+    return cu, src_of, row_of, overflow
+
+
+def rows_gather_masked(src, idx, out=None):
+    """out[r] = src[idx[r]] where idx[r] >= 0, zeros elsewhere (rows of f32 or bf16; idx int32)."""
+    _chk(src, "src")
+    _chk(idx, "idx", torch.int32)
+    n, dim = idx.numel(), src.shape[-1]
+    if out is None:
+        out = torch.empty(n, dim, dtype=src.dtype, device=src.device)
+    lib.call("mhr_rows_gather_masked", src.data_ptr(), _dt(src), idx.data_ptr(), out.data_ptr(), n, dim, _stream())
+    return out
+
+
+PACK_ROWS = os.environ.get("MHR_PACK_ROWS", "1") != "0"          # encoder over the valid rows only when the batch carries a row capacity
 DEAD_ROWS = os.environ.get("MHR_DEAD_ROWS", "1") != "0"          # row-wise encoder kernels do not load rows in front of a sequence's first valid key
 SEQ_LAYOUT = os.environ.get("MHR_ATTN_SEQ_LAYOUT", "1") != "0"   # skip leading all-padding blocks + longest-sequences-first launch order
 

@@ -10,6 +10,7 @@ real ids with mask 0 (`pad_random_sample`); each item joins each category w.p. 0
 negatives uniform from the category pool / the global pool; n_neg = ceil(num_negatives / world / B).
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -81,6 +82,10 @@ class SyntheticData:
             tags = self.item_tags[items].long()
         else:
             tags = torch.zeros(B, 0, dtype=torch.long, device=dev)
+        if getattr(self, "rows_hint", False):
+            # what a host-side loader knows when it builds the batch (the reference's collate runs on the CPU: trainset.py:111-137):
+            # how many valid positions the windows hold - as a static capacity, rounded up to ROWS_BUCKET, for the packed encoder
+            mask._mhr_rows_cap = rows_capacity(int(ctx_len.sum()), n_rows=B * L)
         return items, neg, mask, tags
 
     def eval_batch(self, B, hist_extra=40):
@@ -103,6 +108,20 @@ class SyntheticData:
         users = torch.arange(B, device=dev)
         outlier = torch.zeros(B, dtype=torch.bool, device=dev)
         return users, item_seq, target, (hu, hi), positive_u, [], target_tags, outlier
+
+
+def rows_capacity(n_valid, n_rows=None, bucket=None):
+    """Static row capacity for a batch with n_valid valid window positions out of n_rows: the next multiple of `bucket`.  Every
+    capacity is its own captured step graph and alternating between graphs costs (measured at cfg1: five capacities of 1024 rows
+    lose to two of 2048 although they fit tighter), so the default bucket is coarse: the power of two nearest below n_rows / 12
+    (2048 at cfg1's 25 600 rows; MHR_ROWS_BUCKET overrides)."""
+    if bucket is None:
+        env = os.environ.get("MHR_ROWS_BUCKET")
+        if env:
+            bucket = int(env)
+        else:
+            bucket = max(256, 1 << max(0, int(math.log2(max(1, (n_rows or 12 * 1024) / 12.0)))))
+    return max(bucket, -(-int(n_valid) // bucket) * bucket)
 
 
 def base_config(**kw):

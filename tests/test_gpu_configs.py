@@ -222,6 +222,31 @@ def test_cfg1_assembled_train_step_through_the_hand_written_uvqk_projection(rec,
     assert len(calls) >= cfg["n_layers"] and all(tuple(c) == (4 * 200, 256) for c in calls), calls
 
 
+def test_cfg1_assembled_train_step_on_packed_rows(rec, monkeypatch):
+    """The same comparison with the encoder on PACKED rows: the mask carries the loader's row capacity (`_mhr_rows_cap`), the
+    layers run over the valid positions only (csrc/rows_pack.hip, attention through cu_rows) and the result is scattered back
+    to the windows.  Against the mixed oracle with the window path's tolerances; a count proves the packed path ran, and a
+    capacity below the batch's valid positions is refused."""
+    import mhr_amd.synth as synth
+    from mhr_amd import ops
+    cfg, ocfg, data, model, N = _build("cfg1", seed=21)
+    batch = data.train_batch(4)
+    n_valid = int(batch[2][:, :200].sum())
+    assert 0 < n_valid < 4 * 200
+    batch[2]._mhr_rows_cap = synth.rows_capacity(n_valid, bucket=64)
+    calls = []
+    real = ops.seq_pack_maps
+    monkeypatch.setattr(ops, "seq_pack_maps", lambda *a, **k: (calls.append(a[3]), real(*a, **k))[1])
+    _train_step_vs_mixed_oracle(model, ocfg, batch, "cfg1 (packed rows)", grad_tol=5e-2, min_cos=0.999, table_tol=4e-2)
+    assert calls == [synth.rows_capacity(n_valid, bucket=64)]
+    batch[2]._mhr_rows_cap = max(32, n_valid - 64)                                      # a wrong hint must not pass silently
+    with pytest.raises(RuntimeError, match="capacity"):
+        model(batch)
+    model.zero_grad()
+    if hasattr(model, "reset_step_state"):
+        model.reset_step_state()
+
+
 def test_cfg1_eval_batch_vs_oracle_decode(rec):
     cfg, ocfg, data, model, N = _build("cfg1", seed=22)
     eb = data.eval_batch(6)

@@ -514,6 +514,37 @@ def test_hstu_attention_packed_sequences(ops, B, L, Hh, hd):
         assert float(dh_p[n_live:, D:].float().abs().max()) == 0.0
 
 
+def test_seq_pack_maps_and_masked_gather(ops):
+    """mhr_seq_pack_maps numbers the valid positions sequence by sequence in window order; mhr_rows_gather_masked moves rows
+    both ways.  Masks with holes, an empty and a full sequence; a capacity that is too small drops the rows past it and says so."""
+    B, L, D = 6, 45, 64
+    g = torch.Generator().manual_seed(3)
+    valid = torch.rand(B, L, generator=g) > 0.4
+    valid[1] = False
+    valid[2] = True
+    kv = dev(valid.to(torch.uint8))
+    n_valid = int(valid.sum())
+    cap = n_valid + 9
+    cu, src_of, row_of, overflow = ops.seq_pack_maps(kv, B, L, cap)
+    lens = valid.sum(1).tolist()
+    assert cu.cpu().tolist() == [0] + list(np.cumsum(lens)) and int(overflow) == 0
+    want_src = torch.nonzero(valid.view(-1)).flatten().tolist()
+    assert src_of.cpu().tolist() == want_src + [-1] * 9
+    ro = row_of.cpu()
+    assert ro[~valid.view(-1)].eq(-1).all() and ro[valid.view(-1)].tolist() == list(range(n_valid))
+    x = dev(torch.randn(B * L, D, generator=g))
+    xp = ops.rows_gather_masked(x, src_of)
+    assert torch.equal(xp[:n_valid], x[valid.view(-1).cuda()]) and float(xp[n_valid:].abs().max()) == 0.0
+    back = ops.rows_gather_masked(xp, row_of)
+    assert torch.equal(back[valid.view(-1).cuda()], x[valid.view(-1).cuda()]) and float(back[~valid.view(-1).cuda()].abs().max()) == 0.0
+    xb = dev(bf(torch.randn(B * L, D, generator=g)))
+    assert torch.equal(ops.rows_gather_masked(xb, src_of)[:n_valid], xb[valid.view(-1).cuda()])
+    small = n_valid - 7
+    cu2, src2, row2, ov2 = ops.seq_pack_maps(kv, B, L, small)
+    assert int(ov2) == n_valid and int(cu2[-1]) == small
+    assert int((row2 >= 0).sum()) == small and int(row2.max()) == small - 1
+
+
 def test_hstu_attention_golden(ops):
     """The reference's own attention outputs (tests/golden/attention_unit.npz), bf16 tolerance."""
     from conftest import load_golden
