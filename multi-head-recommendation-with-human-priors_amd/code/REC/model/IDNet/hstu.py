@@ -470,7 +470,10 @@ class HSTU(MultiHeadDecoding, BaseModel):
         else:
             rows, _ = ops.embedding_gather(self.item_embedding.weight, item_seq.contiguous(), torch.float32)
             x = self.item_id_proj_tower(rows) + self.position_embedding.weight[:L][None]
-        out = self._encode(x, (item_seq != 0).to(torch.uint8).contiguous(), training=False)   # dropout off, like .eval()
+        key_valid = (item_seq != 0).to(torch.uint8).contiguous()
+        if getattr(item_seq, "_mhr_rows_cap", None) is not None and not torch.cuda.is_current_stream_capturing():
+            key_valid._mhr_rows_cap = item_seq._mhr_rows_cap       # the loader's row capacity: the encoder runs on packed rows
+        out = self._encode(x, key_valid, training=False)   # dropout off, like .eval()
         return out[:, -1]
 
     @torch.no_grad()

@@ -94,6 +94,8 @@ class SyntheticData:
         ctx_len = torch.randint(math.ceil(L / 4), L + 1, (B,), generator=self.gen, device=dev)
         pos = torch.arange(L, device=dev)[None, :]
         item_seq = torch.where(pos >= (L - ctx_len)[:, None], seq, torch.zeros_like(seq))
+        if getattr(self, "rows_hint", False):            # (eval steps are host-issued: no graph per capacity, fine buckets)
+            item_seq._mhr_rows_cap = rows_capacity(int(ctx_len.sum()), n_rows=B * L, bucket=256)
         target = self._zipf((B, E))
         # full history = the visible sequence plus older interactions that fell out of the window
         older = self._zipf((B, hist_extra))

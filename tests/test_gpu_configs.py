@@ -267,6 +267,26 @@ def test_cfg1_eval_batch_vs_oracle_decode(rec):
 # ----------------------------------------------------------------------------------------------------------------------
 # the exact top-k's rare path: rows that cannot be certified
 # ----------------------------------------------------------------------------------------------------------------------
+def test_cfg1_eval_user_heads_on_packed_rows(rec):
+    """The eval encoder pass on packed rows (`_mhr_rows_cap` on item_seq): the user heads at the last position against the
+    window path's - same products in another 32-row blocking, bf16 rounding apart - and the decode through them against the
+    oracle as above."""
+    import mhr_amd.synth as synth
+    cfg, ocfg, data, model, N = _build("cfg1", seed=22)
+    model.eval()
+    eb = list(data.eval_batch(6))
+    with torch.no_grad():
+        plain = model._user_heads(eb[1]).float()
+        seq = eb[1].clone()
+        seq._mhr_rows_cap = synth.rows_capacity(int((seq != 0).sum()), bucket=32)
+        packed = model._user_heads(seq).float()
+    assert float((packed - plain).abs().max()) <= 2e-2 * float(plain.abs().max())
+    cos = torch.nn.functional.cosine_similarity(packed.flatten(1), plain.flatten(1)).min()
+    assert float(cos) > 0.9995
+    eb[1] = seq
+    _decode_vs_oracle(model, cfg, ocfg, data, tuple(eb), N, 200, "cfg1 (packed rows)")
+
+
 @pytest.mark.parametrize("D", [256, 64, 512])                        # 512: the wide scorer's threshold / margin bookkeeping
 def test_exact_topk_uncertified_rows_take_the_dense_hip_path(rec, D):
     """2 000 IDENTICAL item rows near the users' direction: the margin set of every row holds more near-ties than the candidate
