@@ -123,6 +123,43 @@ def test_replayed_steps_follow_the_host_issued_trajectory(rec, loss):
     assert abs(lg[10] - lg[4]) > 0 or loss == "nce"
 
 
+def test_packed_rows_replayed_steps_are_the_host_issued_steps_bit_for_bit(rec):
+    """Batches that carry the loader's row capacity (`_mhr_rows_cap`): the encoder runs on packed rows and the trainer keeps one
+    captured step graph per capacity.  In deterministic mode the replayed run - alternating between its per-capacity graphs - and
+    the host-issued run agree bit for bit over 40 steps (losses, weights), and each differs from the window-row run only by
+    rounding (another 32-row blocking in the attention, another M in the library GEMMs)."""
+    import mhr_amd.synth as synth
+    from mhr_amd import ops
+    dev = torch.device("cuda", 0)
+    ops.set_deterministic(True)
+    try:
+        tr_e, m_e, data = _trainer(rec, False, dev, hidden_dropout_prob=0.0)    # (dropout masks are keyed by the row index, which
+        tr_g, m_g, _ = _trainer(rec, True, dev, hidden_dropout_prob=0.0)       #  packing changes: off for the window comparison)
+        tr_w, m_w, _ = _trainer(rec, False, dev, hidden_dropout_prob=0.0)
+        batches = [data.train_batch(16) for _ in range(6)]
+        hinted = []
+        for bt in batches:
+            m2 = bt[2].clone()
+            m2._mhr_rows_cap = synth.rows_capacity(int(bt[2][:, :24].sum()), bucket=32)
+            hinted.append((bt[0], bt[1], m2, bt[3]))
+        caps = {b[2]._mhr_rows_cap for b in hinted}
+        assert len(caps) >= 2                                   # more than one capacity: the replayed run switches graphs
+        le, lg, lw = [], [], []
+        for i in range(40):
+            le.append(float(tr_e.train_step_fn(hinted[i % 6])["loss"]))
+            lg.append(float(tr_g.train_step_fn(hinted[i % 6])["loss"]))
+            lw.append(float(tr_w.train_step_fn(batches[i % 6])["loss"]))
+        assert tr_g.graph_active and len(tr_g._step_graphs) == len(caps)
+        assert le == lg
+        sd_e, sd_g = m_e.state_dict(), m_g.state_dict()
+        for k in sd_e:
+            assert torch.equal(sd_e[k], sd_g[k]), k
+        np.testing.assert_allclose(np.array(le[:6]), np.array(lw[:6]), rtol=2e-3)
+        assert le[-1] < le[0]
+    finally:
+        ops.set_deterministic(False)
+
+
 @pytest.mark.parametrize("loss", ["prior", "nce"])
 def test_deterministic_mode_makes_replayed_and_host_issued_runs_bitwise_equal(rec, loss):
     """`ops.set_deterministic(True)` (include/mhr.h: deterministic mode): the float-atomic reductions of the loss backward - the
