@@ -692,19 +692,6 @@ def main():
             caps = sorted({int(getattr(bt[2], "_mhr_rows_cap", 0) or 0) for bt in main_leg["batches"]})
             out["packed_rows"] = {"window_rows_per_batch": B * L, "capacities": caps,
                                   "mean_valid_rows": round(float(sum(float(bt[2][:, :L].sum()) for bt in main_leg["batches"])) / max(1, len(main_leg["batches"])), 1)}
-            if not args.no_graph:
-                # the same steps on WINDOW rows (the same batches without the loader's hint), timed the same way right behind the
-                # main leg: what the packed layout is worth on this box, in the line
-                plain = [(bt[0], bt[1], bt[2].clone(), bt[3]) for bt in main_leg["batches"]]
-                for i in range(4 + 3):
-                    trainer.train_step_fn(plain[i % len(plain)])
-                sync()
-                t0w = time.perf_counter()
-                n_w = min(20, args.steps)
-                for i in range(n_w):
-                    trainer.train_step_fn(plain[i % len(plain)])
-                sync()
-                out["packed_rows"]["window_rows_ms_per_step"] = round(1000 * max_over_ranks(time.perf_counter() - t0w) / n_w, 3)
         assert out["n_gpus"] == args.gpus
         out["graph_active"] = graph_on if args.mode == "train" else any(
             g_.graph is not None for g_ in trainer.__dict__.get("_eval_graphs", {}).values())
