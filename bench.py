@@ -437,6 +437,8 @@ def main():
     trainer = Trainer(cfg)
     trainer.setup_model(model)
     trainer.train_step = 3000            # past the warm-up so lr > 0: every step really moves the parameters
+    if data.rows_hint and not (model._packable(cfg["MAX_ITEM_LIST_LENGTH"]) and model._dead_rows_allowed()):
+        data.rows_hint = False           # (a model that cannot run on packed rows: no hint, one step graph)
     L, P, D, C = cfg["MAX_ITEM_LIST_LENGTH"], cfg["pred_len"], cfg["hstu_embedding_size"], data.C
     H = model.medusa_num_heads
     standard = not args.batch
