@@ -41,15 +41,10 @@ class _GraphSegments:
     normalised negatives) is alive until the backward of the same step, what the main segments read from its pool (token
     lists, bit table, accumulators) is written before the join and not touched by it again."""
 
-    def __init__(self, device, pools=None):
+    def __init__(self, device):
         self.main = torch.cuda.Stream(device=device)
         self.side = torch.cuda.Stream(device=device)
         self.plan, self.cur, self.pool = [], None, None
-        # pools (optional, a dict the caller keeps): the memory pools of the main segments / of the side graphs, SHARED by the step
-        # graphs of one trainer - alternatives of the same step (one per batch signature) that never run concurrently
-        self.shared = pools
-        if pools is not None:
-            self.pool = pools.get("main")
         self.host_s, self.n_replays = 0.0, 0          # host time spent inside the plan's host calls (the collectives), replays
         self.ev_fork, self.ev_side = torch.cuda.Event(), torch.cuda.Event()
 
@@ -74,8 +69,6 @@ class _GraphSegments:
         g = torch.cuda.CUDAGraph()
         if self.pool is None:
             self.pool = torch.cuda.graph_pool_handle()
-            if self.shared is not None:
-                self.shared["main"] = self.pool
         g.capture_begin(pool=self.pool, capture_error_mode=self._capture_mode())
         self.cur = g
 
@@ -88,12 +81,7 @@ class _GraphSegments:
         self._close()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.stream(self.side):
-            side_pool = self.shared.get("side") if self.shared is not None else None
-            if side_pool is None:
-                side_pool = torch.cuda.graph_pool_handle()
-                if self.shared is not None:
-                    self.shared["side"] = side_pool
-            g.capture_begin(pool=side_pool, capture_error_mode=self._capture_mode())
+            g.capture_begin(pool=torch.cuda.graph_pool_handle(), capture_error_mode=self._capture_mode())
             try:
                 fn()
             finally:
@@ -174,7 +162,7 @@ class _StepGraph:
             if getattr(t, "_mhr_rows_cap", None) is not None:
                 st_._mhr_rows_cap = t._mhr_rows_cap
         keep = (model._step_seed, opt.step_count, tr.train_step, tr._micro_step, opt.param_groups[0]["lr"])
-        graph = _GraphSegments(dev, pools=tr.__dict__.setdefault("_graph_pools", {}) if os.environ.get("MHR_SHARE_GRAPH_POOLS", "0") == "1" else None)
+        graph = _GraphSegments(dev)
         model._seed_dev, opt.step_dev, opt.in_graph = opt.ctrl[0:1], opt.ctrl[1:2], True
         # no cyclic garbage collection while the stream is capturing: a collected object may own pinned host memory or an
         # event whose release is a synchronising HIP call - illegal under capture, and it takes the process down (seen with

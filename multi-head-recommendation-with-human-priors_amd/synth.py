@@ -114,9 +114,9 @@ class SyntheticData:
 
 def rows_capacity(n_valid, n_rows=None, bucket=None):
     """Static row capacity for a batch with n_valid valid window positions out of n_rows: the next multiple of `bucket`.  Every
-    capacity is its own captured step graph and alternating between graphs costs (measured at cfg1: five capacities of 1024 rows
-    lose to two of 2048 although they fit tighter), so the default bucket is coarse: the power of two nearest below n_rows / 12
-    (2048 at cfg1's 25 600 rows; MHR_ROWS_BUCKET overrides)."""
+    capacity is its own captured step graph, and the step's time is not monotone in the row count (measured at cfg1: capacities
+    of 15 360 / 17 408 rows lose to 16 384 / 18 432 - library GEMM heuristics, stream counts), so the default bucket is coarse
+    and a power of two: the one nearest below n_rows / 12 (2048 at cfg1's 25 600 rows; MHR_ROWS_BUCKET overrides)."""
     if bucket is None:
         env = os.environ.get("MHR_ROWS_BUCKET")
         if env:
