@@ -12,20 +12,27 @@
 
 namespace {
 
-// cu_rows[b] = number of valid positions in sequences 0 .. b-1 (one workgroup; B <= 65536)
-__global__ __launch_bounds__(256) void seq_cu_kernel(const uint8_t* __restrict__ key_valid, int B, int L, int cap,
-                                                     int32_t* __restrict__ cu_rows, int32_t* __restrict__ overflow) {
+// lens[b] = valid positions of sequence b: one wave per sequence, ballots over the mask bytes (written into cu_rows[b + 1])
+__global__ __launch_bounds__(64) void seq_len_kernel(const uint8_t* __restrict__ key_valid, int L, int32_t* __restrict__ cu_rows) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const uint8_t* kv = key_valid + (int64_t)b * L;
+  int n = 0;
+  for (int l0 = 0; l0 < L; l0 += 64) {
+    const int l = l0 + lane;
+    n += __popcll(__ballot(l < L && kv[l] != 0));
+  }
+  if (lane == 0) cu_rows[b + 1] = n;
+}
+
+// in place: cu_rows[1 .. B] hold the lengths -> cu_rows[b] = number of valid positions in sequences 0 .. b-1, clamped to the capacity
+// (one workgroup; B <= 65536: a thread owns B / 256 consecutive sequences)
+__global__ __launch_bounds__(256) void seq_cu_kernel(int B, int cap, int32_t* __restrict__ cu_rows, int32_t* __restrict__ overflow) {
   __shared__ int s_part[256];
   const int t = threadIdx.x;
-  const int per = (B + 255) / 256;                        // consecutive sequences per thread
-  const int b0 = t * per, b1 = min(B, b0 + per);
+  const int per = (B + 255) / 256;
+  const int b0 = min(B, t * per), b1 = min(B, b0 + per);
   int mine = 0;
-  for (int b = b0; b < b1; ++b) {
-    const uint8_t* kv = key_valid + (int64_t)b * L;
-    int n = 0;
-    for (int l = 0; l < L; ++l) n += kv[l] != 0;
-    mine += n;
-  }
+  for (int b = b0; b < b1; ++b) mine += cu_rows[b + 1];
   s_part[t] = mine;
   __syncthreads();
   if (t == 0) {
@@ -35,18 +42,16 @@ __global__ __launch_bounds__(256) void seq_cu_kernel(const uint8_t* __restrict__
       s_part[i] = run;
       run += c;
     }
-    cu_rows[B] = min(run, cap);
     if (overflow) overflow[0] = run > cap ? run : 0;      // the batch does not fit the capacity: the rows past it are DROPPED
   }
   __syncthreads();
   int run = s_part[t];
-  for (int b = b0; b < b1; ++b) {
-    cu_rows[b] = min(run, cap);
-    const uint8_t* kv = key_valid + (int64_t)b * L;
-    int n = 0;
-    for (int l = 0; l < L; ++l) n += kv[l] != 0;
+  for (int b = b0; b < b1; ++b) {                          // (reads its own b + 1 before any other thread could have written it:
+    const int n = cu_rows[b + 1];                          //  thread t writes entries b0 + 1 .. b1 only, and entry b0 + 1 after reading it)
     run += n;
+    cu_rows[b + 1] = min(run, cap);
   }
+  if (t == 0) cu_rows[0] = 0;
 }
 
 // one wave per sequence: row_of[(b, l)] = packed row of a valid position (-1: padding / past the capacity), src_of[packed] = b L + l;
@@ -110,7 +115,8 @@ extern "C" int mhr_seq_pack_maps(const uint8_t* key_valid, int B, int L, int cap
   MHR_REQUIRE(key_valid && cu_rows && src_of && row_of, "seq_pack_maps: null pointer");
   MHR_REQUIRE(B > 0 && B <= 65536 && L > 0 && capacity > 0 && (int64_t)B * L < (1ll << 31), "seq_pack_maps: bad sizes");
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(seq_cu_kernel, dim3(1), dim3(256), 0, s, key_valid, B, L, capacity, cu_rows, overflow);
+  hipLaunchKernelGGL(seq_len_kernel, dim3(B), dim3(64), 0, s, key_valid, L, cu_rows);
+  hipLaunchKernelGGL(seq_cu_kernel, dim3(1), dim3(256), 0, s, B, capacity, cu_rows, overflow);
   hipLaunchKernelGGL(seq_maps_kernel, dim3(B + 16), dim3(64), 0, s, key_valid, B, L, capacity, cu_rows, src_of, row_of);
   MHR_CHECK_LAUNCH("seq_pack_maps");
   return MHR_OK;
