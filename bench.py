@@ -429,8 +429,8 @@ def main():
     # the loader's host-side count of a batch's valid positions, as a bucketed static capacity on the mask (synth.rows_capacity):
     # with it the encoder runs over the valid rows only (packed rows, csrc/rows_pack.hip); batches are generated outside the
     # timed region, as a CPU collate would produce the count for free
-    # (one rank only: data-parallel steps keep the window rows, and a hint would only split their step into per-capacity graphs)
-    data.rows_hint = not args.no_pack and world == 1 and os.environ.get("MHR_FORCE_DP", "0") != "1"
+    # (data parallel: every rank must see the same capacity for a step - run_leg takes the maximum over the ranks)
+    data.rows_hint = not args.no_pack
     cfg["int_to_category"] = data.int_to_category
     torch.manual_seed(2020)
     model = get_model("HSTU")(cfg, data).to(dev)
@@ -467,6 +467,13 @@ def main():
         n_steps = warmup + steps
         if mode == "train":
             batches = [data.train_batch(B) for _ in range(min(n_steps, 8))]
+            if world > 1 and getattr(data, "rows_hint", False):
+                # one capacity per step for ALL ranks (the largest): the step graphs are keyed on it and the ranks must capture /
+                # replay in lockstep - a capturing rank issues no collective
+                caps = torch.tensor([int(bt[2]._mhr_rows_cap) for bt in batches], dtype=torch.int64, device=dev)
+                dist.all_reduce(caps, op=dist.ReduceOp.MAX)
+                for bt, c_ in zip(batches, caps.tolist()):
+                    bt[2]._mhr_rows_cap = int(c_)
             model.train()
 
             def step(i, eager=False):

@@ -222,11 +222,13 @@ class HSTU(MultiHeadDecoding, BaseModel):
         # PACKED rows: the batch carries a static capacity for its valid positions (`_mhr_rows_cap` on the mask: a bucketed count
         # the loader knows on the host) - the layers then run over the valid rows only, back to back in a [capacity, D] buffer
         # (csrc/rows_pack.hip), the attention addresses the sequences through cu_rows.  Same condition as the dead rows: nothing
-        # may read the hidden states of padding positions.
+        # may read the hidden states of padding positions.  Data parallel: the capacity is part of the batch signature the step
+        # graphs are keyed on, and every rank must capture and replay in the same steps (a capture issues no collective) - the
+        # loaders must hand all ranks the SAME capacity for a step (the maximum over the ranks; bench.py does that).
         cap = getattr(key_valid, "_mhr_rows_cap", None)
         pack = None
         if (cap is not None and ops.PACK_ROWS and n and lay is not None and self._dead_rows_allowed() and 0 < int(cap) < B * L
-                and D % 8 == 0 and self._packable(L) and not self._dp_active()):
+                and D % 8 == 0 and self._packable(L)):
             from REC.model.hstu_functional import MoveRowsFn
             cap = int(cap)
             cu, src_of, row_of, overflow = ops.seq_pack_maps(key_valid, B, L, cap)
@@ -289,13 +291,6 @@ class HSTU(MultiHeadDecoding, BaseModel):
         if pack is not None:
             x2 = MoveRowsFn.apply(x2, pack[1], pack[0])
         return (x2.view(B, L, D), None) if want_bf16 else x2.view(B, L, D)
-
-    @staticmethod
-    def _dp_active():
-        """(data-parallel steps keep the window rows: every rank would capture per-capacity graphs of its own around the shared
-        collectives - never exercised)"""
-        from mhr_amd import distributed as dist_
-        return dist_.active()
 
     def _packable(self, L):
         """Packed rows need the attention's resident form (sequence offsets are not wired into the streamed one)."""

@@ -702,9 +702,16 @@ cfg["int_to_category"] = data.int_to_category
 torch.manual_seed(5)
 model = get_model("HSTU")(cfg, data).to(dev)
 tr = Trainer(cfg); tr.setup_model(model); tr.train_step = 30
+data.rows_hint = os.environ.get("HINT", "0") == "1"
 batches = [data.train_batch(8) for _ in range(4)]
+if data.rows_hint:                                  # one capacity per step for all ranks: the largest
+    caps = torch.tensor([int(bt[2]._mhr_rows_cap) for bt in batches], dtype=torch.int64, device=dev if os.environ.get("BACKEND", "gloo") == "nccl" else "cpu")
+    dist.all_reduce(caps, op=dist.ReduceOp.MAX)
+    for bt, c_ in zip(batches, caps.tolist()):
+        bt[2]._mhr_rows_cap = int(c_)
+n_caps = len({getattr(bt[2], "_mhr_rows_cap", None) for bt in batches})
 losses = []
-for i in range(12):
+for i in range(int(os.environ.get("STEPS", "12"))):
     losses.append(float(tr.train_step_fn(batches[i % 4])["loss"]))
 model.sync_table()
 torch.cuda.synchronize()
@@ -712,7 +719,8 @@ st = tr._step_graph
 plan = [k for k, _ in st.graph.plan] if (st is not None and st.graph is not None) else []
 np.savez(os.path.join(out_dir, f"{tag}{rank}.npz"), table=model.item_embedding.weight.detach().cpu().numpy(),
          flat=tr.optimizer.flat_w.cpu().numpy(), losses=np.array(losses), graph_active=np.array(bool(tr.graph_active)),
-         replays=np.array(st.n if st is not None else 0), host_calls=np.array(sum(k == "host" for k in plan)))
+         replays=np.array(st.n if st is not None else 0), host_calls=np.array(sum(k == "host" for k in plan)),
+         n_caps=np.array(n_caps), n_graphs=np.array(len(getattr(tr, "_step_graphs", {}))))
 dist.barrier()
 dist.destroy_process_group()
 '''
@@ -752,6 +760,37 @@ def test_data_parallel_steps_replay_from_graph_segments_around_the_exchange(rec,
     np.testing.assert_allclose(g[0]["losses"], h[0]["losses"], rtol=2e-2)
     scale = np.abs(h[0]["flat"]).max()
     assert np.abs(g[0]["flat"] - h[0]["flat"]).mean() <= 1e-3 * scale and np.abs(g[0]["flat"] - h[0]["flat"]).max() <= 0.1 * scale
+
+
+def test_data_parallel_steps_on_packed_rows(rec, tmp_path):
+    """The same two-rank run with the loader's row capacities on the batches (the maximum over the ranks for every step, so that
+    all ranks key their step graphs alike and capture / replay in lockstep): the encoder runs on packed rows, one graph per
+    capacity.  Replicas bitwise identical; the run is the window-row data-parallel run up to rounding."""
+    import subprocess
+    kw = dict(MAX_ITEM_LIST_LENGTH=16, pred_len=2, eval_pred_len=2, n_layers=2, n_heads=2, item_embedding_size=64,
+              hstu_embedding_size=64, num_negatives=256, total_iters=100, eval_interval=0, checkpoint_dir=None,
+              save_model_note="t", hidden_dropout_prob=0.0, attn_dropout_prob=0.0, loss='prior', num_prior_head=3,
+              medusa_num_layers=1, eval_num_cats=3)
+    (tmp_path / "cfg.txt").write_text(repr(kw))
+    script = tmp_path / "dp_graph.py"
+    script.write_text(DP_GRAPH_SCRIPT)
+    res = {}
+    for tag, hint, port in (("packed", "1", 29671), ("window", "0", 29672)):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2", HSA_ENABLE_IPC_MODE_LEGACY="0",
+                   MHR_DP_GRAPH="1", HINT=hint, STEPS="20", MHR_ROWS_BUCKET="16")
+        procs = [subprocess.Popen([sys.executable, str(script), ROOT, CODE, str(tmp_path), tag], env=dict(env, RANK=str(r)),
+                                  stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+        outs = [p.communicate(timeout=600) for p in procs]
+        for p, (o, e) in zip(procs, outs):
+            assert p.returncode == 0, (tag, o[-2000:], e[-4000:])
+        res[tag] = [np.load(tmp_path / f"{tag}{i}.npz") for i in range(2)]
+    pk, wd = res["packed"], res["window"]
+    assert bool(pk[0]["graph_active"]) and bool(pk[1]["graph_active"])
+    assert int(pk[0]["n_caps"]) >= 2 and int(pk[0]["n_graphs"]) == int(pk[0]["n_caps"]) == int(pk[1]["n_graphs"])
+    for r_ in (pk, wd):
+        assert np.array_equal(r_[0]["table"], r_[1]["table"]) and np.array_equal(r_[0]["flat"], r_[1]["flat"])
+    np.testing.assert_allclose(pk[0]["losses"][:8], wd[0]["losses"][:8], rtol=3e-3)
+    np.testing.assert_allclose(pk[0]["losses"], wd[0]["losses"], rtol=3e-2)
 
 
 def test_rccl_one_rank_rehearsal_of_the_replayed_data_parallel_step(rec, tmp_path):
